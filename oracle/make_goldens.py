@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.json.gz from the UNMODIFIED reference objects (development container only).
+
+Runs oracle/_ref/ref_harness (built by `make -C oracle ref` from /root/reference, see
+oracle/Makefile and oracle/ref_harness.c) on the reference's example alignments and on blocks
+from the deterministic synthetic generator, and stores inputs + reference outputs as JSON.
+Only data is committed: alignment rows, tree/kappa, parameters, seed base -> models, HSS table,
+per-sample maxima, mu, lambda, p-values, Sk digests, backtrack paths.
+
+Usage:  python oracle/make_goldens.py            (needs /root/reference)
+"""
+from __future__ import annotations
+
+import gzip
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from rnacode_amd.alnio import AlnBlock, AlnRow, read_alignment_file, write_harness_blocks  # noqa: E402
+from rnacode_amd.synth import synth_blocks  # noqa: E402
+
+REF = os.environ.get("RNACODE_REF", "/root/reference")
+HARNESS = os.path.join(HERE, "_ref", "ref_harness")
+OUT = os.path.join(ROOT, "tests", "golden")
+SEED = 42
+
+
+def run_harness(blocks, samples, extra=()):
+    with tempfile.NamedTemporaryFile("w", suffix=".blk", delete=False) as fh:
+        path = fh.name
+    try:
+        write_harness_blocks(blocks, path)
+        out = subprocess.check_output([HARNESS, path, "--samples", str(samples), "--seed", str(SEED), *extra])
+    finally:
+        os.unlink(path)
+    return [json.loads(l) for l in out.decode().splitlines() if l.strip()]
+
+
+def block_json(b: AlnBlock):
+    return dict(id=b.block_id, tree=b.tree, kappa=b.kappa,
+                rows=[dict(name=r.name, seq=r.seq, start=r.start, length=r.length, strand=r.strand,
+                           full_length=r.full_length) for r in b.rows])
+
+
+def emit(name, blocks, samples, params=None, extra=(), note=""):
+    res = run_harness(blocks, samples, extra)
+    assert len(res) == len(blocks), (len(res), len(blocks))
+    doc = dict(fixture=name, note=note, seed_base=SEED, samples=samples,
+               params=params or {}, harness_args=list(extra),
+               blocks=[dict(input=block_json(b), ref=r) for b, r in zip(blocks, res)])
+    path = os.path.join(OUT, name + ".json.gz")
+    with gzip.GzipFile(path, "wb", mtime=0) as fh:
+        fh.write(json.dumps(doc, separators=(",", ":")).encode())
+    nscored = sum(1 for r in res if "skipped" not in r)
+    print(f"{name}: {len(blocks)} blocks ({nscored} scored), n={samples}, {os.path.getsize(path)} bytes")
+
+
+def edge_blocks():
+    """Hand-made blocks for edge cases the reference handles (tree/kappa fitted by treeML)."""
+    out = []
+    # lower case + U + N + IUPAC in several rows, gaps in the reference row incl. leading gaps
+    rows = [
+        ("e1.a", "--atgGCUaaaNNNgcaugc---gatcgaucgRYKatgccgUAA"),
+        ("e1.b", "ccATGGCTAAAGGGGCATGC---GATCGATCGTTTATGCCGTAA"),
+        ("e1.c", "--ATGGCAAAAGGTGCNTGCTTTGATCG-TCGTTTATGCCGTGA"),
+        ("e1.d", "--ATGGCTAAGGGGGCATGC---GACCGATCGTTCATGCC-TAA"),
+    ]
+    out.append(AlnBlock([AlnRow(n, s, 100, sum(c != "-" for c in s), "+", 5000) for n, s in rows], "edge_chars"))
+    # minimal: three rows, nine columns
+    rows = [("m.a", "ATGGCTAAA"), ("m.b", "ATGGCAAAA"), ("m.c", "ATGGCTAAG")]
+    out.append(AlnBlock([AlnRow(n, s, 0, 0, "?", 0) for n, s in rows], "edge_min3x9"))
+    # too short / too few rows: skipped by the driver (RNAcode.c:142-150)
+    out.append(AlnBlock([AlnRow("s.a", "A-T", 0, 0, "?", 0), AlnRow("s.b", "ACT", 0, 0, "?", 0),
+                         AlnRow("s.c", "AGT", 0, 0, "?", 0)], "edge_short"))
+    out.append(AlnBlock([AlnRow("t.a", "ATGGCTAAA", 0, 0, "?", 0), AlnRow("t.b", "ATGGCAAAA", 0, 0, "?", 0)],
+                        "edge_two_rows"))
+    # reference row on the minus strand with MAF coordinates
+    rows = [("r.a", "ATGGCTAAAGGGGCATGCGATCGATCGTTTATGCCGTAA"), ("r.b", "ATGGCTAAAGGAGCATGCGATCGTTCGTTTATGCCGTAA"),
+            ("r.c", "ATGGCAAAAGGGGCATGTGATCGATCGTTTATGCCTTAA"), ("r.d", "ATGGCTAAGGGGGCTTGCGATCGATCCTTTATGCCGTAA")]
+    out.append(AlnBlock([AlnRow(n, s, 777, len(s), "-", 9999) for n, s in rows], "edge_minus_ref"))
+    return out
+
+
+def main():
+    if not os.path.exists(HARNESS):
+        subprocess.check_call(["make", "-C", HERE, "ref"])
+    os.makedirs(OUT, exist_ok=True)
+    ex = os.path.join(REF, "examples")
+
+    for stem in ("coding.aln", "noncoding.aln", "coding.maf", "noncoding.maf"):
+        emit(stem.replace(".", "_") + "_n100", read_alignment_file(os.path.join(ex, stem)), 100,
+             note=f"reference example {stem}, tree+kappa from the reference's treeML")
+    gp = read_alignment_file(os.path.join(ex, "genomic-preprocessed.maf"))
+    emit("genomic_preprocessed_n100", gp, 100, note="BASELINE config 2 input, all 34 blocks")
+    emit("genomic_preprocessed_n1000", gp, 1000, extra=("--no-backtrack",), note="BASELINE config 2")
+
+    emit("edge_cases_n50", edge_blocks(), 50, note="character classes, minimal sizes, skip rules, minus-strand ref")
+
+    s6 = synth_blocks(6, 6, 120, seed=1)
+    emit("synth_6x120_n200", s6, 200, note="BASELINE config 3 shape (6 seqs x 120 cols), sidecar tree+kappa")
+    s12 = synth_blocks(2, 12, 300, seed=2)
+    emit("synth_12x300_n40", s12, 40, note="BASELINE config 5 shape (12 seqs x 300 cols), sidecar tree+kappa")
+    s4 = synth_blocks(4, 5, 60, seed=3)
+    emit("synth_5x60_blosum90_n100", s4, 100, params=dict(blosum=90), extra=("--blosum", "90"))
+    emit("synth_5x60_pars_n100", s4, 100, params=dict(Delta=-7.5, Omega=-3.0, omega=-1.5, stopPenalty_k=-6.0),
+         extra=("--pars", "-7.5", "-3.0", "-1.5", "-6.0"))
+    emit("synth_5x60_stopearly_n100", s4, 100, params=dict(stopEarly=1, cutoff=0.05),
+         extra=("--stop-early", "--cutoff", "0.05"))
+    # many sequences (wide N), short
+    s20 = synth_blocks(2, 20, 45, seed=4)
+    emit("synth_20x45_n50", s20, 50, note="wide alignment")
+    # rooted (bifurcating root) sidecar tree: Seq-Gen then evolves only two root branches (evolve.c:429-432)
+    rooted = synth_blocks(2, 4, 48, seed=5)
+    for b in rooted:
+        # (A,B,(C,D)) -> ((A,B):0.01,(C,D)) keeps names; re-root by grouping the first two root children
+        t = b.tree
+        depth = 0
+        cut = []
+        for i, ch in enumerate(t):
+            if ch == "(":
+                depth += 1
+            elif ch == ")":
+                depth -= 1
+            elif ch == "," and depth == 1:
+                cut.append(i)
+        b.tree = "(" + t[:cut[1]] + "):0.010000" + t[cut[1]:]
+    emit("synth_rooted_4x48_n100", rooted, 100, note="rooted sidecar tree")
+
+
+if __name__ == "__main__":
+    main()
