@@ -1,0 +1,157 @@
+/* rnacode_hip.h -- C-ABI of the MI355X-native RNAcode scoring path (librnacode_hip.so).
+ *
+ * The reference has no plugin/FFI layer: the drop-in boundary is the link-level symbol set of
+ * its scoring object (src/score.h:83-118 as used by src/RNAcode.c:164-216 and
+ * src/postscript.c:303-305).  Each entry point below names the reference interface it
+ * replaces.  Plain pointers and sizes only; no C++ or torch types.  All functions return
+ * RC_OK (0) or a negative RC_ERR_* code; rc_last_error() gives the message.  The library
+ * never falls back to a CPU implementation of the hot path: without a usable HIP device
+ * every compute entry point fails with RC_ERR_DEVICE.
+ */
+#ifndef RNACODE_HIP_H
+#define RNACODE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RC_OK 0
+#define RC_ERR_ARG (-1)         /* malformed block / tree / parameter */
+#define RC_ERR_DEVICE (-2)      /* no HIP device, or a HIP call failed */
+#define RC_ERR_UNSUPPORTED (-3) /* shape outside the built kernels (N > RC_MAX_ROWS) */
+#define RC_ERR_SKIP (-4)        /* block the reference driver skips (RNAcode.c:142-150) */
+
+#define RC_MAX_ROWS 32          /* rows per block handled by the device kernels (N-1 <= 31) */
+
+/* Scoring parameters: the members of `parameters pars` (src/RNAcode.h:29-54) that the
+ * scoring path reads (score.c:415,419,508-533,842,992,1040), plus the seed base that
+ * replaces Seq-Gen's time-based CreateSeed (seqgen/twister.c:195-224):
+ * sample s of every block is simulated with MT19937 seeded by seed_base + s. */
+typedef struct rc_params {
+  float Delta;          /* -10   */
+  float Omega;          /* -4    */
+  float omega;          /* -2    */
+  float stopPenalty_0;  /* -9999 */
+  float stopPenalty_k;  /* -8    */
+  int32_t blosum;       /* 62 | 90 */
+  int32_t sampleN;      /* --num-samples */
+  float cutoff;         /* --cutoff, only used by stop-early (score.c:992) */
+  int32_t stopEarly;    /* --stop-early */
+  uint32_t seed_base;
+} rc_params;
+
+void rc_default_params(rc_params *p); /* RNAcode.c:68-85 */
+
+/* One alignment block: `struct aln *[]` (src/rnaz_utils.h:12-20) flattened, plus what
+ * treeML/string2tree hand to the scorer (RNAcode.c:153-158): Newick text and kappa. */
+typedef struct rc_block {
+  int32_t n_rows;            /* N, row 0 = reference sequence */
+  int32_t n_cols;            /* alignment columns */
+  const char *const *rows;   /* n_rows strings of n_cols chars (A C G T U N - ...); upper-cased internally */
+  const char *const *names;  /* n_rows row names; must match the tree's tip labels */
+  int32_t ref_start;         /* aln[0]->start  (0 for ClustalW input) */
+  int32_t ref_length;        /* aln[0]->length (0 for ClustalW input) */
+  const char *newick;        /* tree with branch lengths (phyml Write_Tree format) */
+  float kappa;               /* ts/tv ratio from treeML */
+} rc_block;
+
+/* segmentStats (src/score.h:48-63) without the heap-allocated name. */
+typedef struct rc_hss {
+  int32_t start, end;                /* nt positions in the reference row, 1-based */
+  int32_t startGenomic, endGenomic;
+  int32_t startSite, endSite;        /* codon indices, 0-based */
+  int32_t strand;                    /* '+' or '-' */
+  int32_t frame;                     /* 0..2 */
+  float score;
+  float pvalue;                      /* filled by rc_batch_run (RNAcode.c:180-188); 99 on fit failure */
+} rc_hss;
+
+/* bgModel (src/score.h:34-44) as computed by getModels (score.c:291-344). */
+typedef struct rc_model {
+  float scores[4];
+  float probs[4];
+  float kappa, dist;
+  float freqs[4];
+} rc_model;
+
+typedef struct rc_ctx rc_ctx;     /* one per process and GPU: device, stream, caches */
+typedef struct rc_batch rc_batch; /* blocks resident in HBM + their results */
+
+const char *rc_last_error(void);
+int rc_device_count(void);
+
+/* One context per process and GPU (one process per GPU; multi-GPU sharding is done by the
+ * caller). */
+int rc_ctx_create(int device, rc_ctx **out);
+void rc_ctx_destroy(rc_ctx *ctx);
+
+/* getModels x2 (RNAcode.c:164-165) + everything block-constant the kernels need, built on
+ * the host and uploaded.  Blocks that the reference driver would skip (N <= 2, L < 3,
+ * RNAcode.c:142-150) are kept in the batch with status RC_ERR_SKIP and produce no work. */
+int rc_batch_create(rc_ctx *ctx, const rc_block *blocks, int32_t n_blocks, const rc_params *par, rc_batch **out);
+void rc_batch_destroy(rc_batch *b);
+
+/* Optional: make the kernels write the per-sample maxima ([n_blocks][sampleN] floats) straight
+ * into a caller-owned DEVICE buffer (e.g. a torch tensor handed to an RCCL all-gather).  Must be
+ * called before rc_batch_run; the buffer must outlive the batch. */
+int rc_batch_bind_maxima(rc_batch *b, void *device_ptr);
+
+/* The hot path for the whole batch, all on the device:
+ *   scoreAln(native, backtrack=1)      score.c:1067-1147  -> HSS lists
+ *   getExtremeValuePars                score.c:976-1064   -> per-sample maxima, mu, lambda
+ *   p-values                           RNAcode.c:180-188
+ * Synchronous: returns when results are in HBM. */
+int rc_batch_run(rc_batch *b);
+
+/* By default the MT19937 output streams (one per sample index, shared by all blocks because
+ * seed = seed_base + s) are cached in the context between runs with the same seed_base and
+ * sampleN; rc_set_stream_cache(0) regenerates them in every rc_batch_run. */
+void rc_set_stream_cache(int enabled);
+
+/* Number of (block, sample) units and alignment-columns x samples of the last run. */
+int rc_batch_work(const rc_batch *b, int64_t *sample_alignments, int64_t *column_samples);
+
+/* HIP-event timings (ms) of the last rc_batch_run on the context's stream:
+ * t[0] total, t[1] MT19937 stream kernel, t[2] null-sampling kernels (simulate+score),
+ * t[3] native scoring kernels, t[4] EVD fit kernel.  n_launch[i] = launches behind t[i]. */
+int rc_batch_timing(const rc_batch *b, float t[5], int32_t n_launch[5]);
+
+/* Per-block results (host copies).  status: RC_OK or RC_ERR_SKIP. */
+int rc_batch_status(const rc_batch *b, int32_t blk);
+int rc_batch_models(const rc_batch *b, int32_t blk, rc_model *fwd, rc_model *rev); /* n_rows entries each */
+/* maxScores[] of score.c:1044: sampleN floats (-1 = sample without HSS) */
+int rc_batch_maxima(const rc_batch *b, int32_t blk, float *out);
+/* all blocks at once, [n_blocks][sampleN]; skipped blocks are filled with -1 */
+int rc_batch_maxima_all(const rc_batch *b, float *out);
+/* getExtremeValuePars' outputs: rc 1 / -1 like the reference, mu and lambda narrowed to float */
+int rc_batch_fit(const rc_batch *b, int32_t blk, int32_t *evd_rc, float *mu, float *lambda);
+/* HSS list sorted by score descending as main() does (RNAcode.c:173-176); returns the count
+ * (may exceed cap; only cap entries are written) */
+int rc_batch_hss(const rc_batch *b, int32_t blk, rc_hss *out, int32_t cap);
+/* draws that fell past the cumulative probability vector (reference reads out of bounds
+ * there, seqgen/evolve.c:173; we clamp to state 3 and count) */
+int rc_batch_clamped(const rc_batch *b, int64_t *count);
+
+/* Debug/parity access: multiple-score matrix S[a][j] of the native block for one strand and
+ * frame (score.c:811-848 restricted to that frame): sites x sites floats, row a = start
+ * codon, column j = end codon; entries with j < a are 0.  Returns sites. */
+int rc_batch_native_S(const rc_batch *b, int32_t blk, int32_t strand /*0:'+',1:'-'*/, int32_t frame, float *out, int32_t cap);
+
+/* backtrack (score.c:558-797) for the native block: states/z/transitions for rows 1..N-1 at
+ * i = opt_i, opt_i-3, ... >= opt_b+2.  Arrays are [n_rows][n_cols+1]; untouched entries -9. */
+int rc_batch_backtrack(const rc_batch *b, int32_t blk, int32_t strand, int32_t opt_b, int32_t opt_i,
+                       int32_t *states, int32_t *z, int32_t *transitions);
+
+/* EVDMaxLikelyFit (src/extreme_fit.c:157-251) on the device for n doubles; returns 1 / 0. */
+int rc_evd_fit(rc_ctx *ctx, const double *x, int32_t n, double *mu, double *lambda);
+
+/* First n MT19937 outputs for a seed, generated by the device stream kernel (parity hook
+ * for seqgen/twister.c:73-152). */
+int rc_mt_stream(rc_ctx *ctx, uint32_t seed, uint32_t *out, int32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RNACODE_HIP_H */

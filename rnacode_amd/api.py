@@ -1,0 +1,306 @@
+"""Host-side mirror of RNAcode's scoring interface on top of librnacode_hip.so (ctypes).
+
+The reference is compiled C with no Python layer; this module exists so that tests, the
+benchmark and the multi-GPU launcher can drive the C-ABI of include/rnacode_hip.h.  Names
+follow the reference's score.h surface (src/score.h:83-118):
+
+    getModels(block)                       -> rc_batch_models
+    scoreAln(block)                        -> native HSS list      (score.c:1067-1147)
+    getExtremeValuePars(block)             -> (rc, mu, lambda)     (score.c:976-1064)
+    backtrack(block, strand, b, i)         -> states / z / transitions (score.c:558-797)
+
+There is no CPU implementation behind these calls: if the HIP library or a GPU is missing
+they raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .alnio import AlnBlock
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librnacode_hip.so")
+
+RC_OK, RC_ERR_ARG, RC_ERR_DEVICE, RC_ERR_UNSUPPORTED, RC_ERR_SKIP = 0, -1, -2, -3, -4
+
+
+class RcParams(C.Structure):
+    _fields_ = [("Delta", C.c_float), ("Omega", C.c_float), ("omega", C.c_float),
+                ("stopPenalty_0", C.c_float), ("stopPenalty_k", C.c_float), ("blosum", C.c_int32),
+                ("sampleN", C.c_int32), ("cutoff", C.c_float), ("stopEarly", C.c_int32), ("seed_base", C.c_uint32)]
+
+
+class RcBlock(C.Structure):
+    _fields_ = [("n_rows", C.c_int32), ("n_cols", C.c_int32), ("rows", C.POINTER(C.c_char_p)),
+                ("names", C.POINTER(C.c_char_p)), ("ref_start", C.c_int32), ("ref_length", C.c_int32),
+                ("newick", C.c_char_p), ("kappa", C.c_float)]
+
+
+class RcHss(C.Structure):
+    _fields_ = [("start", C.c_int32), ("end", C.c_int32), ("startGenomic", C.c_int32), ("endGenomic", C.c_int32),
+                ("startSite", C.c_int32), ("endSite", C.c_int32), ("strand", C.c_int32), ("frame", C.c_int32),
+                ("score", C.c_float), ("pvalue", C.c_float)]
+
+    def as_dict(self):
+        return dict(strand=chr(self.strand), frame=self.frame, startSite=self.startSite, endSite=self.endSite,
+                    start=self.start, end=self.end, startGenomic=self.startGenomic, endGenomic=self.endGenomic,
+                    score=float(np.float32(self.score)), pvalue=float(np.float32(self.pvalue)))
+
+
+class RcModel(C.Structure):
+    _fields_ = [("scores", C.c_float * 4), ("probs", C.c_float * 4), ("kappa", C.c_float), ("dist", C.c_float),
+                ("freqs", C.c_float * 4)]
+
+    def as_dict(self):
+        return dict(dist=float(self.dist), kappa=float(self.kappa), freqs=list(self.freqs),
+                    scores=list(self.scores), probs=list(self.probs))
+
+
+class RnacodeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"librnacode_hip error {code}: {msg}")
+        self.code = code
+
+
+def build_library(force: bool = False) -> str:
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcdir = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-s", "-C", srcdir, "clean"])
+    subprocess.check_call(["make", "-s", "-j4", "-C", srcdir])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load librnacode_hip.so.  Fails loudly if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RnacodeError(RC_ERR_DEVICE, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        l = C.CDLL(LIB_PATH)
+        l.rc_last_error.restype = C.c_char_p
+        l.rc_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        l.rc_ctx_destroy.argtypes = [C.c_void_p]
+        l.rc_batch_create.argtypes = [C.c_void_p, C.POINTER(RcBlock), C.c_int32, C.POINTER(RcParams), C.POINTER(C.c_void_p)]
+        l.rc_batch_destroy.argtypes = [C.c_void_p]
+        l.rc_batch_run.argtypes = [C.c_void_p]
+        l.rc_batch_bind_maxima.argtypes = [C.c_void_p, C.c_void_p]
+        l.rc_batch_work.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        l.rc_batch_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+        l.rc_batch_status.argtypes = [C.c_void_p, C.c_int32]
+        l.rc_batch_models.argtypes = [C.c_void_p, C.c_int32, C.POINTER(RcModel), C.POINTER(RcModel)]
+        l.rc_batch_maxima.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float)]
+        l.rc_batch_maxima_all.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        l.rc_batch_fit.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        l.rc_batch_hss.argtypes = [C.c_void_p, C.c_int32, C.POINTER(RcHss), C.c_int32]
+        l.rc_batch_clamped.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        l.rc_batch_native_S.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_int32]
+        l.rc_batch_backtrack.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                         C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        l.rc_evd_fit.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        l.rc_mt_stream.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_int32]
+        l.rc_set_stream_cache.argtypes = [C.c_int]
+        l.rc_set_stream_cache.restype = None
+        _lib = l
+    return _lib
+
+
+EXPORTED_SYMBOLS = [
+    "rc_default_params", "rc_last_error", "rc_device_count", "rc_ctx_create", "rc_ctx_destroy", "rc_batch_create",
+    "rc_batch_destroy", "rc_batch_bind_maxima", "rc_batch_run", "rc_set_stream_cache", "rc_batch_work", "rc_batch_timing", "rc_batch_status",
+    "rc_batch_models", "rc_batch_maxima", "rc_batch_maxima_all", "rc_batch_fit", "rc_batch_hss", "rc_batch_clamped",
+    "rc_batch_native_S", "rc_batch_backtrack", "rc_evd_fit", "rc_mt_stream",
+]
+
+
+def _check(code: int) -> int:
+    if code < 0:
+        raise RnacodeError(code, lib().rc_last_error().decode())
+    return code
+
+
+def default_params(**kw) -> RcParams:
+    p = RcParams()
+    lib().rc_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise KeyError(k)
+        setattr(p, k, v)
+    return p
+
+
+class Context:
+    """One per process and GPU (rc_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        _check(lib().rc_ctx_create(device, C.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().rc_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def evd_fit(self, x) -> Tuple[int, float, float]:
+        """EVDMaxLikelyFit (extreme_fit.c:157-251) on the device."""
+        arr = np.ascontiguousarray(x, dtype=np.float64)
+        mu, lam = C.c_double(), C.c_double()
+        rc = _check(lib().rc_evd_fit(self._h, arr.ctypes.data_as(C.POINTER(C.c_double)), len(arr), C.byref(mu), C.byref(lam)))
+        return rc, mu.value, lam.value
+
+    def mt_stream(self, seed: int, n: int) -> np.ndarray:
+        out = np.zeros(n, dtype=np.uint32)
+        _check(lib().rc_mt_stream(self._h, seed, out.ctypes.data_as(C.POINTER(C.c_uint32)), n))
+        return out
+
+
+@dataclass
+class BlockScores:
+    """What RNAcode.c:164-188 has for one block before printing."""
+    status: int
+    hss: List[dict]
+    evd_rc: int = -1
+    mu: float = 0.0
+    lam: float = 0.0
+    maxScores: Optional[np.ndarray] = None
+
+
+class Batch:
+    """Alignment blocks resident in HBM (rc_batch)."""
+
+    def __init__(self, ctx: Context, blocks: Sequence[AlnBlock], params: RcParams):
+        self.ctx = ctx
+        self.params = params
+        self.blocks = list(blocks)
+        n = len(self.blocks)
+        arr = (RcBlock * max(n, 1))()
+        self._keep = []
+        for i, b in enumerate(self.blocks):
+            if b.tree is None or b.kappa is None:
+                raise ValueError(f"block {b.block_id}: tree and kappa are required (sidecar or fitted upstream)")
+            rows = (C.c_char_p * b.n)(*[r.seq.encode() for r in b.rows])
+            names = (C.c_char_p * b.n)(*[r.name.encode() for r in b.rows])
+            tree = b.tree.encode()
+            self._keep.append((rows, names, tree))
+            arr[i] = RcBlock(b.n, b.cols, rows, names, b.rows[0].start, b.rows[0].length, tree, b.kappa)
+        self._h = C.c_void_p()
+        _check(lib().rc_batch_create(ctx._h, arr, n, C.byref(params), C.byref(self._h)))
+        self.n = n
+
+    def close(self):
+        if self._h:
+            lib().rc_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def bind_maxima(self, device_ptr: int):
+        """Write maxima into a caller-owned device buffer (e.g. torch tensor .data_ptr())."""
+        _check(lib().rc_batch_bind_maxima(self._h, C.c_void_p(device_ptr)))
+        return self
+
+    def run(self):
+        _check(lib().rc_batch_run(self._h))
+        return self
+
+    def work(self) -> Tuple[int, int]:
+        a, c = C.c_int64(), C.c_int64()
+        _check(lib().rc_batch_work(self._h, C.byref(a), C.byref(c)))
+        return a.value, c.value
+
+    def timing(self):
+        t = (C.c_float * 5)()
+        nl = (C.c_int32 * 5)()
+        _check(lib().rc_batch_timing(self._h, t, nl))
+        keys = ("total", "mt_stream", "null", "native", "evd_fit")
+        return {k: float(t[i]) for i, k in enumerate(keys)}, {k: int(nl[i]) for i, k in enumerate(keys)}
+
+    def status(self, blk: int) -> int:
+        return lib().rc_batch_status(self._h, blk)
+
+    # ---- score.h-shaped accessors -------------------------------------------------------
+    def getModels(self, blk: int):
+        n = self.blocks[blk].n
+        f, r = (RcModel * n)(), (RcModel * n)()
+        _check(lib().rc_batch_models(self._h, blk, f, r))
+        return [m.as_dict() for m in f], [m.as_dict() for m in r]
+
+    def scoreAln(self, blk: int, cap: int = 4096) -> List[dict]:
+        out = (RcHss * cap)()
+        n = _check(lib().rc_batch_hss(self._h, blk, out, cap))
+        return [out[i].as_dict() for i in range(min(n, cap))]
+
+    def getExtremeValuePars(self, blk: int) -> Tuple[int, float, float]:
+        rc, mu, lam = C.c_int32(), C.c_float(), C.c_float()
+        _check(lib().rc_batch_fit(self._h, blk, C.byref(rc), C.byref(mu), C.byref(lam)))
+        return rc.value, float(mu.value), float(lam.value)
+
+    def maxScores(self, blk: int) -> np.ndarray:
+        out = np.zeros(self.params.sampleN, dtype=np.float32)
+        _check(lib().rc_batch_maxima(self._h, blk, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def maxScores_all(self) -> np.ndarray:
+        out = np.zeros((self.n, self.params.sampleN), dtype=np.float32)
+        if self.n:
+            _check(lib().rc_batch_maxima_all(self._h, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def clamped(self) -> int:
+        c = C.c_int64()
+        _check(lib().rc_batch_clamped(self._h, C.byref(c)))
+        return c.value
+
+    def native_S(self, blk: int, strand: int, frame: int) -> np.ndarray:
+        L = self.blocks[blk].ref_len
+        sites = (L - frame) // 3
+        out = np.zeros(max(sites * sites, 1), dtype=np.float32)
+        got = _check(lib().rc_batch_native_S(self._h, blk, strand, frame, out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
+        return out[: got * got].reshape(got, got)
+
+    def backtrack(self, blk: int, strand: int, b: int, i: int):
+        blkobj = self.blocks[blk]
+        shape = (blkobj.n, blkobj.cols + 1)
+        st, z, tr = (np.zeros(shape, dtype=np.int32) for _ in range(3))
+        ip = C.POINTER(C.c_int32)
+        _check(lib().rc_batch_backtrack(self._h, blk, strand, b, i, st.ctypes.data_as(ip), z.ctypes.data_as(ip), tr.ctypes.data_as(ip)))
+        return st, z, tr
+
+    def results(self, blk: int, with_maxima: bool = False) -> BlockScores:
+        st = self.status(blk)
+        if st != RC_OK:
+            return BlockScores(st, [])
+        rc, mu, lam = self.getExtremeValuePars(blk)
+        return BlockScores(st, self.scoreAln(blk), rc, mu, lam, self.maxScores(blk) if with_maxima else None)
+
+
+def score_blocks(blocks: Sequence[AlnBlock], device: int = 0, **params) -> List[BlockScores]:
+    """Convenience: one context, one batch, everything RNAcode.c:164-188 computes per block."""
+    ctx = Context(device)
+    try:
+        batch = Batch(ctx, blocks, default_params(**params)).run()
+        out = [batch.results(i, with_maxima=True) for i in range(batch.n)]
+        batch.close()
+        return out
+    finally:
+        ctx.close()

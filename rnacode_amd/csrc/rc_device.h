@@ -1,0 +1,55 @@
+// rc_device.h -- data layout shared by the host-side block preparation and the HIP kernels.
+//
+// Everything that is constant for one alignment block (tree, HKY thresholds, gap pattern,
+// expected-score tables) is packed by the host into one byte blob per batch; a DevBlock header
+// per block holds offsets into that blob.  See DESIGN.md "Data layout in HBM".
+#pragma once
+#include <cstdint>
+
+namespace rc {
+
+constexpr int kMaxRows = 32;      // N <= 32 (RC_MAX_ROWS)
+constexpr int kMaxNodes = 2 * kMaxRows;
+constexpr int kWave = 64;         // CDNA wavefront
+constexpr int kLutSize = 64;      // sigma codes are indices into a 64-entry per-(strand,k) table
+
+// One node of the guide tree in Seq-Gen's evolution order (seqgen/evolve.c:400-433: pre-order,
+// branch1, branch2, then branch0 of an unrooted root).  thr[p][j]: integer form of the
+// cumulative transition row for parent state p (see rc_host.cpp, threshold_of): with
+// u = genrand_int32(), child state = base[p] + [u > thr[p][0]] + [u > thr[p][1]] + [u > thr[p][2]];
+// u > thr[p][3] marks a draw past the end of the cumulative vector (clamped to state 3).
+struct NodeRec {
+  uint32_t thr[4][4];
+  uint8_t base[4];
+  uint8_t parent;   // index of the parent node in this order (root: 0)
+  int8_t tiprow;    // alignment row of this tip, -1 for internal nodes
+  uint8_t pad[2];
+};
+static_assert(sizeof(NodeRec) == 72, "NodeRec layout");
+
+struct DevBlock {
+  int32_t N, NK, cols, L;
+  int32_t nnodes, status, ref_start, ref_length;
+  float Delta, Omega, omega, nkf;          // nkf = (float)(N-1)
+  float stop0, stopk;
+  int32_t code_zero, code_stop0, code_stopk, pad0;   // sigma-code values of the special cases
+  // offsets (bytes) into the batch blob
+  uint32_t off_nodes;    // NodeRec[nnodes]
+  uint32_t off_qtip;     // u8[N]        node index of row r's tip
+  uint32_t off_refcol;   // u16[2][L+1]  strand s: 0-based column of reference residue i (1..L) in that strand's alignment
+  uint32_t off_zw;       // u64[2][L+1]  2 bits per k (bit 2(k-1)): 0 -> z=0, 1 -> z=+1, 2 -> z=-1
+  uint32_t off_mask;     // u8[2][NK][L+1] 6-bit AND mask zeroing the codon fields where row k has '-'
+  uint32_t off_lut;      // f32[2][NK][64] sigma value per code
+  uint32_t off_chars;    // u8[2][N][cols] native characters (strand 1 = reverse complement, rnaz_utils.c:316)
+  uint32_t off_sigma;    // f32[2][NK][L+1] native sigma (written by k_native_sigma)
+  uint32_t out_index;    // position of this block in the batch (rows of the maxima matrix)
+  uint32_t pad1[3];
+};
+
+// HSS record produced by the native scan kernel
+struct DevHss {
+  int32_t strand, frame, startSite, endSite;
+  float score;
+};
+
+}  // namespace rc

@@ -1,0 +1,72 @@
+// rc_launch.h -- kernel argument blocks and launcher prototypes (rc_kernels.hip <-> rc_api.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "rc_device.h"
+
+namespace rc {
+
+struct NullArgs {
+  const uint8_t *blob;
+  const DevBlock *dblocks;
+  const int *classBlocks;     // batch indices of the blocks of this N-1 class
+  int nClassBlocks;
+  int groups;                 // ceil(sampleN / 64)
+  int sampleN;
+  int Spad;                   // groups * 64: row pitch of U
+  const uint32_t *U;          // MT19937 streams [draw][Spad]
+  const uint8_t *pair;        // [64][64] codon pair -> sigma code
+  uint32_t *scratch;          // per-workgroup sigma-code staging
+  size_t scratchStride;       // uint32 per workgroup
+  float *maxima;              // [n_blocks][sampleN]
+  unsigned long long *clampCount;
+  float tieThr;               // float form of the 0.0001 tie tolerance (score.c:954)
+};
+
+struct NativeArgs {
+  uint8_t *blob;
+  const DevBlock *dblocks;
+  const int *blocks;          // batch indices handled by this launch
+  const uint8_t *pair;
+  float *S;                   // native multiple-score matrices
+  const size_t *offS;         // per batch index: offset (floats) of its 6 * (L/3)^2 matrices
+  DevHss *hss;                // [n_blocks][6][kHssCap]
+  int *hssCount;              // [n_blocks][6]
+  int hssCap;                 // records per (block, strand, frame)
+  float tieThr;
+};
+
+struct FitOut {
+  double mu, lambda;
+  int rc;                     // 1 ok, -1 failed or stopped early (score.c:1041,1061)
+  int better;                 // samples scoring above the best native HSS
+};
+
+struct FitArgs {
+  const DevBlock *dblocks;
+  const int *blocks;
+  const float *maxima;
+  const DevHss *hss;
+  const int *hssCount;
+  int hssCap;
+  FitOut *out;                // [n_blocks]
+  int sampleN;
+  int stopEarly;
+  int stopCutoff;
+};
+
+void launch_mt_stream(uint32_t seedBase, int Spad, int D, uint32_t *U, hipStream_t stream);
+int null_occupancy(int NK);
+bool launch_null(int NK, const NullArgs &a, int grid, hipStream_t stream);
+void launch_native_sigma(const NativeArgs &a, int nblocks, hipStream_t stream);
+bool launch_native_dp(int NK, const NativeArgs &a, int nblocks, hipStream_t stream);
+void launch_native_scan(const NativeArgs &a, int nblocks, hipStream_t stream);
+void launch_sk_row(const uint8_t *blob, const DevBlock *dblocks, int bi, int s, int b, int iMax, float *out, int stride,
+                   hipStream_t stream);
+void launch_evd_fit(const FitArgs &a, int nblocks, hipStream_t stream);
+void launch_evd_fit_f64(const double *x, int n, FitOut *out, hipStream_t stream);
+
+}  // namespace rc

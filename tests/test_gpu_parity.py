@@ -1,0 +1,237 @@
+"""Parity tests proper: the HIP path (through the C-ABI, rnacode_amd.api -> librnacode_hip.so)
+against (1) golden vectors captured from the unmodified reference objects and (2) the CPU
+oracle on the same seeded inputs.  Bars: HSS coordinates / frames / strands bit-exact; scores
+and per-sample maxima exact in binary32; mu, lambda and p-values within 1e-6 relative
+(north_star tolerance; the fit runs in binary64 on the device with a different summation
+order and a different libm than the host)."""
+import numpy as np
+import pytest
+
+from conftest import golden_names, hss_key, load_golden
+from helpers import block_from_golden, param_kwargs
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from rnacode_amd import api
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def api_params(doc):
+    from rnacode_amd import api
+    kw = param_kwargs(doc)
+    return api.default_params(seed_base=doc["seed_base"], **kw)
+
+
+def close(a, b, rel=REL):
+    return abs(a - b) <= rel * max(1.0, abs(b))
+
+
+def run_golden(ctx, doc, max_blocks=None):
+    from rnacode_amd import api
+    entries = doc["blocks"][:max_blocks] if max_blocks else doc["blocks"]
+    blocks = []
+    for e in entries:
+        b = block_from_golden(e)
+        if b.tree is None:  # blocks the reference skipped never got a tree; give the parser something
+            b.tree, b.kappa = "(a:0.1,b:0.1,c:0.1);", 2.0
+        blocks.append(b)
+    batch = api.Batch(ctx, blocks, api_params(doc)).run()
+    return entries, blocks, batch
+
+
+def check_entry(batch, i, entry):
+    from rnacode_amd import api
+    ref = entry["ref"]
+    if "skipped" in ref:
+        assert batch.status(i) == api.RC_ERR_SKIP
+        return
+    assert batch.status(i) == api.RC_OK
+    fwd, rev = batch.getModels(i)
+    for got, want in ((fwd, ref["models"]), (rev, ref["modelsRev"])):
+        for g, w in zip(got, want):
+            assert np.float32(g["dist"]) == np.float32(w["dist"])
+            np.testing.assert_array_equal(np.float32(g["freqs"]), np.float32(w["freqs"]))
+            np.testing.assert_array_equal(np.float32(g["scores"]), np.float32(w["scores"]))
+    got = sorted(batch.scoreAln(i), key=hss_key)
+    want = sorted(ref["hss"], key=hss_key)
+    assert len(got) == len(want)
+    rc, mu, lam = batch.getExtremeValuePars(i)
+    assert rc == ref["evd_rc"]
+    for g, w in zip(got, want):
+        for k in ("strand", "frame", "startSite", "endSite", "start", "end", "startGenomic", "endGenomic"):
+            assert g[k] == w[k], (k, g, w)
+        assert np.float32(g["score"]) == np.float32(w["score"])
+        if rc == 1:
+            assert close(g["pvalue"], w["pvalue"]), (g, w)
+        else:
+            assert g["pvalue"] == 99.0
+    if ref["maxScores"]:
+        np.testing.assert_array_equal(batch.maxScores(i), np.float32(ref["maxScores"]))
+    if rc == 1:
+        assert close(mu, ref["mu"]) and close(lam, ref["lambda"]), (mu, lam, ref["mu"], ref["lambda"])
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_parity(ctx, name):
+    doc = load_golden(name)
+    entries, blocks, batch = run_golden(ctx, doc)
+    assert batch.clamped() == 0
+    for i, e in enumerate(entries):
+        check_entry(batch, i, e)
+    batch.close()
+
+
+def test_mt_stream_matches_twister(ctx):
+    from oracle import binding as ob
+    for seed in (0, 1, 42, 5489, 2**32 - 1):
+        got = ctx.mt_stream(seed, 2000)
+        np.testing.assert_array_equal(got, ob.mt_stream(seed, 2000))
+
+
+def test_native_score_matrix_bit_exact(ctx):
+    """S[b][i] of the native block (score.c:811-848), every cell, against the oracle."""
+    from oracle import binding as ob
+    for name in ("coding_aln_n100", "synth_6x120_n200", "edge_cases_n50", "synth_20x45_n50"):
+        doc = load_golden(name)
+        entries, blocks, batch = run_golden(ctx, doc)
+        p = ob.default_params(doc["samples"], doc.get("params", {}).get("blosum", 62))
+        for i, (e, b) in enumerate(zip(entries, blocks)):
+            if "skipped" in e["ref"]:
+                continue
+            rows = [r.seq for r in b.rows]
+            names = [r.name for r in b.rows]
+            for strand, rr in ((0, rows), (1, ob.rev_aln(rows))):
+                m = ob.get_models(b.tree, rr, names, b.kappa, p.blosum)
+                S = ob.score_matrix(rr, m, p)
+                L = b.ref_len
+                for f in range(3):
+                    got = batch.native_S(i, strand, f)
+                    sites = (L - f) // 3
+                    assert got.shape == (sites, sites)
+                    for a in range(sites):
+                        jj = np.arange(a, sites)
+                        np.testing.assert_array_equal(got[a, a:], S[3 * a + 1 + f, 3 * jj + 3 + f])
+        batch.close()
+
+
+def test_backtrack_matches_reference(ctx):
+    for name in ("coding_aln_n100", "synth_6x120_n200", "edge_cases_n50"):
+        doc = load_golden(name)
+        entries, blocks, batch = run_golden(ctx, doc)
+        for i, e in enumerate(entries):
+            bt = e["ref"].get("backtrack")
+            if not bt:
+                continue
+            top = sorted(e["ref"]["hss"], key=hss_key)[0]
+            st, z, tr = batch.backtrack(i, 0 if top["strand"] == "+" else 1, bt["b"], bt["i"])
+            idx = list(range(bt["i"], bt["b"] + 1, -3))
+            for k in range(1, blocks[i].n):
+                assert list(st[k, idx]) == bt["k"][k - 1]["states"]
+                assert list(z[k, idx]) == bt["k"][k - 1]["z"]
+                assert list(tr[k, idx]) == bt["k"][k - 1]["transitions"]
+        batch.close()
+
+
+def test_evd_fit_device_vs_oracle(ctx):
+    from oracle import binding as ob
+    rng = np.random.RandomState(7)
+    for n, mu, beta in ((100, 6.0, 1.6), (1000, 5.0, 2.0), (37, 8.0, 0.7)):
+        x = np.float32(mu + beta * rng.gumbel(size=n)).astype(np.float64)
+        rc_o, mu_o, lam_o = ob.evd_fit(x)
+        rc_d, mu_d, lam_d = ctx.evd_fit(x)
+        assert rc_o == rc_d == 1
+        assert close(mu_d, mu_o, 1e-9) and close(lam_d, lam_o, 1e-9)
+    # pathological input: the fit must fail the same way (all samples without HSS)
+    x = np.full(50, -1.0)
+    assert ob.evd_fit(x)[0] == ctx.evd_fit(x)[0]
+
+
+def test_errors_and_empty(ctx):
+    from rnacode_amd import api
+    from rnacode_amd.alnio import AlnBlock, AlnRow
+    batch = api.Batch(ctx, [], api.default_params()).run()
+    assert batch.n == 0
+    batch.close()
+    rows = [AlnRow("a", "ATGGCTAAA"), AlnRow("b", "ATGGCAAAA"), AlnRow("c", "ATGGCTAAG")]
+    with pytest.raises(api.RnacodeError) as ei:
+        api.Batch(ctx, [AlnBlock(rows, "x", "(a:0.1,b:0.1,zzz:0.1);", 2.0)], api.default_params())
+    assert ei.value.code == api.RC_ERR_ARG
+    with pytest.raises(api.RnacodeError):
+        api.Batch(ctx, [AlnBlock(rows, "x", "(a:0.1,b:0.1", 2.0)], api.default_params())
+    ragged = [AlnRow("a", "ATGGCTAAA"), AlnRow("b", "ATGGCAAA"), AlnRow("c", "ATGGCTAAG")]
+    with pytest.raises(api.RnacodeError):
+        api.Batch(ctx, [AlnBlock(ragged, "x", "(a:0.1,b:0.1,c:0.1);", 2.0)], api.default_params())
+    with pytest.raises(api.RnacodeError):
+        api.Batch(ctx, [AlnBlock(rows, "x", "(a:0.1,b:0.1,c:0.1);", 2.0)], api.default_params(blosum=45))
+
+
+def test_oracle_parity_on_fresh_seeds(ctx):
+    """Same seeded inputs through HIP path and oracle, on blocks and seeds no golden covers."""
+    from oracle import binding as ob
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_blocks
+    blocks = synth_blocks(3, 7, 90, seed=11) + synth_blocks(2, 3, 33, seed=12) + synth_blocks(1, 9, 150, seed=13)
+    blocks = [b.upper() for b in blocks]
+    n, seed = 130, 1234567  # not a multiple of 64: exercises the ragged last wavefront
+    batch = api.Batch(ctx, blocks, api.default_params(sampleN=n, seed_base=seed)).run()
+    assert batch.clamped() == 0
+    for i, b in enumerate(blocks):
+        rows = [r.seq for r in b.rows]
+        names = [r.name for r in b.rows]
+        res = ob.run_block(rows, names, b.rows[0].start, b.rows[0].length, b.tree, b.kappa, ob.default_params(n), seed)
+        np.testing.assert_array_equal(batch.maxScores(i), np.float32(res.maxScores))
+        got = sorted(batch.scoreAln(i), key=hss_key)
+        want = sorted(res.hss, key=hss_key)
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            for k in ("strand", "frame", "startSite", "endSite", "start", "end", "startGenomic", "endGenomic"):
+                assert g[k] == w[k]
+            assert np.float32(g["score"]) == np.float32(w["score"])
+            assert close(g["pvalue"], w["pvalue"])
+        rc, mu, lam = batch.getExtremeValuePars(i)
+        assert rc == res.evd_rc
+        if rc == 1:
+            assert close(mu, res.mu) and close(lam, res.lam)
+    batch.close()
+
+
+def test_full_size_properties(ctx):
+    """BASELINE config 3 shape at full sample count (6 seqs x 120 cols, n = 1000): properties
+    that need no oracle at this size -- batch-composition invariance, idempotence, sharding
+    invariance of the per-sample maxima (seed = seed_base + sample index), plus an oracle check
+    on a bounded sub-sample."""
+    from oracle import binding as ob
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_blocks
+    blocks = [b.upper() for b in synth_blocks(24, 6, 120, seed=1)]
+    p = api.default_params(sampleN=1000, seed_base=42)
+    big = api.Batch(ctx, blocks, p).run()
+    allmax = big.maxScores_all()
+    assert allmax.shape == (24, 1000)
+    assert np.isfinite(allmax).all() and ((allmax > 0) | (allmax == -1.0)).all()
+    # idempotence
+    big.run()
+    np.testing.assert_array_equal(allmax, big.maxScores_all())
+    # a block scored alone gives the same row
+    solo = api.Batch(ctx, [blocks[5]], p).run()
+    np.testing.assert_array_equal(solo.maxScores(0), allmax[5])
+    solo.close()
+    # sharding by samples: the second half of the samples is seeds seed_base+500.. of a 500-sample run
+    half = api.Batch(ctx, [blocks[7]], api.default_params(sampleN=500, seed_base=42 + 500)).run()
+    np.testing.assert_array_equal(half.maxScores(0), allmax[7, 500:])
+    half.close()
+    # oracle on a bounded sub-sample (first 64 samples of two blocks)
+    for i in (0, 23):
+        b = blocks[i]
+        rows = [r.seq for r in b.rows]
+        names = [r.name for r in b.rows]
+        res = ob.run_block(rows, names, b.rows[0].start, b.rows[0].length, b.tree, b.kappa, ob.default_params(64), 42)
+        np.testing.assert_array_equal(allmax[i, :64], np.float32(res.maxScores))
+    big.close()
