@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- alignment-columns x samples scored per second on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path (MT19937 streams -> native scoring -> null sampling ->
+EVD fit) over one batch of synthetic alignment blocks already resident in HBM.  Workload at
+N=1: BASELINE.json configs[2], the configuration the north_star target is quoted on
+("10k-block MAF stream at num-samples=1000": 10 000 blocks x 120 cols x 6 seqs, n=1000) --
+configs[1] (genomic-preprocessed.maf, 33 scored blocks) is a parity case (tests/), it cannot
+fill one GPU.  With --gpus N every rank scores its own 10 000-block shard (weak scaling, no
+data-path collective) and the per-sample maxima are exchanged by one RCCL all-gather.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+VALU_PEAK_GOPS = 78643.2       # 256 CU x 4 SIMD x 64 lanes / 2 cycles x 2.4 GHz (v_add/v_max wave64 = 2 cyc/SIMD)
+
+
+def cells(L: int) -> int:
+    """#{(b,i): 1<=b, i=b+2+3t<=L}."""
+    return sum(m // 3 + 1 for m in range(0, L - 2))
+
+
+def algorithmic_work(blocks, sampleN):
+    """Per launch of the null kernel: bytes B = N*cols + 4 and flops F = 2*cells(L)*(6(N-1)+5)
+    per sample-alignment, summed over the batch."""
+    by = fl = 0
+    for b in blocks:
+        by += (b.n * b.cols + 4) * sampleN
+        fl += 2 * cells(b.ref_len) * (6 * (b.n - 1) + 5) * sampleN
+    return by, fl
+
+
+def cpu_baseline(blocks, sampleN, seed, target_s=12.0):
+    """The unmodified reference objects (oracle/_ref/ref_harness, kind "reference") on a bounded
+    sample of the same workload, single thread (the reference has no threading).  Falls back to
+    the oracle restatement (kind "port") only if the harness binary did not travel."""
+    harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    from rnacode_amd.alnio import write_harness_blocks
+    nblk = max(1, min(len(blocks), int(target_s / 0.55)))   # ~0.54 s per 6x120 block at n=1000
+    sub = blocks[:nblk]
+    units = sum(b.cols for b in sub) * sampleN
+    if os.path.exists(harness):
+        with tempfile.NamedTemporaryFile("w", suffix=".blk", delete=False) as fh:
+            path = fh.name
+        try:
+            write_harness_blocks(sub, path)
+            t0 = time.perf_counter()
+            subprocess.check_output([harness, path, "--samples", str(sampleN), "--seed", str(seed), "--no-backtrack"])
+            dt = time.perf_counter() - t0
+        finally:
+            os.unlink(path)
+        kind = "reference"
+    else:
+        from oracle import binding as ob
+        t0 = time.perf_counter()
+        for b in sub:
+            ob.run_block([r.seq for r in b.rows], [r.name for r in b.rows], b.rows[0].start, b.rows[0].length,
+                         b.tree, b.kappa, ob.default_params(sampleN), seed)
+        dt = time.perf_counter() - t0
+        kind = "port"
+    return dict(value=units / dt, unit="alignment-columns*samples/s", cores=1, kind=kind,
+                sample=f"first {nblk} blocks of the workload at n={sampleN} (tree+kappa given), {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--blocks", type=int, default=10000)
+    ap.add_argument("--cols", type=int, default=120)
+    ap.add_argument("--seqs", type=int, default=6)
+    ap.add_argument("--samples", type=int, default=1000)
+    ap.add_argument("--seed-base", type=int, default=42)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_blocks
+
+    # this rank's shard: generator seed 1 + rank (generator seed 1)
+    t0 = time.perf_counter()
+    blocks = [b.upper() for b in synth_blocks(args.blocks, args.seqs, args.cols, seed=1 + rank)]
+    t_gen = time.perf_counter() - t0
+
+    ctx = api.Context(local_rank)
+    api.lib().rc_set_stream_cache(0)   # the MT19937 streams are part of every step
+    params = api.default_params(sampleN=args.samples, seed_base=args.seed_base)
+    t0 = time.perf_counter()
+    batch = api.Batch(ctx, blocks, params)   # host prep (getModels etc.) + upload: inputs now resident in HBM
+    t_prep = time.perf_counter() - t0
+
+    gathered = None
+    if world > 1:
+        mine = torch.empty((args.blocks, args.samples), dtype=torch.float32, device=f"cuda:{local_rank}")
+        gathered = torch.empty((world * args.blocks, args.samples), dtype=torch.float32, device=f"cuda:{local_rank}")
+        batch.bind_maxima(mine.data_ptr())
+
+    def step():
+        batch.run()                      # synchronous: kernels done, small results on the host
+        if world > 1:                    # the path's one exchange: all-gather of per-sample maxima (RCCL over xGMI)
+            dist.all_gather_into_tensor(gathered, mine)
+
+    def sync():
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    tk = {"total": 0.0, "mt_stream": 0.0, "null": 0.0, "native": 0.0, "evd_fit": 0.0}
+    nlaunch = {}
+    for _ in range(args.steps):
+        step()
+        t, nl = batch.timing()
+        for k in tk:
+            tk[k] += t[k]
+        nlaunch = nl
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    sa, cs = batch.work()
+    total_units = cs * world * args.steps
+    value = total_units / elapsed
+    out = None
+    if rank == 0:
+        by, fl = algorithmic_work(blocks, args.samples)
+        null_ms = tk["null"] / args.steps / max(1, nlaunch.get("null", 1))   # average duration of one k_null launch
+        ach = by / (null_ms * 1e-3) / 1e9
+        out = {
+            "metric": "alignment-columns x samples scored /sec",
+            "value": value,
+            "unit": "alignment-columns*samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"synthetic MAF {args.blocks} blocks x {args.cols} cols x {args.seqs} seqs, "
+                                   f"--num-samples {args.samples}, per GPU (BASELINE.json configs[2]/[3])",
+                       "blocks_per_gpu": args.blocks, "cols": args.cols, "seqs": args.seqs, "samples": args.samples,
+                       "seed_base": args.seed_base, "sharding": f"blocks x{world}"},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "k_null<%d>" % (args.seqs - 1), "kernel_ms": null_ms,
+                         "algorithmic_bytes_per_launch": by,
+                         "valu": {"achieved_gops": fl / (null_ms * 1e-3) / 1e9, "peak_gops": VALU_PEAK_GOPS,
+                                  "frac": fl / (null_ms * 1e-3) / 1e9 / VALU_PEAK_GOPS,
+                                  "algorithmic_flops_per_launch": fl}},
+            "device_ms_per_step": {k: v / args.steps for k, v in tk.items()},
+            "host_prep_s": {"generate": t_gen, "models_and_upload": t_prep},
+            "sample_alignments_per_s": sa * world * args.steps / elapsed,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(blocks, args.samples, args.seed_base)
+            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    batch.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
