@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 csv output (kernel stats + PMC passes) into a small text table."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def short(name):
+    name = name.replace("rc::", "")
+    return name.split("(")[0][:60]
+
+
+for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    print("== kernel stats (rocprofv3 --kernel-trace --stats):", os.path.relpath(f, out))
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            print(f"{short(row['Name']):60s} calls={row['Calls']:>6s} total_ns={row['TotalDurationNs']:>14s} "
+                  f"avg_ns={float(row['AverageNs']):14.1f} pct={row['Percentage']}")
+
+for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        agg = defaultdict(lambda: defaultdict(float))
+        cnt = defaultdict(lambda: defaultdict(int))
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                k = short(row["Kernel_Name"])
+                agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
+                cnt[k][row["Counter_Name"]] += 1
+        print("== PMC per dispatch (mean over dispatches):", os.path.relpath(f, out))
+        for k in agg:
+            for c in agg[k]:
+                print(f"{k:60s} {c:24s} mean={agg[k][c] / cnt[k][c]:18.1f} dispatches={cnt[k][c]}")
