@@ -10,6 +10,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -49,7 +50,9 @@ struct rc_ctx {
   size_t scratch_cap = 0;
   unsigned long long *d_clamp = nullptr;
   float tieThr = 0.0f;
-  std::map<int, int> occ;   // N-1 -> resident workgroups per CU of k_null
+  std::map<std::pair<int, size_t>, int> occ;   // (N-1, LDS bytes) -> resident workgroups per CU of k_null
+  size_t ldsMaxBytes = 10240;   // per wavefront: keeps >= 16 wavefronts (4 per SIMD) on a CU
+  int debugSkip = 0;
 };
 
 struct rc_batch {
@@ -126,6 +129,8 @@ int rc_ctx_create(int device, rc_ctx **out) {
   HIP_TRY(hipMemcpy(c->d_pair90, c->pt90.pair, 4096, hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc(&c->d_clamp, sizeof(unsigned long long)));
   c->tieThr = float_threshold_lt(0.0001);
+  if (const char *e = std::getenv("RC_LDS_MAX_BYTES")) c->ldsMaxBytes = static_cast<size_t>(std::atol(e));
+  if (const char *e = std::getenv("RC_DEBUG_SKIP")) c->debugSkip = std::atoi(e);   // profiling only: results are wrong
   *out = c;
   return RC_OK;
 }
@@ -221,6 +226,7 @@ int rc_batch_create(rc_ctx *ctx, const rc_block *blocks, int32_t n_blocks, const
     d.nkf = static_cast<float>(h.N - 1);
     d.stop0 = par->stopPenalty_0; d.stopk = par->stopPenalty_k;
     d.code_zero = pt.code_zero; d.code_stop0 = pt.code_stop0; d.code_stopk = pt.code_stopk;
+    d.exact_div = h.exact_div;
     const int L1 = h.L + 1;
     auto put = [&](const void *p, size_t bytes) {
       size_t off = align16(blob.size());
@@ -252,6 +258,16 @@ int rc_batch_create(rc_ctx *ctx, const rc_block *blocks, int32_t n_blocks, const
         for (int r = 0; r < h.N; r++) std::memcpy(ch.data() + (static_cast<size_t>(s) * h.N + r) * h.cols, h.rows[s][r].data(), h.cols);
       d.off_chars = put(ch.data(), ch.size());
       d.off_sigma = put(nullptr, 2 * static_cast<size_t>(h.NK) * L1 * 4);
+      {
+        const int smax = h.L / 3, zmw = (smax + 63) / 64;
+        std::vector<uint64_t> zm(static_cast<size_t>(6) * zmw, 0);
+        for (int s = 0; s < 2; s++)
+          for (int f = 0; f < 3; f++)
+            for (int j = 0; j < (h.L - f) / 3; j++)
+              if (h.zw[s][3 * j + 3 + f] != 0) zm[static_cast<size_t>(s * 3 + f) * zmw + (j >> 6)] |= 1ull << (j & 63);
+        d.off_zmask = put(zm.data(), zm.size() * 8);
+        d.zm_words = zmw;
+      }
     }
     if (blob.size() > 0xFFFFFFF0ull) { delete b; return fail(RC_ERR_UNSUPPORTED, "batch too large: split it (blob > 4 GiB)"); }
     const size_t smax = h.L / 3;
@@ -372,11 +388,19 @@ int rc_batch_run(rc_batch *b) {
     const int NK = kv.first;
     int maxLc = 0;
     for (int bi : kv.second) maxLc = std::max(maxLc, b->hb[bi].L);
-    const int NCW = (NK + 3) / 4;
+    const int NCW = (NK + 4) / 5;   // 5 six-bit sigma codes per word
     const size_t stride = static_cast<size_t>(2) * (maxLc + 1) * NCW * kWave;
-    if (!c->occ.count(NK)) c->occ[NK] = null_occupancy(NK);
+    // sigma codes of one strand x frame are staged in LDS when that still leaves >= 16 wavefronts per
+    // CU (RC_LDS_MAX_BYTES overrides the per-wavefront budget); otherwise they are read from the
+    // per-workgroup scratch in global memory.
+    size_t ldsBytes = static_cast<size_t>(maxLc / 3) * NCW * kWave * sizeof(uint32_t);
+    if (ldsBytes > c->ldsMaxBytes) ldsBytes = 0;
+    const std::pair<int, size_t> key(NK, ldsBytes);
+    if (!c->occ.count(key)) c->occ[key] = null_occupancy(NK, ldsBytes);
+    if (c->occ[key] <= 0 && ldsBytes) { ldsBytes = 0; const std::pair<int, size_t> k2(NK, 0); if (!c->occ.count(k2)) c->occ[k2] = null_occupancy(NK, 0); }
+    const int occ = std::max(1, c->occ[std::pair<int, size_t>(NK, ldsBytes)]);
     const int items = static_cast<int>(kv.second.size()) * groups;
-    int grid = std::min(items, c->numCU * std::max(1, c->occ[NK]));
+    int grid = std::min(items, c->numCU * occ);
     const size_t need = stride * grid;
     if (need > c->scratch_cap) {
       HIP_TRY(hipStreamSynchronize(c->stream));
@@ -389,8 +413,8 @@ int rc_batch_run(rc_batch *b) {
     a.blob = b->d_blob; a.dblocks = b->d_dblocks; a.classBlocks = b->d_classBlocks[NK];
     a.nClassBlocks = static_cast<int>(kv.second.size()); a.groups = groups; a.sampleN = sampleN; a.Spad = Spad;
     a.U = c->d_U; a.pair = d_pair; a.scratch = c->d_scratch; a.scratchStride = stride;
-    a.maxima = b->d_maxima; a.clampCount = c->d_clamp; a.tieThr = c->tieThr;
-    if (!launch_null(NK, a, grid, c->stream)) return fail(RC_ERR_UNSUPPORTED, "no null kernel for this number of rows");
+    a.maxima = b->d_maxima; a.clampCount = c->d_clamp; a.tieThr = c->tieThr; a.debugSkip = c->debugSkip;
+    if (!launch_null(NK, a, grid, ldsBytes, c->stream)) return fail(RC_ERR_UNSUPPORTED, "no null kernel for this number of rows");
     b->nl[2]++;
   }
   HIP_TRY(hipEventRecord(ev[4], c->stream));

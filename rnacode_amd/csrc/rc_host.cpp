@@ -272,17 +272,19 @@ int64_t threshold_of(double P) {
   return lo;
 }
 
-void pack_thresholds(const double cum[4], uint32_t thr[4], uint8_t *base) {
+void pack_thresholds(const double cum[4], U4 *out, uint32_t *base) {
+  uint32_t thr[4];
   int64_t T[4];
   for (int j = 0; j < 4; j++) T[j] = threshold_of(cum[j]);
   for (int j = 1; j < 4; j++) T[j] = std::max(T[j], T[j - 1]);   // "first j with r <= P[j]" needs only the running max
   int b = 0;
   while (b < 3 && T[b] < 0) b++;
-  *base = static_cast<uint8_t>(b);
+  *base = static_cast<uint32_t>(b);
   int m = 0;
   for (int j = b; j < 3; j++) thr[m++] = static_cast<uint32_t>(T[j]);
   for (; m < 3; m++) thr[m] = 0xFFFFFFFFu;
   thr[3] = T[3] < 0 ? 0u : static_cast<uint32_t>(T[3]);
+  out->x = thr[0]; out->y = thr[1]; out->z = thr[2]; out->w = thr[3];
 }
 }  // namespace
 
@@ -346,6 +348,15 @@ static void gap_tables(const std::vector<std::string> &rows, int L, std::vector<
 }
 
 // ---------------------------------------------------------------------------------- block
+
+// Every DP value is a float sum of table entries and gap parameters.  If each of them is 0 or
+// has 2^-14 <= |v| < 2^20 it is a multiple of 2^-37, so is every partial sum, hence any non-zero
+// sum has |x| >= 2^-37; with at most 2^16 terms |x| < 2^40.  That is the range in which the
+// kernel's 3-instruction division by N-1 was proven exact (tools/verify_const_div.c).
+static bool in_div_range(float v) {
+  const float a = std::fabs(v);
+  return a == 0.0f || (a >= 6.103515625e-05f && a < 1048576.0f);
+}
 
 int prepare_block(const rc_block &in, const rc_params &par, const CodeTables &ct, const PairTable &pt,
                   HostBlock &hb, std::string &err) {
@@ -416,6 +427,7 @@ int prepare_block(const rc_block &in, const rc_params &par, const CodeTables &ct
       lut[pt.code_zero] = 0.0f;
       lut[pt.code_stop0] = par.stopPenalty_0;
       lut[pt.code_stopk] = par.stopPenalty_k;
+      for (int code = 0; code <= pt.code_stopk; code++) if (!in_div_range(lut[code])) hb.exact_div = 1;
     }
   }
 
@@ -427,14 +439,15 @@ int prepare_block(const rc_block &in, const rc_params &par, const CodeTables &ct
     std::memset(&nr, 0, sizeof nr);
     nr.parent = static_cast<uint8_t>(t.parent[q]);
     nr.tiprow = -1;
-    if (q == 0) {
-      for (int p = 0; p < 4; p++) pack_thresholds(hky.addFreq, nr.thr[p], &nr.base[p]);
-    } else {
-      double M[4][4];
-      hky.cumulative(t.length[q], M);                                // evolve.c:404 (scale 1.0), :292
-      for (int p = 0; p < 4; p++) pack_thresholds(M[p], nr.thr[p], &nr.base[p]);
+    double M[4][4];
+    if (q != 0) hky.cumulative(t.length[q], M);                      // evolve.c:404 (scale 1.0), :292
+    for (int p = 0; p < 4; p++) {
+      uint32_t base = 0;
+      pack_thresholds(q == 0 ? hky.addFreq : M[p], &nr.thr[p], &base);
+      nr.basepack |= base << (2 * p);
     }
   }
+  if (!in_div_range(par.Delta) || !in_div_range(par.Omega) || !in_div_range(par.omega)) hb.exact_div = 1;
   hb.qtip.assign(N, 0);
   for (int r = 0; r < N; r++) {
     const int q = t.tipnode[rowtip[r]];

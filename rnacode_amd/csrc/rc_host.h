@@ -37,6 +37,7 @@ struct HostBlock {
   int status = RC_OK;
   int N = 0, NK = 0, cols = 0, L = 0;
   int ref_start = 0, ref_length = 0;
+  int exact_div = 0;                      // see rc_host.cpp in_div_range
   std::vector<std::string> rows[2];       // upper-cased forward rows, reverse-complement rows
   std::vector<rc_model> models[2];        // getModels for both strands
   std::vector<uint16_t> refcol[2];        // [L+1]

@@ -15,6 +15,9 @@
 // order; compile with -ffp-contract=off; float division is hipcc's correctly rounded default.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "rc_device.h"
 #include "rc_launch.h"
 
@@ -115,112 +118,279 @@ __device__ __forceinline__ void scan_step(ScanState &st, float v, int a, int j, 
 __device__ __forceinline__ uint32_t codon_flip(uint32_t c) { return ((c & 3u) << 4) | (c & 12u) | ((c >> 4) & 3u); }
 
 // ------------------------------------------------------------------------------------------
-// k_null<NK>: the null-distribution loop body, lane = sample
+// k_null<NK, LDSC>: the null-distribution loop body, lane = sample
 // ------------------------------------------------------------------------------------------
-template <int NK>
-__global__ __launch_bounds__(64) void k_null(NullArgs A) {
+
+// Per-sequence registers as distinct scalar members (not an array): keeps every chain in its own
+// VGPR across the wave-uniform z branches instead of a register tuple that is copied at each join.
+template <int K> struct KReg { float s0, s1, s2; int lut; };
+template <typename Seq> struct KRegs;
+template <int... K> struct KRegs<std::integer_sequence<int, K...>> : KReg<K>... {
+  template <int I> __device__ __forceinline__ KReg<I> &at() { return static_cast<KReg<I> &>(*this); }
+};
+template <int NK, typename F, int... K>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, K...>) {
+  (f(std::integral_constant<int, K>{}), ...);
+}
+template <int NK, typename F> __device__ __forceinline__ void static_for(F &&f) {
+  static_for_impl<NK>(static_cast<F &&>(f), std::make_integer_sequence<int, NK>{});
+}
+
+// x / NK, correctly rounded.  Power of two: exact scaling.  Otherwise Markstein's two-FMA
+// correction of x * RN(1/NK), proven equal to IEEE division for every NK in 2..31 and every
+// |x| in {0} U [2^-40, 2^40) by exhaustion (tools/verify_const_div.c).  Blocks whose score
+// tables could leave that range are flagged by the host (DevBlock::exact_div) and use '/'.
+template <int NK> __device__ __forceinline__ float div_by_nk(float x, float nkf, bool exact_div) {
+  if constexpr ((NK & (NK - 1)) == 0) {
+    return x * (1.0f / static_cast<float>(NK));
+  } else {
+    if (exact_div) return x / nkf;
+    constexpr float y = 1.0f / static_cast<float>(NK);
+    const float q0 = x * y;
+    const float r = __builtin_fmaf(-static_cast<float>(NK), q0, x);
+    return __builtin_fmaf(r, y, q0);
+  }
+}
+
+// getHSS's state machine as the null samples need it: only the best emitted score matters, so the
+// segment start is carried as len = segmentEnd - segmentStart (score.c:892-959).
+// key = segmentEnd << 16 | (segmentEnd - segmentStart); codon sites < 32767.  Before the first
+// segment of a frame segmentEnd holds the sentinel 0x7FFF, which makes "currMax > 0 && segmentEnd < i"
+// (score.c:900) equivalent to key < (i << 16): currMax is positive exactly when a segment was opened.
+struct SampleScan { float cm; uint32_t key; };
+constexpr uint32_t kScanInitKey = 0x7FFFu << 16;
+// every entry except the frame's final one
+__device__ __forceinline__ void sample_scan_step(SampleScan &st, float &best, float v, uint32_t a, uint32_t span, uint32_t newkey,
+                                                 float tieThr) {
+  const uint32_t len = st.key & 0xFFFFu;
+  const bool pos = v > 0.0f;
+  const bool fresh = st.key < (a << 16);
+  const bool rep = (v > st.cm) | ((fabsf(v - st.cm) < tieThr) & (len <= span));   // (j-i) >= (segEnd-segStart), score.c:953-954
+  const bool emit = pos & fresh & (len >= 2u);                                    // minSegmentLength, score.c:902
+  best = (emit & (st.cm > best)) ? st.cm : best;
+  const bool upd = pos & (fresh | rep);
+  st.cm = upd ? v : st.cm;
+  st.key = upd ? newkey : st.key;
+}
+// the final entry of a frame is entered unconditionally and always reports the open segment
+__device__ __forceinline__ void sample_scan_last(const SampleScan &st, float &best) {
+  best = (((st.key & 0xFFFFu) >= 2u) & (st.cm > best)) ? st.cm : best;
+}
+
+// Read-only inputs are separate __restrict__ kernel parameters (not members of the by-value
+// argument block) so that the compiler may prove them unclobbered and fetch the wave-uniform
+// block tables (z words, tree records, masks) with scalar loads.
+template <int NK, bool LDSC>
+__global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restrict__ blob,
+                                             const DevBlock *__restrict__ dblocks, const int *__restrict__ classBlocks,
+                                             const uint32_t *__restrict__ Ustream, const uint8_t *__restrict__ pairTab,
+                                             uint32_t *__restrict__ scratch, float *__restrict__ maxima) {
   constexpr int N = NK + 1;
-  constexpr int NCW = (NK + 3) / 4;
-  __shared__ uint8_t ns[kMaxNodes][kWave];  // state of every tree node at the current site, per lane
+  constexpr int CPW = 5;                  // 6-bit sigma codes per 32-bit word
+  constexpr int NCW = (NK + CPW - 1) / CPW;
+  using Regs = KRegs<std::make_integer_sequence<int, NK>>;
+  extern __shared__ uint32_t lds_codes[];  // LDSC: [site][NCW][64] sigma codes of the current strand x frame
 
   const int lane = threadIdx.x;
-  uint32_t *__restrict__ cod = A.scratch + static_cast<size_t>(blockIdx.x) * A.scratchStride;
+  uint32_t *__restrict__ cod = scratch + static_cast<size_t>(blockIdx.x) * A.scratchStride;
   const int nItems = A.nClassBlocks * A.groups;
 
   for (int item = blockIdx.x; item < nItems; item += gridDim.x) {
-    const int bi = A.classBlocks[item / A.groups];
+    const int bi = classBlocks[item / A.groups];
     const int grp = item % A.groups;
-    const DevBlock *__restrict__ db = A.dblocks + bi;
+    const DevBlock *__restrict__ db = dblocks + bi;
     const int cols = db->cols, L = db->L, nnodes = db->nnodes;
     const float Delta = db->Delta, Omega = db->Omega, omega = db->omega, nkf = db->nkf;
-    const uint8_t *__restrict__ blob = A.blob;
+    const bool exact_div = db->exact_div != 0;
     const NodeRec *__restrict__ nodes = reinterpret_cast<const NodeRec *>(blob + db->off_nodes);
     const uint8_t *__restrict__ qtip = blob + db->off_qtip;
     const uint16_t *__restrict__ refcol = reinterpret_cast<const uint16_t *>(blob + db->off_refcol);
     const unsigned long long *__restrict__ zw = reinterpret_cast<const unsigned long long *>(blob + db->off_zw);
+    const unsigned long long *__restrict__ zmask = reinterpret_cast<const unsigned long long *>(blob + db->off_zmask);
+    const int zmWords = db->zm_words;
     const uint8_t *__restrict__ mask = blob + db->off_mask;
     const float *__restrict__ lut = reinterpret_cast<const float *>(blob + db->off_lut);
     const int sidx = grp * kWave + lane;
     const int L1 = L + 1;
 
-    // ---- phase A: simulate the L reference-residue columns, emit sigma codes for both strands
-    uint32_t win[N];
+    // ---- phase A: simulate the L reference-residue columns (evolve.c:416-433 for one site at a
+    // time), emit sigma codes for both strands.  Node states of the current site live in two
+    // 64-bit registers, 2 bits per node (nnodes <= 64).
+    if (!(A.debugSkip & 2)) {
+      uint32_t win[N];
 #pragma unroll
-    for (int r = 0; r < N; r++) win[r] = 0;
-    unsigned int clamped = 0;
-    for (int i = 1; i <= L; i++) {
-      const int c = refcol[i];
-      for (int q = 0; q < nnodes; q++) {
-        const NodeRec *nr = nodes + q;
-        const uint32_t u = A.U[(static_cast<size_t>(q) * cols + c) * A.Spad + sidx];
-        const int ps = (q == 0) ? 0 : ns[nr->parent][lane];
-        const uint4 t = *reinterpret_cast<const uint4 *>(&nr->thr[ps][0]);
-        const int st = nr->base[ps] + (u > t.x) + (u > t.y) + (u > t.z);
-        clamped += (u > t.w);
-        ns[q][lane] = static_cast<uint8_t>(st);
-      }
+      for (int r = 0; r < N; r++) win[r] = 0;
+      unsigned int clamped = 0;
+      for (int i = 1; i <= L; i++) {
+        const int c = refcol[i];
+        unsigned long long nsLo = 0, nsHi = 0;
+        for (int q = 0; q < nnodes; q++) {
+          const NodeRec *nr = nodes + q;
+          const uint32_t u = Ustream[(static_cast<size_t>(q) * cols + c) * A.Spad + sidx];
+          const int pq = nr->parent;
+          const uint32_t ps = (q == 0) ? 0u : (pq < 32 ? static_cast<uint32_t>(nsLo >> (2 * pq)) : static_cast<uint32_t>(nsHi >> (2 * (pq - 32)))) & 3u;
+          const U4 t = nr->thr[ps];
+          uint32_t st = (u > t.x) + (u > t.y) + (u > t.z);
+          const uint32_t bp = nr->basepack;
+          if (bp) st += (bp >> (2 * ps)) & 3u;
+          clamped += (u > t.w);
+          if (q < 32) nsLo |= static_cast<unsigned long long>(st) << (2 * q);
+          else nsHi |= static_cast<unsigned long long>(st) << (2 * (q - 32));
+        }
 #pragma unroll
-      for (int r = 0; r < N; r++) win[r] = ((win[r] << 2) | ns[qtip[r]][lane]) & 63u;
-      if (i >= 3) {
-        const int ip = L + 3 - i;  // reverse-strand position whose codon is these three columns
-        const uint32_t aF = win[0];
-        const uint32_t aR = codon_flip(aF) ^ 63u;
+        for (int r = 0; r < N; r++) {
+          const int qt = qtip[r];
+          const uint32_t st = (qt < 32 ? static_cast<uint32_t>(nsLo >> (2 * qt)) : static_cast<uint32_t>(nsHi >> (2 * (qt - 32)))) & 3u;
+          win[r] = ((win[r] << 2) | st) & 63u;
+        }
+        if (i >= 3) {
+          const int ip = L + 3 - i;  // reverse-strand position whose codon is these three columns
+          const uint32_t aF = win[0];
+          const uint32_t aR = codon_flip(aF) ^ 63u;
 #pragma unroll
-        for (int w = 0; w < NCW; w++) {
-          uint32_t wf = 0, wr = 0;
+          for (int w = 0; w < NCW; w++) {
+            uint32_t wf = 0, wr = 0;
 #pragma unroll
-          for (int t = 0; t < 4; t++) {
-            const int k = w * 4 + t;  // 0-based index of sequence k+1
-            if (k < NK) {
-              const uint32_t bF = win[k + 1] & mask[(0 * NK + k) * L1 + i];
-              const uint32_t bR = (codon_flip(win[k + 1]) ^ 63u) & mask[(1 * NK + k) * L1 + ip];
-              wf |= (static_cast<uint32_t>(A.pair[aF * 64 + bF]) << 2) << (8 * t);
-              wr |= (static_cast<uint32_t>(A.pair[aR * 64 + bR]) << 2) << (8 * t);
+            for (int t = 0; t < CPW; t++) {
+              const int k = w * CPW + t;  // 0-based index of sequence k+1
+              if (k < NK) {
+                const uint32_t bF = win[k + 1] & mask[(0 * NK + k) * L1 + i];
+                const uint32_t bR = (codon_flip(win[k + 1]) ^ 63u) & mask[(1 * NK + k) * L1 + ip];
+                wf |= static_cast<uint32_t>(pairTab[aF * 64 + bF]) << (6 * t);
+                wr |= static_cast<uint32_t>(pairTab[aR * 64 + bR]) << (6 * t);
+              }
             }
+            cod[(static_cast<size_t>(0 * L1 + i) * NCW + w) * kWave + lane] = wf;
+            cod[(static_cast<size_t>(1 * L1 + ip) * NCW + w) * kWave + lane] = wr;
           }
-          cod[(static_cast<size_t>(0 * L1 + i) * NCW + w) * kWave + lane] = wf;
-          cod[(static_cast<size_t>(1 * L1 + ip) * NCW + w) * kWave + lane] = wr;
         }
       }
+      if (clamped) atomicAdd(A.clampCount, static_cast<unsigned long long>(clamped));
     }
-    if (clamped) atomicAdd(A.clampCount, static_cast<unsigned long long>(clamped));
 
     // ---- phase B: both strands x 3 frames: DP over (start a, end j) + serial HSS scan
     float best = -1.0f;
+    // omega and Delta as per-lane values: v_add_f32 with two VGPR operands issues at the full rate,
+    // with an SGPR operand at ~60 % of it (tools/microbench.hip)
+    float omega_v, Delta_v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(omega_v) : "s"(omega));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(Delta_v) : "s"(Delta));
+    if (!(A.debugSkip & 1))
     for (int s = 0; s < 2; s++) {
-      int lutreg[NK];  // 64-entry sigma table of sequence k spread over the 64 lanes
-#pragma unroll
-      for (int k = 0; k < NK; k++) lutreg[k] = __float_as_int(lut[(s * NK + k) * kLutSize + lane]);
+      Regs R;
+      static_for<NK>([&](auto kc) {  // 64-entry sigma table of sequence k spread over the 64 lanes
+        constexpr int k = decltype(kc)::value;
+        R.template at<k>().lut = __float_as_int(lut[(s * NK + k) * kLutSize + lane]);
+      });
       for (int f = 0; f < 3; f++) {
         const int sites = (L - f) / 3;
-        ScanState st{0.0f, -1, -1};
+        if (sites <= 0) continue;
+        const uint32_t *__restrict__ cbase = cod + (static_cast<size_t>(s * L1 + 3 + f) * NCW) * kWave + lane;  // site j: + j*3*NCW*64
+        const unsigned long long *__restrict__ zbase = zw + s * L1 + 3 + f;                                       // site j: [3j]
+        const unsigned long long *__restrict__ zany = zmask + static_cast<size_t>(s * 3 + f) * zmWords;            // bit j: some z != 0 at site j
+        if constexpr (LDSC) {
+          for (int idx = 0; idx < sites * NCW; idx++)
+            lds_codes[idx * kWave + lane] = cbase[static_cast<size_t>(idx / NCW) * 3 * NCW * kWave + (idx % NCW) * kWave];
+        }
+        auto load_words = [&](int j, uint32_t (&w)[NCW]) {
+#pragma unroll
+          for (int x = 0; x < NCW; x++) {
+            if constexpr (LDSC) w[x] = lds_codes[(j * NCW + x) * kWave + lane];
+            else w[x] = cbase[(static_cast<size_t>(j) * 3 * NCW + x) * kWave];
+          }
+        };
+        // sigma of every sequence at the site whose code words are w (all table look-ups first: their
+        // LDS round trips overlap).  ds_bpermute uses address bits [7:2] as the source lane.
+        auto lookup = [&](const uint32_t (&w)[NCW], float (&sig)[NK]) {
+          static_for<NK>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            constexpr int t = k % CPW;
+            const uint32_t addr = (t == 0) ? (w[k / CPW] << 2) : (w[k / CPW] >> (6 * t - 2));
+            sig[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(static_cast<int>(addr), R.template at<k>().lut));
+          });
+        };
+        // S[a][j] = MAX3(sum, 0+Delta, 0+Delta)/(N-1) (score.c:841-843).  The reference starts the sum
+        // from 0; 0 + m == m except for the sign of a zero, which nothing observes.
+        auto finish = [&](float sum) -> float {
+          const float top = (sum > Delta_v) ? sum : Delta_v;
+          return div_by_nk<NK>(top, nkf, exact_div);
+        };
+        // codon without a frame shift in any sequence (z == 0 for all k, score.c:506-510): straight-line
+        auto fast_cell = [&](const uint32_t (&w)[NCW]) -> float {
+          float sig[NK];
+          lookup(w, sig);
+          float sum = 0.0f;
+          static_for<NK>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            auto &r = R.template at<k>();
+            r.s0 = r.s0 + sig[k];
+            r.s1 = r.s1 + omega_v;
+            r.s2 = r.s2 + omega_v;
+            const float m = fmaxf(fmaxf(r.s0, r.s1), r.s2);
+            sum = (k == 0) ? m : sum + m;
+          });
+          return finish(sum);
+        };
+        // codon where some sequence has z != 0 (score.c:512-533), wave-uniform branch per sequence
+        auto event_cell = [&](const uint32_t (&w)[NCW], int j) -> float {
+          float sig[NK];
+          lookup(w, sig);
+          const unsigned long long z = zbase[3 * j];
+          float sum = 0.0f;
+          static_for<NK>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            auto &r = R.template at<k>();
+            pair_step(static_cast<int>((z >> (2 * k)) & 3ull), sig[k], Delta, Omega, omega, r.s0, r.s1, r.s2);
+            const float m = fmaxf(fmaxf(r.s0, r.s1), r.s2);
+            sum = (k == 0) ? m : sum + m;
+          });
+          return finish(sum);
+        };
+        // first site >= j (and < end) with an event, or end
+        auto next_event = [&](int j, int end) -> int {
+          while (j < end) {
+            const unsigned long long mword = zany[j >> 6] >> (j & 63);
+            if (mword) { const int e = j + __builtin_ctzll(mword); return e < end ? e : end; }
+            j = (j | 63) + 1;
+          }
+          return end;
+        };
+        SampleScan st{0.0f, kScanInitKey};
         for (int a = 0; a < sites; a++) {
-          float s0[NK], s1[NK], s2[NK];
+          static_for<NK>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            auto &r = R.template at<k>();
+            r.s0 = r.s1 = r.s2 = 0.0f;
+          });
+          uint32_t wcur[NCW];
+          load_words(a, wcur);
+          const int jend = (a == sites - 1) ? sites - 1 : sites;   // the frame's final entry is handled below
+          int j = a;
+          while (j < jend) {
+            const int e = next_event(j, jend);
+            for (; j < e; j++) {                                   // tight loop: no events
+              uint32_t wnext[NCW];
+              load_words(j + 1 < sites ? j + 1 : j, wnext);
+              const float v = fast_cell(wcur);
+              sample_scan_step(st, best, v, static_cast<uint32_t>(a), static_cast<uint32_t>(j - a), (static_cast<uint32_t>(j) << 16) | static_cast<uint32_t>(j - a), A.tieThr);
 #pragma unroll
-          for (int k = 0; k < NK; k++) s0[k] = s1[k] = s2[k] = 0.0f;
-          for (int j = a; j < sites; j++) {
-            const int i = 3 * j + 3 + f;
-            const unsigned long long z = zw[s * L1 + i];
-            uint32_t words[NCW];
-#pragma unroll
-            for (int w = 0; w < NCW; w++) words[w] = cod[(static_cast<size_t>(s * L1 + i) * NCW + w) * kWave + lane];
-            float sum = 0.0f;
-#pragma unroll
-            for (int k = 0; k < NK; k++) {
-              const int addr = (words[k >> 2] >> (8 * (k & 3))) & 0xFF;
-              const float sig = __int_as_float(__builtin_amdgcn_ds_bpermute(addr, lutreg[k]));
-              const int zc = static_cast<int>((z >> (2 * k)) & 3ull);
-              pair_step(zc, sig, Delta, Omega, omega, s0[k], s1[k], s2[k]);
-              sum = sum + fmaxf(fmaxf(s0[k], s1[k]), s2[k]);
+              for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
             }
-            const float v = fmaxf(sum, Delta) / nkf;  // S[b][i] = MAX3(sum, 0+Delta, 0+Delta)/(N-1), score.c:841-843
-            const bool last = (a == sites - 1) && (j == sites - 1);
-            scan_step(st, v, a, j, last, A.tieThr, [&](const ScanState &e) { best = fmaxf(best, e.cm); });
+            if (j < jend) {
+              uint32_t wnext[NCW];
+              load_words(j + 1 < sites ? j + 1 : j, wnext);
+              const float v = event_cell(wcur, j);
+              sample_scan_step(st, best, v, static_cast<uint32_t>(a), static_cast<uint32_t>(j - a), (static_cast<uint32_t>(j) << 16) | static_cast<uint32_t>(j - a), A.tieThr);
+#pragma unroll
+              for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
+              j++;
+            }
           }
         }
+        sample_scan_last(st, best);   // entry (sites-1, sites-1): its own value can never be reported
       }
     }
-    if (sidx < A.sampleN) A.maxima[static_cast<size_t>(db->out_index) * A.sampleN + sidx] = best;
+    if (sidx < A.sampleN) maxima[static_cast<size_t>(db->out_index) * A.sampleN + sidx] = best;
   }
 }
 
@@ -516,28 +686,42 @@ void launch_mt_stream(uint32_t seedBase, int Spad, int D, uint32_t *U, hipStream
 }
 
 template <int NK>
-static int null_occupancy_t() {
+static int null_occupancy_t(size_t ldsBytes) {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_null<NK>, 64, 0) != hipSuccess) return 8;
-  return nb > 0 ? nb : 1;
+  hipError_t e = ldsBytes ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_null<NK, true>, 64, ldsBytes)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_null<NK, false>, 64, 0);
+  if (e != hipSuccess) return 0;
+  return nb;
 }
 
 #define RC_FOR_NK(X) \
   X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) \
   X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31)
 
-int null_occupancy(int NK) {
+int null_occupancy(int NK, size_t ldsBytes) {
   switch (NK) {
-#define X(n) case n: return null_occupancy_t<n>();
+#define X(n) case n: return null_occupancy_t<n>(ldsBytes);
     RC_FOR_NK(X)
 #undef X
     default: return 0;
   }
 }
 
-bool launch_null(int NK, const NullArgs &a, int grid, hipStream_t stream) {
+bool launch_null(int NK, const NullArgs &a, int grid, size_t ldsBytes, hipStream_t stream) {
   switch (NK) {
-#define X(n) case n: hipLaunchKernelGGL(k_null<n>, dim3(grid), dim3(64), 0, stream, a); return true;
+#define X(n)                                                                                         \
+  case n:                                                                                            \
+    if (ldsBytes) {                                                                                  \
+      if (ldsBytes > 48 * 1024)                                                                      \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_null<n, true>),                   \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsBytes)); \
+      hipLaunchKernelGGL((k_null<n, true>), dim3(grid), dim3(64), ldsBytes, stream, a, a.blob, a.dblocks, a.classBlocks, \
+                         a.U, a.pair, a.scratch, a.maxima);              \
+    } else {                                                                                         \
+      hipLaunchKernelGGL((k_null<n, false>), dim3(grid), dim3(64), 0, stream, a, a.blob, a.dblocks, a.classBlocks, \
+                         a.U, a.pair, a.scratch, a.maxima);                    \
+    }                                                                                                \
+    return true;
     RC_FOR_NK(X)
 #undef X
     default: return false;

@@ -24,6 +24,7 @@ struct NullArgs {
   float *maxima;              // [n_blocks][sampleN]
   unsigned long long *clampCount;
   float tieThr;               // float form of the 0.0001 tie tolerance (score.c:954)
+  int debugSkip;              // profiling only (RC_DEBUG_SKIP): bit0 skip the DP/scan phase, bit1 skip simulation
 };
 
 struct NativeArgs {
@@ -59,8 +60,8 @@ struct FitArgs {
 };
 
 void launch_mt_stream(uint32_t seedBase, int Spad, int D, uint32_t *U, hipStream_t stream);
-int null_occupancy(int NK);
-bool launch_null(int NK, const NullArgs &a, int grid, hipStream_t stream);
+int null_occupancy(int NK, size_t ldsBytes);   // resident workgroups per CU (0 = cannot launch)
+bool launch_null(int NK, const NullArgs &a, int grid, size_t ldsBytes, hipStream_t stream);
 void launch_native_sigma(const NativeArgs &a, int nblocks, hipStream_t stream);
 bool launch_native_dp(int NK, const NativeArgs &a, int nblocks, hipStream_t stream);
 void launch_native_scan(const NativeArgs &a, int nblocks, hipStream_t stream);
