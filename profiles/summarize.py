@@ -36,3 +36,25 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
         for k in agg:
             for c in agg[k]:
                 print(f"{k:60s} {c:24s} mean={agg[k][c] / cnt[k][c]:18.1f} dispatches={cnt[k][c]}")
+
+# machine-readable per-dispatch means for bench.py's roofline.traffic (k_null only)
+import json
+res = {}
+for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        agg = defaultdict(float); cnt = defaultdict(int)
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if "k_null" in row["Kernel_Name"]:
+                    agg[row["Counter_Name"]] += float(row["Counter_Value"]); cnt[row["Counter_Name"]] += 1
+        for c in agg:
+            res[c] = agg[c] / cnt[c]
+for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            if "k_null" in row["Name"]:
+                res["kernel_avg_ns"] = float(row["AverageNs"]); res["kernel_calls"] = int(row["Calls"])
+with open(os.path.join(out, "k_null_pmc.json"), "w") as fh:
+    json.dump(res, fh, indent=1, sort_keys=True)

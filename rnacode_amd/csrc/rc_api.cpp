@@ -394,7 +394,10 @@ int rc_batch_run(rc_batch *b) {
     // CU (RC_LDS_MAX_BYTES overrides the per-wavefront budget); otherwise they are read from the
     // per-workgroup scratch in global memory.
     size_t ldsBytes = static_cast<size_t>(maxLc / 3) * NCW * kWave * sizeof(uint32_t);
-    if (ldsBytes > c->ldsMaxBytes) ldsBytes = 0;
+    bool exact = false;
+    for (int bi : kv.second) exact = exact || b->hb[bi].exact_div;
+    if (ldsBytes > c->ldsMaxBytes || exact) ldsBytes = 0;
+    else ldsBytes = std::max<size_t>(ldsBytes, kMaxNodes * 64);   // phase A keeps the tree's threshold table there
     const std::pair<int, size_t> key(NK, ldsBytes);
     if (!c->occ.count(key)) c->occ[key] = null_occupancy(NK, ldsBytes);
     if (c->occ[key] <= 0 && ldsBytes) { ldsBytes = 0; const std::pair<int, size_t> k2(NK, 0); if (!c->occ.count(k2)) c->occ[k2] = null_occupancy(NK, 0); }
@@ -414,7 +417,7 @@ int rc_batch_run(rc_batch *b) {
     a.nClassBlocks = static_cast<int>(kv.second.size()); a.groups = groups; a.sampleN = sampleN; a.Spad = Spad;
     a.U = c->d_U; a.pair = d_pair; a.scratch = c->d_scratch; a.scratchStride = stride;
     a.maxima = b->d_maxima; a.clampCount = c->d_clamp; a.tieThr = c->tieThr; a.debugSkip = c->debugSkip;
-    if (!launch_null(NK, a, grid, ldsBytes, c->stream)) return fail(RC_ERR_UNSUPPORTED, "no null kernel for this number of rows");
+    if (!launch_null(NK, a, grid, ldsBytes, exact, c->stream)) return fail(RC_ERR_UNSUPPORTED, "no null kernel for this number of rows");
     b->nl[2]++;
   }
   HIP_TRY(hipEventRecord(ev[4], c->stream));

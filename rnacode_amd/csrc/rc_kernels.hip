@@ -139,12 +139,14 @@ template <int NK, typename F> __device__ __forceinline__ void static_for(F &&f) 
 // x / NK, correctly rounded.  Power of two: exact scaling.  Otherwise Markstein's two-FMA
 // correction of x * RN(1/NK), proven equal to IEEE division for every NK in 2..31 and every
 // |x| in {0} U [2^-40, 2^40) by exhaustion (tools/verify_const_div.c).  Blocks whose score
-// tables could leave that range are flagged by the host (DevBlock::exact_div) and use '/'.
-template <int NK> __device__ __forceinline__ float div_by_nk(float x, float nkf, bool exact_div) {
+// tables could leave that range are flagged by the host (DevBlock::exact_div) and are scored by
+// the EXACT instantiation, which uses '/'.
+template <int NK, bool EXACT> __device__ __forceinline__ float div_by_nk(float x, float nkf) {
   if constexpr ((NK & (NK - 1)) == 0) {
     return x * (1.0f / static_cast<float>(NK));
+  } else if constexpr (EXACT) {
+    return x / nkf;
   } else {
-    if (exact_div) return x / nkf;
     constexpr float y = 1.0f / static_cast<float>(NK);
     const float q0 = x * y;
     const float r = __builtin_fmaf(-static_cast<float>(NK), q0, x);
@@ -180,7 +182,7 @@ __device__ __forceinline__ void sample_scan_last(const SampleScan &st, float &be
 // Read-only inputs are separate __restrict__ kernel parameters (not members of the by-value
 // argument block) so that the compiler may prove them unclobbered and fetch the wave-uniform
 // block tables (z words, tree records, masks) with scalar loads.
-template <int NK, bool LDSC>
+template <int NK, bool LDSC, bool EXACT>
 __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restrict__ blob,
                                              const DevBlock *__restrict__ dblocks, const int *__restrict__ classBlocks,
                                              const uint32_t *__restrict__ Ustream, const uint8_t *__restrict__ pairTab,
@@ -189,7 +191,9 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
   constexpr int CPW = 5;                  // 6-bit sigma codes per 32-bit word
   constexpr int NCW = (NK + CPW - 1) / CPW;
   using Regs = KRegs<std::make_integer_sequence<int, NK>>;
-  extern __shared__ uint32_t lds_codes[];  // LDSC: [site][NCW][64] sigma codes of the current strand x frame
+  // phase A: threshold table of the tree (nnodes x 64 B); phase B with LDSC: [site][NCW][64] sigma codes
+  // of the current strand x frame
+  extern __shared__ uint32_t lds_codes[];
 
   const int lane = threadIdx.x;
   uint32_t *__restrict__ cod = scratch + static_cast<size_t>(blockIdx.x) * A.scratchStride;
@@ -201,7 +205,6 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
     const DevBlock *__restrict__ db = dblocks + bi;
     const int cols = db->cols, L = db->L, nnodes = db->nnodes;
     const float Delta = db->Delta, Omega = db->Omega, omega = db->omega, nkf = db->nkf;
-    const bool exact_div = db->exact_div != 0;
     const NodeRec *__restrict__ nodes = reinterpret_cast<const NodeRec *>(blob + db->off_nodes);
     const uint8_t *__restrict__ qtip = blob + db->off_qtip;
     const uint16_t *__restrict__ refcol = reinterpret_cast<const uint16_t *>(blob + db->off_refcol);
@@ -213,55 +216,84 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
     const int sidx = grp * kWave + lane;
     const int L1 = L + 1;
 
-    // ---- phase A: simulate the L reference-residue columns (evolve.c:416-433 for one site at a
-    // time), emit sigma codes for both strands.  Node states of the current site live in two
-    // 64-bit registers, 2 bits per node (nnodes <= 64).
+    // ---- phase A: simulate the L reference-residue columns (evolve.c:416-433), SPI sites per pass
+    // so that the stream loads and threshold look-ups of independent sites overlap; emit sigma
+    // codes for both strands.  Node states of a site are packed 2 bits per node into NODEW
+    // registers; the per-branch threshold table sits in LDS (the region phase B reuses for codes).
     if (!(A.debugSkip & 2)) {
+      constexpr int SPI = 4;
+      constexpr int NODEW = (2 * N - 1 + 15) / 16;   // 16 nodes per 32-bit word
+      U4 *ldsThr = reinterpret_cast<U4 *>(lds_codes);
+      {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(nodes);
+        for (int idx = lane; idx < nnodes * 16; idx += kWave) lds_codes[idx] = src[(idx >> 4) * (sizeof(NodeRec) / 4) + (idx & 15)];
+      }
       uint32_t win[N];
 #pragma unroll
       for (int r = 0; r < N; r++) win[r] = 0;
       unsigned int clamped = 0;
-      for (int i = 1; i <= L; i++) {
-        const int c = refcol[i];
-        unsigned long long nsLo = 0, nsHi = 0;
+      auto get_state = [&](const uint32_t (&ns)[NODEW], int q) -> uint32_t {   // q is wave-uniform
+        uint32_t word = ns[0];
+#pragma unroll
+        for (int x = 1; x < NODEW; x++) if ((q >> 4) == x) word = ns[x];
+        return (word >> (2 * (q & 15))) & 3u;
+      };
+      for (int i0 = 1; i0 <= L; i0 += SPI) {
+        size_t ubase[SPI];
+        uint32_t ns[SPI][NODEW];
+#pragma unroll
+        for (int t = 0; t < SPI; t++) {
+          const int i = (i0 + t <= L) ? i0 + t : L;     // tail: repeat the last site, results unused
+          ubase[t] = static_cast<size_t>(refcol[i]) * A.Spad + sidx;
+#pragma unroll
+          for (int x = 0; x < NODEW; x++) ns[t][x] = 0;
+        }
+        const size_t qstride = static_cast<size_t>(cols) * A.Spad;
         for (int q = 0; q < nnodes; q++) {
-          const NodeRec *nr = nodes + q;
-          const uint32_t u = Ustream[(static_cast<size_t>(q) * cols + c) * A.Spad + sidx];
-          const int pq = nr->parent;
-          const uint32_t ps = (q == 0) ? 0u : (pq < 32 ? static_cast<uint32_t>(nsLo >> (2 * pq)) : static_cast<uint32_t>(nsHi >> (2 * (pq - 32)))) & 3u;
-          const U4 t = nr->thr[ps];
-          uint32_t st = (u > t.x) + (u > t.y) + (u > t.z);
-          const uint32_t bp = nr->basepack;
-          if (bp) st += (bp >> (2 * ps)) & 3u;
-          clamped += (u > t.w);
-          if (q < 32) nsLo |= static_cast<unsigned long long>(st) << (2 * q);
-          else nsHi |= static_cast<unsigned long long>(st) << (2 * (q - 32));
+          const int pq = nodes[q].parent;
+          const uint32_t bp = nodes[q].basepack;
+          uint32_t u[SPI];
+#pragma unroll
+          for (int t = 0; t < SPI; t++) u[t] = Ustream[ubase[t] + q * qstride];
+#pragma unroll
+          for (int t = 0; t < SPI; t++) {
+            const uint32_t ps = (q == 0) ? 0u : get_state(ns[t], pq);
+            const U4 th = ldsThr[q * 4 + ps];
+            uint32_t st = (u[t] > th.x) + (u[t] > th.y) + (u[t] > th.z);
+            if (bp) st += (bp >> (2 * ps)) & 3u;
+            clamped += (u[t] > th.w);
+            const uint32_t bits = st << (2 * (q & 15));
+#pragma unroll
+            for (int x = 0; x < NODEW; x++) if (NODEW == 1 || (q >> 4) == x) ns[t][x] |= bits;
+          }
         }
 #pragma unroll
-        for (int r = 0; r < N; r++) {
-          const int qt = qtip[r];
-          const uint32_t st = (qt < 32 ? static_cast<uint32_t>(nsLo >> (2 * qt)) : static_cast<uint32_t>(nsHi >> (2 * (qt - 32)))) & 3u;
-          win[r] = ((win[r] << 2) | st) & 63u;
-        }
-        if (i >= 3) {
-          const int ip = L + 3 - i;  // reverse-strand position whose codon is these three columns
-          const uint32_t aF = win[0];
-          const uint32_t aR = codon_flip(aF) ^ 63u;
+        for (int t = 0; t < SPI; t++) {
+          const int i = i0 + t;
+          if (i <= L) {
 #pragma unroll
-          for (int w = 0; w < NCW; w++) {
-            uint32_t wf = 0, wr = 0;
+            for (int r = 0; r < N; r++) win[r] = ((win[r] << 2) | get_state(ns[t], qtip[r])) & 63u;
+            if (i >= 3) {
+              const int ip = L + 3 - i;  // reverse-strand position whose codon is these three columns
+              const uint32_t aF = win[0];
+              const uint32_t aR = codon_flip(aF) ^ 63u;
 #pragma unroll
-            for (int t = 0; t < CPW; t++) {
-              const int k = w * CPW + t;  // 0-based index of sequence k+1
-              if (k < NK) {
-                const uint32_t bF = win[k + 1] & mask[(0 * NK + k) * L1 + i];
-                const uint32_t bR = (codon_flip(win[k + 1]) ^ 63u) & mask[(1 * NK + k) * L1 + ip];
-                wf |= static_cast<uint32_t>(pairTab[aF * 64 + bF]) << (6 * t);
-                wr |= static_cast<uint32_t>(pairTab[aR * 64 + bR]) << (6 * t);
+              for (int w = 0; w < NCW; w++) {
+                uint32_t wf = 0, wr = 0;
+#pragma unroll
+                for (int c = 0; c < CPW; c++) {
+                  const int k = w * CPW + c;  // 0-based index of sequence k+1
+                  if (k < NK) {
+                    const uint32_t bF = win[k + 1] & mask[(0 * NK + k) * L1 + i];
+                    const uint32_t bR = (codon_flip(win[k + 1]) ^ 63u) & mask[(1 * NK + k) * L1 + ip];
+                    wf |= static_cast<uint32_t>(pairTab[aF * 64 + bF]) << (6 * c);
+                    wr |= static_cast<uint32_t>(pairTab[aR * 64 + bR]) << (6 * c);
+                  }
+                }
+                cod[(static_cast<size_t>(0 * L1 + i) * NCW + w) * kWave + lane] = wf;
+                cod[(static_cast<size_t>(1 * L1 + ip) * NCW + w) * kWave + lane] = wr;
               }
             }
-            cod[(static_cast<size_t>(0 * L1 + i) * NCW + w) * kWave + lane] = wf;
-            cod[(static_cast<size_t>(1 * L1 + ip) * NCW + w) * kWave + lane] = wr;
           }
         }
       }
@@ -291,6 +323,7 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
         if constexpr (LDSC) {
           for (int idx = 0; idx < sites * NCW; idx++)
             lds_codes[idx * kWave + lane] = cbase[static_cast<size_t>(idx / NCW) * 3 * NCW * kWave + (idx % NCW) * kWave];
+          __builtin_amdgcn_s_waitcnt(0);   // everything landed: the row loops below issue no vector memory ops
         }
         auto load_words = [&](int j, uint32_t (&w)[NCW]) {
 #pragma unroll
@@ -308,12 +341,13 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
             const uint32_t addr = (t == 0) ? (w[k / CPW] << 2) : (w[k / CPW] >> (6 * t - 2));
             sig[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(static_cast<int>(addr), R.template at<k>().lut));
           });
+          if constexpr (LDSC) __builtin_amdgcn_s_waitcnt(0xC07F);   // one lgkmcnt(0) instead of one wait per look-up
         };
         // S[a][j] = MAX3(sum, 0+Delta, 0+Delta)/(N-1) (score.c:841-843).  The reference starts the sum
         // from 0; 0 + m == m except for the sign of a zero, which nothing observes.
         auto finish = [&](float sum) -> float {
           const float top = (sum > Delta_v) ? sum : Delta_v;
-          return div_by_nk<NK>(top, nkf, exact_div);
+          return div_by_nk<NK, EXACT>(top, nkf);
         };
         // codon without a frame shift in any sequence (z == 0 for all k, score.c:506-510): straight-line
         auto fast_cell = [&](const uint32_t (&w)[NCW]) -> float {
@@ -368,6 +402,7 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
           int j = a;
           while (j < jend) {
             const int e = next_event(j, jend);
+#pragma unroll 2
             for (; j < e; j++) {                                   // tight loop: no events
               uint32_t wnext[NCW];
               load_words(j + 1 < sites ? j + 1 : j, wnext);
@@ -688,8 +723,8 @@ void launch_mt_stream(uint32_t seedBase, int Spad, int D, uint32_t *U, hipStream
 template <int NK>
 static int null_occupancy_t(size_t ldsBytes) {
   int nb = 0;
-  hipError_t e = ldsBytes ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_null<NK, true>, 64, ldsBytes)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_null<NK, false>, 64, 0);
+  hipError_t e = ldsBytes ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_null<NK, true, false>, 64, ldsBytes)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_null<NK, false, false>, 64, kMaxNodes * 64);
   if (e != hipSuccess) return 0;
   return nb;
 }
@@ -707,23 +742,26 @@ int null_occupancy(int NK, size_t ldsBytes) {
   }
 }
 
-bool launch_null(int NK, const NullArgs &a, int grid, size_t ldsBytes, hipStream_t stream) {
+// exact: the class contains blocks flagged exact_div (never staged in LDS: a rare parameter choice)
+bool launch_null(int NK, const NullArgs &a, int grid, size_t ldsBytes, bool exact, hipStream_t stream) {
+#define RC_NULL_ARGS a, a.blob, a.dblocks, a.classBlocks, a.U, a.pair, a.scratch, a.maxima
   switch (NK) {
-#define X(n)                                                                                         \
-  case n:                                                                                            \
-    if (ldsBytes) {                                                                                  \
-      if (ldsBytes > 48 * 1024)                                                                      \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_null<n, true>),                   \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsBytes)); \
-      hipLaunchKernelGGL((k_null<n, true>), dim3(grid), dim3(64), ldsBytes, stream, a, a.blob, a.dblocks, a.classBlocks, \
-                         a.U, a.pair, a.scratch, a.maxima);              \
-    } else {                                                                                         \
-      hipLaunchKernelGGL((k_null<n, false>), dim3(grid), dim3(64), 0, stream, a, a.blob, a.dblocks, a.classBlocks, \
-                         a.U, a.pair, a.scratch, a.maxima);                    \
-    }                                                                                                \
+#define X(n)                                                                                                   \
+  case n:                                                                                                      \
+    if (exact) {                                                                                               \
+      hipLaunchKernelGGL((k_null<n, false, true>), dim3(grid), dim3(64), kMaxNodes * 64, stream, RC_NULL_ARGS); \
+    } else if (ldsBytes) {                                                                                     \
+      if (ldsBytes > 48 * 1024)                                                                                \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_null<n, true, false>),                      \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsBytes));     \
+      hipLaunchKernelGGL((k_null<n, true, false>), dim3(grid), dim3(64), ldsBytes, stream, RC_NULL_ARGS);      \
+    } else {                                                                                                   \
+      hipLaunchKernelGGL((k_null<n, false, false>), dim3(grid), dim3(64), kMaxNodes * 64, stream, RC_NULL_ARGS); \
+    }                                                                                                          \
     return true;
     RC_FOR_NK(X)
 #undef X
+#undef RC_NULL_ARGS
     default: return false;
   }
 }

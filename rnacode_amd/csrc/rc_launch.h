@@ -61,7 +61,7 @@ struct FitArgs {
 
 void launch_mt_stream(uint32_t seedBase, int Spad, int D, uint32_t *U, hipStream_t stream);
 int null_occupancy(int NK, size_t ldsBytes);   // resident workgroups per CU (0 = cannot launch)
-bool launch_null(int NK, const NullArgs &a, int grid, size_t ldsBytes, hipStream_t stream);
+bool launch_null(int NK, const NullArgs &a, int grid, size_t ldsBytes, bool exact, hipStream_t stream);
 void launch_native_sigma(const NativeArgs &a, int nblocks, hipStream_t stream);
 bool launch_native_dp(int NK, const NativeArgs &a, int nblocks, hipStream_t stream);
 void launch_native_scan(const NativeArgs &a, int nblocks, hipStream_t stream);
