@@ -350,12 +350,14 @@ static void gap_tables(const std::vector<std::string> &rows, int L, std::vector<
 // ---------------------------------------------------------------------------------- block
 
 // Every DP value is a float sum of table entries and gap parameters.  If each of them is 0 or
-// has 2^-14 <= |v| < 2^20 it is a multiple of 2^-37, so is every partial sum, hence any non-zero
-// sum has |x| >= 2^-37; with at most 2^16 terms |x| < 2^40.  That is the range in which the
-// kernel's 3-instruction division by N-1 was proven exact (tools/verify_const_div.c).
+// has 2^-76 <= |v| < 2^40 it is a multiple of 2^-99, so is every partial sum, hence any non-zero
+// sum has |x| >= 2^-99; with fewer than 2^20 terms |x| < 2^60.  That lies inside the range
+// [2^-100, 2^100) in which the kernel's 3-instruction division by N-1 was proven equal to IEEE
+// division by exhaustion (tools/verify_const_div.c).  Anything else (denormal or astronomically
+// large penalties) is scored by the kernel instantiation that uses '/'.
 static bool in_div_range(float v) {
   const float a = std::fabs(v);
-  return a == 0.0f || (a >= 6.103515625e-05f && a < 1048576.0f);
+  return a == 0.0f || (a >= 1.3234889800848443e-23f && a < 1099511627776.0f);
 }
 
 int prepare_block(const rc_block &in, const rc_params &par, const CodeTables &ct, const PairTable &pt,

@@ -138,7 +138,7 @@ template <int NK, typename F> __device__ __forceinline__ void static_for(F &&f) 
 
 // x / NK, correctly rounded.  Power of two: exact scaling.  Otherwise Markstein's two-FMA
 // correction of x * RN(1/NK), proven equal to IEEE division for every NK in 2..31 and every
-// |x| in {0} U [2^-40, 2^40) by exhaustion (tools/verify_const_div.c).  Blocks whose score
+// |x| in {0} U [2^-100, 2^100) by exhaustion (tools/verify_const_div.c).  Blocks whose score
 // tables could leave that range are flagged by the host (DevBlock::exact_div) and are scored by
 // the EXACT instantiation, which uses '/'.
 template <int NK, bool EXACT> __device__ __forceinline__ float div_by_nk(float x, float nkf) {
