@@ -44,6 +44,20 @@ def algorithmic_work(blocks, sampleN):
     return by, fl
 
 
+def measured_traffic():
+    """HBM-side bytes per k_null launch from the committed rocprofv3 PMC passes of this same
+    command (profiles/collect.sh -> profiles/r01/k_null_pmc.json): FETCH_SIZE and WRITE_SIZE are in
+    KiB, collected in separate passes; on gfx950 FETCH_SIZE under-reports streaming reads by 2x
+    (MI355X_MICROARCH.md, HBM), so the read side is doubled.  None if no profile is committed."""
+    path = os.path.join(ROOT, "profiles", "r01", "k_null_pmc.json")
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        return (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
+    except Exception:
+        return None
+
+
 def cpu_baseline(blocks, sampleN, seed, target_s=12.0):
     """The unmodified reference objects (oracle/_ref/ref_harness, kind "reference") on a bounded
     sample of the same workload, single thread (the reference has no threading).  Falls back to
@@ -177,7 +191,7 @@ def main():
                        "blocks_per_gpu": args.blocks, "cols": args.cols, "seqs": args.seqs, "samples": args.samples,
                        "seed_base": args.seed_base, "sharding": f"blocks x{world}"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_null<%d>" % (args.seqs - 1), "kernel_ms": null_ms,
+                         "traffic": measured_traffic() if (args.blocks, args.cols, args.seqs, args.samples) == (10000, 120, 6, 1000) else None, "kernel": "k_null<%d>" % (args.seqs - 1), "kernel_ms": null_ms,
                          "algorithmic_bytes_per_launch": by,
                          "valu": {"achieved_gops": fl / (null_ms * 1e-3) / 1e9, "peak_gops": VALU_PEAK_GOPS,
                                   "frac": fl / (null_ms * 1e-3) / 1e9 / VALU_PEAK_GOPS,
