@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--samples", type=int, default=1000)
     ap.add_argument("--seed-base", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --blocks per GPU (default); strong: --blocks in total, split across ranks (configs[3])")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -115,11 +117,17 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from rnacode_amd import api
+    from rnacode_amd import distributed as rd
     from rnacode_amd.synth import synth_blocks
 
-    # this rank's shard: generator seed 1 + rank (generator seed 1)
     t0 = time.perf_counter()
-    blocks = [b.upper() for b in synth_blocks(args.blocks, args.seqs, args.cols, seed=1 + rank)]
+    if args.scaling == "weak":   # this rank's own shard: generator seed 1 + rank (generator seed 1)
+        blocks = [b.upper() for b in synth_blocks(args.blocks, args.seqs, args.cols, seed=1 + rank)]
+        counts = [args.blocks] * world
+    else:                        # one stream of --blocks blocks, contiguous shards
+        lo, hi = rd.shard_range(args.blocks, rank, world)
+        blocks = [b.upper() for b in synth_blocks(args.blocks, args.seqs, args.cols, seed=1)[lo:hi]]
+        counts = [rd.shard_range(args.blocks, r, world)[1] - rd.shard_range(args.blocks, r, world)[0] for r in range(world)]
     t_gen = time.perf_counter() - t0
 
     ctx = api.Context(local_rank)
@@ -131,14 +139,14 @@ def main():
 
     gathered = None
     if world > 1:
-        mine = torch.empty((args.blocks, args.samples), dtype=torch.float32, device=f"cuda:{local_rank}")
-        gathered = torch.empty((world * args.blocks, args.samples), dtype=torch.float32, device=f"cuda:{local_rank}")
+        mine = torch.empty((len(blocks), args.samples), dtype=torch.float32, device=f"cuda:{local_rank}")
         batch.bind_maxima(mine.data_ptr())
 
     def step():
         batch.run()                      # synchronous: kernels done, small results on the host
         if world > 1:                    # the path's one exchange: all-gather of per-sample maxima (RCCL over xGMI)
-            dist.all_gather_into_tensor(gathered, mine)
+            nonlocal gathered
+            gathered = rd.all_gather_maxima(mine, counts)
 
     def sync():
         if world > 1:
@@ -161,12 +169,14 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed = rd.max_over_ranks(elapsed, device=f"cuda:{local_rank}")
 
     sa, cs = batch.work()
-    total_units = cs * world * args.steps
+    if world > 1:   # units of all ranks (shards may differ by one block under strong scaling)
+        tot = torch.tensor([float(cs), float(sa)], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tot)
+        cs, sa = int(tot[0].item()), int(tot[1].item())
+    total_units = cs * args.steps
     value = total_units / elapsed
     out = None
     if rank == 0:
@@ -182,13 +192,13 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"synthetic MAF {args.blocks} blocks x {args.cols} cols x {args.seqs} seqs, "
                                    f"--num-samples {args.samples}, per GPU (BASELINE.json configs[2]/[3])",
-                       "blocks_per_gpu": args.blocks, "cols": args.cols, "seqs": args.seqs, "samples": args.samples,
+                       "blocks_per_gpu": len(blocks), "cols": args.cols, "seqs": args.seqs, "samples": args.samples,
                        "seed_base": args.seed_base, "sharding": f"blocks x{world}"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": measured_traffic() if (args.blocks, args.cols, args.seqs, args.samples) == (10000, 120, 6, 1000) else None, "kernel": "k_null<%d>" % (args.seqs - 1), "kernel_ms": null_ms,
@@ -198,7 +208,7 @@ def main():
                                   "algorithmic_flops_per_launch": fl}},
             "device_ms_per_step": {k: v / args.steps for k, v in tk.items()},
             "host_prep_s": {"generate": t_gen, "models_and_upload": t_prep},
-            "sample_alignments_per_s": sa * world * args.steps / elapsed,
+            "sample_alignments_per_s": sa * args.steps / elapsed,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(blocks, args.samples, args.seed_base)

@@ -56,7 +56,8 @@ long int hitCounter;
 void freeModels(bgModel *models, int N);
 
 /* ---- deterministic seeding ---- */
-static unsigned long g_seed_base = 42;
+unsigned long rc_harness_seed_base = 42;   /* also read by integration/score_hip_shim.c */
+#define g_seed_base rc_harness_seed_base
 static unsigned long g_seed_counter = 0;
 unsigned long __wrap_CreateSeed(void) { return g_seed_base + g_seed_counter++; }
 
@@ -76,6 +77,15 @@ int __wrap_EVDMaxLikelyFit(double *x, int *c, int n, double *ret_mu, double *ret
   g_fit_rc = rc;
   if (rc == 1) { g_mu_d = *ret_mu; g_lambda_d = *ret_lambda; }
   return rc;
+}
+
+/* hook for integration/score_hip_shim.c: the drop-in scorer hands over its per-sample maxima */
+void rc_harness_capture(const float *maxima, int n) {
+  int i;
+  free(g_max);
+  g_max = (double *)malloc(sizeof(double) * (n > 0 ? n : 1));
+  for (i = 0; i < n; i++) g_max[i] = maxima[i];
+  g_max_n = n;
 }
 
 /* ---- alignment container helpers (see header comment) ---- */
@@ -206,7 +216,7 @@ int main(int argc, char **argv) {
   int haveKappa = 0;
   float userKappa = 0;
   char blockId[256] = "";
-  int want_bt = 1;
+  int want_bt = 1, want_digest = 1;
 
   pars.Delta = -10.0; pars.Omega = -4.0; pars.omega = -2.0;
   pars.stopPenalty_k = -8.0; pars.stopPenalty_0 = -9999.0;
@@ -222,6 +232,7 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[a], "--stop-early")) pars.stopEarly = 1;
     else if (!strcmp(argv[a], "--cutoff") && a + 1 < argc) pars.cutoff = (float)atof(argv[++a]);
     else if (!strcmp(argv[a], "--no-backtrack")) want_bt = 0;
+    else if (!strcmp(argv[a], "--no-digest")) want_digest = 0;
     else if (!strcmp(argv[a], "--pars") && a + 4 < argc) {
       pars.Delta = (float)atof(argv[++a]); pars.Omega = (float)atof(argv[++a]);
       pars.omega = (float)atof(argv[++a]); pars.stopPenalty_k = (float)atof(argv[++a]);
@@ -296,8 +307,10 @@ int main(int argc, char **argv) {
       while (results[hssCount++].score > 0.0);
       qsort((segmentStats *)results, hssCount, sizeof(segmentStats), compareScores);
       maxScore = results[0].score;
-      putchar(','); dump_sk_digest("sk_digest_fwd", Sk_native, N, L);
-      putchar(','); dump_sk_digest("sk_digest_rev", Sk_native_rev, N, L);
+      if (want_digest) {
+        putchar(','); dump_sk_digest("sk_digest_fwd", Sk_native, N, L);
+        putchar(','); dump_sk_digest("sk_digest_rev", Sk_native_rev, N, L);
+      }
 
       if (want_bt && results[0].score > 0.0) {
         putchar(',');

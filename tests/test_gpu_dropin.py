@@ -1,0 +1,60 @@
+"""Link-level drop-in: the caller-side harness (the call sequence of RNAcode.c:153-221) linked
+against integration/score_hip_shim.c + librnacode_hip.so INSTEAD of the reference's score.o
+(oracle/_ref/ref_harness_hip, built by `make -C oracle ref` where the reference tree exists).
+Its output must agree with the goldens the unmodified reference produced."""
+import json
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, hss_key, load_golden
+from helpers import block_from_golden
+from rnacode_amd.alnio import write_harness_blocks
+
+pytestmark = pytest.mark.gpu
+
+BIN = os.path.join(ROOT, "oracle", "_ref", "ref_harness_hip")
+
+
+@pytest.mark.skipif(not os.path.exists(BIN), reason="oracle/_ref/ref_harness_hip was not built (needs the reference tree)")
+@pytest.mark.parametrize("name", ["coding_aln_n100", "noncoding_maf_n100", "synth_6x120_n200", "edge_cases_n50"])
+def test_harness_on_hip_backend_matches_reference(name):
+    doc = load_golden(name)
+    blocks = []
+    for e in doc["blocks"]:
+        b = block_from_golden(e)
+        if "skipped" in e["ref"]:
+            b.tree = None
+        blocks.append(b)
+    with tempfile.NamedTemporaryFile("w", suffix=".blk", delete=False) as fh:
+        path = fh.name
+    try:
+        write_harness_blocks(blocks, path)   # tree + kappa given: the scorer, not PhyML, is under test
+        out = subprocess.check_output([BIN, path, "--samples", str(doc["samples"]), "--seed", str(doc["seed_base"]),
+                                       "--no-digest", *doc["harness_args"]])
+    finally:
+        os.unlink(path)
+    got = [json.loads(l) for l in out.decode().splitlines() if l.strip()]
+    assert len(got) == len(doc["blocks"])
+    for g, e in zip(got, doc["blocks"]):
+        w = e["ref"]
+        if "skipped" in w:
+            assert "skipped" in g
+            continue
+        gh = sorted(g["hss"], key=hss_key)
+        wh = sorted(w["hss"], key=hss_key)
+        assert len(gh) == len(wh)
+        for a, b in zip(gh, wh):
+            for k in ("strand", "frame", "startSite", "endSite", "start", "end", "startGenomic", "endGenomic", "name"):
+                assert a[k] == b[k]
+            assert np.float32(a["score"]) == np.float32(b["score"])
+            assert abs(a["pvalue"] - b["pvalue"]) <= 1e-6 * max(1.0, abs(b["pvalue"]))
+        assert g["evd_rc"] == w["evd_rc"]
+        np.testing.assert_array_equal(np.float32(g["maxScores"]), np.float32(w["maxScores"]))
+        for mg, mw in zip(g["models"] + g["modelsRev"], w["models"] + w["modelsRev"]):
+            np.testing.assert_array_equal(np.float32(mg["scores"]), np.float32(mw["scores"]))
+        if "backtrack" in w:
+            assert g["backtrack"] == w["backtrack"]
