@@ -120,6 +120,18 @@ static void make_batch(TTree *tree, struct aln *alignment[], float kappa) {
   free(rows); free(names); free(nwk);
 }
 
+/* revAln's mapping (rnaz_utils.c:316-348): is s the reverse complement of the batch's forward row 0? */
+static int is_revcomp_of(const char *s, const char *fwd) {
+  size_t n = strlen(fwd), j;
+  if (strlen(s) != n) return 0;
+  for (j = 0; j < n; j++) {
+    char c = fwd[n - 1 - j];
+    switch (c) { case 'T': case 'U': c = 'A'; break; case 'A': c = 'T'; break; case 'C': c = 'G'; break; case 'G': c = 'C'; break; default: break; }
+    if (s[j] != c) return 0;
+  }
+  return strcmp(s, fwd) != 0;   /* a row equal to its own reverse complement starts a new block */
+}
+
 int **getScoringMatrix(void) {   /* score.c:50-76; only the 24x24 shape matters to callers */
   int i, **m = (int **)malloc(sizeof(int *) * 24);
   for (i = 0; i < 24; i++) m[i] = (int *)calloc(24, sizeof(int));
@@ -133,8 +145,7 @@ bgModel *getModels(TTree *tree, struct aln *alignment[], float kappa) {
   rc_model *f, *r;
   bgModel *out;
   for (N = 0; alignment[N] != NULL; N++);
-  is_fwd = !(g_batch && g_N == N && g_fwd_row0 && strlen(alignment[0]->seq) == strlen(g_fwd_row0) &&
-             strcmp(alignment[0]->seq, g_fwd_row0) != 0);
+  is_fwd = !(g_batch && g_N == N && g_fwd_row0 && is_revcomp_of(alignment[0]->seq, g_fwd_row0));
   if (is_fwd) make_batch(tree, alignment, kappa);
   f = (rc_model *)malloc(sizeof(rc_model) * N);
   r = (rc_model *)malloc(sizeof(rc_model) * N);
