@@ -402,7 +402,10 @@ int rc_batch_run(rc_batch *b) {
     if (!c->occ.count(key)) c->occ[key] = null_occupancy(NK, ldsBytes);
     if (c->occ[key] <= 0 && ldsBytes) { ldsBytes = 0; const std::pair<int, size_t> k2(NK, 0); if (!c->occ.count(k2)) c->occ[k2] = null_occupancy(NK, 0); }
     const int occ = std::max(1, c->occ[std::pair<int, size_t>(NK, ldsBytes)]);
-    const int items = static_cast<int>(kv.second.size()) * groups;
+    int items = static_cast<int>(kv.second.size()) * groups;
+    // small batches: split every item into its six strand x frame parts to fill the chip
+    const int comboSplit = (items * 2 <= c->numCU * occ) ? 1 : 0;
+    if (comboSplit) items *= 6;
     int grid = std::min(items, c->numCU * occ);
     const size_t need = stride * grid;
     if (need > c->scratch_cap) {
@@ -416,7 +419,7 @@ int rc_batch_run(rc_batch *b) {
     a.blob = b->d_blob; a.dblocks = b->d_dblocks; a.classBlocks = b->d_classBlocks[NK];
     a.nClassBlocks = static_cast<int>(kv.second.size()); a.groups = groups; a.sampleN = sampleN; a.Spad = Spad;
     a.U = c->d_U; a.pair = d_pair; a.scratch = c->d_scratch; a.scratchStride = stride;
-    a.maxima = b->d_maxima; a.clampCount = c->d_clamp; a.tieThr = c->tieThr; a.debugSkip = c->debugSkip;
+    a.maxima = b->d_maxima; a.clampCount = c->d_clamp; a.tieThr = c->tieThr; a.debugSkip = c->debugSkip; a.comboSplit = comboSplit;
     if (!launch_null(NK, a, grid, ldsBytes, exact, c->stream)) return fail(RC_ERR_UNSUPPORTED, "no null kernel for this number of rows");
     b->nl[2]++;
   }

@@ -197,11 +197,16 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
 
   const int lane = threadIdx.x;
   uint32_t *__restrict__ cod = scratch + static_cast<size_t>(blockIdx.x) * A.scratchStride;
-  const int nItems = A.nClassBlocks * A.groups;
+  // comboSplit (small batches): an item is one (block, group, strand x frame) so that 6x more
+  // wavefronts exist; each recomputes phase A and the six partial maxima meet in an atomic max.
+  const int perBlock = A.groups * (A.comboSplit ? 6 : 1);
+  const int nItems = A.nClassBlocks * perBlock;
 
   for (int item = blockIdx.x; item < nItems; item += gridDim.x) {
-    const int bi = classBlocks[item / A.groups];
-    const int grp = item % A.groups;
+    const int bi = classBlocks[item / perBlock];
+    const int sub = item % perBlock;
+    const int grp = A.comboSplit ? sub / 6 : sub;
+    const int onlyCombo = A.comboSplit ? sub % 6 : -1;
     const DevBlock *__restrict__ db = dblocks + bi;
     const int cols = db->cols, L = db->L, nnodes = db->nnodes;
     const float Delta = db->Delta, Omega = db->Omega, omega = db->omega, nkf = db->nkf;
@@ -309,6 +314,7 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
     asm volatile("v_mov_b32 %0, %1" : "=v"(Delta_v) : "s"(Delta));
     if (!(A.debugSkip & 1))
     for (int s = 0; s < 2; s++) {
+      if (onlyCombo >= 0 && onlyCombo / 3 != s) continue;
       Regs R;
       static_for<NK>([&](auto kc) {  // 64-entry sigma table of sequence k spread over the 64 lanes
         constexpr int k = decltype(kc)::value;
@@ -317,6 +323,7 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
       for (int f = 0; f < 3; f++) {
         const int sites = (L - f) / 3;
         if (sites <= 0) continue;
+        if (onlyCombo >= 0 && onlyCombo % 3 != f) continue;
         const uint32_t *__restrict__ cbase = cod + (static_cast<size_t>(s * L1 + 3 + f) * NCW) * kWave + lane;  // site j: + j*3*NCW*64
         const unsigned long long *__restrict__ zbase = zw + s * L1 + 3 + f;                                       // site j: [3j]
         const unsigned long long *__restrict__ zany = zmask + static_cast<size_t>(s * 3 + f) * zmWords;            // bit j: some z != 0 at site j
@@ -425,7 +432,12 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
         sample_scan_last(st, best);   // entry (sites-1, sites-1): its own value can never be reported
       }
     }
-    if (sidx < A.sampleN) maxima[static_cast<size_t>(db->out_index) * A.sampleN + sidx] = best;
+    if (sidx < A.sampleN) {
+      float *dst = maxima + static_cast<size_t>(db->out_index) * A.sampleN + sidx;
+      // scores are positive floats or the -1 sentinel: integer order == float order on that set
+      if (A.comboSplit) atomicMax(reinterpret_cast<int *>(dst), __float_as_int(best));
+      else *dst = best;
+    }
   }
 }
 
@@ -571,6 +583,20 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
   return r;
 }
 
+// all four sums of Lawless 4.1.6 in one pass over the workgroup (one barrier pair per evaluation)
+__device__ __forceinline__ void block_sum4(double &a, double &b, double &c, double &d, double *sh) {
+  const int tid = threadIdx.x, nw = static_cast<int>(blockDim.x >> 6);
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64);
+    c += __shfl_down(c, off, 64); d += __shfl_down(d, off, 64);
+  }
+  __syncthreads();
+  if ((tid & 63) == 0) { sh[(tid >> 6) * 4 + 0] = a; sh[(tid >> 6) * 4 + 1] = b; sh[(tid >> 6) * 4 + 2] = c; sh[(tid >> 6) * 4 + 3] = d; }
+  __syncthreads();
+  a = b = c = d = 0.0;
+  for (int w = 0; w < nw; w++) { a += sh[w * 4 + 0]; b += sh[w * 4 + 1]; c += sh[w * 4 + 2]; d += sh[w * 4 + 3]; }
+}
+
 __device__ void lawless416(const float *x, int n, double lambda, double *sh, double *f, double *df) {
   double e = 0, xe = 0, xxe = 0, xs = 0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -578,7 +604,7 @@ __device__ void lawless416(const float *x, int n, double lambda, double *sh, dou
     const double ex = exp(-1. * lambda * xi);
     xs += xi; xe += xi * ex; xxe += xi * xi * ex; e += ex;
   }
-  e = block_sum(e, sh); xe = block_sum(xe, sh); xxe = block_sum(xxe, sh); xs = block_sum(xs, sh);
+  block_sum4(e, xe, xxe, xs, sh);
   const double total = static_cast<double>(n);
   *f = 1. / lambda - xs / total + xe / e;
   *df = ((xe / e) * (xe / e)) - (xxe / e) - (1. / (lambda * lambda));
@@ -629,7 +655,7 @@ __device__ int evd_fit_block(const float *x, int n, double *sh, double *mu_out, 
 }
 
 __global__ __launch_bounds__(256) void k_evd_fit(FitArgs A) {
-  __shared__ double sh[8];
+  __shared__ double sh[16];
   __shared__ float maxNativeSh;
   const int bi = A.blocks[blockIdx.x];
   const DevBlock *db = A.dblocks + bi;

@@ -24,6 +24,7 @@ struct NullArgs {
   float *maxima;              // [n_blocks][sampleN]
   unsigned long long *clampCount;
   float tieThr;               // float form of the 0.0001 tie tolerance (score.c:954)
+  int comboSplit;             // 1: items are (block, group, strand x frame); maxima combined by atomic max
   int debugSkip;              // profiling only (RC_DEBUG_SKIP): bit0 skip the DP/scan phase, bit1 skip simulation
 };
 
