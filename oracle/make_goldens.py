@@ -48,12 +48,41 @@ def block_json(b: AlnBlock):
                            full_length=r.full_length) for r in b.rows])
 
 
-def emit(name, blocks, samples, params=None, extra=(), note=""):
+PRINT_VARIANTS = {   # reference printResults (misc.c:392-552) under these option sets
+    "list": ["--format", "0"],
+    "gtf": ["--format", "1"],
+    "tabular": ["--format", "2"],
+    "tabular_p0.05": ["--format", "2", "--cutoff", "0.05"],
+    "list_best_only": ["--format", "0", "--best-only"],
+    "tabular_best_region": ["--format", "2", "--best-region"],
+}
+
+
+def run_print(blocks, samples, extra, variant_args):
+    with tempfile.NamedTemporaryFile("w", suffix=".blk", delete=False) as fh:
+        path = fh.name
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as fh:
+        outp = fh.name
+    try:
+        write_harness_blocks(blocks, path)
+        subprocess.check_output([HARNESS, path, "--samples", str(samples), "--seed", str(SEED), "--no-backtrack",
+                                 *extra, "--print-to", outp, *variant_args])
+        with open(outp) as fh:
+            return fh.read()
+    finally:
+        os.unlink(path)
+        os.unlink(outp)
+
+
+def emit(name, blocks, samples, params=None, extra=(), note="", with_print=False):
     res = run_harness(blocks, samples, extra)
     assert len(res) == len(blocks), (len(res), len(blocks))
     doc = dict(fixture=name, note=note, seed_base=SEED, samples=samples,
                params=params or {}, harness_args=list(extra),
                blocks=[dict(input=block_json(b), ref=r) for b, r in zip(blocks, res)])
+    if with_print:
+        ex = [a for a in extra if a != "--no-backtrack"]
+        doc["print"] = {k: run_print(blocks, samples, ex, v) for k, v in PRINT_VARIANTS.items()}
     path = os.path.join(OUT, name + ".json.gz")
     with gzip.GzipFile(path, "wb", mtime=0) as fh:
         fh.write(json.dumps(doc, separators=(",", ":")).encode())
@@ -95,9 +124,9 @@ def main():
 
     for stem in ("coding.aln", "noncoding.aln", "coding.maf", "noncoding.maf"):
         emit(stem.replace(".", "_") + "_n100", read_alignment_file(os.path.join(ex, stem)), 100,
-             note=f"reference example {stem}, tree+kappa from the reference's treeML")
+             note=f"reference example {stem}, tree+kappa from the reference's treeML", with_print=True)
     gp = read_alignment_file(os.path.join(ex, "genomic-preprocessed.maf"))
-    emit("genomic_preprocessed_n100", gp, 100, note="BASELINE config 2 input, all 34 blocks")
+    emit("genomic_preprocessed_n100", gp, 100, note="BASELINE config 2 input, all 34 blocks", with_print=True)
     emit("genomic_preprocessed_n1000", gp, 1000, extra=("--no-backtrack",), note="BASELINE config 2")
 
     emit("edge_cases_n50", edge_blocks(), 50, note="character classes, minimal sizes, skip rules, minus-strand ref")

@@ -217,6 +217,7 @@ int main(int argc, char **argv) {
   float userKappa = 0;
   char blockId[256] = "";
   int want_bt = 1, want_digest = 1;
+  FILE *printTo = NULL;   /* --print-to: also run the reference's printResults (misc.c:392-552) into this file */
 
   pars.Delta = -10.0; pars.Omega = -4.0; pars.omega = -2.0;
   pars.stopPenalty_k = -8.0; pars.stopPenalty_0 = -9999.0;
@@ -233,6 +234,10 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[a], "--cutoff") && a + 1 < argc) pars.cutoff = (float)atof(argv[++a]);
     else if (!strcmp(argv[a], "--no-backtrack")) want_bt = 0;
     else if (!strcmp(argv[a], "--no-digest")) want_digest = 0;
+    else if (!strcmp(argv[a], "--print-to") && a + 1 < argc) printTo = fopen(argv[++a], "w");
+    else if (!strcmp(argv[a], "--format") && a + 1 < argc) pars.outputFormat = atoi(argv[++a]);
+    else if (!strcmp(argv[a], "--best-only")) pars.bestOnly = 1;
+    else if (!strcmp(argv[a], "--best-region")) pars.bestRegion = 1;
     else if (!strcmp(argv[a], "--pars") && a + 4 < argc) {
       pars.Delta = (float)atof(argv[++a]); pars.Omega = (float)atof(argv[++a]);
       pars.omega = (float)atof(argv[++a]); pars.stopPenalty_k = (float)atof(argv[++a]);
@@ -342,6 +347,7 @@ int main(int argc, char **argv) {
       }
       printf("]}\n");
       fflush(stdout);
+      if (printTo) printResults(printTo, pars.outputFormat, (const struct aln **)inputAln, results);
 
       for (k = 0; k < N; k++) {
         int x;
@@ -364,5 +370,6 @@ int main(int argc, char **argv) {
   }
   free(line);
   fclose(fp);
+  if (printTo) fclose(printTo);
   return 0;
 }

@@ -1,0 +1,109 @@
+"""Thin stand-alone driver around the HIP scoring path.
+
+Mirrors the reference's command line (src/cmdline.ggo:6-20, src/RNAcode.c:236-373) for the
+options that concern the scoring path and the listings:
+
+    python -m rnacode_amd.cli [-n N] [-p CUTOFF] [-g | -t] [-b] [-r] [-s] [-m 62|90] [-c D,O,o,S]
+                              [-o OUT] --trees SIDECAR [FILE]
+
+The tree + kappa fit (PhyML, RNAcode.c:153) is not part of the hot path and is not built: every
+block needs a sidecar entry `<newick> TAB <kappa>` (one line per alignment block, in file order;
+`-` for blocks the driver skips).  All blocks of the file are scored as ONE batch on the GPU.
+Quirk kept from the reference: the 4th value of --pars goes to stopPenalty_0 (RNAcode.c:318)."""
+from __future__ import annotations
+
+import argparse
+import sys
+import time
+from typing import List, Optional
+
+from . import api, report
+from .alnio import AlnBlock, read_alignment_file
+
+
+def read_sidecar(path: str) -> List[Optional[tuple]]:
+    out = []
+    with open(path) as fh:
+        for line in fh:
+            line = line.rstrip("\n")
+            if not line.strip():
+                continue
+            if line.strip() == "-":
+                out.append(None)
+                continue
+            tree, kappa = line.split("\t")
+            out.append((tree, float(kappa)))
+    return out
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser(prog="rnacode-hip", description="RNAcode scoring path on MI355X")
+    ap.add_argument("file", nargs="?", help="alignment file (MAF or ClustalW); default stdin")
+    ap.add_argument("-o", "--outfile")
+    ap.add_argument("-g", "--gtf", action="store_true")
+    ap.add_argument("-t", "--tabular", action="store_true")
+    ap.add_argument("-b", "--best-only", action="store_true")
+    ap.add_argument("-r", "--best-region", action="store_true")
+    ap.add_argument("-s", "--stop-early", action="store_true")
+    ap.add_argument("-n", "--num-samples", type=int, default=100)
+    ap.add_argument("-p", "--cutoff", type=float, default=1.0)
+    ap.add_argument("-c", "--pars")
+    ap.add_argument("-m", "--blosum", type=int, default=62)
+    ap.add_argument("--trees", required=True, help="sidecar: one '<newick>\\t<kappa>' line per block")
+    ap.add_argument("--seed-base", type=int, default=42)
+    ap.add_argument("--device", type=int, default=0)
+    a = ap.parse_args(argv)
+
+    if a.blosum not in (62, 90):
+        print("ERROR: Currently only BLOSUM62 and BLOSUM90 are supported.", file=sys.stderr)
+        return 1
+    kw = dict(sampleN=a.num_samples, cutoff=a.cutoff, stopEarly=int(a.stop_early), blosum=a.blosum, seed_base=a.seed_base)
+    if a.pars:
+        vals = [float(x) for x in a.pars.split(",")]
+        for key, v in zip(("Delta", "Omega", "omega", "stopPenalty_0"), vals):
+            kw[key] = v
+    params = api.default_params(**kw)
+
+    if a.file:
+        blocks = read_alignment_file(a.file)
+    else:
+        import tempfile
+        with tempfile.NamedTemporaryFile("w", delete=False) as fh:
+            fh.write(sys.stdin.read())
+        blocks = read_alignment_file(fh.name)
+    side = read_sidecar(a.trees)
+    if len(side) != len(blocks):
+        print(f"ERROR: {len(blocks)} alignment blocks but {len(side)} sidecar entries", file=sys.stderr)
+        return 1
+    prepared: List[AlnBlock] = []
+    for b, s in zip(blocks, side):
+        b = b.upper()
+        b.tree, b.kappa = s if s is not None else ("(a:0.1,b:0.1,c:0.1);", 2.0)   # skipped blocks never reach the tree
+        prepared.append(b)
+
+    out = open(a.outfile, "w") if a.outfile else sys.stdout
+    fmt = 2 if a.tabular else (1 if a.gtf else 0)
+    t0 = time.perf_counter()
+    ctx = api.Context(a.device)
+    batch = api.Batch(ctx, prepared, params).run()
+    st = report.ReportState()
+    for i, b in enumerate(prepared):
+        code = batch.status(i)
+        if code == api.RC_ERR_SKIP:   # RNAcode.c:142-150
+            msg = "There must be at least three sequences in the alignment." if b.n <= 2 else "Too short."
+            print(f"Skipping alignment. {msg}", file=sys.stderr)
+            continue
+        report.print_results(out, fmt, batch.scoreAln(i), b.rows[0].name, st, cutoff=a.cutoff, best_only=a.best_only,
+                             best_region=a.best_region)
+    if fmt == 0:
+        report.print_footer(out, len(prepared), time.perf_counter() - t0, params.sampleN, params.Delta, params.Omega,
+                            params.omega, params.stopPenalty_k)
+    batch.close()
+    ctx.close()
+    if a.outfile:
+        out.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

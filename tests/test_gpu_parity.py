@@ -235,3 +235,25 @@ def test_full_size_properties(ctx):
         res = ob.run_block(rows, names, b.rows[0].start, b.rows[0].length, b.tree, b.kappa, ob.default_params(64), 42)
         np.testing.assert_array_equal(allmax[i, :64], np.float32(res.maxScores))
     big.close()
+
+
+def test_cli_end_to_end_matches_reference_listing(tmp_path):
+    """File in, listing out (section 8f-1): MAF/ClustalW reader -> one GPU batch -> printResults
+    formats, against the reference's own printResults output for the same seeds."""
+    from rnacode_amd import cli
+    from rnacode_amd.synth import to_maf
+    for name, variant, flags in (("genomic_preprocessed_n100", "tabular", ["-t"]),
+                                 ("genomic_preprocessed_n100", "tabular_best_region", ["-t", "-r"]),
+                                 ("coding_maf_n100", "gtf", ["-g"])):
+        doc = load_golden(name)
+        blocks = [block_from_golden(e) for e in doc["blocks"]]
+        maf = tmp_path / "in.maf"
+        maf.write_text(to_maf(blocks))
+        side = tmp_path / "trees.tsv"
+        side.write_text("".join("-\n" if "skipped" in e["ref"] else f"{e['ref']['tree']}\t{e['ref']['kappa']!r}\n"
+                                for e in doc["blocks"]))
+        outp = tmp_path / "out.txt"
+        rc = cli.main([str(maf), "--trees", str(side), "-n", str(doc["samples"]), "--seed-base", str(doc["seed_base"]),
+                       "-o", str(outp), *flags])
+        assert rc == 0
+        assert outp.read_text() == doc["print"][variant]
