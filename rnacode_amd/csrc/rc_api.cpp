@@ -407,6 +407,8 @@ int rc_batch_run(rc_batch *b) {
     const int comboSplit = (items * 2 <= c->numCU * occ) ? 1 : 0;
     if (comboSplit) items *= 6;
     int grid = std::min(items, c->numCU * occ);
+    // very long blocks: bound the sigma-code staging area (4 GiB of uint32) by running fewer workgroups
+    grid = static_cast<int>(std::max<size_t>(1, std::min<size_t>(grid, (static_cast<size_t>(1) << 30) / std::max<size_t>(stride, 1))));
     const size_t need = stride * grid;
     if (need > c->scratch_cap) {
       HIP_TRY(hipStreamSynchronize(c->stream));

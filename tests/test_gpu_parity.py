@@ -257,3 +257,30 @@ def test_cli_end_to_end_matches_reference_listing(tmp_path):
                        "-o", str(outp), *flags])
         assert rc == 0
         assert outp.read_text() == doc["print"][variant]
+
+
+def test_extreme_shapes_against_oracle(ctx):
+    """Maximum row count of the kernels (N = 32), a long block (1500 columns) and the smallest
+    legal block, same seeds through the HIP path and the oracle."""
+    from oracle import binding as ob
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_blocks
+    cases = [(synth_blocks(1, 32, 48, seed=21), 70), (synth_blocks(1, 5, 1500, seed=22), 64), (synth_blocks(1, 3, 3, seed=23, gaps=False), 64)]
+    for blocks, n in cases:
+        blocks = [b.upper() for b in blocks]
+        batch = api.Batch(ctx, blocks, api.default_params(sampleN=n, seed_base=7)).run()
+        b = blocks[0]
+        rows = [r.seq for r in b.rows]
+        names = [r.name for r in b.rows]
+        res = ob.run_block(rows, names, b.rows[0].start, b.rows[0].length, b.tree, b.kappa, ob.default_params(n), 7)
+        np.testing.assert_array_equal(batch.maxScores(0), np.float32(res.maxScores))
+        got = sorted(batch.scoreAln(0), key=hss_key)
+        want = sorted(res.hss, key=hss_key)
+        assert [(g["strand"], g["frame"], g["start"], g["end"], np.float32(g["score"])) for g in got] == \
+               [(w["strand"], w["frame"], w["start"], w["end"], np.float32(w["score"])) for w in want]
+        batch.close()
+    # one row too many for the kernels: a clear error, not a wrong answer
+    big = [b.upper() for b in synth_blocks(1, 33, 30, seed=24)]
+    with pytest.raises(api.RnacodeError) as ei:
+        api.Batch(ctx, big, api.default_params())
+    assert ei.value.code == api.RC_ERR_UNSUPPORTED
