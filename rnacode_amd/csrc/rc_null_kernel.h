@@ -1,0 +1,432 @@
+// rc_null_kernel.h -- device pieces shared by the kernels and the k_null<N-1, LDSC, EXACT> template.
+// Included by rc_kernels.hip (native path) and by the rc_null_*.hip units, each of which
+// instantiates k_null for a range of N-1 so that the ranges compile in parallel.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "rc_device.h"
+#include "rc_launch.h"
+
+namespace rc {
+
+// ------------------------------------------------------------------------------------------
+// shared device pieces
+// ------------------------------------------------------------------------------------------
+
+// One step of the 3-state max-plus recurrence for one sequence k (score.c:506-533).
+// zc: 0 -> z = 0, 1 -> z = +1, 2 -> z = -1 (wave-uniform).
+__device__ __forceinline__ void pair_step(int zc, float sig, float Delta, float Omega, float omega,
+                                          float &s0, float &s1, float &s2) {
+  if (zc == 0) {
+    s0 = s0 + sig;
+    s1 = s1 + omega;
+    s2 = s2 + omega;
+  } else if (zc == 1) {
+    const float n0 = fmaxf(s0 + Delta, s2 + Omega);
+    const float n1 = fmaxf(s0 + Omega, s1 + Delta);
+    const float n2 = fmaxf(s1 + Omega, s2 + Delta);
+    s0 = n0; s1 = n1; s2 = n2;
+  } else {
+    const float n0 = fmaxf(s0 + Delta, s1 + Omega);
+    const float n1 = fmaxf(s1 + Delta, s2 + Omega);
+    const float n2 = fmaxf(s2 + Delta, s0 + Omega);
+    s0 = n0; s1 = n1; s2 = n2;
+  }
+}
+
+// getHSS's serial state machine for one entry (score.c:892-959), emission reduced to a callback.
+struct ScanState {
+  float cm;  // currMax
+  int ss, se;
+};
+
+template <typename Emit>
+__device__ __forceinline__ void scan_step(ScanState &st, float v, int a, int j, bool last, float tieThr, Emit emit) {
+  if (v > 0.0f || last) {
+    if ((st.cm > 0.0f && st.se < a) || last) {
+      if (st.se - st.ss >= 2) emit(st);
+      st.cm = v; st.ss = a; st.se = j;
+    } else if (v > st.cm || (fabsf(v - st.cm) < tieThr && (j - a) >= (st.se - st.ss))) {
+      st.cm = v; st.ss = a; st.se = j;
+    }
+  }
+}
+
+// reverse the three 2-bit fields of a codon index
+__device__ __forceinline__ uint32_t codon_flip(uint32_t c) { return ((c & 3u) << 4) | (c & 12u) | ((c >> 4) & 3u); }
+
+// ------------------------------------------------------------------------------------------
+// k_null<NK, LDSC>: the null-distribution loop body, lane = sample
+// ------------------------------------------------------------------------------------------
+
+// Per-sequence registers as distinct scalar members (not an array): keeps every chain in its own
+// VGPR across the wave-uniform z branches instead of a register tuple that is copied at each join.
+template <int K> struct KReg { float s0, s1, s2; int lut; };
+template <typename Seq> struct KRegs;
+template <int... K> struct KRegs<std::integer_sequence<int, K...>> : KReg<K>... {
+  template <int I> __device__ __forceinline__ KReg<I> &at() { return static_cast<KReg<I> &>(*this); }
+};
+template <int NK, typename F, int... K>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, K...>) {
+  (f(std::integral_constant<int, K>{}), ...);
+}
+template <int NK, typename F> __device__ __forceinline__ void static_for(F &&f) {
+  static_for_impl<NK>(static_cast<F &&>(f), std::make_integer_sequence<int, NK>{});
+}
+
+// x / NK, correctly rounded.  Power of two: exact scaling.  Otherwise Markstein's two-FMA
+// correction of x * RN(1/NK), proven equal to IEEE division for every NK in 2..31 and every
+// |x| in {0} U [2^-100, 2^100) by exhaustion (tools/verify_const_div.c).  Blocks whose score
+// tables could leave that range are flagged by the host (DevBlock::exact_div) and are scored by
+// the EXACT instantiation, which uses '/'.
+template <int NK, bool EXACT> __device__ __forceinline__ float div_by_nk(float x, float nkf) {
+  if constexpr ((NK & (NK - 1)) == 0) {
+    return x * (1.0f / static_cast<float>(NK));
+  } else if constexpr (EXACT) {
+    return x / nkf;
+  } else {
+    constexpr float y = 1.0f / static_cast<float>(NK);
+    const float q0 = x * y;
+    const float r = __builtin_fmaf(-static_cast<float>(NK), q0, x);
+    return __builtin_fmaf(r, y, q0);
+  }
+}
+
+// getHSS's state machine as the null samples need it: only the best emitted score matters, so the
+// segment start is carried as len = segmentEnd - segmentStart (score.c:892-959).
+// key = segmentEnd << 16 | (segmentEnd - segmentStart); codon sites < 32767.  Before the first
+// segment of a frame segmentEnd holds the sentinel 0x7FFF, which makes "currMax > 0 && segmentEnd < i"
+// (score.c:900) equivalent to key < (i << 16): currMax is positive exactly when a segment was opened.
+struct SampleScan { float cm; uint32_t key; };
+constexpr uint32_t kScanInitKey = 0x7FFFu << 16;
+// every entry except the frame's final one
+__device__ __forceinline__ void sample_scan_step(SampleScan &st, float &best, float v, uint32_t a, uint32_t span, uint32_t newkey,
+                                                 float tieThr) {
+  const uint32_t len = st.key & 0xFFFFu;
+  const bool pos = v > 0.0f;
+  const bool fresh = st.key < (a << 16);
+  const bool rep = (v > st.cm) | ((fabsf(v - st.cm) < tieThr) & (len <= span));   // (j-i) >= (segEnd-segStart), score.c:953-954
+  const bool emit = pos & fresh & (len >= 2u);                                    // minSegmentLength, score.c:902
+  best = (emit & (st.cm > best)) ? st.cm : best;
+  const bool upd = pos & (fresh | rep);
+  st.cm = upd ? v : st.cm;
+  st.key = upd ? newkey : st.key;
+}
+// the final entry of a frame is entered unconditionally and always reports the open segment
+__device__ __forceinline__ void sample_scan_last(const SampleScan &st, float &best) {
+  best = (((st.key & 0xFFFFu) >= 2u) & (st.cm > best)) ? st.cm : best;
+}
+
+// Read-only inputs are separate __restrict__ kernel parameters (not members of the by-value
+// argument block) so that the compiler may prove them unclobbered and fetch the wave-uniform
+// block tables (z words, tree records, masks) with scalar loads.
+template <int NK, bool LDSC, bool EXACT>
+__global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restrict__ blob,
+                                             const DevBlock *__restrict__ dblocks, const int *__restrict__ classBlocks,
+                                             const uint32_t *__restrict__ Ustream, const uint8_t *__restrict__ pairTab,
+                                             uint32_t *__restrict__ scratch, float *__restrict__ maxima) {
+  constexpr int N = NK + 1;
+  constexpr int CPW = 5;                  // 6-bit sigma codes per 32-bit word
+  constexpr int NCW = (NK + CPW - 1) / CPW;
+  using Regs = KRegs<std::make_integer_sequence<int, NK>>;
+  // phase A: threshold table of the tree (nnodes x 64 B); phase B with LDSC: [site][NCW][64] sigma codes
+  // of the current strand x frame
+  extern __shared__ uint32_t lds_codes[];
+
+  const int lane = threadIdx.x;
+  uint32_t *__restrict__ cod = scratch + static_cast<size_t>(blockIdx.x) * A.scratchStride;
+  // comboSplit (small batches): an item is one (block, group, strand x frame) so that 6x more
+  // wavefronts exist; each recomputes phase A and the six partial maxima meet in an atomic max.
+  const int perBlock = A.groups * (A.comboSplit ? 6 : 1);
+  const int nItems = A.nClassBlocks * perBlock;
+
+  for (int item = blockIdx.x; item < nItems; item += gridDim.x) {
+    const int bi = classBlocks[item / perBlock];
+    const int sub = item % perBlock;
+    const int grp = A.comboSplit ? sub / 6 : sub;
+    const int onlyCombo = A.comboSplit ? sub % 6 : -1;
+    const DevBlock *__restrict__ db = dblocks + bi;
+    const int cols = db->cols, L = db->L, nnodes = db->nnodes;
+    const float Delta = db->Delta, Omega = db->Omega, omega = db->omega, nkf = db->nkf;
+    const NodeRec *__restrict__ nodes = reinterpret_cast<const NodeRec *>(blob + db->off_nodes);
+    const uint8_t *__restrict__ qtip = blob + db->off_qtip;
+    const uint16_t *__restrict__ refcol = reinterpret_cast<const uint16_t *>(blob + db->off_refcol);
+    const unsigned long long *__restrict__ zw = reinterpret_cast<const unsigned long long *>(blob + db->off_zw);
+    const unsigned long long *__restrict__ zmask = reinterpret_cast<const unsigned long long *>(blob + db->off_zmask);
+    const int zmWords = db->zm_words;
+    const uint8_t *__restrict__ mask = blob + db->off_mask;
+    const float *__restrict__ lut = reinterpret_cast<const float *>(blob + db->off_lut);
+    const int sidx = grp * kWave + lane;
+    const int L1 = L + 1;
+
+    // ---- phase A: simulate the L reference-residue columns (evolve.c:416-433), SPI sites per pass
+    // so that the stream loads and threshold look-ups of independent sites overlap; emit sigma
+    // codes for both strands.  Node states of a site are packed 2 bits per node into NODEW
+    // registers; the per-branch threshold table sits in LDS (the region phase B reuses for codes).
+    if (!(A.debugSkip & 2)) {
+      constexpr int SPI = 4;
+      constexpr int NODEW = (2 * N - 1 + 15) / 16;   // 16 nodes per 32-bit word
+      U4 *ldsThr = reinterpret_cast<U4 *>(lds_codes);
+      {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(nodes);
+        for (int idx = lane; idx < nnodes * 16; idx += kWave) lds_codes[idx] = src[(idx >> 4) * (sizeof(NodeRec) / 4) + (idx & 15)];
+      }
+      uint32_t win[N];
+#pragma unroll
+      for (int r = 0; r < N; r++) win[r] = 0;
+      unsigned int clamped = 0;
+      auto get_state = [&](const uint32_t (&ns)[NODEW], int q) -> uint32_t {   // q is wave-uniform
+        uint32_t word = ns[0];
+#pragma unroll
+        for (int x = 1; x < NODEW; x++) if ((q >> 4) == x) word = ns[x];
+        return (word >> (2 * (q & 15))) & 3u;
+      };
+      for (int i0 = 1; i0 <= L; i0 += SPI) {
+        size_t ubase[SPI];
+        uint32_t ns[SPI][NODEW];
+#pragma unroll
+        for (int t = 0; t < SPI; t++) {
+          const int i = (i0 + t <= L) ? i0 + t : L;     // tail: repeat the last site, results unused
+          ubase[t] = static_cast<size_t>(refcol[i]) * A.Spad + sidx;
+#pragma unroll
+          for (int x = 0; x < NODEW; x++) ns[t][x] = 0;
+        }
+        const size_t qstride = static_cast<size_t>(cols) * A.Spad;
+        for (int q = 0; q < nnodes; q++) {
+          const int pq = nodes[q].parent;
+          const uint32_t bp = nodes[q].basepack;
+          uint32_t u[SPI];
+#pragma unroll
+          for (int t = 0; t < SPI; t++) u[t] = Ustream[ubase[t] + q * qstride];
+#pragma unroll
+          for (int t = 0; t < SPI; t++) {
+            const uint32_t ps = (q == 0) ? 0u : get_state(ns[t], pq);
+            const U4 th = ldsThr[q * 4 + ps];
+            uint32_t st = (u[t] > th.x) + (u[t] > th.y) + (u[t] > th.z);
+            if (bp) st += (bp >> (2 * ps)) & 3u;
+            clamped += (u[t] > th.w);
+            const uint32_t bits = st << (2 * (q & 15));
+#pragma unroll
+            for (int x = 0; x < NODEW; x++) if (NODEW == 1 || (q >> 4) == x) ns[t][x] |= bits;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < SPI; t++) {
+          const int i = i0 + t;
+          if (i <= L) {
+#pragma unroll
+            for (int r = 0; r < N; r++) win[r] = ((win[r] << 2) | get_state(ns[t], qtip[r])) & 63u;
+            if (i >= 3) {
+              const int ip = L + 3 - i;  // reverse-strand position whose codon is these three columns
+              const uint32_t aF = win[0];
+              const uint32_t aR = codon_flip(aF) ^ 63u;
+#pragma unroll
+              for (int w = 0; w < NCW; w++) {
+                uint32_t wf = 0, wr = 0;
+#pragma unroll
+                for (int c = 0; c < CPW; c++) {
+                  const int k = w * CPW + c;  // 0-based index of sequence k+1
+                  if (k < NK) {
+                    const uint32_t bF = win[k + 1] & mask[(0 * NK + k) * L1 + i];
+                    const uint32_t bR = (codon_flip(win[k + 1]) ^ 63u) & mask[(1 * NK + k) * L1 + ip];
+                    wf |= static_cast<uint32_t>(pairTab[aF * 64 + bF]) << (6 * c);
+                    wr |= static_cast<uint32_t>(pairTab[aR * 64 + bR]) << (6 * c);
+                  }
+                }
+                cod[(static_cast<size_t>(0 * L1 + i) * NCW + w) * kWave + lane] = wf;
+                cod[(static_cast<size_t>(1 * L1 + ip) * NCW + w) * kWave + lane] = wr;
+              }
+            }
+          }
+        }
+      }
+      if (clamped) atomicAdd(A.clampCount, static_cast<unsigned long long>(clamped));
+    }
+
+    // ---- phase B: both strands x 3 frames: DP over (start a, end j) + serial HSS scan
+    float best = -1.0f;
+    // omega and Delta as per-lane values: v_add_f32 with two VGPR operands issues at the full rate,
+    // with an SGPR operand at ~60 % of it (tools/microbench.hip)
+    float omega_v, Delta_v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(omega_v) : "s"(omega));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(Delta_v) : "s"(Delta));
+    if (!(A.debugSkip & 1))
+    for (int s = 0; s < 2; s++) {
+      if (onlyCombo >= 0 && onlyCombo / 3 != s) continue;
+      Regs R;
+      static_for<NK>([&](auto kc) {  // 64-entry sigma table of sequence k spread over the 64 lanes
+        constexpr int k = decltype(kc)::value;
+        R.template at<k>().lut = __float_as_int(lut[(s * NK + k) * kLutSize + lane]);
+      });
+      for (int f = 0; f < 3; f++) {
+        const int sites = (L - f) / 3;
+        if (sites <= 0) continue;
+        if (onlyCombo >= 0 && onlyCombo % 3 != f) continue;
+        const uint32_t *__restrict__ cbase = cod + (static_cast<size_t>(s * L1 + 3 + f) * NCW) * kWave + lane;  // site j: + j*3*NCW*64
+        const unsigned long long *__restrict__ zbase = zw + s * L1 + 3 + f;                                       // site j: [3j]
+        const unsigned long long *__restrict__ zany = zmask + static_cast<size_t>(s * 3 + f) * zmWords;            // bit j: some z != 0 at site j
+        if constexpr (LDSC) {
+          for (int idx = 0; idx < sites * NCW; idx++)
+            lds_codes[idx * kWave + lane] = cbase[static_cast<size_t>(idx / NCW) * 3 * NCW * kWave + (idx % NCW) * kWave];
+          __builtin_amdgcn_s_waitcnt(0);   // everything landed: the row loops below issue no vector memory ops
+        }
+        auto load_words = [&](int j, uint32_t (&w)[NCW]) {
+#pragma unroll
+          for (int x = 0; x < NCW; x++) {
+            if constexpr (LDSC) w[x] = lds_codes[(j * NCW + x) * kWave + lane];
+            else w[x] = cbase[(static_cast<size_t>(j) * 3 * NCW + x) * kWave];
+          }
+        };
+        // sigma of every sequence at the site whose code words are w (all table look-ups first: their
+        // LDS round trips overlap).  ds_bpermute uses address bits [7:2] as the source lane.
+        auto lookup = [&](const uint32_t (&w)[NCW], float (&sig)[NK]) {
+          static_for<NK>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            constexpr int t = k % CPW;
+            uint32_t addr;
+            if constexpr (t == 0) addr = w[k / CPW] << 2; else addr = w[k / CPW] >> (6 * t - 2);
+            sig[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(static_cast<int>(addr), R.template at<k>().lut));
+          });
+          if constexpr (LDSC) __builtin_amdgcn_s_waitcnt(0xC07F);   // one lgkmcnt(0) instead of one wait per look-up
+        };
+        // S[a][j] = MAX3(sum, 0+Delta, 0+Delta)/(N-1) (score.c:841-843).  The reference starts the sum
+        // from 0; 0 + m == m except for the sign of a zero, which nothing observes.
+        auto finish = [&](float sum) -> float {
+          const float top = (sum > Delta_v) ? sum : Delta_v;
+          return div_by_nk<NK, EXACT>(top, nkf);
+        };
+        // codon without a frame shift in any sequence (z == 0 for all k, score.c:506-510): straight-line
+        auto fast_cell = [&](const uint32_t (&w)[NCW]) -> float {
+          float sig[NK];
+          lookup(w, sig);
+          float sum = 0.0f;
+          static_for<NK>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            auto &r = R.template at<k>();
+            r.s0 = r.s0 + sig[k];
+            r.s1 = r.s1 + omega_v;
+            r.s2 = r.s2 + omega_v;
+            const float m = fmaxf(fmaxf(r.s0, r.s1), r.s2);
+            sum = (k == 0) ? m : sum + m;
+          });
+          return finish(sum);
+        };
+        // codon where some sequence has z != 0 (score.c:512-533), wave-uniform branch per sequence
+        auto event_cell = [&](const uint32_t (&w)[NCW], int j) -> float {
+          float sig[NK];
+          lookup(w, sig);
+          const unsigned long long z = zbase[3 * j];
+          float sum = 0.0f;
+          static_for<NK>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            auto &r = R.template at<k>();
+            pair_step(static_cast<int>((z >> (2 * k)) & 3ull), sig[k], Delta, Omega, omega, r.s0, r.s1, r.s2);
+            const float m = fmaxf(fmaxf(r.s0, r.s1), r.s2);
+            sum = (k == 0) ? m : sum + m;
+          });
+          return finish(sum);
+        };
+        // first site >= j (and < end) with an event, or end
+        auto next_event = [&](int j, int end) -> int {
+          while (j < end) {
+            const unsigned long long mword = zany[j >> 6] >> (j & 63);
+            if (mword) { const int e = j + __builtin_ctzll(mword); return e < end ? e : end; }
+            j = (j | 63) + 1;
+          }
+          return end;
+        };
+        SampleScan st{0.0f, kScanInitKey};
+        for (int a = 0; a < sites; a++) {
+          static_for<NK>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            auto &r = R.template at<k>();
+            r.s0 = r.s1 = r.s2 = 0.0f;
+          });
+          uint32_t wcur[NCW];
+          load_words(a, wcur);
+          const int jend = (a == sites - 1) ? sites - 1 : sites;   // the frame's final entry is handled below
+          int j = a;
+          while (j < jend) {
+            const int e = next_event(j, jend);
+            for (; j < e; j++) {                                   // tight loop: no events
+              uint32_t wnext[NCW];
+              load_words(j + 1 < sites ? j + 1 : j, wnext);
+              const float v = fast_cell(wcur);
+              sample_scan_step(st, best, v, static_cast<uint32_t>(a), static_cast<uint32_t>(j - a), (static_cast<uint32_t>(j) << 16) | static_cast<uint32_t>(j - a), A.tieThr);
+#pragma unroll
+              for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
+            }
+            if (j < jend) {
+              uint32_t wnext[NCW];
+              load_words(j + 1 < sites ? j + 1 : j, wnext);
+              const float v = event_cell(wcur, j);
+              sample_scan_step(st, best, v, static_cast<uint32_t>(a), static_cast<uint32_t>(j - a), (static_cast<uint32_t>(j) << 16) | static_cast<uint32_t>(j - a), A.tieThr);
+#pragma unroll
+              for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
+              j++;
+            }
+          }
+        }
+        sample_scan_last(st, best);   // entry (sites-1, sites-1): its own value can never be reported
+      }
+    }
+    if (sidx < A.sampleN) {
+      float *dst = maxima + static_cast<size_t>(db->out_index) * A.sampleN + sidx;
+      // scores are positive floats or the -1 sentinel: integer order == float order on that set
+      if (A.comboSplit) atomicMax(reinterpret_cast<int *>(dst), __float_as_int(best));
+      else *dst = best;
+    }
+  }
+}
+
+
+// launch / occupancy of one N-1 value, used by the range units
+template <int NK>
+inline int null_occupancy_one(size_t ldsBytes) {
+  int nb = 0;
+  hipError_t e = ldsBytes ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_null<NK, true, false>, 64, ldsBytes)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_null<NK, false, false>, 64, kMaxNodes * 64);
+  if (e != hipSuccess) return 0;
+  return nb;
+}
+
+// exact: the class contains blocks flagged exact_div (never staged in LDS: a rare parameter choice)
+template <int NK>
+inline void launch_null_one(const NullArgs &a, int grid, size_t ldsBytes, bool exact, hipStream_t stream) {
+  if (exact) {
+    hipLaunchKernelGGL((k_null<NK, false, true>), dim3(grid), dim3(64), kMaxNodes * 64, stream, a, a.blob, a.dblocks,
+                       a.classBlocks, a.U, a.pair, a.scratch, a.maxima);
+  } else if (ldsBytes) {
+    if (ldsBytes > 48 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_null<NK, true, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsBytes));
+    hipLaunchKernelGGL((k_null<NK, true, false>), dim3(grid), dim3(64), ldsBytes, stream, a, a.blob, a.dblocks,
+                       a.classBlocks, a.U, a.pair, a.scratch, a.maxima);
+  } else {
+    hipLaunchKernelGGL((k_null<NK, false, false>), dim3(grid), dim3(64), kMaxNodes * 64, stream, a, a.blob, a.dblocks,
+                       a.classBlocks, a.U, a.pair, a.scratch, a.maxima);
+  }
+}
+
+// one translation unit per range [LO, HI]
+#define RC_DEFINE_NULL_RANGE(SUFFIX, LO, HI)                                                        \
+  template <int NK> static int occ_rec_##SUFFIX(int nk, size_t lds) {                                \
+    if constexpr (NK > HI) return 0;                                                                 \
+    else return nk == NK ? null_occupancy_one<NK>(lds) : occ_rec_##SUFFIX<NK + 1>(nk, lds);           \
+  }                                                                                                  \
+  template <int NK> static bool launch_rec_##SUFFIX(int nk, const NullArgs &a, int grid, size_t lds, bool exact, hipStream_t st) { \
+    if constexpr (NK > HI) return false;                                                             \
+    else {                                                                                           \
+      if (nk == NK) { launch_null_one<NK>(a, grid, lds, exact, st); return true; }                   \
+      return launch_rec_##SUFFIX<NK + 1>(nk, a, grid, lds, exact, st);                               \
+    }                                                                                                \
+  }                                                                                                  \
+  int null_occupancy_##SUFFIX(int nk, size_t lds) { return occ_rec_##SUFFIX<LO>(nk, lds); }          \
+  bool launch_null_##SUFFIX(int nk, const NullArgs &a, int grid, size_t lds, bool exact, hipStream_t st) { \
+    return launch_rec_##SUFFIX<LO>(nk, a, grid, lds, exact, st);                                     \
+  }
+
+}  // namespace rc
