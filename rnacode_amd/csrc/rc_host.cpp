@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 namespace rc {
 
@@ -296,23 +297,40 @@ void PairTable::build(const CodeTables &ct) {
     for (int j = 0; j < 20; j++) seen[ct.blosum[i][j] + 32] = true;
   nB = 0;
   for (int v = -32; v < 32; v++) if (seen[v + 32]) bval[nB++] = v;
-  code_zero = 3 * nB; code_stop0 = 3 * nB + 1; code_stopk = 3 * nB + 2;
+  const int nCodes = 3 * nB + 3;
+  // "natural" numbering: 3*bIdx + (h-1), then zero / stop0 / stopk
+  auto natural = [&](int a, int b) {
+    const int x = a ^ b;
+    const int h = ((x & 48) != 0) + ((x & 12) != 0) + ((x & 3) != 0);
+    if (h == 0) return 3 * nB;                          // score.c:409
+    if (ct.pep[a] == -1) return 3 * nB + 1;             // score.c:414
+    if (ct.pep[b] == -1) return 3 * nB + 2;             // score.c:418
+    const int v = ct.blosum[ct.pep[a]][ct.pep[b]];
+    int bi = 0;
+    while (bval[bi] != v) bi++;
+    return 3 * bi + (h - 1);
+  };
+  // The kernel looks sigma up with ds_bpermute, whose source lanes l and l+32 share a bank: two
+  // DIFFERENT codes in one bank cost an extra LDS cycle per wavefront.  Number the codes so that
+  // the 32 most frequent ones (under a generic neutral model: uniform codons, 20 % per-site
+  // divergence) get distinct banks and the rare rest shares banks with the rarest of those.
+  std::vector<double> weight(nCodes, 0.0);
   for (int a = 0; a < 64; a++)
     for (int b = 0; b < 64; b++) {
       const int x = a ^ b;
       const int h = ((x & 48) != 0) + ((x & 12) != 0) + ((x & 3) != 0);
-      int code;
-      if (h == 0) code = code_zero;                       // score.c:409
-      else if (ct.pep[a] == -1) code = code_stop0;        // score.c:414
-      else if (ct.pep[b] == -1) code = code_stopk;        // score.c:418
-      else {
-        const int v = ct.blosum[ct.pep[a]][ct.pep[b]];
-        int bi = 0;
-        while (bval[bi] != v) bi++;
-        code = 3 * bi + (h - 1);
-      }
-      pair[a * 64 + b] = static_cast<uint8_t>(code);
+      weight[natural(a, b)] += std::pow(0.8, 3 - h) * std::pow(0.2 / 3.0, h);
     }
+  std::vector<int> order(nCodes);
+  for (int i = 0; i < nCodes; i++) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return weight[x] > weight[y]; });
+  std::vector<int> slot(nCodes);
+  for (int r = 0; r < nCodes; r++) slot[order[r]] = r < 32 ? r : 32 + (31 - (r - 32));
+  for (int i = 0; i < 64; i++) { nat_of_slot[i] = -1; }
+  for (int i = 0; i < nCodes; i++) nat_of_slot[slot[i]] = i;
+  code_zero = slot[3 * nB]; code_stop0 = slot[3 * nB + 1]; code_stopk = slot[3 * nB + 2];
+  for (int a = 0; a < 64; a++)
+    for (int b = 0; b < 64; b++) pair[a * 64 + b] = static_cast<uint8_t>(slot[natural(a, b)]);
 }
 
 // ---------------------------------------------------------------------------------- gap pattern
@@ -424,12 +442,14 @@ int prepare_block(const rc_block &in, const rc_params &par, const CodeTables &ct
     hb.lut[s].assign(static_cast<size_t>(hb.NK) * kLutSize, 0.0f);
     for (int k = 1; k < N; k++) {
       float *lut = &hb.lut[s][static_cast<size_t>(k - 1) * kLutSize];
-      for (int code = 0; code < 3 * pt.nB; code++)   // (float)matrix[pepA][pepB] - scores[h], score.c:422-425
+      for (int code = 0; code < kLutSize; code++) {   // (float)matrix[pepA][pepB] - scores[h], score.c:422-425
+        if (!pt.is_score_code(code)) continue;
         lut[code] = static_cast<float>(pt.b_of_code(code)) - hb.models[s][k].scores[pt.h_of_code(code)];
+      }
       lut[pt.code_zero] = 0.0f;
       lut[pt.code_stop0] = par.stopPenalty_0;
       lut[pt.code_stopk] = par.stopPenalty_k;
-      for (int code = 0; code <= pt.code_stopk; code++) if (!in_div_range(lut[code])) hb.exact_div = 1;
+      for (int code = 0; code < kLutSize; code++) if (!in_div_range(lut[code])) hb.exact_div = 1;
     }
   }
 
@@ -450,6 +470,7 @@ int prepare_block(const rc_block &in, const rc_params &par, const CodeTables &ct
     }
   }
   if (!in_div_range(par.Delta) || !in_div_range(par.Omega) || !in_div_range(par.omega)) hb.exact_div = 1;
+  if (!(par.Delta < 0.0f)) hb.exact_div = 1;   // the fast kernel drops MAX3(sum, Delta, Delta): only valid for Delta < 0
   hb.qtip.assign(N, 0);
   for (int r = 0; r < N; r++) {
     const int q = t.tipnode[rowtip[r]];

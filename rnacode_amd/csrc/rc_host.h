@@ -28,8 +28,10 @@ struct PairTable {
   int bval[32];               // sorted distinct values
   int code_zero = 0, code_stop0 = 0, code_stopk = 0;
   uint8_t pair[64 * 64];      // [codonA][codonB] -> code  (calculateSigma, score.c:406-425, minus the 'N' test)
-  int h_of_code(int code) const { return code < 3 * nB ? code % 3 + 1 : 0; }
-  int b_of_code(int code) const { return bval[code / 3]; }
+  int nat_of_slot[64];        // code -> natural number 3*bIdx + (h-1) (or 3nB.. for the specials), -1 = unused
+  bool is_score_code(int code) const { return nat_of_slot[code] >= 0 && nat_of_slot[code] < 3 * nB; }
+  int h_of_code(int code) const { return nat_of_slot[code] % 3 + 1; }
+  int b_of_code(int code) const { return bval[nat_of_slot[code] / 3]; }
   void build(const CodeTables &ct);
 };
 

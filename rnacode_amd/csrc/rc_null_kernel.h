@@ -232,8 +232,9 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
                   if (k < NK) {
                     const uint32_t bF = win[k + 1] & mask[(0 * NK + k) * L1 + i];
                     const uint32_t bR = (codon_flip(win[k + 1]) ^ 63u) & mask[(1 * NK + k) * L1 + ip];
+                    if (A.debugSkip & 4) { wf |= ((aF ^ bF) & 63u) << (6 * c); wr |= ((aR ^ bR) & 63u) << (6 * c); } else {
                     wf |= static_cast<uint32_t>(pairTab[aF * 64 + bF]) << (6 * c);
-                    wr |= static_cast<uint32_t>(pairTab[aR * 64 + bR]) << (6 * c);
+                    wr |= static_cast<uint32_t>(pairTab[aR * 64 + bR]) << (6 * c); }
                   }
                 }
                 cod[(static_cast<size_t>(0 * L1 + i) * NCW + w) * kWave + lane] = wf;
@@ -250,9 +251,9 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
     float best = -1.0f;
     // omega and Delta as per-lane values: v_add_f32 with two VGPR operands issues at the full rate,
     // with an SGPR operand at ~60 % of it (tools/microbench.hip)
-    float omega_v, Delta_v;
+    float omega_v, Delta_v = 0.0f;
     asm volatile("v_mov_b32 %0, %1" : "=v"(omega_v) : "s"(omega));
-    asm volatile("v_mov_b32 %0, %1" : "=v"(Delta_v) : "s"(Delta));
+    if constexpr (EXACT) asm volatile("v_mov_b32 %0, %1" : "=v"(Delta_v) : "s"(Delta));
     if (!(A.debugSkip & 1))
     for (int s = 0; s < 2; s++) {
       if (onlyCombo >= 0 && onlyCombo / 3 != s) continue;
@@ -280,23 +281,54 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
             else w[x] = cbase[(static_cast<size_t>(j) * 3 * NCW + x) * kWave];
           }
         };
-        // sigma of every sequence at the site whose code words are w (all table look-ups first: their
-        // LDS round trips overlap).  ds_bpermute uses address bits [7:2] as the source lane.
+        // sigma of every sequence at the site whose code words are w: a 64-entry table look-up per
+        // sequence through ds_bpermute (address bits [7:2] select the source lane).  Written as asm so
+        // that all look-ups of a code word are in flight together and ONE lgkmcnt(0) covers them (the
+        // compiler would put a wait in front of every use); the "+v" operands tie the wait between
+        // the look-ups and their first use.
         auto lookup = [&](const uint32_t (&w)[NCW], float (&sig)[NK]) {
           static_for<NK>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             constexpr int t = k % CPW;
             uint32_t addr;
             if constexpr (t == 0) addr = w[k / CPW] << 2; else addr = w[k / CPW] >> (6 * t - 2);
-            sig[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(static_cast<int>(addr), R.template at<k>().lut));
+            const int lutv = R.template at<k>().lut;
+            float got;
+            asm volatile("ds_bpermute_b32 %0, %1, %2" : "=v"(got) : "v"(addr), "v"(lutv));
+            sig[k] = got;
           });
-          if constexpr (LDSC) __builtin_amdgcn_s_waitcnt(0xC07F);   // one lgkmcnt(0) instead of one wait per look-up
+          {   // one wait for everything in flight; operands of the last code word pin its position
+            constexpr int k0 = (NCW - 1) * CPW;
+            constexpr int cnt = NK - k0;
+            float a0 = sig[k0], a1 = sig[cnt > 1 ? k0 + 1 : k0], a2 = sig[cnt > 2 ? k0 + 2 : k0], a3 = sig[cnt > 3 ? k0 + 3 : k0],
+                  a4 = sig[cnt > 4 ? k0 + 4 : k0];
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4));
+            if constexpr (cnt > 1) sig[k0 + 1] = a1;
+            if constexpr (cnt > 2) sig[k0 + 2] = a2;
+            if constexpr (cnt > 3) sig[k0 + 3] = a3;
+            if constexpr (cnt > 4) sig[k0 + 4] = a4;
+            // earlier words: make their values depend on the wait as well (no instruction emitted)
+            static_for<NK>([&](auto kc) {
+              constexpr int k = decltype(kc)::value;
+              if constexpr (k < k0) {
+                float b = sig[k];
+                asm volatile("" : "+v"(b), "+v"(a0));
+                sig[k] = b;
+              }
+            });
+            sig[k0] = a0;
+          }
         };
-        // S[a][j] = MAX3(sum, 0+Delta, 0+Delta)/(N-1) (score.c:841-843).  The reference starts the sum
-        // from 0; 0 + m == m except for the sign of a zero, which nothing observes.
+        // Only positive S values ever reach a sample's result (getHSS ignores the rest and the frame's
+        // final entry is never reported), and for Delta < 0 a positive S equals sum/(N-1): the fast
+        // instantiation skips the MAX3 with Delta; blocks with Delta >= 0 are routed to EXACT.
         auto finish = [&](float sum) -> float {
-          const float top = (sum > Delta_v) ? sum : Delta_v;
-          return div_by_nk<NK, EXACT>(top, nkf);
+          if constexpr (EXACT) {
+            const float top = (sum > Delta_v) ? sum : Delta_v;
+            return div_by_nk<NK, EXACT>(top, nkf);
+          } else {
+            return div_by_nk<NK, EXACT>(sum, nkf);
+          }
         };
         // codon without a frame shift in any sequence (z == 0 for all k, score.c:506-510): straight-line
         auto fast_cell = [&](const uint32_t (&w)[NCW]) -> float {
@@ -310,6 +342,23 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
             r.s1 = r.s1 + omega_v;
             r.s2 = r.s2 + omega_v;
             const float m = fmaxf(fmaxf(r.s0, r.s1), r.s2);
+            sum = (k == 0) ? m : sum + m;
+          });
+          return finish(sum);
+        };
+        // the same before the row has met its first event: states 1 and 2 of EVERY sequence have only
+        // ever received "+ omega" from 0, so they all hold the one value w (identical operations on
+        // identical operands); MAX3(s0, w, w) = max(s0, w).  w advances once per codon.
+        auto pristine_cell = [&](const uint32_t (&w)[NCW], float &wv) -> float {
+          float sig[NK];
+          lookup(w, sig);
+          wv = wv + omega_v;
+          float sum = 0.0f;
+          static_for<NK>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            auto &r = R.template at<k>();
+            r.s0 = r.s0 + sig[k];
+            const float m = fmaxf(r.s0, wv);
             sum = (k == 0) ? m : sum + m;
           });
           return finish(sum);
@@ -349,7 +398,34 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
           load_words(a, wcur);
           const int jend = (a == sites - 1) ? sites - 1 : sites;   // the frame's final entry is handled below
           int j = a;
+          {   // pristine segment: up to the row's first event
+            const int e = next_event(j, jend);
+            float wv = 0.0f;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(wv));   // keep w a per-lane register (full-rate v_add/v_max operands)
+            for (; j < e; j++) {
+              uint32_t wnext[NCW];
+              load_words(j + 1 < sites ? j + 1 : j, wnext);
+              const float v = pristine_cell(wcur, wv);
+              sample_scan_step(st, best, v, static_cast<uint32_t>(a), static_cast<uint32_t>(j - a), (static_cast<uint32_t>(j) << 16) | static_cast<uint32_t>(j - a), A.tieThr);
+#pragma unroll
+              for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
+            }
+            static_for<NK>([&](auto kc) {
+              constexpr int k = decltype(kc)::value;
+              auto &r = R.template at<k>();
+              r.s1 = r.s2 = wv;
+            });
+          }
           while (j < jend) {
+            if ((zany[j >> 6] >> (j & 63)) & 1ull) {               // event codon
+              uint32_t wnext[NCW];
+              load_words(j + 1 < sites ? j + 1 : j, wnext);
+              const float v = event_cell(wcur, j);
+              sample_scan_step(st, best, v, static_cast<uint32_t>(a), static_cast<uint32_t>(j - a), (static_cast<uint32_t>(j) << 16) | static_cast<uint32_t>(j - a), A.tieThr);
+#pragma unroll
+              for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
+              j++;
+            }
             const int e = next_event(j, jend);
             for (; j < e; j++) {                                   // tight loop: no events
               uint32_t wnext[NCW];
@@ -358,15 +434,6 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
               sample_scan_step(st, best, v, static_cast<uint32_t>(a), static_cast<uint32_t>(j - a), (static_cast<uint32_t>(j) << 16) | static_cast<uint32_t>(j - a), A.tieThr);
 #pragma unroll
               for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
-            }
-            if (j < jend) {
-              uint32_t wnext[NCW];
-              load_words(j + 1 < sites ? j + 1 : j, wnext);
-              const float v = event_cell(wcur, j);
-              sample_scan_step(st, best, v, static_cast<uint32_t>(a), static_cast<uint32_t>(j - a), (static_cast<uint32_t>(j) << 16) | static_cast<uint32_t>(j - a), A.tieThr);
-#pragma unroll
-              for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
-              j++;
             }
           }
         }
