@@ -144,6 +144,16 @@ int rc_batch_native_S(const rc_batch *b, int32_t blk, int32_t strand /*0:'+',1:'
 int rc_batch_backtrack(const rc_batch *b, int32_t blk, int32_t strand, int32_t opt_b, int32_t opt_i,
                        int32_t *states, int32_t *z, int32_t *transitions);
 
+/* Tree + kappa for one block, the inputs treeML() hands to the scorer (src/treeML.c:35-152 via the
+ * bundled PhyML): BIONJ topology from pairwise ML distances, HKY85 maximum-likelihood branch lengths
+ * and kappa.  Host code, re-entrant (call it from several threads); blk->newick/kappa are ignored.
+ * Agreement with PhyML is to optimiser tolerance, not bitwise.
+ * Writes a NUL-terminated Newick string ("%f" branch lengths) into newick_out[cap]. */
+int rc_fit_tree(const rc_block *blk, char *newick_out, int32_t cap, float *kappa_out);
+/* HKY85 log-likelihood of blk->newick / blk->kappa on blk's rows under the same model and data
+ * handling (diagnostic: compares a tree from elsewhere with rc_fit_tree's on equal terms). */
+int rc_tree_lnl(const rc_block *blk, double *lnl_out);
+
 /* EVDMaxLikelyFit (src/extreme_fit.c:157-251) on the device for n doubles; returns 1 / 0. */
 int rc_evd_fit(rc_ctx *ctx, const double *x, int32_t n, double *mu, double *lambda);
 

@@ -108,6 +108,8 @@ def lib():
                                          C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         l.rc_evd_fit.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         l.rc_mt_stream.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_int32]
+        l.rc_fit_tree.argtypes = [C.POINTER(RcBlock), C.c_char_p, C.c_int32, C.POINTER(C.c_float)]
+        l.rc_tree_lnl.argtypes = [C.POINTER(RcBlock), C.POINTER(C.c_double)]
         l.rc_set_stream_cache.argtypes = [C.c_int]
         l.rc_set_stream_cache.restype = None
         _lib = l
@@ -118,7 +120,7 @@ EXPORTED_SYMBOLS = [
     "rc_default_params", "rc_last_error", "rc_device_count", "rc_ctx_create", "rc_ctx_destroy", "rc_batch_create",
     "rc_batch_destroy", "rc_batch_bind_maxima", "rc_batch_run", "rc_set_stream_cache", "rc_batch_work", "rc_batch_timing", "rc_batch_status",
     "rc_batch_models", "rc_batch_maxima", "rc_batch_maxima_all", "rc_batch_fit", "rc_batch_hss", "rc_batch_clamped",
-    "rc_batch_native_S", "rc_batch_backtrack", "rc_evd_fit", "rc_mt_stream",
+    "rc_batch_native_S", "rc_batch_backtrack", "rc_fit_tree", "rc_tree_lnl", "rc_evd_fit", "rc_mt_stream",
 ]
 
 
@@ -136,6 +138,27 @@ def default_params(**kw) -> RcParams:
             raise KeyError(k)
         setattr(p, k, v)
     return p
+
+
+def fit_tree(block: AlnBlock) -> Tuple[str, float]:
+    """Tree + kappa of one block (what treeML hands to the scorer, src/treeML.c:35-152); host code."""
+    rows = (C.c_char_p * block.n)(*[r.seq.encode() for r in block.rows])
+    names = (C.c_char_p * block.n)(*[r.name.encode() for r in block.rows])
+    blk = RcBlock(block.n, block.cols, rows, names, block.rows[0].start, block.rows[0].length, None, 0.0)
+    buf = C.create_string_buffer(1 << 16)
+    kappa = C.c_float()
+    _check(lib().rc_fit_tree(C.byref(blk), buf, len(buf), C.byref(kappa)))
+    return buf.value.decode(), float(kappa.value)
+
+
+def tree_lnl(block: AlnBlock, newick: str, kappa: float) -> float:
+    """HKY85 log-likelihood of a given tree + kappa on the block (same model/data handling as fit_tree)."""
+    rows = (C.c_char_p * block.n)(*[r.seq.encode() for r in block.rows])
+    names = (C.c_char_p * block.n)(*[r.name.encode() for r in block.rows])
+    blk = RcBlock(block.n, block.cols, rows, names, block.rows[0].start, block.rows[0].length, newick.encode(), kappa)
+    out = C.c_double()
+    _check(lib().rc_tree_lnl(C.byref(blk), C.byref(out)))
+    return out.value
 
 
 class Context:

@@ -6,9 +6,10 @@ options that concern the scoring path and the listings:
     python -m rnacode_amd.cli [-n N] [-p CUTOFF] [-g | -t] [-b] [-r] [-s] [-m 62|90] [-c D,O,o,S]
                               [-o OUT] --trees SIDECAR [FILE]
 
-The tree + kappa fit (PhyML, RNAcode.c:153) is not part of the hot path and is not built: every
-block needs a sidecar entry `<newick> TAB <kappa>` (one line per alignment block, in file order;
-`-` for blocks the driver skips).  All blocks of the file are scored as ONE batch on the GPU.
+Tree + kappa per block (PhyML in the reference, RNAcode.c:153) come either from a sidecar
+(`--trees`: one `<newick> TAB <kappa>` line per alignment block, in file order; `-` for blocks the
+driver skips) or, without it, from the built-in estimator (rc_fit_tree, host threads).  All blocks
+of the file are scored as ONE batch on the GPU.
 Quirk kept from the reference: the 4th value of --pars goes to stopPenalty_0 (RNAcode.c:318)."""
 from __future__ import annotations
 
@@ -36,6 +37,18 @@ def read_sidecar(path: str) -> List[Optional[tuple]]:
     return out
 
 
+def fit_trees(blocks: List[AlnBlock], threads: int = 0) -> List[Optional[tuple]]:
+    """rc_fit_tree for every block the driver will score (ctypes releases the GIL: real threads)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(b):
+        return None if (b.n <= 2 or b.ref_len < 3) else api.fit_tree(b)
+
+    with ThreadPoolExecutor(threads or min(32, os.cpu_count() or 1)) as ex:
+        return list(ex.map(one, blocks))
+
+
 def main(argv=None) -> int:
     ap = argparse.ArgumentParser(prog="rnacode-hip", description="RNAcode scoring path on MI355X")
     ap.add_argument("file", nargs="?", help="alignment file (MAF or ClustalW); default stdin")
@@ -49,7 +62,7 @@ def main(argv=None) -> int:
     ap.add_argument("-p", "--cutoff", type=float, default=1.0)
     ap.add_argument("-c", "--pars")
     ap.add_argument("-m", "--blosum", type=int, default=62)
-    ap.add_argument("--trees", required=True, help="sidecar: one '<newick>\\t<kappa>' line per block")
+    ap.add_argument("--trees", help="sidecar: one '<newick>\\t<kappa>' line per block (default: fit them)")
     ap.add_argument("--seed-base", type=int, default=42)
     ap.add_argument("--device", type=int, default=0)
     a = ap.parse_args(argv)
@@ -71,13 +84,16 @@ def main(argv=None) -> int:
         with tempfile.NamedTemporaryFile("w", delete=False) as fh:
             fh.write(sys.stdin.read())
         blocks = read_alignment_file(fh.name)
-    side = read_sidecar(a.trees)
-    if len(side) != len(blocks):
-        print(f"ERROR: {len(blocks)} alignment blocks but {len(side)} sidecar entries", file=sys.stderr)
-        return 1
+    blocks = [b.upper() for b in blocks]
+    if a.trees:
+        side = read_sidecar(a.trees)
+        if len(side) != len(blocks):
+            print(f"ERROR: {len(blocks)} alignment blocks but {len(side)} sidecar entries", file=sys.stderr)
+            return 1
+    else:
+        side = fit_trees(blocks)
     prepared: List[AlnBlock] = []
     for b, s in zip(blocks, side):
-        b = b.upper()
         b.tree, b.kappa = s if s is not None else ("(a:0.1,b:0.1,c:0.1);", 2.0)   # skipped blocks never reach the tree
         prepared.append(b)
 

@@ -650,6 +650,28 @@ int rc_batch_backtrack(const rc_batch *b, int32_t blk, int32_t strand, int32_t o
   return RC_OK;
 }
 
+int rc_fit_tree(const rc_block *blk, char *newick_out, int32_t cap, float *kappa_out) {
+  if (!blk || !newick_out || cap < 8 || !kappa_out || !blk->rows || !blk->names) return fail(RC_ERR_ARG, "bad argument");
+  std::vector<std::string> rows(blk->n_rows), names(blk->n_rows);
+  for (int r = 0; r < blk->n_rows; r++) { rows[r] = blk->rows[r]; names[r] = blk->names[r]; }
+  std::string nwk, err;
+  float kappa = 0;
+  if (!fit_tree(rows, names, nwk, kappa, nullptr, err)) return fail(RC_ERR_ARG, err);
+  if (static_cast<int>(nwk.size()) + 1 > cap) return fail(RC_ERR_ARG, "newick buffer too small");
+  std::memcpy(newick_out, nwk.c_str(), nwk.size() + 1);
+  *kappa_out = kappa;
+  return RC_OK;
+}
+
+int rc_tree_lnl(const rc_block *blk, double *lnl_out) {
+  if (!blk || !lnl_out || !blk->rows || !blk->names || !blk->newick) return fail(RC_ERR_ARG, "bad argument");
+  std::vector<std::string> rows(blk->n_rows), names(blk->n_rows);
+  for (int r = 0; r < blk->n_rows; r++) { rows[r] = blk->rows[r]; names[r] = blk->names[r]; }
+  std::string err;
+  if (!tree_lnl(rows, names, blk->newick, blk->kappa, lnl_out, err)) return fail(RC_ERR_ARG, err);
+  return RC_OK;
+}
+
 int rc_evd_fit(rc_ctx *c, const double *x, int32_t n, double *mu, double *lambda) {
   if (!c || !x || n < 1) return fail(RC_ERR_ARG, "bad argument");
   HIP_TRY(hipSetDevice(c->device));

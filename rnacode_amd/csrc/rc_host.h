@@ -54,6 +54,13 @@ struct HostBlock {
 int prepare_block(const rc_block &in, const rc_params &par, const CodeTables &ct, const PairTable &pt,
                   HostBlock &out, std::string &err);
 
+// tree + kappa estimator (rc_tree.cpp)
+bool fit_tree(const std::vector<std::string> &rows, const std::vector<std::string> &names, std::string &newick,
+              float &kappa, double *lnl_out, std::string &err);
+
+bool tree_lnl(const std::vector<std::string> &rows, const std::vector<std::string> &names, const char *newick, float kappa,
+              double *lnl_out, std::string &err);
+
 // extreme_fit.c / RNAcode.c:182 pieces that stay on the host
 float pvalue_of(float score, float mu, float lambda);
 

@@ -284,3 +284,37 @@ def test_extreme_shapes_against_oracle(ctx):
     with pytest.raises(api.RnacodeError) as ei:
         api.Batch(ctx, big, api.default_params())
     assert ei.value.code == api.RC_ERR_UNSUPPORTED
+
+
+def test_built_in_trees_give_the_same_calls_as_phyml_trees(ctx):
+    """Section 8f-2 end to end: with trees from rc_fit_tree instead of PhyML the strong HSS keep their
+    coordinates and their scores move by well under a percent (the null samples differ: another tree
+    orientation means other draws, so p-values are compared on the log scale only)."""
+    from rnacode_amd import api, cli
+    doc = load_golden("genomic_preprocessed_n1000")
+    blocks = [block_from_golden(e) for e in doc["blocks"]]
+    trees = cli.fit_trees(blocks)
+    mine = []
+    for b, t in zip(blocks, trees):
+        nb = block_from_golden({"input": dict(id=b.block_id, rows=[dict(name=r.name, seq=r.seq, start=r.start, length=r.length,
+                               strand=r.strand, full_length=r.full_length) for r in b.rows]), "ref": {}})
+        nb.tree, nb.kappa = t if t is not None else ("(a:0.1,b:0.1,c:0.1);", 2.0)
+        mine.append(nb)
+    batch = api.Batch(ctx, mine, api.default_params(sampleN=1000, seed_base=42)).run()
+    checked = 0
+    for i, e in enumerate(doc["blocks"]):
+        if "skipped" in e["ref"]:
+            continue
+        want = sorted(e["ref"]["hss"], key=hss_key)
+        got = sorted(batch.scoreAln(i), key=hss_key)
+        for w in want:
+            if w["score"] < 15.0:
+                break
+            g = next((h for h in got if (h["strand"], h["frame"], h["start"], h["end"]) == (w["strand"], w["frame"], w["start"], w["end"])), None)
+            assert g is not None, (i, w)
+            assert abs(g["score"] - w["score"]) <= 0.01 * w["score"]
+            if w["pvalue"] > 0:
+                assert abs(np.log10(max(g["pvalue"], 1e-300)) - np.log10(w["pvalue"])) < 1.5
+            checked += 1
+    assert checked >= 20
+    batch.close()
