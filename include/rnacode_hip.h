@@ -150,6 +150,10 @@ int rc_batch_backtrack(const rc_batch *b, int32_t blk, int32_t strand, int32_t o
  * Agreement with PhyML is to optimiser tolerance, not bitwise.
  * Writes a NUL-terminated Newick string ("%f" branch lengths) into newick_out[cap]. */
 int rc_fit_tree(const rc_block *blk, char *newick_out, int32_t cap, float *kappa_out);
+/* The same for n_blocks blocks on `threads` host threads (0 = hardware concurrency).  newick_out is one
+ * buffer of n_blocks * cap bytes (block i at i*cap); blocks the driver skips (N <= 2, L < 3) or that
+ * fail get an empty string and kappa 0.  Returns the number of fitted blocks. */
+int rc_fit_trees(const rc_block *blocks, int32_t n_blocks, char *newick_out, int32_t cap, float *kappa_out, int32_t threads);
 /* HKY85 log-likelihood of blk->newick / blk->kappa on blk's rows under the same model and data
  * handling (diagnostic: compares a tree from elsewhere with rc_fit_tree's on equal terms). */
 int rc_tree_lnl(const rc_block *blk, double *lnl_out);

@@ -38,15 +38,8 @@ def read_sidecar(path: str) -> List[Optional[tuple]]:
 
 
 def fit_trees(blocks: List[AlnBlock], threads: int = 0) -> List[Optional[tuple]]:
-    """rc_fit_tree for every block the driver will score (ctypes releases the GIL: real threads)."""
-    import os
-    from concurrent.futures import ThreadPoolExecutor
-
-    def one(b):
-        return None if (b.n <= 2 or b.ref_len < 3) else api.fit_tree(b)
-
-    with ThreadPoolExecutor(threads or min(32, os.cpu_count() or 1)) as ex:
-        return list(ex.map(one, blocks))
+    """Trees + kappas for every block the driver will score (rc_fit_trees, host threads)."""
+    return api.fit_trees(blocks, threads)
 
 
 def main(argv=None) -> int:

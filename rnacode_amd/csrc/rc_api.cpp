@@ -663,6 +663,39 @@ int rc_fit_tree(const rc_block *blk, char *newick_out, int32_t cap, float *kappa
   return RC_OK;
 }
 
+int rc_fit_trees(const rc_block *blocks, int32_t n_blocks, char *newick_out, int32_t cap, float *kappa_out, int32_t threads) {
+  if (!blocks || !newick_out || !kappa_out || n_blocks < 0 || cap < 8) return fail(RC_ERR_ARG, "bad argument");
+  std::atomic<int> next{0}, done{0};
+  unsigned nt = threads > 0 ? static_cast<unsigned>(threads) : std::max(1u, std::thread::hardware_concurrency());
+  nt = std::min<unsigned>(nt, static_cast<unsigned>(std::max(1, n_blocks)));
+  auto work = [&]() {
+    for (;;) {
+      const int i = next.fetch_add(1);
+      if (i >= n_blocks) break;
+      char *dst = newick_out + static_cast<size_t>(i) * cap;
+      dst[0] = 0; kappa_out[i] = 0.0f;
+      const rc_block &b = blocks[i];
+      if (!b.rows || !b.names || b.n_rows <= 2) continue;
+      int L = 0;
+      for (const char *p = b.rows[0]; *p; p++) L += (*p != '-');
+      if (L < 3) continue;
+      std::vector<std::string> rows(b.n_rows), names(b.n_rows);
+      for (int r = 0; r < b.n_rows; r++) { rows[r] = b.rows[r]; names[r] = b.names[r]; }
+      std::string nwk, err;
+      float kappa = 0;
+      if (!fit_tree(rows, names, nwk, kappa, nullptr, err) || static_cast<int>(nwk.size()) + 1 > cap) continue;
+      std::memcpy(dst, nwk.c_str(), nwk.size() + 1);
+      kappa_out[i] = kappa;
+      done.fetch_add(1);
+    }
+  };
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+  work();
+  for (auto &x : th) x.join();
+  return done.load();
+}
+
 int rc_tree_lnl(const rc_block *blk, double *lnl_out) {
   if (!blk || !lnl_out || !blk->rows || !blk->names || !blk->newick) return fail(RC_ERR_ARG, "bad argument");
   std::vector<std::string> rows(blk->n_rows), names(blk->n_rows);

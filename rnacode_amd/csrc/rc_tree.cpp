@@ -105,7 +105,6 @@ struct Fitter {
   std::vector<int> parent;
   std::vector<std::vector<int>> child;
   std::vector<double> len;                // branch to parent
-  std::vector<std::vector<double>> down, up;   // [node][pattern*4]
 
   void compress(const std::vector<std::string> &rows) {
     N = static_cast<int>(rows.size());
@@ -217,54 +216,61 @@ struct Fitter {
     for (int k = 0; k < 3; k++) { parent[node[s3[k]]] = root; child[root].push_back(node[s3[k]]); }
   }
 
-  void tip_partial(int t, std::vector<double> &L) const {
-    L.assign(static_cast<size_t>(P) * 4, 0.0);
-    for (int p = 0; p < P; p++) for (int s = 0; s < 4; s++) L[p * 4 + s] = (pat[t][p] >> s & 1) ? 1.0 : 0.0;
+  // flat work arrays [node][pattern][state], allocated once per fit
+  std::vector<double> downA, upA, msgA;
+  std::vector<int> preorder;
+  double *dn(int v) { return downA.data() + static_cast<size_t>(v) * P * 4; }
+  double *upp(int v) { return upA.data() + static_cast<size_t>(v) * P * 4; }
+  double *ms(int v) { return msgA.data() + static_cast<size_t>(v) * P * 4; }
+  const double *dn(int v) const { return downA.data() + static_cast<size_t>(v) * P * 4; }
+  const double *upp(int v) const { return upA.data() + static_cast<size_t>(v) * P * 4; }
+
+  void prepare() {
+    const size_t sz = static_cast<size_t>(nn) * P * 4;
+    downA.assign(sz, 0.0); upA.assign(sz, 0.0); msgA.assign(sz, 0.0);
+    preorder.clear();
+    std::vector<int> stack{root};
+    while (!stack.empty()) { int v = stack.back(); stack.pop_back(); preorder.push_back(v); for (int c : child[v]) stack.push_back(c); }
+    for (int t = 0; t < N; t++) {
+      double *L = dn(t);
+      for (int p = 0; p < P; p++) for (int s = 0; s < 4; s++) L[p * 4 + s] = (pat[t][p] >> s & 1) ? 1.0 : 0.0;
+    }
   }
 
   // conditional likelihoods of the subtree below each node (down) and of the rest of the tree as seen
   // from the top of each node's branch (up, excluding pi)
   void partials() {
-    down.assign(nn, {}); up.assign(nn, {});
-    std::vector<int> order;   // pre-order
-    std::vector<int> stack{root};
-    while (!stack.empty()) { int v = stack.back(); stack.pop_back(); order.push_back(v); for (int c : child[v]) stack.push_back(c); }
-    std::vector<std::vector<double>> msg(nn);   // msg[v][p*4+i] = sum_j P_ij(len v) down[v][j]
-    for (auto it = order.rbegin(); it != order.rend(); ++it) {
+    const int PS = P * 4;
+    for (auto it = preorder.rbegin(); it != preorder.rend(); ++it) {
       const int v = *it;
-      if (v < N) tip_partial(v, down[v]);
-      else {
-        down[v].assign(static_cast<size_t>(P) * 4, 1.0);
-        for (int c : child[v]) for (size_t x = 0; x < down[v].size(); x++) down[v][x] *= msg[c][x];
+      if (v >= N) {
+        double *d = dn(v);
+        for (int x = 0; x < PS; x++) d[x] = 1.0;
+        for (int c : child[v]) { const double *m = ms(c); for (int x = 0; x < PS; x++) d[x] *= m[x]; }
       }
       if (v != root) {
         double Pm[4][4];
         mod.probs(len[v], Pm);
-        msg[v].assign(static_cast<size_t>(P) * 4, 0.0);
-        for (int p = 0; p < P; p++) for (int i = 0; i < 4; i++) {
-          double s = 0;
-          for (int j = 0; j < 4; j++) s += Pm[i][j] * down[v][p * 4 + j];
-          msg[v][p * 4 + i] = s;
-        }
+        const double *d = dn(v);
+        double *m = ms(v);
+        for (int p = 0; p < P; p++) for (int i = 0; i < 4; i++)
+          m[p * 4 + i] = Pm[i][0] * d[p * 4] + Pm[i][1] * d[p * 4 + 1] + Pm[i][2] * d[p * 4 + 2] + Pm[i][3] * d[p * 4 + 3];
       }
     }
-    for (int v : order) {
+    for (int v : preorder) {
       if (v == root) continue;
       const int par = parent[v];
-      up[v].assign(static_cast<size_t>(P) * 4, 1.0);
-      for (int c : child[par]) if (c != v) for (size_t x = 0; x < up[v].size(); x++) up[v][x] *= msg[c][x];
+      double *u = upp(v);
+      for (int x = 0; x < PS; x++) u[x] = 1.0;
+      for (int c : child[par]) if (c != v) { const double *m = ms(c); for (int x = 0; x < PS; x++) u[x] *= m[x]; }
       if (par != root) {   // what comes from above the parent, through the parent's own branch
-        double Pm[4][4];
+        double Pm[4][4], W[4][4];
         mod.probs(len[par], Pm);
-        for (int p = 0; p < P; p++) {
-          double t4[4];
-          for (int i = 0; i < 4; i++) {   // state i at par; sum over the state at par's parent
-            double s = 0;
-            for (int j = 0; j < 4; j++) s += Pm[j][i] * mod.pi[j] / mod.pi[i] * up[par][p * 4 + j];   // reversibility
-            t4[i] = s;
-          }
-          for (int i = 0; i < 4; i++) up[v][p * 4 + i] *= t4[i];
-        }
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) W[i][j] = Pm[j][i] * mod.pi[j] / mod.pi[i];
+        const double *up_par = upp(par);
+        for (int p = 0; p < P; p++)
+          for (int i = 0; i < 4; i++)
+            u[p * 4 + i] *= W[i][0] * up_par[p * 4] + W[i][1] * up_par[p * 4 + 1] + W[i][2] * up_par[p * 4 + 2] + W[i][3] * up_par[p * 4 + 3];
       }
     }
   }
@@ -276,8 +282,8 @@ struct Fitter {
       double s = 0;
       for (int i = 0; i < 4; i++) {
         double m = 0;
-        for (int j = 0; j < 4; j++) m += Pm[i][j] * down[v][p * 4 + j];
-        s += mod.pi[i] * up[v][p * 4 + i] * m;
+        for (int j = 0; j < 4; j++) m += Pm[i][j] * dn(v)[p * 4 + j];
+        s += mod.pi[i] * upp(v)[p * 4 + i] * m;
       }
       lnl += w[p] * std::log(std::max(s, 1e-300));
     }
@@ -291,6 +297,7 @@ struct Fitter {
   }
 
   double optimise() {
+    prepare();
     double prev = lnl();
     for (int round = 0; round < 60; round++) {
       for (int v = 0; v < nn; v++) {
@@ -390,6 +397,7 @@ bool tree_lnl(const std::vector<std::string> &rows_in, const std::vector<std::st
     f.child[id[t.parent[q]]].push_back(id[q]);
     f.len[id[q]] = std::max(t.length[q], kBlMin);
   }
+  f.prepare();
   *lnl_out = f.lnl();
   return true;
 }
