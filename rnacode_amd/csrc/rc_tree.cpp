@@ -312,7 +312,7 @@ struct Fitter {
         mod.set(pi, k);
       }
       const double cur = lnl();
-      if (std::fabs(cur - prev) < 1e-6) { prev = cur; break; }
+      if (std::fabs(cur - prev) < 1e-4) { prev = cur; break; }   // PhyML stops at 1e-3 (min_diff_lk_global)
       prev = cur;
     }
     return prev;

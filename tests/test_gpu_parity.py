@@ -318,3 +318,19 @@ def test_built_in_trees_give_the_same_calls_as_phyml_trees(ctx):
             checked += 1
     assert checked >= 20
     batch.close()
+
+
+def test_cli_without_sidecar_fits_its_own_trees(tmp_path):
+    """The stand-alone driver end to end with nothing but an alignment file (section 8f-1 + 8f-2)."""
+    from rnacode_amd import cli
+    from rnacode_amd.synth import to_maf
+    doc = load_golden("coding_maf_n100")
+    maf = tmp_path / "in.maf"
+    maf.write_text(to_maf([block_from_golden(e) for e in doc["blocks"]]))
+    outp = tmp_path / "out.txt"
+    assert cli.main([str(maf), "-n", "200", "-t", "-o", str(outp)]) == 0
+    rows = [l.split("\t") for l in outp.read_text().splitlines()]
+    top = sorted(doc["blocks"][0]["ref"]["hss"], key=hss_key)[0]
+    assert rows[0][1] == top["strand"] and int(rows[0][2]) == top["frame"] + 1
+    assert int(rows[0][7]) == top["startGenomic"] and int(rows[0][8]) == top["endGenomic"]
+    assert abs(float(rows[0][9]) - top["score"]) < 0.01 * top["score"] and float(rows[0][10]) < 1e-4
