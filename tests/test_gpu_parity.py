@@ -334,3 +334,40 @@ def test_cli_without_sidecar_fits_its_own_trees(tmp_path):
     assert rows[0][1] == top["strand"] and int(rows[0][2]) == top["frame"] + 1
     assert int(rows[0][7]) == top["startGenomic"] and int(rows[0][8]) == top["endGenomic"]
     assert abs(float(rows[0][9]) - top["score"]) < 0.01 * top["score"] and float(rows[0][10]) < 1e-4
+
+
+def test_sample_count_edges_and_config5_shape(ctx):
+    """n = 1, 63, 65 (ragged wavefronts) against the oracle; BASELINE config 5 shape (12 seqs x 300
+    cols) at its full n = 10000 through the seed-sharding property (first 1000 samples == an n=1000 run)."""
+    from oracle import binding as ob
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_blocks
+    (b,) = [x.upper() for x in synth_blocks(1, 6, 90, seed=31)]
+    rows = [r.seq for r in b.rows]
+    names = [r.name for r in b.rows]
+    for n in (1, 63, 65):
+        batch = api.Batch(ctx, [b], api.default_params(sampleN=n, seed_base=5)).run()
+        res = ob.run_block(rows, names, b.rows[0].start, b.rows[0].length, b.tree, b.kappa, ob.default_params(n), 5)
+        np.testing.assert_array_equal(batch.maxScores(0), np.float32(res.maxScores))
+        rc, mu, lam = batch.getExtremeValuePars(0)
+        assert rc == res.evd_rc
+        if rc == 1:
+            assert close(mu, res.mu) and close(lam, res.lam)
+        batch.close()
+    big = [x.upper() for x in synth_blocks(2, 12, 300, seed=2)]
+    full = api.Batch(ctx, big, api.default_params(sampleN=10000, seed_base=42)).run()
+    part = api.Batch(ctx, big, api.default_params(sampleN=1000, seed_base=42)).run()
+    np.testing.assert_array_equal(full.maxScores_all()[:, :1000], part.maxScores_all())
+    doc = load_golden("synth_12x300_n40")   # the same two blocks, first 40 samples pinned by the reference
+    for i, e in enumerate(doc["blocks"]):
+        np.testing.assert_array_equal(full.maxScores(i)[:40], np.float32(e["ref"]["maxScores"]))
+    assert full.clamped() == 0
+    full.close(); part.close()
+
+
+def test_duplicate_row_names_are_rejected(ctx):
+    from rnacode_amd import api
+    from rnacode_amd.alnio import AlnBlock, AlnRow
+    rows = [AlnRow("a", "ATGGCTAAA"), AlnRow("a", "ATGGCAAAA"), AlnRow("c", "ATGGCTAAG")]
+    with pytest.raises(api.RnacodeError):
+        api.Batch(ctx, [AlnBlock(rows, "x", "(a:0.1,a:0.1,c:0.1);", 2.0)], api.default_params())
