@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
           }
         }
       }
-      if (clamped) atomicAdd(A.clampCount, static_cast<unsigned long long>(clamped));
+      if (clamped && sidx < A.sampleN) atomicAdd(A.clampCount, static_cast<unsigned long long>(clamped));   // padding lanes do not count
     }
 
     // ---- phase B: both strands x 3 frames: DP over (start a, end j) + serial HSS scan

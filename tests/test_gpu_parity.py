@@ -361,7 +361,9 @@ def test_sample_count_edges_and_config5_shape(ctx):
     doc = load_golden("synth_12x300_n40")   # the same two blocks, first 40 samples pinned by the reference
     for i, e in enumerate(doc["blocks"]):
         np.testing.assert_array_equal(full.maxScores(i)[:40], np.float32(e["ref"]["maxScores"]))
-    assert full.clamped() == 0
+    # 1.3e8 draws: a handful fall beyond the float-rounded cumulative frequencies (the reference reads out
+    # of bounds there, seqgen/evolve.c:173; we clamp and count) -- about 1e-7 per root draw
+    assert full.clamped() <= 100 and part.clamped() <= 10
     full.close(); part.close()
 
 
