@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -31,6 +32,14 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
     hipError_t e_ = (expr);                                                                   \
     if (e_ != hipSuccess) return fail(RC_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
+
+// hipEvent that is destroyed on every exit path
+struct Event {
+  hipEvent_t e = nullptr;
+  ~Event() { if (e) (void)hipEventDestroy(e); }
+  hipError_t create() { return hipEventCreate(&e); }
+  operator hipEvent_t() const { return e; }
+};
 
 struct rc_ctx {
   int device = 0;
@@ -173,6 +182,7 @@ int rc_batch_create(rc_ctx *ctx, const rc_block *blocks, int32_t n_blocks, const
   HIP_TRY(hipSetDevice(ctx->device));
   rc_batch *b = new rc_batch();
   b->ctx = ctx; b->par = *par; b->n = n_blocks;
+  std::unique_ptr<rc_batch, void (*)(rc_batch *)> guard(b, rc_batch_destroy);   // released on success only
   b->hb.resize(n_blocks);
   const CodeTables &ct = (par->blosum == 90) ? ctx->ct90 : ctx->ct62;
   const PairTable &pt = (par->blosum == 90) ? ctx->pt90 : ctx->pt62;
@@ -198,7 +208,6 @@ int rc_batch_create(rc_ctx *ctx, const rc_block *blocks, int32_t n_blocks, const
       if (b->hb[i].status != RC_OK && b->hb[i].status != RC_ERR_SKIP) {
         int st = b->hb[i].status;
         std::string msg = "block " + std::to_string(i) + ": " + errs[i];
-        delete b;
         return fail(st, msg);
       }
   }
@@ -269,7 +278,7 @@ int rc_batch_create(rc_ctx *ctx, const rc_block *blocks, int32_t n_blocks, const
         d.zm_words = zmw;
       }
     }
-    if (blob.size() > 0xFFFFFFF0ull) { delete b; return fail(RC_ERR_UNSUPPORTED, "batch too large: split it (blob > 4 GiB)"); }
+    if (blob.size() > 0xFFFFFFF0ull) return fail(RC_ERR_UNSUPPORTED, "batch too large: split it (blob > 4 GiB)");
     const size_t smax = h.L / 3;
     b->offS[i] = sOff;
     sOff += 6 * smax * smax;
@@ -287,16 +296,16 @@ int rc_batch_create(rc_ctx *ctx, const rc_block *blocks, int32_t n_blocks, const
   };
   int rcv;
   std::vector<uint8_t> pad(16, 0);
-  if ((rcv = up(reinterpret_cast<void **>(&b->d_blob), blob.empty() ? pad.data() : blob.data(), blob.empty() ? 16 : blob.size()))) { rc_batch_destroy(b); return rcv; }
+  if ((rcv = up(reinterpret_cast<void **>(&b->d_blob), blob.empty() ? pad.data() : blob.data(), blob.empty() ? 16 : blob.size()))) return rcv;
   if (n_blocks > 0) {
-    if ((rcv = up(reinterpret_cast<void **>(&b->d_dblocks), b->db.data(), sizeof(DevBlock) * n_blocks))) { rc_batch_destroy(b); return rcv; }
-    if ((rcv = up(reinterpret_cast<void **>(&b->d_offS), b->offS.data(), sizeof(size_t) * n_blocks))) { rc_batch_destroy(b); return rcv; }
+    if ((rcv = up(reinterpret_cast<void **>(&b->d_dblocks), b->db.data(), sizeof(DevBlock) * n_blocks))) return rcv;
+    if ((rcv = up(reinterpret_cast<void **>(&b->d_offS), b->offS.data(), sizeof(size_t) * n_blocks))) return rcv;
   }
   if (!b->okBlocks.empty()) {
-    if ((rcv = up(reinterpret_cast<void **>(&b->d_okBlocks), b->okBlocks.data(), sizeof(int) * b->okBlocks.size()))) { rc_batch_destroy(b); return rcv; }
+    if ((rcv = up(reinterpret_cast<void **>(&b->d_okBlocks), b->okBlocks.data(), sizeof(int) * b->okBlocks.size()))) return rcv;
     for (auto &kv : b->classes) {
       int *p = nullptr;
-      if ((rcv = up(reinterpret_cast<void **>(&p), kv.second.data(), sizeof(int) * kv.second.size()))) { rc_batch_destroy(b); return rcv; }
+      if ((rcv = up(reinterpret_cast<void **>(&p), kv.second.data(), sizeof(int) * kv.second.size()))) return rcv;
       b->d_classBlocks[kv.first] = p;
     }
   }
@@ -306,7 +315,7 @@ int rc_batch_create(rc_ctx *ctx, const rc_block *blocks, int32_t n_blocks, const
   HIP_TRY(hipMalloc(&b->d_hss, static_cast<size_t>(std::max(n_blocks, 1)) * 6 * b->hssCap * sizeof(DevHss)));
   HIP_TRY(hipMalloc(&b->d_hssCount, static_cast<size_t>(std::max(n_blocks, 1)) * 6 * sizeof(int)));
   HIP_TRY(hipMalloc(&b->d_fit, static_cast<size_t>(std::max(n_blocks, 1)) * sizeof(FitOut)));
-  *out = b;
+  *out = guard.release();
   return RC_OK;
 }
 
@@ -320,15 +329,14 @@ static int ensure_stream(rc_ctx *c, uint32_t seed, int Spad, int D, float *ms, i
     HIP_TRY(hipMalloc(&c->d_U, need * sizeof(uint32_t)));
     c->U_cap = need;
   }
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  Event e0, e1;
+  HIP_TRY(e0.create()); HIP_TRY(e1.create());
   HIP_TRY(hipEventRecord(e0, c->stream));
   launch_mt_stream(seed, Spad, D, c->d_U, c->stream);
   HIP_TRY(hipEventRecord(e1, c->stream));
   HIP_TRY(hipEventSynchronize(e1));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventElapsedTime(ms, e0, e1));
-  hipEventDestroy(e0); hipEventDestroy(e1);
   *launches = 1;
   c->U_seed = seed; c->U_Spad = Spad; c->U_D = D; c->U_valid = true;
   return RC_OK;
@@ -354,8 +362,8 @@ int rc_batch_run(rc_batch *b) {
   if (b->okBlocks.empty()) { b->ran = true; return RC_OK; }
   const uint8_t *d_pair = (b->par.blosum == 90) ? c->d_pair90 : c->d_pair62;
 
-  hipEvent_t ev[8];
-  for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
+  Event ev[6];
+  for (auto &e : ev) HIP_TRY(e.create());
   HIP_TRY(hipEventRecord(ev[0], c->stream));
 
   if (g_no_stream_cache) c->U_valid = false;
@@ -441,7 +449,6 @@ int rc_batch_run(rc_batch *b) {
   HIP_TRY(hipEventElapsedTime(&ms, ev[3], ev[4])); b->t[2] = ms;
   HIP_TRY(hipEventElapsedTime(&ms, ev[4], ev[5])); b->t[4] = ms;
   HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[5])); b->t[0] = ms;
-  for (auto &e : ev) hipEventDestroy(e);
 
   // small results back to the host
   {
