@@ -154,6 +154,13 @@ int rc_fit_tree(const rc_block *blk, char *newick_out, int32_t cap, float *kappa
  * buffer of n_blocks * cap bytes (block i at i*cap); blocks the driver skips (N <= 2, L < 3) or that
  * fail get an empty string and kappa 0.  Returns the number of fitted blocks. */
 int rc_fit_trees(const rc_block *blocks, int32_t n_blocks, char *newick_out, int32_t cap, float *kappa_out, int32_t threads);
+/* The same estimator on the GPU of `ctx`, one wavefront per block, all blocks concurrently (the host
+ * only compresses site patterns and writes the Newick text).  Same algorithm as rc_fit_trees; the
+ * per-site sums are taken in a different order, so branch lengths agree to ~1e-6, not bitwise.
+ * lnl_out (may be NULL) receives the log-likelihoods.  Returns the number of fitted blocks or a
+ * negative error code. */
+int rc_fit_trees_device(rc_ctx *ctx, const rc_block *blocks, int32_t n_blocks, char *newick_out, int32_t cap, float *kappa_out,
+                        double *lnl_out);
 /* HKY85 log-likelihood of blk->newick / blk->kappa on blk's rows under the same model and data
  * handling (diagnostic: compares a tree from elsewhere with rc_fit_tree's on equal terms). */
 int rc_tree_lnl(const rc_block *blk, double *lnl_out);

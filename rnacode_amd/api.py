@@ -111,6 +111,8 @@ def lib():
         l.rc_fit_tree.argtypes = [C.POINTER(RcBlock), C.c_char_p, C.c_int32, C.POINTER(C.c_float)]
         l.rc_fit_trees.argtypes = [C.POINTER(RcBlock), C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_float), C.c_int32]
         l.rc_tree_lnl.argtypes = [C.POINTER(RcBlock), C.POINTER(C.c_double)]
+        l.rc_fit_trees_device.argtypes = [C.c_void_p, C.POINTER(RcBlock), C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_float),
+                                          C.POINTER(C.c_double)]
         l.rc_set_stream_cache.argtypes = [C.c_int]
         l.rc_set_stream_cache.restype = None
         _lib = l
@@ -121,7 +123,7 @@ EXPORTED_SYMBOLS = [
     "rc_default_params", "rc_last_error", "rc_device_count", "rc_ctx_create", "rc_ctx_destroy", "rc_batch_create",
     "rc_batch_destroy", "rc_batch_bind_maxima", "rc_batch_run", "rc_set_stream_cache", "rc_batch_work", "rc_batch_timing", "rc_batch_status",
     "rc_batch_models", "rc_batch_maxima", "rc_batch_maxima_all", "rc_batch_fit", "rc_batch_hss", "rc_batch_clamped",
-    "rc_batch_native_S", "rc_batch_backtrack", "rc_fit_tree", "rc_fit_trees", "rc_tree_lnl", "rc_evd_fit", "rc_mt_stream",
+    "rc_batch_native_S", "rc_batch_backtrack", "rc_fit_tree", "rc_fit_trees", "rc_fit_trees_device", "rc_tree_lnl", "rc_evd_fit", "rc_mt_stream",
 ]
 
 
@@ -152,8 +154,10 @@ def fit_tree(block: AlnBlock) -> Tuple[str, float]:
     return buf.value.decode(), float(kappa.value)
 
 
-def fit_trees(blocks: Sequence[AlnBlock], threads: int = 0, cap: int = 1 << 14) -> List[Optional[Tuple[str, float]]]:
-    """rc_fit_trees: trees + kappas of many blocks on host threads; None for blocks the driver skips."""
+def fit_trees(blocks: Sequence[AlnBlock], threads: int = 0, cap: int = 1 << 14, ctx: "Optional[Context]" = None,
+              lnl: Optional[list] = None) -> List[Optional[Tuple[str, float]]]:
+    """Trees + kappas of many blocks; None for blocks the driver skips.  With ctx: rc_fit_trees_device (one wavefront
+    per block on that context's GPU; `lnl`, if a list, receives the log-likelihoods); without: rc_fit_trees on host threads."""
     n = len(blocks)
     arr = (RcBlock * max(n, 1))()
     keep = []
@@ -164,7 +168,13 @@ def fit_trees(blocks: Sequence[AlnBlock], threads: int = 0, cap: int = 1 << 14) 
         arr[i] = RcBlock(b.n, b.cols, rows, names, b.rows[0].start, b.rows[0].length, None, 0.0)
     buf = C.create_string_buffer(max(n, 1) * cap)
     kap = (C.c_float * max(n, 1))()
-    _check(lib().rc_fit_trees(arr, n, buf, cap, kap, threads))
+    if ctx is not None:
+        ll = (C.c_double * max(n, 1))()
+        _check(lib().rc_fit_trees_device(ctx._h, arr, n, buf, cap, kap, ll))
+        if lnl is not None:
+            lnl[:] = [float(x) for x in ll[:n]]
+    else:
+        _check(lib().rc_fit_trees(arr, n, buf, cap, kap, threads))
     out = []
     raw = buf.raw   # one copy (buf.raw copies the whole buffer on every access)
     for i in range(n):

@@ -37,9 +37,10 @@ def read_sidecar(path: str) -> List[Optional[tuple]]:
     return out
 
 
-def fit_trees(blocks: List[AlnBlock], threads: int = 0) -> List[Optional[tuple]]:
-    """Trees + kappas for every block the driver will score (rc_fit_trees, host threads)."""
-    return api.fit_trees(blocks, threads)
+def fit_trees(blocks: List[AlnBlock], threads: int = 0, ctx: "Optional[api.Context]" = None) -> List[Optional[tuple]]:
+    """Trees + kappas for every block the driver will score: on ctx's GPU (rc_fit_trees_device) when a
+    context is given, else on host threads (rc_fit_trees)."""
+    return api.fit_trees(blocks, threads, ctx=ctx)
 
 
 def main(argv=None) -> int:
@@ -78,13 +79,15 @@ def main(argv=None) -> int:
             fh.write(sys.stdin.read())
         blocks = read_alignment_file(fh.name)
     blocks = [b.upper() for b in blocks]
+    ctx = api.Context(a.device)
     if a.trees:
         side = read_sidecar(a.trees)
         if len(side) != len(blocks):
             print(f"ERROR: {len(blocks)} alignment blocks but {len(side)} sidecar entries", file=sys.stderr)
+            ctx.close()
             return 1
     else:
-        side = fit_trees(blocks)
+        side = fit_trees(blocks, ctx=ctx)
     prepared: List[AlnBlock] = []
     for b, s in zip(blocks, side):
         b.tree, b.kappa = s if s is not None else ("(a:0.1,b:0.1,c:0.1);", 2.0)   # skipped blocks never reach the tree
@@ -93,7 +96,6 @@ def main(argv=None) -> int:
     out = open(a.outfile, "w") if a.outfile else sys.stdout
     fmt = 2 if a.tabular else (1 if a.gtf else 0)
     t0 = time.perf_counter()
-    ctx = api.Context(a.device)
     batch = api.Batch(ctx, prepared, params).run()
     st = report.ReportState()
     for i, b in enumerate(prepared):

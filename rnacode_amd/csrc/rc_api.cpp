@@ -703,6 +703,90 @@ int rc_fit_trees(const rc_block *blocks, int32_t n_blocks, char *newick_out, int
   return done.load();
 }
 
+// The same fits on the GPU, one wavefront per block (rc_tree_kernel.hip).  Host work: pattern
+// compression (threads) and writing the Newick text.
+int rc_fit_trees_device(rc_ctx *c, const rc_block *blocks, int32_t n_blocks, char *newick_out, int32_t cap, float *kappa_out,
+                        double *lnl_out) {
+  if (!c || !blocks || !newick_out || !kappa_out || n_blocks < 0 || cap < 8) return fail(RC_ERR_ARG, "bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  std::vector<PatternSet> ps(n_blocks);
+  std::vector<char> ok(n_blocks, 0);
+  {
+    std::atomic<int> next{0};
+    const unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), static_cast<unsigned>(std::max(1, n_blocks)));
+    auto work = [&]() {
+      for (;;) {
+        const int i = next.fetch_add(1);
+        if (i >= n_blocks) break;
+        const rc_block &b = blocks[i];
+        if (!b.rows || !b.names || b.n_rows <= 2) continue;
+        int L = 0;
+        for (const char *p = b.rows[0]; *p; p++) L += (*p != '-');
+        if (L < 3) continue;
+        std::vector<std::string> rows(b.n_rows);
+        for (int r = 0; r < b.n_rows; r++) rows[r] = b.rows[r];
+        std::string err;
+        ok[i] = compress_patterns(rows, ps[i], err) ? 1 : 0;
+      }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto &x : th) x.join();
+  }
+  std::vector<TreeJob> jobs;
+  std::vector<int> owner;
+  std::vector<uint8_t> in;
+  size_t work_doubles = 0;
+  for (int i = 0; i < n_blocks; i++) {
+    newick_out[static_cast<size_t>(i) * cap] = 0; kappa_out[i] = 0.0f;
+    if (lnl_out) lnl_out[i] = 0.0;
+    if (!ok[i]) continue;
+    TreeJob j{};
+    j.N = ps[i].N; j.P = ps[i].P;
+    j.off_mask = in.size();
+    in.insert(in.end(), ps[i].mask.begin(), ps[i].mask.end());
+    in.resize((in.size() + 7) & ~static_cast<size_t>(7));
+    j.off_w = in.size();
+    const uint8_t *wp = reinterpret_cast<const uint8_t *>(ps[i].w.data());
+    in.insert(in.end(), wp, wp + sizeof(double) * ps[i].P);
+    j.off_work = work_doubles;
+    work_doubles += 2 * static_cast<size_t>(j.N) * j.N + 3 * static_cast<size_t>(2 * j.N - 2) * 4 * j.P;
+    jobs.push_back(j);
+    owner.push_back(i);
+  }
+  const int nj = static_cast<int>(jobs.size());
+  if (nj == 0) return 0;
+  struct DevMem { void *p = nullptr; ~DevMem() { if (p) hipFree(p); } } d_jobs, d_in, d_work, d_out;
+  HIP_TRY(hipMalloc(&d_jobs.p, sizeof(TreeJob) * nj));
+  HIP_TRY(hipMalloc(&d_in.p, in.size()));
+  HIP_TRY(hipMalloc(&d_work.p, sizeof(double) * work_doubles));
+  HIP_TRY(hipMalloc(&d_out.p, sizeof(TreeOut) * nj));
+  HIP_TRY(hipMemcpyAsync(d_jobs.p, jobs.data(), sizeof(TreeJob) * nj, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(d_in.p, in.data(), in.size(), hipMemcpyHostToDevice, c->stream));
+  launch_tree_fit(static_cast<const TreeJob *>(d_jobs.p), nj, static_cast<const uint8_t *>(d_in.p), static_cast<double *>(d_work.p),
+                  static_cast<TreeOut *>(d_out.p), c->stream);
+  HIP_TRY(hipGetLastError());
+  std::vector<TreeOut> out(nj);
+  HIP_TRY(hipMemcpyAsync(out.data(), d_out.p, sizeof(TreeOut) * nj, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  int done = 0;
+  for (int q = 0; q < nj; q++) {
+    const int i = owner[q];
+    const rc_block &b = blocks[i];
+    std::vector<std::string> names(b.n_rows);
+    for (int r = 0; r < b.n_rows; r++) names[r] = b.names[r];
+    const TreeOut &o = out[q];
+    const std::string nwk = newick_of(b.n_rows, o.root, o.nchild, o.child, o.len, names);
+    if (static_cast<int>(nwk.size()) + 1 > cap) continue;
+    std::memcpy(newick_out + static_cast<size_t>(i) * cap, nwk.c_str(), nwk.size() + 1);
+    kappa_out[i] = static_cast<float>(o.kappa);
+    if (lnl_out) lnl_out[i] = o.lnl;
+    done++;
+  }
+  return done;
+}
+
 int rc_tree_lnl(const rc_block *blk, double *lnl_out) {
   if (!blk || !lnl_out || !blk->rows || !blk->names || !blk->newick) return fail(RC_ERR_ARG, "bad argument");
   std::vector<std::string> rows(blk->n_rows), names(blk->n_rows);

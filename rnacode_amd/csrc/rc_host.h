@@ -54,7 +54,14 @@ struct HostBlock {
 int prepare_block(const rc_block &in, const rc_params &par, const CodeTables &ct, const PairTable &pt,
                   HostBlock &out, std::string &err);
 
-// tree + kappa estimator (rc_tree.cpp)
+// tree + kappa estimator (rc_tree.cpp on host threads, rc_tree_kernel.hip on the GPU; both run rc_tree_core.h)
+struct PatternSet {
+  int N = 0, P = 0;
+  std::vector<uint8_t> mask;   // [N][P] allowed-state masks of the distinct alignment columns
+  std::vector<double> w;       // [P] how many columns show the pattern
+};
+bool compress_patterns(const std::vector<std::string> &rows, PatternSet &ps, std::string &err);
+std::string newick_of(int N, int root, const int *nchild, const int *child, const double *len, const std::vector<std::string> &names);
 bool fit_tree(const std::vector<std::string> &rows, const std::vector<std::string> &names, std::string &newick,
               float &kappa, double *lnl_out, std::string &err);
 

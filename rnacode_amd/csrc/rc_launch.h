@@ -60,6 +60,21 @@ struct FitArgs {
   int stopCutoff;
 };
 
+// tree estimator (rc_tree_kernel.hip): one job = one alignment block
+struct TreeJob {
+  int N, P;
+  uint64_t off_mask;          // bytes into the input blob: [N][P] state masks
+  uint64_t off_w;             // bytes into the input blob (8-aligned): [P] pattern weights
+  uint64_t off_work;          // doubles into the scratch: 2 N^2 + 3 (2N-2) 4 P
+};
+struct TreeOut {
+  int root;
+  int parent[63], nchild[63], child[63 * 3], preorder[63];
+  double len[63];
+  double kappa, lnl;
+};
+void launch_tree_fit(const TreeJob *jobs, int njobs, const uint8_t *in, double *scratch, TreeOut *out, hipStream_t stream);
+
 void launch_mt_stream(uint32_t seedBase, int Spad, int D, uint32_t *U, hipStream_t stream);
 int null_occupancy(int NK, size_t ldsBytes);   // resident workgroups per CU (0 = cannot launch)
 bool launch_null(int NK, const NullArgs &a, int grid, size_t ldsBytes, bool exact, hipStream_t stream);

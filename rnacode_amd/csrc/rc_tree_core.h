@@ -1,0 +1,360 @@
+// rc_tree_core.h -- the tree + kappa estimator as one piece of source that
+// runs on a host thread (rc_tree.cpp, Exec = SerialExec) and as one wavefront per alignment block on
+// the GPU (rc_tree_kernel.hip, Exec = WaveExec): same algorithm, the only difference is the order in
+// which per-site terms are summed.
+//
+// Model (what RNAcode gets from its bundled PhyML through src/treeML.c:35-152): BIONJ topology from
+// pairwise HKY85 ML distances (kappa 4.0, empirical base frequencies), then maximum-likelihood
+// branch lengths and kappa on that topology; ambiguity codes as partial information, gaps as missing.
+//
+// Exec supplies: lane(), nlanes() (site patterns p = lane, lane + nlanes, ... belong to a lane for the
+// whole fit, so per-pattern arrays need no synchronisation), sum(x) (the same total on every lane),
+// sync() (makes lane 0's serial work visible).
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#ifdef __HIPCC__
+#define RC_HD __host__ __device__
+#else
+#define RC_HD
+#endif
+
+namespace rc {
+namespace treefit {
+
+constexpr double kBlMin = 1e-6, kBlMax = 100.0, kDistMax = 2.0;   // phyml/utilities.h:78,80,88
+constexpr int kMaxTips = 32, kMaxNodes = 2 * kMaxTips - 1;   // a rooted input tree (tree_lnl) has 2N-1 nodes
+
+// allowed-state mask of a character: A=1 C=2 G=4 T=8 (IUPAC as in phyml Get_Base_Freqs); the rest is missing data
+RC_HD inline int state_mask(char c) {
+  switch (c) {
+    case 'A': case 'a': return 1; case 'C': case 'c': return 2; case 'G': case 'g': return 4;
+    case 'T': case 't': case 'U': case 'u': return 8;
+    case 'M': return 3; case 'R': return 5; case 'W': return 9; case 'S': return 6; case 'Y': return 10; case 'K': return 12;
+    case 'B': return 14; case 'D': return 13; case 'H': return 11; case 'V': return 7;
+    default: return 15;
+  }
+}
+
+struct Hky {
+  double pi[4], kappa, beta, grp[4];
+  RC_HD void set(const double p[4], double k) {
+    for (int i = 0; i < 4; i++) pi[i] = p[i];
+    kappa = k;
+    const double R = pi[0] + pi[2], Y = pi[1] + pi[3];
+    grp[0] = grp[2] = R; grp[1] = grp[3] = Y;
+    beta = 1.0 / (2.0 * (R * Y + kappa * (pi[0] * pi[2] + pi[1] * pi[3])));   // mean rate 1
+  }
+  RC_HD void probs(double t, double P[4][4]) const {
+    const double e1 = exp(-beta * t);
+    for (int i = 0; i < 4; i++) {
+      const double e2 = exp(-beta * t * (1.0 + grp[i] * (kappa - 1.0)));
+      for (int j = 0; j < 4; j++) {
+        if (i == j) P[i][j] = pi[j] + pi[j] * (1.0 / grp[j] - 1.0) * e1 + (grp[j] - pi[j]) / grp[j] * e2;
+        else if (((i ^ j) & 1) == 0) P[i][j] = pi[j] + pi[j] * (1.0 / grp[j] - 1.0) * e1 - pi[j] / grp[j] * e2;
+        else P[i][j] = pi[j] * (1.0 - e1);
+      }
+    }
+  }
+};
+
+// 1-D minimiser on [lo, hi]: golden section with parabolic steps
+template <typename F>
+RC_HD double minimise(F f, double lo, double hi, double x0, double xtol, int itmax) {
+  const double cg = 0.3819660112501051;
+  double a = lo, b = hi, x = x0 < lo ? lo : (x0 > hi ? hi : x0), w = x, v = x;
+  double fx = f(x), fw = fx, fv = fx, d = 0, e = 0;
+  for (int it = 0; it < itmax; it++) {
+    const double xm = 0.5 * (a + b), tol1 = xtol * fabs(x) + 1e-10, tol2 = 2 * tol1;
+    if (fabs(x - xm) <= tol2 - 0.5 * (b - a)) break;
+    bool golden = true;
+    if (fabs(e) > tol1) {
+      double r = (x - w) * (fx - fv), q = (x - v) * (fx - fw), p = (x - v) * q - (x - w) * r;
+      q = 2 * (q - r);
+      if (q > 0) p = -p;
+      q = fabs(q);
+      const double etemp = e;
+      e = d;
+      if (!(fabs(p) >= fabs(0.5 * q * etemp) || p <= q * (a - x) || p >= q * (b - x))) {
+        d = p / q;
+        const double u = x + d;
+        if (u - a < tol2 || b - u < tol2) d = (xm >= x) ? tol1 : -tol1;
+        golden = false;
+      }
+    }
+    if (golden) { e = (x >= xm) ? a - x : b - x; d = cg * e; }
+    const double u = (fabs(d) >= tol1) ? x + d : x + ((d > 0) ? tol1 : -tol1);
+    const double fu = f(u);
+    if (fu <= fx) {
+      if (u >= x) a = x; else b = x;
+      v = w; fv = fw; w = x; fw = fx; x = u; fx = fu;
+    } else {
+      if (u < x) a = u; else b = u;
+      if (fu <= fw || w == x) { v = w; fv = fw; w = u; fw = fu; }
+      else if (fu <= fv || v == x || v == w) { v = u; fv = fu; }
+    }
+  }
+  return x;
+}
+
+// everything one fit works on; the arrays are provided by the caller (host vectors / GPU scratch)
+struct Work {
+  int N, P, nn, root;
+  const uint8_t *mask;   // [N][P] allowed-state masks
+  const double *w;       // [P] pattern weights
+  double pi[4];
+  Hky mod;
+  // tree (filled by bionj): nodes 0..N-1 tips, N.. internal
+  int *parent;           // [nn]
+  int *nchild;           // [nn]
+  int *child;            // [nn][3]
+  int *preorder;         // [nn]
+  double *len;           // [nn]
+  double *D, *V;         // [N][N]
+  double *down, *msg, *up;   // [nn][4][P]
+  RC_HD double &dn(int v, int s, int p) const { return down[(static_cast<size_t>(v) * 4 + s) * P + p]; }
+  RC_HD double &ms(int v, int s, int p) const { return msg[(static_cast<size_t>(v) * 4 + s) * P + p]; }
+  RC_HD double &upp(int v, int s, int p) const { return up[(static_cast<size_t>(v) * 4 + s) * P + p]; }
+};
+
+// empirical base frequencies; ambiguous characters are shared out by the current estimate (8 rounds,
+// as phyml/utilities.c:1926-1990)
+template <typename Exec>
+RC_HD void base_freqs(Work &k, Exec &ex) {
+  double f[4] = {0.25, 0.25, 0.25, 0.25};
+  for (int it = 0; it < 8; it++) {
+    double cnt[4] = {0, 0, 0, 0};
+    for (int p = ex.lane(); p < k.P; p += ex.nlanes())
+      for (int r = 0; r < k.N; r++) {
+        const int m = k.mask[static_cast<size_t>(r) * k.P + p];
+        double tot = 0;
+        for (int s = 0; s < 4; s++) if (m >> s & 1) tot += f[s];
+        for (int s = 0; s < 4; s++) if (m >> s & 1) cnt[s] += k.w[p] * f[s] / tot;
+      }
+    for (int s = 0; s < 4; s++) cnt[s] = ex.sum(cnt[s]);
+    const double sum = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    for (int s = 0; s < 4; s++) f[s] = cnt[s] / sum;
+  }
+  for (int s = 0; s < 4; s++) k.pi[s] = f[s];
+}
+
+// ML distance of two rows from the joint frequencies of their unambiguous sites (one lane does a pair)
+RC_HD inline double pair_distance(const Work &k, int x, int y) {
+  double F[4][4] = {{0}}, tot = 0;
+  for (int p = 0; p < k.P; p++) {
+    const int a = k.mask[static_cast<size_t>(x) * k.P + p], b = k.mask[static_cast<size_t>(y) * k.P + p];
+    if ((a & (a - 1)) || (b & (b - 1))) continue;   // ambiguous in either row: hidden
+    const int ia = (a == 1) ? 0 : (a == 2) ? 1 : (a == 4) ? 2 : 3, ib = (b == 1) ? 0 : (b == 2) ? 1 : (b == 4) ? 2 : 3;
+    F[ia][ib] += k.w[p];
+    tot += k.w[p];
+  }
+  if (tot <= 0) return -1.0;
+  double diff = 0;
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) if (i != j) diff += F[i][j];
+  if (diff == 0) return 0.0;
+  const Hky &mod = k.mod;
+  auto nll = [&](double d) {
+    double Pm[4][4], s = 0;
+    mod.probs(d, Pm);
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) if (F[i][j] > 0) s -= F[i][j] * log(Pm[i][j] > 1e-300 ? Pm[i][j] : 1e-300);
+    return s;
+  };
+  double x0 = 1.5 * diff / tot + 0.01;
+  if (x0 > 1.0) x0 = 1.0;
+  const double d = minimise(nll, kBlMin, 5.0, x0, 1e-6, 100);
+  return d < kDistMax ? d : kDistMax;
+}
+
+// BIONJ (Gascuel 1997), serial.  Conventions that decide near-ties follow the reference's bundled
+// implementation (phyml/bionj.c:25-395): slots scanned i ascending, j < i; a pair replaces the
+// incumbent only if its Q is smaller by more than 1e-5; the merged cluster keeps slot i; a lambda
+// outside [0,1] becomes 0.5.
+RC_HD inline void bionj(Work &k) {
+  const int N = k.N;
+  double *D = k.D, *V = k.V;
+  for (int i = 0; i < N * N; i++) V[i] = D[i];
+  int node[kMaxTips], on[kMaxTips];
+  double S[kMaxTips];
+  for (int i = 0; i < N; i++) { node[i] = i; on[i] = 1; }
+  for (int v = 0; v < k.nn; v++) { k.parent[v] = -1; k.nchild[v] = 0; k.len[v] = kBlMin; }
+  int r = N, next = N;
+  while (r > 3) {
+    for (int i = 0; i < N; i++) { S[i] = 0; if (on[i]) for (int c = 0; c < N; c++) if (c != i && on[c]) S[i] += D[i * N + c]; }
+    double qmin = 1e300; int x = -1, y = -1;
+    for (int i = 0; i < N; i++) if (on[i]) for (int j = 0; j < i; j++) if (on[j]) {
+      const double q = (r - 2.0) * D[i * N + j] - S[i] - S[j];
+      if (q < qmin - 1e-5) { x = i; y = j; qmin = q; }
+    }
+    const double vxy = V[x * N + y];
+    const double lx = 0.5 * (D[x * N + y] + (S[x] - S[y]) / (r - 2.0)), ly = 0.5 * (D[x * N + y] + (S[y] - S[x]) / (r - 2.0));
+    double lam = 0.5;
+    if (vxy != 0.0) {
+      double t = 0;
+      for (int c = 0; c < N; c++) if (c != x && c != y && on[c]) t += V[y * N + c] - V[x * N + c];
+      lam = 0.5 + t / (2.0 * (r - 2) * vxy);
+      if (lam > 1.0 || lam < 0.0) lam = 0.5;
+    }
+    for (int c = 0; c < N; c++) if (c != x && c != y && on[c]) {
+      const double d = lam * (D[x * N + c] - lx) + (1 - lam) * (D[y * N + c] - ly);
+      const double v = lam * V[x * N + c] + (1 - lam) * V[y * N + c] - lam * (1 - lam) * vxy;
+      D[x * N + c] = D[c * N + x] = d;
+      V[x * N + c] = V[c * N + x] = v;
+    }
+    const int u = next++;
+    k.parent[node[x]] = u; k.parent[node[y]] = u;
+    k.child[u * 3 + 0] = node[x]; k.child[u * 3 + 1] = node[y]; k.nchild[u] = 2;
+    k.len[node[x]] = lx > kBlMin ? lx : kBlMin; k.len[node[y]] = ly > kBlMin ? ly : kBlMin;
+    node[x] = u; on[y] = 0; r--;
+  }
+  int s3[3], c = 0;
+  for (int i = 0; i < N; i++) if (on[i]) s3[c++] = i;
+  k.root = next++;
+  const double dxy = D[s3[0] * N + s3[1]], dxz = D[s3[0] * N + s3[2]], dyz = D[s3[1] * N + s3[2]];
+  const double l0 = 0.5 * (dxy - dyz + dxz), l1 = 0.5 * (dyz - dxz + dxy), l2 = 0.5 * (dxz - dxy + dyz);
+  k.len[node[s3[0]]] = l0 > kBlMin ? l0 : kBlMin;
+  k.len[node[s3[1]]] = l1 > kBlMin ? l1 : kBlMin;
+  k.len[node[s3[2]]] = l2 > kBlMin ? l2 : kBlMin;
+  for (int i = 0; i < 3; i++) { k.parent[node[s3[i]]] = k.root; k.child[k.root * 3 + i] = node[s3[i]]; }
+  k.nchild[k.root] = 3;
+  // pre-order
+  int stack[kMaxNodes], sp = 0, n = 0;
+  stack[sp++] = k.root;
+  while (sp) {
+    const int v = stack[--sp];
+    k.preorder[n++] = v;
+    for (int i = 0; i < k.nchild[v]; i++) stack[sp++] = k.child[v * 3 + i];
+  }
+}
+
+template <typename Exec>
+RC_HD void tip_partials(Work &k, Exec &ex) {
+  for (int t = 0; t < k.N; t++)
+    for (int p = ex.lane(); p < k.P; p += ex.nlanes())
+      for (int s = 0; s < 4; s++) k.dn(t, s, p) = (k.mask[static_cast<size_t>(t) * k.P + p] >> s & 1) ? 1.0 : 0.0;
+}
+
+// conditional likelihoods of the subtree below each node (down), their images across the node's
+// branch (msg), and the rest of the tree as seen from the top of each node's branch (up, excluding pi)
+template <typename Exec>
+RC_HD void partials(Work &k, Exec &ex) {
+  for (int o = k.nn - 1; o >= 0; o--) {
+    const int v = k.preorder[o];
+    if (v >= k.N)
+      for (int p = ex.lane(); p < k.P; p += ex.nlanes())
+        for (int s = 0; s < 4; s++) {
+          double d = 1.0;
+          for (int c = 0; c < k.nchild[v]; c++) d *= k.ms(k.child[v * 3 + c], s, p);
+          k.dn(v, s, p) = d;
+        }
+    if (v != k.root) {
+      double Pm[4][4];
+      k.mod.probs(k.len[v], Pm);
+      for (int p = ex.lane(); p < k.P; p += ex.nlanes()) {
+        const double d0 = k.dn(v, 0, p), d1 = k.dn(v, 1, p), d2 = k.dn(v, 2, p), d3 = k.dn(v, 3, p);
+        for (int i = 0; i < 4; i++) k.ms(v, i, p) = Pm[i][0] * d0 + Pm[i][1] * d1 + Pm[i][2] * d2 + Pm[i][3] * d3;
+      }
+    }
+  }
+  for (int o = 0; o < k.nn; o++) {
+    const int v = k.preorder[o];
+    if (v == k.root) continue;
+    const int par = k.parent[v];
+    double W[4][4];
+    if (par != k.root) {   // what comes from above the parent, through the parent's own branch
+      double Pm[4][4];
+      k.mod.probs(k.len[par], Pm);
+      for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) W[i][j] = Pm[j][i] * k.mod.pi[j] / k.mod.pi[i];
+    }
+    for (int p = ex.lane(); p < k.P; p += ex.nlanes()) {
+      double u[4] = {1.0, 1.0, 1.0, 1.0};
+      for (int c = 0; c < k.nchild[par]; c++) {
+        const int sib = k.child[par * 3 + c];
+        if (sib != v) for (int s = 0; s < 4; s++) u[s] *= k.ms(sib, s, p);
+      }
+      if (par != k.root) {
+        const double a0 = k.upp(par, 0, p), a1 = k.upp(par, 1, p), a2 = k.upp(par, 2, p), a3 = k.upp(par, 3, p);
+        for (int i = 0; i < 4; i++) u[i] *= W[i][0] * a0 + W[i][1] * a1 + W[i][2] * a2 + W[i][3] * a3;
+      }
+      for (int s = 0; s < 4; s++) k.upp(v, s, p) = u[s];
+    }
+  }
+}
+
+template <typename Exec>
+RC_HD double edge_lnl(const Work &k, Exec &ex, int v, double t) {
+  double Pm[4][4], lnl = 0;
+  k.mod.probs(t, Pm);
+  for (int p = ex.lane(); p < k.P; p += ex.nlanes()) {
+    const double d0 = k.dn(v, 0, p), d1 = k.dn(v, 1, p), d2 = k.dn(v, 2, p), d3 = k.dn(v, 3, p);
+    double s = 0;
+    for (int i = 0; i < 4; i++)
+      s += k.mod.pi[i] * k.upp(v, i, p) * (Pm[i][0] * d0 + Pm[i][1] * d1 + Pm[i][2] * d2 + Pm[i][3] * d3);
+    lnl += k.w[p] * log(s > 1e-300 ? s : 1e-300);
+  }
+  return ex.sum(lnl);
+}
+
+template <typename Exec>
+RC_HD double total_lnl(Work &k, Exec &ex) {
+  partials(k, ex);
+  const int v = k.child[k.root * 3];
+  return edge_lnl(k, ex, v, k.len[v]);
+}
+
+// coordinate-wise ML: every branch, then kappa, until the log-likelihood moves by less than 1e-4
+// (PhyML's Round_Optimize stops at 1e-3, phyml/utilities.c:5207)
+template <typename Exec>
+RC_HD double optimise(Work &k, Exec &ex) {
+  tip_partials(k, ex);
+  double prev = total_lnl(k, ex);
+  for (int round = 0; round < 60; round++) {
+    for (int v = 0; v < k.nn; v++) {
+      if (v == k.root) continue;
+      partials(k, ex);
+      k.len[v] = minimise([&](double t) { return -edge_lnl(k, ex, v, t); }, kBlMin, kBlMax, k.len[v], 1e-5, 60);
+    }
+    const double kap = minimise(
+        [&](double kk) {
+          const Hky save = k.mod;
+          k.mod.set(k.pi, kk);
+          const double r = -total_lnl(k, ex);
+          k.mod = save;
+          return r;
+        },
+        0.1, 100.0, k.mod.kappa, 1e-5, 60);
+    k.mod.set(k.pi, kap);
+    const double cur = total_lnl(k, ex);
+    if (fabs(cur - prev) < 1e-4) { prev = cur; break; }
+    prev = cur;
+  }
+  return prev;
+}
+
+// the whole fit; D must hold no data yet.  Returns the log-likelihood.
+template <typename Exec>
+RC_HD double fit(Work &k, Exec &ex) {
+  base_freqs(k, ex);
+  k.mod.set(k.pi, 4.0);   // treeML.c:75
+  const int N = k.N, npairs = N * (N - 1) / 2;
+  for (int q = ex.lane(); q < npairs; q += ex.nlanes()) {   // pair q -> (i, j), i < j
+    int i = 0, rem = q;
+    while (rem >= N - 1 - i) { rem -= N - 1 - i; i++; }
+    const int j = i + 1 + rem;
+    const double d = pair_distance(k, i, j);
+    k.D[i * N + j] = k.D[j * N + i] = d;
+  }
+  ex.sync();
+  if (ex.lane() == 0) {
+    double dmax = 0;
+    for (int i = 0; i < N; i++) { k.D[i * N + i] = 0; for (int j = 0; j < N; j++) if (i != j && k.D[i * N + j] > dmax) dmax = k.D[i * N + j]; }
+    for (int i = 0; i < N * N; i++) if (k.D[i] < 0) k.D[i] = dmax > 0.1 ? dmax : 0.1;   // pairs without a shared site
+    bionj(k);
+  }
+  ex.sync();
+  k.root = ex.broadcast_root(k.root);
+  return optimise(k, ex);
+}
+
+}  // namespace treefit
+}  // namespace rc

@@ -373,3 +373,36 @@ def test_duplicate_row_names_are_rejected(ctx):
     rows = [AlnRow("a", "ATGGCTAAA"), AlnRow("a", "ATGGCAAAA"), AlnRow("c", "ATGGCTAAG")]
     with pytest.raises(api.RnacodeError):
         api.Batch(ctx, [AlnBlock(rows, "x", "(a:0.1,a:0.1,c:0.1);", 2.0)], api.default_params())
+
+
+def _newick_parts(nwk):
+    import re
+    return re.sub(r":[0-9.]+", "", nwk), [float(x) for x in re.findall(r":([0-9.]+)", nwk)]
+
+
+def test_device_tree_fit_matches_the_host_fit(ctx):
+    """rc_fit_trees_device (one wavefront per block) runs the same estimator as rc_fit_trees (host
+    threads) -- rc_tree_core.h -- so topologies are identical and lengths / kappa / lnL agree to the
+    optimiser's tolerance; checked on the real-data goldens (IUPAC codes, gaps, 3..~12 rows), on
+    synthetic blocks, on the widest shape (32 rows) and on blocks the driver skips."""
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_blocks
+    blocks = []
+    for name in ("genomic_preprocessed_n100", "coding_maf_n100", "noncoding_maf_n100", "edge_cases_n50"):
+        blocks += [block_from_golden(e) for e in load_golden(name)["blocks"]]
+    blocks += synth_blocks(40, 6, 120, seed=3) + synth_blocks(3, 32, 90, seed=4) + synth_blocks(2, 3, 30, seed=5) + synth_blocks(2, 12, 600, seed=6)
+    lnl = []
+    dev = api.fit_trees(blocks, ctx=ctx, lnl=lnl)
+    host = api.fit_trees(blocks)
+    fitted = 0
+    for b, d, h, l in zip(blocks, dev, host, lnl):
+        assert (d is None) == (h is None)
+        if d is None:
+            continue
+        (td, ld), (th, lh) = _newick_parts(d[0]), _newick_parts(h[0])
+        assert td == th, b.block_id
+        assert max(abs(x - y) for x, y in zip(ld, lh)) < 2e-4
+        assert abs(d[1] - h[1]) <= 1e-3 * h[1]
+        assert abs(l - api.tree_lnl(b, d[0], d[1])) < 1e-2   # lnL of the printed (%f-rounded) tree, host evaluation
+        fitted += 1
+    assert fitted >= 60
