@@ -95,29 +95,50 @@ template <int NK, bool EXACT> __device__ __forceinline__ float div_by_nk(float x
   }
 }
 
-// getHSS's state machine as the null samples need it: only the best emitted score matters, so the
-// segment start is carried as len = segmentEnd - segmentStart (score.c:892-959).
-// key = segmentEnd << 16 | (segmentEnd - segmentStart); codon sites < 32767.  Before the first
-// segment of a frame segmentEnd holds the sentinel 0x7FFF, which makes "currMax > 0 && segmentEnd < i"
-// (score.c:900) equivalent to key < (i << 16): currMax is positive exactly when a segment was opened.
-struct SampleScan { float cm; uint32_t key; };
-constexpr uint32_t kScanInitKey = 0x7FFFu << 16;
-// every entry except the frame's final one
-__device__ __forceinline__ void sample_scan_step(SampleScan &st, float &best, float v, uint32_t a, uint32_t span, uint32_t newkey,
-                                                 float tieThr) {
-  const uint32_t len = st.key & 0xFFFFu;
-  const bool pos = v > 0.0f;
-  const bool fresh = st.key < (a << 16);
-  const bool rep = (v > st.cm) | ((fabsf(v - st.cm) < tieThr) & (len <= span));   // (j-i) >= (segEnd-segStart), score.c:953-954
-  const bool emit = pos & fresh & (len >= 2u);                                    // minSegmentLength, score.c:902
-  best = (emit & (st.cm > best)) ? st.cm : best;
-  const bool upd = pos & (fresh | rep);
+// getHSS's state machine as the null samples need it (score.c:892-959): only the best emitted score
+// matters.  The serial rule per entry (a, j) with value v > 0 is
+//   open segment ended before row a (segmentEnd < a, currMax > 0)  -> report it, start (v, a, j)
+//   else v > currMax, or |v - currMax| < 1e-4 and j - a >= segmentEnd - segmentStart -> replace.
+// Restated per row so that an entry costs 4 compares and 2 selects:
+//  * A segment that ended before row a can no longer change, and it is reported either at the next
+//    positive entry or at the frame's final entry -- so reporting it at the START of row a and
+//    turning the state into "no segment" (currMax 0, which any positive v replaces through v > currMax)
+//    yields the same set of reported values.
+//  * Within row a the state is either carried in (segment (ss0, se0) with se0 >= a) or was set in
+//    this row at some j' (segment (a, j')).  "j - a >= segmentEnd - segmentStart" is j >= se0 - ss0 + a
+//    for the former and j >= j' (always true later in the row) for the latter: one threshold Q per
+//    lane, kept as 2(se0 - ss0 + a) when carried in and 2j' + 1 when set in this row, compared with
+//    2j + 1; its low bit tells at the end of the row which of the two happened.
+//  * v <= currMax together with |v - currMax| < thr is fl(v - currMax) > -thr.
+struct SampleScan {
+  float cm;        // currMax
+  uint32_t Q;      // see above; valid inside a row
+  uint32_t se;     // segmentEnd, valid between rows
+  uint32_t len;    // segmentEnd - segmentStart, valid between rows
+};
+__device__ __forceinline__ void sample_scan_row_begin(SampleScan &st, float &best, uint32_t a) {
+  const bool done = (st.cm > 0.0f) & (st.se < a);                 // score.c:900
+  best = (done & (st.len >= 2u) & (st.cm > best)) ? st.cm : best;  // minSegmentLength, score.c:902
+  st.cm = done ? 0.0f : st.cm;
+  st.len = done ? 0u : st.len;
+  st.Q = 2u * (st.len + a);
+}
+// every entry except the frame's final one; j2 = 2j + 1 (wave-uniform)
+__device__ __forceinline__ void sample_scan_step(SampleScan &st, float v, uint32_t j2, float negTieThr) {
+  const float d = v - st.cm;
+  const bool upd = (v > st.cm) | ((v > 0.0f) & (d > negTieThr) & (st.Q <= j2));   // score.c:953-954
   st.cm = upd ? v : st.cm;
-  st.key = upd ? newkey : st.key;
+  st.Q = upd ? j2 : st.Q;
+}
+__device__ __forceinline__ void sample_scan_row_end(SampleScan &st, uint32_t a) {
+  const bool inrow = (st.Q & 1u) != 0u;
+  const uint32_t j = st.Q >> 1;
+  st.se = inrow ? j : st.se;
+  st.len = inrow ? j - a : st.len;
 }
 // the final entry of a frame is entered unconditionally and always reports the open segment
 __device__ __forceinline__ void sample_scan_last(const SampleScan &st, float &best) {
-  best = (((st.key & 0xFFFFu) >= 2u) & (st.cm > best)) ? st.cm : best;
+  best = ((st.len >= 2u) & (st.cm > best)) ? st.cm : best;
 }
 
 // Read-only inputs are separate __restrict__ kernel parameters (not members of the by-value
@@ -387,8 +408,10 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
           }
           return end;
         };
-        SampleScan st{0.0f, kScanInitKey};
+        SampleScan st{0.0f, 0u, 0u, 0u};
+        const float negTie = -A.tieThr;
         for (int a = 0; a < sites; a++) {
+          sample_scan_row_begin(st, best, static_cast<uint32_t>(a));
           static_for<NK>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             auto &r = R.template at<k>();
@@ -406,7 +429,7 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
               uint32_t wnext[NCW];
               load_words(j + 1 < sites ? j + 1 : j, wnext);
               const float v = pristine_cell(wcur, wv);
-              sample_scan_step(st, best, v, static_cast<uint32_t>(a), static_cast<uint32_t>(j - a), (static_cast<uint32_t>(j) << 16) | static_cast<uint32_t>(j - a), A.tieThr);
+              sample_scan_step(st, v, 2u * static_cast<uint32_t>(j) + 1u, negTie);
 #pragma unroll
               for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
             }
@@ -421,7 +444,7 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
               uint32_t wnext[NCW];
               load_words(j + 1 < sites ? j + 1 : j, wnext);
               const float v = event_cell(wcur, j);
-              sample_scan_step(st, best, v, static_cast<uint32_t>(a), static_cast<uint32_t>(j - a), (static_cast<uint32_t>(j) << 16) | static_cast<uint32_t>(j - a), A.tieThr);
+              sample_scan_step(st, v, 2u * static_cast<uint32_t>(j) + 1u, negTie);
 #pragma unroll
               for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
               j++;
@@ -431,11 +454,12 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
               uint32_t wnext[NCW];
               load_words(j + 1 < sites ? j + 1 : j, wnext);
               const float v = fast_cell(wcur);
-              sample_scan_step(st, best, v, static_cast<uint32_t>(a), static_cast<uint32_t>(j - a), (static_cast<uint32_t>(j) << 16) | static_cast<uint32_t>(j - a), A.tieThr);
+              sample_scan_step(st, v, 2u * static_cast<uint32_t>(j) + 1u, negTie);
 #pragma unroll
               for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
             }
           }
+          sample_scan_row_end(st, static_cast<uint32_t>(a));
         }
         sample_scan_last(st, best);   // entry (sites-1, sites-1): its own value can never be reported
       }
