@@ -254,10 +254,15 @@ int rc_batch_create(rc_ctx *ctx, const rc_block *blocks, int32_t n_blocks, const
       std::memcpy(z2.data(), h.zw[0].data(), L1 * 8);
       std::memcpy(z2.data() + L1, h.zw[1].data(), L1 * 8);
       d.off_zw = put(z2.data(), z2.size() * 8);
-      std::vector<uint8_t> m2(2 * static_cast<size_t>(h.NK) * L1);
-      std::memcpy(m2.data(), h.mask[0].data(), static_cast<size_t>(h.NK) * L1);
-      std::memcpy(m2.data() + static_cast<size_t>(h.NK) * L1, h.mask[1].data(), static_cast<size_t>(h.NK) * L1);
-      d.off_mask = put(m2.data(), m2.size());
+      {   // gap masks, five 6-bit fields per word like the sigma codes: [strand][i][word]
+        const int ncw = (h.NK + 4) / 5;
+        std::vector<uint32_t> mw(2 * static_cast<size_t>(L1) * ncw, 0);
+        for (int s = 0; s < 2; s++)
+          for (int k = 0; k < h.NK; k++)
+            for (int p = 0; p < L1; p++)
+              mw[(static_cast<size_t>(s) * L1 + p) * ncw + k / 5] |= static_cast<uint32_t>(h.mask[s][static_cast<size_t>(k) * L1 + p]) << (6 * (k % 5));
+        d.off_mask = put(mw.data(), mw.size() * 4);
+      }
       std::vector<float> l2(2 * static_cast<size_t>(h.NK) * kLutSize);
       std::memcpy(l2.data(), h.lut[0].data(), static_cast<size_t>(h.NK) * kLutSize * 4);
       std::memcpy(l2.data() + static_cast<size_t>(h.NK) * kLutSize, h.lut[1].data(), static_cast<size_t>(h.NK) * kLutSize * 4);
@@ -405,7 +410,7 @@ int rc_batch_run(rc_batch *b) {
     bool exact = false;
     for (int bi : kv.second) exact = exact || b->hb[bi].exact_div;
     if (ldsBytes > c->ldsMaxBytes || exact) ldsBytes = 0;
-    else ldsBytes = std::max<size_t>(ldsBytes, kMaxNodes * 64);   // phase A keeps the tree's threshold table there
+    else ldsBytes = std::max<size_t>(ldsBytes, kPhaseALds);   // phase A keeps the tree's threshold table and the pair table there
     const std::pair<int, size_t> key(NK, ldsBytes);
     if (!c->occ.count(key)) c->occ[key] = null_occupancy(NK, ldsBytes);
     if (c->occ[key] <= 0 && ldsBytes) { ldsBytes = 0; const std::pair<int, size_t> k2(NK, 0); if (!c->occ.count(k2)) c->occ[k2] = null_occupancy(NK, 0); }

@@ -12,6 +12,7 @@ constexpr int kMaxRows = 32;      // N <= 32 (RC_MAX_ROWS)
 constexpr int kMaxNodes = 2 * kMaxRows;
 constexpr int kWave = 64;         // CDNA wavefront
 constexpr int kLutSize = 64;      // sigma codes are indices into a 64-entry per-(strand,k) table
+constexpr int kPhaseALds = kMaxNodes * 64 + 64 * 64;   // k_null phase A: threshold table + codon-pair table (bytes)
 
 // One node of the guide tree in Seq-Gen's evolution order (seqgen/evolve.c:400-433: pre-order,
 // branch1, branch2, then branch0 of an unrooted root).  thr[p][j]: integer form of the
@@ -41,7 +42,7 @@ struct DevBlock {
   uint32_t off_qtip;     // u8[N]        node index of row r's tip
   uint32_t off_refcol;   // u16[2][L+1]  strand s: 0-based column of reference residue i (1..L) in that strand's alignment
   uint32_t off_zw;       // u64[2][L+1]  2 bits per k (bit 2(k-1)): 0 -> z=0, 1 -> z=+1, 2 -> z=-1
-  uint32_t off_mask;     // u8[2][NK][L+1] 6-bit AND mask zeroing the codon fields where row k has '-'
+  uint32_t off_mask;     // u32[2][L+1][ceil(NK/5)] 6-bit AND masks (field k%5 of word k/5) zeroing the codon fields where row k has '-'
   uint32_t off_lut;      // f32[2][NK][64] sigma value per code
   uint32_t off_chars;    // u8[2][N][cols] native characters (strand 1 = reverse complement, rnaz_utils.c:316)
   uint32_t off_sigma;    // f32[2][NK][L+1] native sigma (written by k_native_sigma)

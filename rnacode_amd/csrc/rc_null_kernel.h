@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
     const unsigned long long *__restrict__ zw = reinterpret_cast<const unsigned long long *>(blob + db->off_zw);
     const unsigned long long *__restrict__ zmask = reinterpret_cast<const unsigned long long *>(blob + db->off_zmask);
     const int zmWords = db->zm_words;
-    const uint8_t *__restrict__ mask = blob + db->off_mask;
+    const uint32_t *__restrict__ maskw = reinterpret_cast<const uint32_t *>(blob + db->off_mask);
     const float *__restrict__ lut = reinterpret_cast<const float *>(blob + db->off_lut);
     const int sidx = grp * kWave + lane;
     const int L1 = L + 1;
@@ -191,9 +191,15 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
       constexpr int SPI = 4;
       constexpr int NODEW = (2 * N - 1 + 15) / 16;   // 16 nodes per 32-bit word
       U4 *ldsThr = reinterpret_cast<U4 *>(lds_codes);
+      // behind it the 64 x 64 codon-pair -> sigma-code table (4 KB): the 2 NK gathers per site are LDS
+      // byte reads instead of global ones
+      const uint8_t *ldsPair = reinterpret_cast<const uint8_t *>(lds_codes + nnodes * 16);
       {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(nodes);
         for (int idx = lane; idx < nnodes * 16; idx += kWave) lds_codes[idx] = src[(idx >> 4) * (sizeof(NodeRec) / 4) + (idx & 15)];
+        const uint32_t *psrc = reinterpret_cast<const uint32_t *>(pairTab);
+#pragma unroll
+        for (int x = 0; x < 64 * 64 / 4 / kWave; x++) lds_codes[nnodes * 16 + x * kWave + lane] = psrc[x * kWave + lane];
       }
       uint32_t win[N];
 #pragma unroll
@@ -247,15 +253,16 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
 #pragma unroll
               for (int w = 0; w < NCW; w++) {
                 uint32_t wf = 0, wr = 0;
+                const uint32_t mF = maskw[(0 * L1 + i) * NCW + w], mR = maskw[(1 * L1 + ip) * NCW + w];   // wave-uniform
 #pragma unroll
                 for (int c = 0; c < CPW; c++) {
                   const int k = w * CPW + c;  // 0-based index of sequence k+1
                   if (k < NK) {
-                    const uint32_t bF = win[k + 1] & mask[(0 * NK + k) * L1 + i];
-                    const uint32_t bR = (codon_flip(win[k + 1]) ^ 63u) & mask[(1 * NK + k) * L1 + ip];
-                    if (A.debugSkip & 4) { wf |= ((aF ^ bF) & 63u) << (6 * c); wr |= ((aR ^ bR) & 63u) << (6 * c); } else {
-                    wf |= static_cast<uint32_t>(pairTab[aF * 64 + bF]) << (6 * c);
-                    wr |= static_cast<uint32_t>(pairTab[aR * 64 + bR]) << (6 * c); }
+                    const uint32_t bF = win[k + 1] & ((mF >> (6 * c)) & 63u);
+                    const uint32_t bR = (codon_flip(win[k + 1]) ^ 63u) & ((mR >> (6 * c)) & 63u);
+                    // field c sits at bits [6c+7 : 6c+2]: shifted down by 6c it is a ds_bpermute address
+                    wf |= static_cast<uint32_t>(ldsPair[aF * 64 + bF]) << (6 * c + 2);
+                    wr |= static_cast<uint32_t>(ldsPair[aR * 64 + bR]) << (6 * c + 2);
                   }
                 }
                 cod[(static_cast<size_t>(0 * L1 + i) * NCW + w) * kWave + lane] = wf;
@@ -312,7 +319,7 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
             constexpr int k = decltype(kc)::value;
             constexpr int t = k % CPW;
             uint32_t addr;
-            if constexpr (t == 0) addr = w[k / CPW] << 2; else addr = w[k / CPW] >> (6 * t - 2);
+            if constexpr (t == 0) addr = w[k / CPW]; else addr = w[k / CPW] >> (6 * t);   // bits [7:2] select the lane
             const int lutv = R.template at<k>().lut;
             float got;
             asm volatile("ds_bpermute_b32 %0, %1, %2" : "=v"(got) : "v"(addr), "v"(lutv));
@@ -479,7 +486,7 @@ template <int NK>
 inline int null_occupancy_one(size_t ldsBytes) {
   int nb = 0;
   hipError_t e = ldsBytes ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_null<NK, true, false>, 64, ldsBytes)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_null<NK, false, false>, 64, kMaxNodes * 64);
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_null<NK, false, false>, 64, kPhaseALds);
   if (e != hipSuccess) return 0;
   return nb;
 }
@@ -488,7 +495,7 @@ inline int null_occupancy_one(size_t ldsBytes) {
 template <int NK>
 inline void launch_null_one(const NullArgs &a, int grid, size_t ldsBytes, bool exact, hipStream_t stream) {
   if (exact) {
-    hipLaunchKernelGGL((k_null<NK, false, true>), dim3(grid), dim3(64), kMaxNodes * 64, stream, a, a.blob, a.dblocks,
+    hipLaunchKernelGGL((k_null<NK, false, true>), dim3(grid), dim3(64), kPhaseALds, stream, a, a.blob, a.dblocks,
                        a.classBlocks, a.U, a.pair, a.scratch, a.maxima);
   } else if (ldsBytes) {
     if (ldsBytes > 48 * 1024)
@@ -497,7 +504,7 @@ inline void launch_null_one(const NullArgs &a, int grid, size_t ldsBytes, bool e
     hipLaunchKernelGGL((k_null<NK, true, false>), dim3(grid), dim3(64), ldsBytes, stream, a, a.blob, a.dblocks,
                        a.classBlocks, a.U, a.pair, a.scratch, a.maxima);
   } else {
-    hipLaunchKernelGGL((k_null<NK, false, false>), dim3(grid), dim3(64), kMaxNodes * 64, stream, a, a.blob, a.dblocks,
+    hipLaunchKernelGGL((k_null<NK, false, false>), dim3(grid), dim3(64), kPhaseALds, stream, a, a.blob, a.dblocks,
                        a.classBlocks, a.U, a.pair, a.scratch, a.maxima);
   }
 }
