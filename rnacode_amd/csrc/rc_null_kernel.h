@@ -228,27 +228,31 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
           uint32_t u[SPI];
 #pragma unroll
           for (int t = 0; t < SPI; t++) u[t] = Ustream[ubase[t] + q * qstride];
+          auto evolve = [&](auto withBase) {   // seqgen/evolve.c:416-433 for node q at the pass's sites
 #pragma unroll
-          for (int t = 0; t < SPI; t++) {
-            const uint32_t ps = (q == 0) ? 0u : get_state(ns[t], pq);
-            const U4 th = ldsThr[q * 4 + ps];
-            uint32_t st = (u[t] > th.x) + (u[t] > th.y) + (u[t] > th.z);
-            if (bp) st += (bp >> (2 * ps)) & 3u;
-            clamped += (u[t] > th.w);
-            const uint32_t bits = st << (2 * (q & 15));
+            for (int t = 0; t < SPI; t++) {
+              const uint32_t ps = (q == 0) ? 0u : get_state(ns[t], pq);
+              const U4 th = ldsThr[q * 4 + ps];
+              uint32_t st = (u[t] > th.x) + (u[t] > th.y) + (u[t] > th.z);
+              if constexpr (decltype(withBase)::value) st += (bp >> (2 * ps)) & 3u;
+              clamped += (u[t] > th.w);
+              const uint32_t bits = st << (2 * (q & 15));
 #pragma unroll
-            for (int x = 0; x < NODEW; x++) if (NODEW == 1 || (q >> 4) == x) ns[t][x] |= bits;
-          }
+              for (int x = 0; x < NODEW; x++) if (NODEW == 1 || (q >> 4) == x) ns[t][x] |= bits;
+            }
+          };
+          // base offsets exist only for degenerate cumulative rows: a real (scalar) branch, not a select
+          if (__builtin_expect(bp != 0u, 0)) evolve(std::true_type{}); else evolve(std::false_type{});
         }
 #pragma unroll
         for (int t = 0; t < SPI; t++) {
           const int i = i0 + t;
           if (i <= L) {
 #pragma unroll
-            for (int r = 0; r < N; r++) win[r] = ((win[r] << 2) | get_state(ns[t], qtip[r])) & 63u;
+            for (int r = 0; r < N; r++) win[r] = (win[r] << 2) | get_state(ns[t], qtip[r]);   // low 6 bits = the codon; older sites drift out at the top
             if (i >= 3) {
               const int ip = L + 3 - i;  // reverse-strand position whose codon is these three columns
-              const uint32_t aF = win[0];
+              const uint32_t aF = win[0] & 63u;
               const uint32_t aR = codon_flip(aF) ^ 63u;
 #pragma unroll
               for (int w = 0; w < NCW; w++) {
