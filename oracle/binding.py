@@ -55,6 +55,8 @@ def lib():
         _lib.orc_pvalue.restype = C.c_float
         _lib.orc_pvalue.argtypes = [C.c_float, C.c_float, C.c_float]
         _lib.orc_score_matrix.restype = C.POINTER(C.c_float)
+        _lib.orc_tie_replacements.restype = C.c_ulong
+        _lib.orc_tie_replacements.argtypes = [C.c_int]
     return _lib
 
 
@@ -112,6 +114,11 @@ def evd_fit(x) -> Tuple[int, float, float]:
 
 def pvalue(score, mu, lam) -> float:
     return float(lib().orc_pvalue(C.c_float(score), C.c_float(mu), C.c_float(lam)))
+
+
+def tie_replacements(reset: bool = False) -> int:
+    """How often getHSS's 1e-4 tie rule decided a replacement since the last reset (test diagnostic)."""
+    return int(lib().orc_tie_replacements(1 if reset else 0))
 
 
 def mt_stream(seed: int, n: int) -> np.ndarray:

@@ -519,6 +519,15 @@ static float *multiple_matrix(const float *sk, int N, int L, const orc_params *p
 
 /* ------------------------------------------------------------------ a10: score.c:864-974 */
 
+/* diagnostic for the tests: how often getHSS's "equal score, segment at least as long" rule (score.c:953-954)
+ * decided a replacement that "v > currMax" alone would not have made */
+static unsigned long tie_replacements = 0;
+unsigned long orc_tie_replacements(int reset) {
+  unsigned long r = tie_replacements;
+  if (reset) tie_replacements = 0;
+  return r;
+}
+
 static int get_hss(const float *S, int L, int ref_start, int ref_length, char strand, orc_hss *out, int cap) {
   int frame, sites, i, j, n = 0;
   const int minSegmentLength = 2;
@@ -553,6 +562,7 @@ static int get_hss(const float *S, int L, int ref_start, int ref_length, char st
             }
             currMax = v; segStart = i; segEnd = j;
           } else if (v > currMax || ((fabs(v - currMax) < 0.0001) && ((j - i) >= (segEnd - segStart)))) {
+            if (!(v > currMax)) tie_replacements++;
             currMax = v; segStart = i; segEnd = j;
           }
         }

@@ -102,6 +102,9 @@ int orc_backtrack(int opt_b, int opt_i, const float *sk, const char *const *rows
                   const orc_params *par, int *states, int *z, int *transitions);
 
 /* MT19937 as used by Seq-Gen (twister.c:73-89,118-166): first n outputs for a seed. */
+/* test diagnostic: count of replacements decided by the 1e-4 tie rule of getHSS since the last reset */
+unsigned long orc_tie_replacements(int reset);
+
 void orc_mt_stream(unsigned long seed, unsigned int *out, int n);
 
 /* whole block, the way RNAcode.c:153-188 drives it. Returns number of HSS (sorted by score

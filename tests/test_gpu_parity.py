@@ -406,3 +406,52 @@ def test_device_tree_fit_matches_the_host_fit(ctx):
         assert abs(l - api.tree_lnl(b, d[0], d[1])) < 1e-2   # lnL of the printed (%f-rounded) tree, host evaluation
         fitted += 1
     assert fitted >= 60
+
+
+def test_tie_rich_and_degenerate_blocks_against_oracle(ctx):
+    """Blocks built to hit the rare branches of the path: stretches where every non-reference row is gapped
+    (all sigma = 0, so consecutive entries of the score matrix are exactly equal and getHSS's 'equal score, longer
+    segment' rule decides, score.c:953-954), frame-shifting gap lengths, and zero-length branches (identity
+    transition rows: the degenerate cumulative rows of evolve.c:292).  maxScores and the HSS table must still be
+    bit-identical to the oracle's."""
+    import re
+    from oracle import binding as ob
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_block
+    rng = np.random.RandomState(77)
+    blocks = []
+    for i in range(96):
+        n = int(rng.randint(3, 7))
+        cols = int(rng.randint(45, 121))
+        b = synth_block(rng, n, cols, index=i, gaps=bool(i % 2), mean_branch=(0.02, 0.1, 0.3)[i % 3]).upper()
+        rows = [bytearray(r.seq.encode()) for r in b.rows]
+        for _ in range(int(rng.randint(1, 4))):          # common gap stretches in all non-reference rows
+            length = int((3, 6, 9, 12, 4, 7)[rng.randint(6)])
+            pos = int(rng.randint(0, cols - length))
+            for r in range(1, n):
+                rows[r][pos:pos + length] = b"-" * length
+        for r, row in zip(b.rows, rows):
+            r.seq = row.decode()
+            r.length = sum(1 for ch in r.seq if ch != "-")
+        if i % 4 == 0:                                   # one or two zero-length branches
+            lens = list(re.finditer(r":[0-9.]+", b.tree))
+            for m in [lens[j] for j in rng.choice(len(lens), size=min(2, len(lens)), replace=False)]:
+                b.tree = b.tree[:m.start()] + ":0.000000" + b.tree[m.end():]
+        blocks.append(b)
+    n_samples, seed = 150, 991
+    batch = api.Batch(ctx, blocks, api.default_params(sampleN=n_samples, seed_base=seed)).run()
+    ob.tie_replacements(reset=True)
+    for i, b in enumerate(blocks):
+        rows = [r.seq for r in b.rows]
+        names = [r.name for r in b.rows]
+        res = ob.run_block(rows, names, b.rows[0].start, b.rows[0].length, b.tree, b.kappa, ob.default_params(n_samples), seed)
+        np.testing.assert_array_equal(batch.maxScores(i), np.float32(res.maxScores), err_msg=f"block {i}")
+        got = sorted(batch.scoreAln(i), key=hss_key)
+        want = sorted(res.hss, key=hss_key)
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            for k in ("strand", "frame", "startSite", "endSite", "start", "end"):
+                assert g[k] == w[k]
+            assert np.float32(g["score"]) == np.float32(w["score"])
+    assert ob.tie_replacements() > 1000   # the construction does exercise the tie rule (native and null alignments)
+    batch.close()
