@@ -144,6 +144,12 @@ int rc_batch_native_S(const rc_batch *b, int32_t blk, int32_t strand /*0:'+',1:'
 int rc_batch_backtrack(const rc_batch *b, int32_t blk, int32_t strand, int32_t opt_b, int32_t opt_i,
                        int32_t *states, int32_t *z, int32_t *transitions);
 
+/* The substitution matrix and genetic code the scorer uses, for callers that render results
+ * (getScoringMatrix() score.c:50-76 and transcode[4][4][4] code.c:28-39, which src/postscript.c:362,412
+ * read): pep_out[16a+4b+c] = amino-acid index 0..19 of codon (a,b,c) in A,C,G,T order or -1 for a stop;
+ * matrix_out[20p+q] = BLOSUM entry of amino acids p,q.  blosum is 62 or 90. */
+int rc_code_tables(int32_t blosum, int32_t pep_out[64], int32_t matrix_out[400]);
+
 /* Tree + kappa for one block, the inputs treeML() hands to the scorer (src/treeML.c:35-152 via the
  * bundled PhyML): BIONJ topology from pairwise ML distances, HKY85 maximum-likelihood branch lengths
  * and kappa.  Host code, re-entrant (call it from several threads); blk->newick/kappa are ignored.

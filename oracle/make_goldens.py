@@ -162,5 +162,48 @@ def main():
     emit("synth_rooted_4x48_n100", rooted, 100, note="rooted sidecar tree")
 
 
+
+
+def emit_eps(name, base_fixture, blocks, samples, keep):
+    """EPS plots of the reference (src/postscript.c through printResults --eps) for `blocks`: all file names the
+    run produced, and the text of the files listed in `keep`.  Inputs and HSS tables are those of `base_fixture`."""
+    tmpdir = tempfile.mkdtemp()
+    with tempfile.NamedTemporaryFile("w", suffix=".blk", delete=False) as fh:
+        path = fh.name
+    try:
+        write_harness_blocks(blocks, path)
+        epsdir = os.path.join(tmpdir, "eps")
+        subprocess.check_output([HARNESS, path, "--samples", str(samples), "--seed", str(SEED), "--no-backtrack",
+                                 "--print-to", os.path.join(tmpdir, "list.txt"), "--format", "0", "--eps-dir", epsdir])
+        names = sorted(os.listdir(epsdir), key=lambda s: int(s[4:-4]))
+        files = {}
+        for k in keep:
+            with open(os.path.join(epsdir, k)) as fh:
+                files[k] = fh.read()
+    finally:
+        os.unlink(path)
+        import shutil
+        shutil.rmtree(tmpdir, ignore_errors=True)
+    doc = dict(fixture=name, base=base_fixture, samples=samples, seed_base=SEED, eps_cutoff=0.05, names=names, files=files,
+               note="conservation bars depend on the harness's re-statement of consensus() (see oracle/ref_harness.c)")
+    out = os.path.join(OUT, name + ".json.gz")
+    with gzip.GzipFile(out, "wb", mtime=0) as fh:
+        fh.write(json.dumps(doc, separators=(",", ":")).encode())
+    print(f"{name}: {len(names)} plots, {len(files)} kept, {os.path.getsize(out)} bytes")
+
+
+def main_eps():
+    ex = os.path.join(REF, "examples")
+    emit_eps("eps_coding_aln_n100", "coding_aln_n100", read_alignment_file(os.path.join(ex, "coding.aln")), 100,
+             ["hss-0.eps", "hss-1.eps"])
+    gp = read_alignment_file(os.path.join(ex, "genomic-preprocessed.maf"))
+    emit_eps("eps_genomic_preprocessed_n100", "genomic_preprocessed_n100", gp, 100,
+             ["hss-8.eps", "hss-12.eps", "hss-33.eps", "hss-104.eps", "hss-133.eps"])
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "eps":
+        main_eps()
+    else:
+        main()
+        main_eps()

@@ -21,7 +21,10 @@
  *    388-420).  Consequence: revAln is NOT pinned by the reference build; it is
  *    pinned by the known-answer '-' strand HSS recorded from a full reference
  *    build in SURVEY.md section 8c (coding.aln: "- 3 32 12 43 ... 36 131 19.782").
- *  - colorAln: only reachable from printResults with --eps; never called here.
+ *  - consensus: src/postscript.c (the --eps plots, compiled in place like the other path files) draws
+ *    its conservation bars from rnaz_utils.c:249-264's consensus(), which is in the unbuildable file;
+ *    re-stated below together with librna/pair_mat.h:26-38's encode_char.  Consequence: the bar heights
+ *    of the EPS goldens are pinned by this re-statement, everything else in them by the reference.
  *
  * Input format (written by oracle/make_goldens.py from MAF/ClustalW files):
  *   B <id>
@@ -133,10 +136,26 @@ void revAln(struct aln *AS[]) {
     else if (AS[i]->strand == '-') AS[i]->strand = '+';
   }
 }
-void colorAln(const char *filename, const struct aln *alignment[], segmentStats region) {
-  (void)filename; (void)alignment; (void)region;
-  fprintf(stderr, "colorAln is not part of the harness\n");
-  exit(2);
+/* rnaz_utils.c:249-264 with encode_char of librna/pair_mat.h:26-38 (energy_set == 0): most frequent
+ * character class per column, first maximum wins; the class-to-letter table is indexed with the
+ * T/U-merged code, so class 5 ('X') prints 'T' -- kept as it is. */
+char *consensus(const struct aln *AS[]) {
+  static const char order[] = "_ACGUTXKI";
+  int i, n = (int)strlen(AS[0]->seq);
+  char *string = (char *)calloc((size_t)n + 1, 1);
+  for (i = 0; i < n; i++) {
+    int s, c, fm, freq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (s = 0; AS[s] != NULL; s++) {
+      const char *pos = strchr(order, AS[s]->seq[i]);
+      int code = (pos == NULL || AS[s]->seq[i] == '\0') ? 0 : (int)(pos - order);
+      if (code > 4) code--;
+      freq[code]++;
+    }
+    for (s = c = fm = 0; s < 8; s++)
+      if (freq[s] > fm) { c = s; fm = freq[c]; }
+    string[i] = order[c];
+  }
+  return string;
 }
 
 /* ---- JSON helpers ---- */
@@ -236,6 +255,8 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[a], "--no-digest")) want_digest = 0;
     else if (!strcmp(argv[a], "--print-to") && a + 1 < argc) printTo = fopen(argv[++a], "w");
     else if (!strcmp(argv[a], "--format") && a + 1 < argc) pars.outputFormat = atoi(argv[++a]);
+    else if (!strcmp(argv[a], "--eps-dir") && a + 1 < argc) { pars.postscript = 1; strcpy(pars.postscriptDir, argv[++a]); }
+    else if (!strcmp(argv[a], "--eps-cutoff") && a + 1 < argc) pars.postscript_cutoff = (float)atof(argv[++a]);
     else if (!strcmp(argv[a], "--best-only")) pars.bestOnly = 1;
     else if (!strcmp(argv[a], "--best-region")) pars.bestRegion = 1;
     else if (!strcmp(argv[a], "--pars") && a + 4 < argc) {

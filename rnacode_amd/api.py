@@ -113,6 +113,7 @@ def lib():
         l.rc_tree_lnl.argtypes = [C.POINTER(RcBlock), C.POINTER(C.c_double)]
         l.rc_fit_trees_device.argtypes = [C.c_void_p, C.POINTER(RcBlock), C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_float),
                                           C.POINTER(C.c_double)]
+        l.rc_code_tables.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         l.rc_set_stream_cache.argtypes = [C.c_int]
         l.rc_set_stream_cache.restype = None
         _lib = l
@@ -123,7 +124,7 @@ EXPORTED_SYMBOLS = [
     "rc_default_params", "rc_last_error", "rc_device_count", "rc_ctx_create", "rc_ctx_destroy", "rc_batch_create",
     "rc_batch_destroy", "rc_batch_bind_maxima", "rc_batch_run", "rc_set_stream_cache", "rc_batch_work", "rc_batch_timing", "rc_batch_status",
     "rc_batch_models", "rc_batch_maxima", "rc_batch_maxima_all", "rc_batch_fit", "rc_batch_hss", "rc_batch_clamped",
-    "rc_batch_native_S", "rc_batch_backtrack", "rc_fit_tree", "rc_fit_trees", "rc_fit_trees_device", "rc_tree_lnl", "rc_evd_fit", "rc_mt_stream",
+    "rc_batch_native_S", "rc_batch_backtrack", "rc_fit_tree", "rc_fit_trees", "rc_fit_trees_device", "rc_tree_lnl", "rc_evd_fit", "rc_mt_stream", "rc_code_tables",
 ]
 
 
@@ -141,6 +142,15 @@ def default_params(**kw) -> RcParams:
             raise KeyError(k)
         setattr(p, k, v)
     return p
+
+
+def code_tables(blosum: int = 62) -> Tuple[np.ndarray, np.ndarray]:
+    """(pep[64], matrix[20][20]) of rc_code_tables: genetic code (-1 = stop) and BLOSUM62/90 as the scorer uses them."""
+    pep = np.zeros(64, dtype=np.int32)
+    mat = np.zeros((20, 20), dtype=np.int32)
+    ip = C.POINTER(C.c_int32)
+    _check(lib().rc_code_tables(blosum, pep.ctypes.data_as(ip), mat.ctypes.data_as(ip)))
+    return pep, mat
 
 
 def fit_tree(block: AlnBlock) -> Tuple[str, float]:

@@ -4,21 +4,23 @@ Mirrors the reference's command line (src/cmdline.ggo:6-20, src/RNAcode.c:236-37
 options that concern the scoring path and the listings:
 
     python -m rnacode_amd.cli [-n N] [-p CUTOFF] [-g | -t] [-b] [-r] [-s] [-m 62|90] [-c D,O,o,S]
-                              [-o OUT] --trees SIDECAR [FILE]
+                              [-e [-i CUTOFF] [-d DIR]] [-o OUT] [--trees SIDECAR] [FILE]
 
 Tree + kappa per block (PhyML in the reference, RNAcode.c:153) come either from a sidecar
 (`--trees`: one `<newick> TAB <kappa>` line per alignment block, in file order; `-` for blocks the
-driver skips) or, without it, from the built-in estimator (rc_fit_tree, host threads).  All blocks
-of the file are scored as ONE batch on the GPU.
+driver skips) or, without it, from the built-in estimator (rc_fit_trees_device, one wavefront per
+block).  All blocks of the file are scored as ONE batch on the GPU.  -e writes the reference's colored
+alignment plots (src/postscript.c) as <DIR>/hss-<n>.eps.
 Quirk kept from the reference: the 4th value of --pars goes to stopPenalty_0 (RNAcode.c:318)."""
 from __future__ import annotations
 
 import argparse
+import os
 import sys
 import time
 from typing import List, Optional
 
-from . import api, report
+from . import api, eps, report
 from .alnio import AlnBlock, read_alignment_file
 
 
@@ -56,6 +58,9 @@ def main(argv=None) -> int:
     ap.add_argument("-p", "--cutoff", type=float, default=1.0)
     ap.add_argument("-c", "--pars")
     ap.add_argument("-m", "--blosum", type=int, default=62)
+    ap.add_argument("-e", "--eps", action="store_true", help="Create colored plots in EPS format")
+    ap.add_argument("-i", "--eps-cutoff", type=float, default=0.05, help="Create plots only if p better than this cutoff")
+    ap.add_argument("-d", "--eps-dir", default="eps", help="Directory to put eps-files")
     ap.add_argument("--trees", help="sidecar: one '<newick>\\t<kappa>' line per block (default: fit them)")
     ap.add_argument("--seed-base", type=int, default=42)
     ap.add_argument("--device", type=int, default=0)
@@ -104,8 +109,15 @@ def main(argv=None) -> int:
             msg = "There must be at least three sequences in the alignment." if b.n <= 2 else "Too short."
             print(f"Skipping alignment. {msg}", file=sys.stderr)
             continue
+        hook = None
+        if a.eps:   # misc.c:461-474: hss-<counter>.eps for every listed HSS with p below the plot cutoff
+            def hook(counter, h, i=i, b=b):
+                os.makedirs(a.eps_dir, exist_ok=True)
+                text = eps.color_aln(b, h, lambda strand, lo, hi: batch.backtrack(i, 0 if strand == "+" else 1, lo, hi), a.blosum)
+                with open(os.path.join(a.eps_dir, f"hss-{counter}.eps"), "w") as fh:
+                    fh.write(text)
         report.print_results(out, fmt, batch.scoreAln(i), b.rows[0].name, st, cutoff=a.cutoff, best_only=a.best_only,
-                             best_region=a.best_region)
+                             best_region=a.best_region, eps=hook, eps_cutoff=a.eps_cutoff)
     if fmt == 0:
         report.print_footer(out, len(prepared), time.perf_counter() - t0, params.sampleN, params.Delta, params.Omega,
                             params.omega, params.stopPenalty_k)

@@ -662,6 +662,14 @@ int rc_batch_backtrack(const rc_batch *b, int32_t blk, int32_t strand, int32_t o
   return RC_OK;
 }
 
+int rc_code_tables(int32_t blosum, int32_t pep_out[64], int32_t matrix_out[400]) {
+  if ((blosum != 62 && blosum != 90) || !pep_out || !matrix_out) return fail(RC_ERR_ARG, "bad argument");
+  const CodeTables ct(blosum);
+  for (int c = 0; c < 64; c++) pep_out[c] = ct.pep[c];
+  for (int p = 0; p < 20; p++) for (int q = 0; q < 20; q++) matrix_out[20 * p + q] = ct.blosum[p][q];
+  return RC_OK;
+}
+
 int rc_fit_tree(const rc_block *blk, char *newick_out, int32_t cap, float *kappa_out) {
   if (!blk || !newick_out || cap < 8 || !kappa_out || !blk->rows || !blk->names) return fail(RC_ERR_ARG, "bad argument");
   std::vector<std::string> rows(blk->n_rows), names(blk->n_rows);

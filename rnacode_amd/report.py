@@ -32,8 +32,10 @@ def _c_f(value: float, prec: int, width: int, space_flag: bool) -> str:
 
 
 def print_results(out: IO[str], fmt: int, hss: List[dict], ref_name: str, state: ReportState, cutoff: float = 1.0,
-                  best_only: bool = False, best_region: bool = False) -> None:
-    """hss: the block's HSS (dicts as returned by Batch.scoreAln, any order), p-values filled."""
+                  best_only: bool = False, best_region: bool = False, eps=None, eps_cutoff: float = 0.05) -> None:
+    """hss: the block's HSS (dicts as returned by Batch.scoreAln, any order), p-values filled.
+    eps: optional callback eps(hit_counter, hss_record), called for every listed HSS with p < eps_cutoff
+    before its line is written -- where the reference draws hss-<counter>.eps (misc.c:461-474)."""
     res = [dict(h, hide=False) for h in hss if h["score"] > 0.0]
     if best_region:   # misc.c:408-433: sort by start codon, hide the weaker of two overlapping HSS
         res.sort(key=lambda h: h["startSite"])
@@ -64,6 +66,8 @@ def print_results(out: IO[str], fmt: int, hss: List[dict], ref_name: str, state:
             break
         if h["hide"]:
             continue
+        if eps is not None and p < float(np.float32(eps_cutoff)):
+            eps(state.hit_counter, h)
         length = h["endSite"] - h["startSite"] + 1
         if fmt == 0:
             out.write("%6i %4s%i%7i%6i%6i%12s%12i%12i%9.2f" % (state.hit_counter, h["strand"], h["frame"] + 1, length,

@@ -455,3 +455,38 @@ def test_tie_rich_and_degenerate_blocks_against_oracle(ctx):
             assert np.float32(g["score"]) == np.float32(w["score"])
     assert ob.tie_replacements() > 1000   # the construction does exercise the tie rule (native and null alignments)
     batch.close()
+
+
+@pytest.mark.parametrize("name", ["eps_coding_aln_n100", "eps_genomic_preprocessed_n100"])
+def test_eps_plots_with_device_backtrack(ctx, name):
+    """Section 8f-4: the reference's hss-<n>.eps files byte for byte, with the state paths of the left extension, the
+    segment and the right extension coming from rc_batch_backtrack."""
+    from rnacode_amd import api
+    from test_eps_cpu import collect_plots
+    doc = load_golden(name)
+    base = load_golden(doc["base"])
+    _, blocks, batch = run_golden(ctx, base)
+    index = {b.block_id: i for i, b in enumerate(blocks)}
+
+    def make_backtracker(block, tree, kappa):
+        i = index[block.block_id]
+        return lambda strand, lo, hi: batch.backtrack(i, 0 if strand == "+" else 1, lo, hi)
+    names, texts = collect_plots(doc, base, make_backtracker, set(doc["files"]))
+    assert names == doc["names"]
+    for k, want in doc["files"].items():
+        assert texts[k] == want, k
+    batch.close()
+
+
+def test_cli_writes_eps_files(tmp_path):
+    from rnacode_amd import cli
+    from rnacode_amd.synth import to_maf
+    doc = load_golden("coding_maf_n100")
+    maf = tmp_path / "in.maf"
+    maf.write_text(to_maf([block_from_golden(e) for e in doc["blocks"]]))
+    side = tmp_path / "trees.tsv"
+    side.write_text("".join(f"{e['ref']['tree']}\t{e['ref']['kappa']!r}\n" if "skipped" not in e["ref"] else "-\n" for e in doc["blocks"]))
+    assert cli.main([str(maf), "-n", "100", "--trees", str(side), "-o", str(tmp_path / "out.txt"), "-e", "-d", str(tmp_path / "plots")]) == 0
+    made = sorted(p.name for p in (tmp_path / "plots").iterdir())
+    assert made and all(n.startswith("hss-") and n.endswith(".eps") for n in made)
+    assert (tmp_path / "plots" / made[0]).read_text().startswith("%!PS-Adobe-3.0 EPSF-3.0\n")
