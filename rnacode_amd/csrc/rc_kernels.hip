@@ -152,14 +152,22 @@ __global__ __launch_bounds__(64) void k_native_scan(NativeArgs A) {
   ScanState st{0.0f, -1, -1};
   for (int a = 0; a < sites; a++) {
     for (int j0 = a; j0 < sites; j0 += kWave) {
+      // the state machine only looks at positive entries and at the frame's final one (score.c:898):
+      // the wave finds them with a ballot, lane 0 walks the set bits in order
+      const int j = j0 + lane;
+      const float v = (j < sites) ? S[static_cast<size_t>(a) * sites + j] : 0.0f;
+      const bool last = (a == sites - 1) && (j == sites - 1);
+      unsigned long long m = __ballot((j < sites) && (v > 0.0f || last));
+      if (m == 0ull) continue;
       __syncthreads();
-      if (j0 + lane < sites) row[lane] = S[static_cast<size_t>(a) * sites + j0 + lane];
+      row[lane] = v;
       __syncthreads();
       if (lane == 0) {
-        const int jend = min(sites, j0 + kWave);
-        for (int j = j0; j < jend; j++) {
-          const bool last = (a == sites - 1) && (j == sites - 1);
-          scan_step(st, row[j - j0], a, j, last, A.tieThr, [&](const ScanState &e) {
+        while (m) {
+          const int t = __builtin_ctzll(m);
+          m &= m - 1ull;
+          const int jj = j0 + t;
+          scan_step(st, row[t], a, jj, (a == sites - 1) && (jj == sites - 1), A.tieThr, [&](const ScanState &e) {
             if (n < A.hssCap) out[n] = DevHss{s, f, e.ss, e.se, e.cm};
             n++;
           });
