@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--samples", type=int, default=1000)
     ap.add_argument("--seed-base", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", choices=("fits", "maxima"), default="fits",
+                    help="what the ranks all-gather per step: the per-block fit results (16 B per block, default) or "
+                         "the per-sample maxima (4 B x samples per block, written by the kernel into the gathered tensor)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --blocks per GPU (default); strong: --blocks in total, split across ranks (configs[3])")
     args = ap.parse_args()
@@ -110,11 +113,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     torch = None
+    coll_dev = f"cuda:{local_rank}"
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("RC_BENCH_TEST_BACKEND") == "gloo":
+            # test hook: exercises this file's multi-rank logic on a box with fewer GPUs than ranks
+            # (collectives on CPU tensors over gloo, ranks share the GPUs that exist); never used for numbers
+            local_rank %= max(1, torch.cuda.device_count())
+            coll_dev = "cpu"
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from rnacode_amd import api
     from rnacode_amd import distributed as rd
@@ -138,15 +149,20 @@ def main():
     t_prep = time.perf_counter() - t0
 
     gathered = None
-    if world > 1:
+    mine = None
+    if world > 1 and args.exchange == "maxima":
         mine = torch.empty((len(blocks), args.samples), dtype=torch.float32, device=f"cuda:{local_rank}")
         batch.bind_maxima(mine.data_ptr())
 
     def step():
         batch.run()                      # synchronous: kernels done, small results on the host
-        if world > 1:                    # the path's one exchange: all-gather of per-sample maxima (RCCL over xGMI)
+        if world > 1:                    # the path's one exchange (RCCL over xGMI): results of all blocks on every rank
             nonlocal gathered
-            gathered = rd.all_gather_maxima(mine, counts)
+            if args.exchange == "maxima":
+                gathered = rd.all_gather_maxima(mine if coll_dev != "cpu" else mine.cpu(), counts)
+            else:
+                fits = torch.from_numpy(batch.fits()).to(coll_dev, non_blocking=True)
+                gathered = rd.all_gather_fits(fits, counts)
 
     def sync():
         if world > 1:
@@ -169,11 +185,11 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        elapsed = rd.max_over_ranks(elapsed, device=f"cuda:{local_rank}")
+        elapsed = rd.max_over_ranks(elapsed, device=coll_dev)
 
     sa, cs = batch.work()
     if world > 1:   # units of all ranks (shards may differ by one block under strong scaling)
-        tot = torch.tensor([float(cs), float(sa)], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tot = torch.tensor([float(cs), float(sa)], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tot)
         cs, sa = int(tot[0].item()), int(tot[1].item())
     total_units = cs * args.steps
@@ -199,7 +215,8 @@ def main():
             "config": {"workload": f"synthetic MAF {args.blocks} blocks x {args.cols} cols x {args.seqs} seqs, "
                                    f"--num-samples {args.samples}, per GPU (BASELINE.json configs[2]/[3])",
                        "blocks_per_gpu": len(blocks), "cols": args.cols, "seqs": args.seqs, "samples": args.samples,
-                       "seed_base": args.seed_base, "sharding": f"blocks x{world}"},
+                       "seed_base": args.seed_base, "sharding": f"blocks x{world}",
+                       "exchange": ("all-gather of " + args.exchange) if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": measured_traffic() if (args.blocks, args.cols, args.seqs, args.samples) == (10000, 120, 6, 1000) else None, "kernel": "k_null<%d>" % (args.seqs - 1), "kernel_ms": null_ms,
                          "algorithmic_bytes_per_launch": by,

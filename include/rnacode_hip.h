@@ -127,6 +127,10 @@ int rc_batch_maxima(const rc_batch *b, int32_t blk, float *out);
 int rc_batch_maxima_all(const rc_batch *b, float *out);
 /* getExtremeValuePars' outputs: rc 1 / -1 like the reference, mu and lambda narrowed to float */
 int rc_batch_fit(const rc_batch *b, int32_t blk, int32_t *evd_rc, float *mu, float *lambda);
+/* The same for every block at once: out[4*blk + {0,1,2,3}] = {evd_rc or the block's status if it was
+ * not scored, mu, lambda, number of samples above the best native score}.  This is what leaves a GPU
+ * when blocks are sharded across ranks (the p-values follow from mu and lambda). */
+int rc_batch_fit_all(const rc_batch *b, float *out);
 /* HSS list sorted by score descending as main() does (RNAcode.c:173-176); returns the count
  * (may exceed cap; only cap entries are written) */
 int rc_batch_hss(const rc_batch *b, int32_t blk, rc_hss *out, int32_t cap);

@@ -101,6 +101,7 @@ def lib():
         l.rc_batch_maxima.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float)]
         l.rc_batch_maxima_all.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         l.rc_batch_fit.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        l.rc_batch_fit_all.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         l.rc_batch_hss.argtypes = [C.c_void_p, C.c_int32, C.POINTER(RcHss), C.c_int32]
         l.rc_batch_clamped.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         l.rc_batch_native_S.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_int32]
@@ -123,7 +124,7 @@ def lib():
 EXPORTED_SYMBOLS = [
     "rc_default_params", "rc_last_error", "rc_device_count", "rc_ctx_create", "rc_ctx_destroy", "rc_batch_create",
     "rc_batch_destroy", "rc_batch_bind_maxima", "rc_batch_run", "rc_set_stream_cache", "rc_batch_work", "rc_batch_timing", "rc_batch_status",
-    "rc_batch_models", "rc_batch_maxima", "rc_batch_maxima_all", "rc_batch_fit", "rc_batch_hss", "rc_batch_clamped",
+    "rc_batch_models", "rc_batch_maxima", "rc_batch_maxima_all", "rc_batch_fit", "rc_batch_fit_all", "rc_batch_hss", "rc_batch_clamped",
     "rc_batch_native_S", "rc_batch_backtrack", "rc_fit_tree", "rc_fit_trees", "rc_fit_trees_device", "rc_tree_lnl", "rc_evd_fit", "rc_mt_stream", "rc_code_tables",
 ]
 
@@ -319,6 +320,12 @@ class Batch:
         rc, mu, lam = C.c_int32(), C.c_float(), C.c_float()
         _check(lib().rc_batch_fit(self._h, blk, C.byref(rc), C.byref(mu), C.byref(lam)))
         return rc.value, float(mu.value), float(lam.value)
+
+    def fits(self) -> np.ndarray:
+        """rc_batch_fit_all: [n_blocks, 4] float32 rows (evd_rc or status, mu, lambda, samples above the best native score)."""
+        out = np.zeros((self.n, 4), dtype=np.float32)
+        _check(lib().rc_batch_fit_all(self._h, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
 
     def maxScores(self, blk: int) -> np.ndarray:
         out = np.zeros(self.params.sampleN, dtype=np.float32)

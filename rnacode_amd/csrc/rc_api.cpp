@@ -552,6 +552,18 @@ int rc_batch_fit(const rc_batch *b, int32_t blk, int32_t *evd_rc, float *mu, flo
   return RC_OK;
 }
 
+int rc_batch_fit_all(const rc_batch *b, float *out) {
+  if (!b || !out || !b->ran) return fail(RC_ERR_ARG, "batch has not been run");
+  for (size_t i = 0; i < b->hb.size(); i++) {
+    float *o = out + 4 * i;
+    if (b->hb[i].status != RC_OK) { o[0] = static_cast<float>(b->hb[i].status); o[1] = o[2] = o[3] = 0.0f; continue; }
+    const FitOut &f = b->fit[i];
+    o[0] = static_cast<float>(f.rc); o[1] = static_cast<float>(f.mu); o[2] = static_cast<float>(f.lambda);
+    o[3] = static_cast<float>(f.better);
+  }
+  return RC_OK;
+}
+
 int rc_batch_hss(const rc_batch *b, int32_t blk, rc_hss *out, int32_t cap) {
   int r = check_blk(b, blk, true);
   if (r) return r;

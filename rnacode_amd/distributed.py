@@ -1,10 +1,12 @@
-"""Multi-GPU plumbing: one process per GPU, blocks sharded across ranks, one all-gather of the
-per-sample maxima (RCCL over xGMI when the backend is "nccl"; "gloo" in the CPU tests).
+"""Multi-GPU plumbing: one process per GPU, blocks sharded across ranks, one all-gather of per-block
+results (RCCL over xGMI when the backend is "nccl"; "gloo" in the CPU tests).
 
 The scoring path has no exchange step inside a block: every (block, sample) unit is independent
 given the block constants, and seeds depend only on the sample index, so any sharding gives the
-same numbers.  The only collective is the final gather of `maxima[blocks][sampleN]` (SURVEY.md
-section 8e)."""
+same numbers.  The only collective is the final gather of either the fit
+results `[blocks][4]` (evd_rc, mu, lambda, samples above the best native score: all that p-values
+need, 16 B per block) or, if the caller wants the null distributions themselves, of
+`maxima[blocks][sampleN]`."""
 from __future__ import annotations
 
 from typing import List, Sequence, Tuple
@@ -22,9 +24,9 @@ def shard_blocks(blocks: Sequence, rank: int, world: int) -> List:
     return list(blocks[lo:hi])
 
 
-def all_gather_maxima(local, counts: Sequence[int]):
-    """Gather per-rank maxima tensors [n_r, sampleN] into one [sum n_r, sampleN] tensor on every
-    rank, in rank order.  Equal shards use a single all_gather_into_tensor (one ring pass);
+def all_gather_rows(local, counts: Sequence[int]):
+    """Gather per-rank tensors [n_r, width] (one row per block) into one [sum n_r, width] tensor on
+    every rank, in rank order.  Equal shards use a single all_gather_into_tensor (one ring pass);
     ragged shards are padded to the largest shard first."""
     import torch
     import torch.distributed as dist
@@ -44,6 +46,10 @@ def all_gather_maxima(local, counts: Sequence[int]):
     if all(c == n_max for c in counts):
         return out
     return torch.cat([out[r * n_max:r * n_max + counts[r]] for r in range(world)], dim=0)
+
+
+all_gather_maxima = all_gather_rows   # [n_r, sampleN] per-sample maxima
+all_gather_fits = all_gather_rows     # [n_r, 4] rows of rc_batch_fit_all
 
 
 def max_over_ranks(seconds: float, device=None) -> float:

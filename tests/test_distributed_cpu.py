@@ -1,5 +1,6 @@
 """world_size-2 gloo test of the multi-GPU plumbing on CPU: block sharding, the single
-all-gather of per-sample maxima, max-over-ranks timing.  The per-rank maxima come from the CPU
+all-gather (of the per-block fit results, bench.py's default exchange, and of the per-sample
+maxima), max-over-ranks timing.  The per-rank maxima come from the CPU
 oracle (the HIP path cannot run here); what is under test is that sharding + gather reproduces
 the single-process result bit for bit, i.e. the property bench.py --gpus N relies on."""
 import os
@@ -34,16 +35,18 @@ def _worker(rank, world, port, nblocks, n, out_path):
     blocks = [b.upper() for b in synth_blocks(nblocks, 4, 36, seed=9)]
     mine = rd.shard_blocks(blocks, rank, world)
     counts = [rd.shard_range(nblocks, r, world)[1] - rd.shard_range(nblocks, r, world)[0] for r in range(world)]
-    rows = []
+    rows, fits = [], []
     for b in mine:
         res = ob.run_block([r.seq for r in b.rows], [r.name for r in b.rows], b.rows[0].start, b.rows[0].length,
                            b.tree, b.kappa, ob.default_params(n), 42)
         rows.append(np.float32(res.maxScores))
+        fits.append(np.float32([res.evd_rc, res.mu, res.lam, 0.0]))
     local = torch.from_numpy(np.stack(rows)) if rows else torch.empty((0, n), dtype=torch.float32)
     gathered = rd.all_gather_maxima(local, counts)
+    gfits = rd.all_gather_fits(torch.from_numpy(np.stack(fits)) if fits else torch.empty((0, 4), dtype=torch.float32), counts)
     slowest = rd.max_over_ranks(1.0 + rank)
     if rank == 0:
-        np.save(out_path, gathered.numpy())
+        np.savez(out_path, maxima=gathered.numpy(), fits=gfits.numpy())
         assert slowest == float(world)
     dist.barrier()
     dist.destroy_process_group()
@@ -57,14 +60,14 @@ def test_sharded_gather_equals_single_process(tmp_path, nblocks):
     from rnacode_amd.synth import synth_blocks
 
     n, world = 24, 2
-    out = str(tmp_path / "g.npy")
+    out = str(tmp_path / "g.npz")
     mp.spawn(_worker, args=(world, _free_port(), nblocks, n, out), nprocs=world, join=True)
     got = np.load(out)
     blocks = [b.upper() for b in synth_blocks(nblocks, 4, 36, seed=9)]
-    want = np.stack([np.float32(ob.run_block([r.seq for r in b.rows], [r.name for r in b.rows], b.rows[0].start,
-                                             b.rows[0].length, b.tree, b.kappa, ob.default_params(n), 42).maxScores)
-                     for b in blocks])
-    np.testing.assert_array_equal(got, want)
+    res = [ob.run_block([r.seq for r in b.rows], [r.name for r in b.rows], b.rows[0].start, b.rows[0].length, b.tree,
+                        b.kappa, ob.default_params(n), 42) for b in blocks]
+    np.testing.assert_array_equal(got["maxima"], np.stack([np.float32(r.maxScores) for r in res]))
+    np.testing.assert_array_equal(got["fits"], np.stack([np.float32([r.evd_rc, r.mu, r.lam, 0.0]) for r in res]))
 
 
 def test_shard_range_is_a_partition():
