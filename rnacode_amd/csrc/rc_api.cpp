@@ -58,6 +58,7 @@ struct rc_ctx {
   uint32_t *d_scratch = nullptr;
   size_t scratch_cap = 0;
   unsigned long long *d_clamp = nullptr;
+  unsigned int *d_work = nullptr;   // one item counter per row-count class (k_null pulls work items from it)
   float tieThr = 0.0f;
   std::map<std::pair<int, size_t>, int> occ;   // (N-1, LDS bytes) -> resident workgroups per CU of k_null
   size_t ldsMaxBytes = 10240;   // per wavefront: keeps >= 16 wavefronts (4 per SIMD) on a CU
@@ -137,6 +138,7 @@ int rc_ctx_create(int device, rc_ctx **out) {
   HIP_TRY(hipMemcpy(c->d_pair62, c->pt62.pair, 4096, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(c->d_pair90, c->pt90.pair, 4096, hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc(&c->d_clamp, sizeof(unsigned long long)));
+  HIP_TRY(hipMalloc(&c->d_work, sizeof(unsigned int) * (kMaxRows + 1)));
   c->tieThr = float_threshold_lt(0.0001);
   if (const char *e = std::getenv("RC_LDS_MAX_BYTES")) c->ldsMaxBytes = static_cast<size_t>(std::atol(e));
   if (const char *e = std::getenv("RC_DEBUG_SKIP")) c->debugSkip = std::atoi(e);   // profiling only: results are wrong
@@ -152,6 +154,7 @@ void rc_ctx_destroy(rc_ctx *c) {
   if (c->d_U) hipFree(c->d_U);
   if (c->d_scratch) hipFree(c->d_scratch);
   if (c->d_clamp) hipFree(c->d_clamp);
+  if (c->d_work) hipFree(c->d_work);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -309,6 +312,9 @@ int rc_batch_create(rc_ctx *ctx, const rc_block *blocks, int32_t n_blocks, const
   if (!b->okBlocks.empty()) {
     if ((rcv = up(reinterpret_cast<void **>(&b->d_okBlocks), b->okBlocks.data(), sizeof(int) * b->okBlocks.size()))) return rcv;
     for (auto &kv : b->classes) {
+      // longest blocks first: k_null's workgroups pull items from a shared counter, so the order of the
+      // list is the order of dispatch (longest-processing-time-first keeps the tail short)
+      std::stable_sort(kv.second.begin(), kv.second.end(), [&](int x, int y) { return b->hb[x].L > b->hb[y].L; });
       int *p = nullptr;
       if ((rcv = up(reinterpret_cast<void **>(&p), kv.second.data(), sizeof(int) * kv.second.size()))) return rcv;
       b->d_classBlocks[kv.first] = p;
@@ -394,6 +400,7 @@ int rc_batch_run(rc_batch *b) {
 
   // ---- null sampling per N-1 class
   HIP_TRY(hipMemsetAsync(c->d_clamp, 0, sizeof(unsigned long long), c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_work, 0, sizeof(unsigned int) * (kMaxRows + 1), c->stream));
   // -1.0f everywhere first: skipped blocks report "no HSS" rows
   HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->d_maxima), 0xBF800000u, static_cast<size_t>(n) * sampleN, c->stream));
   HIP_TRY(hipEventRecord(ev[3], c->stream));
@@ -435,6 +442,7 @@ int rc_batch_run(rc_batch *b) {
     a.nClassBlocks = static_cast<int>(kv.second.size()); a.groups = groups; a.sampleN = sampleN; a.Spad = Spad;
     a.U = c->d_U; a.pair = d_pair; a.scratch = c->d_scratch; a.scratchStride = stride;
     a.maxima = b->d_maxima; a.clampCount = c->d_clamp; a.tieThr = c->tieThr; a.debugSkip = c->debugSkip; a.comboSplit = comboSplit;
+    a.workCounter = c->d_work + NK;
     if (!launch_null(NK, a, grid, ldsBytes, exact, c->stream)) return fail(RC_ERR_UNSUPPORTED, "no null kernel for this number of rows");
     b->nl[2]++;
   }

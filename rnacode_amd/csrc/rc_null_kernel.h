@@ -164,7 +164,13 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
   const int perBlock = A.groups * (A.comboSplit ? 6 : 1);
   const int nItems = A.nClassBlocks * perBlock;
 
-  for (int item = blockIdx.x; item < nItems; item += gridDim.x) {
+  // Items are pulled from a shared counter (not strided): blocks of one launch differ in length, and
+  // wavefronts that share a SIMD do not advance at the same pace.
+  for (;;) {
+    int item = 0;
+    if (lane == 0) item = static_cast<int>(atomicAdd(A.workCounter, 1u));
+    item = __builtin_amdgcn_readfirstlane(item);
+    if (item >= nItems) break;
     const int bi = classBlocks[item / perBlock];
     const int sub = item % perBlock;
     const int grp = A.comboSplit ? sub / 6 : sub;
