@@ -247,7 +247,11 @@ int rc_batch_create(rc_ctx *ctx, const rc_block *blocks, int32_t n_blocks, const
       return static_cast<uint32_t>(off);
     };
     d.off_nodes = put(h.nodes.data(), h.nodes.size() * sizeof(NodeRec));
-    d.off_qtip = put(h.qtip.data(), h.qtip.size());
+    {
+      uint8_t qt[kMaxRows] = {0};   // k_null reads it as 32-bit words
+      std::memcpy(qt, h.qtip.data(), h.qtip.size());
+      d.off_qtip = put(qt, sizeof qt);
+    }
     {
       std::vector<uint16_t> rc2(2 * L1);
       std::memcpy(rc2.data(), h.refcol[0].data(), L1 * 2);

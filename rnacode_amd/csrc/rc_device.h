@@ -39,7 +39,7 @@ struct DevBlock {
   int32_t exact_div;                                 // 1: score tables outside the range proven for div_by_nk -> use '/'
   // offsets (bytes) into the batch blob
   uint32_t off_nodes;    // NodeRec[nnodes]
-  uint32_t off_qtip;     // u8[N]        node index of row r's tip
+  uint32_t off_qtip;     // u8[32]       node index of row r's tip (padded: k_null reads words)
   uint32_t off_refcol;   // u16[2][L+1]  strand s: 0-based column of reference residue i (1..L) in that strand's alignment
   uint32_t off_zw;       // u64[2][L+1]  2 bits per k (bit 2(k-1)): 0 -> z=0, 1 -> z=+1, 2 -> z=-1
   uint32_t off_mask;     // u32[2][L+1][ceil(NK/5)] 6-bit AND masks (field k%5 of word k/5) zeroing the codon fields where row k has '-'

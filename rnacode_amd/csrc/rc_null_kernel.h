@@ -179,8 +179,8 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
     const int cols = db->cols, L = db->L, nnodes = db->nnodes;
     const float Delta = db->Delta, Omega = db->Omega, omega = db->omega, nkf = db->nkf;
     const NodeRec *__restrict__ nodes = reinterpret_cast<const NodeRec *>(blob + db->off_nodes);
-    const uint8_t *__restrict__ qtip = blob + db->off_qtip;
-    const uint16_t *__restrict__ refcol = reinterpret_cast<const uint16_t *>(blob + db->off_refcol);
+    const uint32_t *__restrict__ qtipw = reinterpret_cast<const uint32_t *>(blob + db->off_qtip);   // u8[32] read as words: scalar loads
+    const uint32_t *__restrict__ refcolw = reinterpret_cast<const uint32_t *>(blob + db->off_refcol);   // u16[L+1] (forward strand) read as words
     const unsigned long long *__restrict__ zw = reinterpret_cast<const unsigned long long *>(blob + db->off_zw);
     const unsigned long long *__restrict__ zmask = reinterpret_cast<const unsigned long long *>(blob + db->off_zmask);
     const int zmWords = db->zm_words;
@@ -207,6 +207,7 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
 #pragma unroll
         for (int x = 0; x < 64 * 64 / 4 / kWave; x++) lds_codes[nnodes * 16 + x * kWave + lane] = psrc[x * kWave + lane];
       }
+      const uint32_t *__restrict__ nodew = reinterpret_cast<const uint32_t *>(nodes);
       uint32_t win[N];
 #pragma unroll
       for (int r = 0; r < N; r++) win[r] = 0;
@@ -223,14 +224,15 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
 #pragma unroll
         for (int t = 0; t < SPI; t++) {
           const int i = (i0 + t <= L) ? i0 + t : L;     // tail: repeat the last site, results unused
-          ubase[t] = static_cast<size_t>(refcol[i]) * A.Spad + sidx;
+          const uint32_t col = (refcolw[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+          ubase[t] = static_cast<size_t>(col) * A.Spad + sidx;
 #pragma unroll
           for (int x = 0; x < NODEW; x++) ns[t][x] = 0;
         }
         const size_t qstride = static_cast<size_t>(cols) * A.Spad;
         for (int q = 0; q < nnodes; q++) {
-          const int pq = nodes[q].parent;
-          const uint32_t bp = nodes[q].basepack;
+          const uint32_t bp = nodew[q * 20 + 16];                                // NodeRec as 20 words: scalar loads
+          const int pq = static_cast<int>(nodew[q * 20 + 17] & 255u);
           uint32_t u[SPI];
 #pragma unroll
           for (int t = 0; t < SPI; t++) u[t] = Ustream[ubase[t] + q * qstride];
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
           const int i = i0 + t;
           if (i <= L) {
 #pragma unroll
-            for (int r = 0; r < N; r++) win[r] = (win[r] << 2) | get_state(ns[t], qtip[r]);   // low 6 bits = the codon; older sites drift out at the top
+            for (int r = 0; r < N; r++) win[r] = (win[r] << 2) | get_state(ns[t], static_cast<int>((qtipw[r >> 2] >> (8 * (r & 3))) & 255u));   // low 6 bits = the codon; older sites drift out at the top
             if (i >= 3) {
               const int ip = L + 3 - i;  // reverse-strand position whose codon is these three columns
               const uint32_t aF = win[0] & 63u;
