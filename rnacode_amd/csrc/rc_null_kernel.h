@@ -112,7 +112,7 @@ template <int NK, bool EXACT> __device__ __forceinline__ float div_by_nk(float x
 //  * v <= currMax together with |v - currMax| < thr is fl(v - currMax) > -thr.
 struct SampleScan {
   float cm;        // currMax
-  uint32_t Q;      // see above; valid inside a row
+  float Q;         // see above, as a float (integers < 2^24 are exact): valid inside a row
   uint32_t se;     // segmentEnd, valid between rows
   uint32_t len;    // segmentEnd - segmentStart, valid between rows
 };
@@ -121,18 +121,20 @@ __device__ __forceinline__ void sample_scan_row_begin(SampleScan &st, float &bes
   best = (done & (st.len >= 2u) & (st.cm > best)) ? st.cm : best;  // minSegmentLength, score.c:902
   st.cm = done ? 0.0f : st.cm;
   st.len = done ? 0u : st.len;
-  st.Q = 2u * (st.len + a);
+  st.Q = static_cast<float>(2u * (st.len + a));
 }
-// every entry except the frame's final one; j2 = 2j + 1 (wave-uniform)
-__device__ __forceinline__ void sample_scan_step(SampleScan &st, float v, uint32_t j2, float negTieThr) {
+// every entry except the frame's final one; j2 = 2j + 1, wave-uniform but held in a VGPR as a float: the
+// caller advances it with a double-rate v_add_f32 instead of copying a scalar counter per entry
+__device__ __forceinline__ void sample_scan_step(SampleScan &st, float v, float j2, float negTieThr) {
   const float d = v - st.cm;
   const bool upd = (v > st.cm) | ((v > 0.0f) & (d > negTieThr) & (st.Q <= j2));   // score.c:953-954
   st.cm = upd ? v : st.cm;
   st.Q = upd ? j2 : st.Q;
 }
 __device__ __forceinline__ void sample_scan_row_end(SampleScan &st, uint32_t a) {
-  const bool inrow = (st.Q & 1u) != 0u;
-  const uint32_t j = st.Q >> 1;
+  const uint32_t q = static_cast<uint32_t>(st.Q);
+  const bool inrow = (q & 1u) != 0u;
+  const uint32_t j = q >> 1;
   st.se = inrow ? j : st.se;
   st.len = inrow ? j - a : st.len;
 }
@@ -323,10 +325,19 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
         };
         // sigma of every sequence at the site whose code words are w: a 64-entry table look-up per
         // sequence through ds_bpermute (address bits [7:2] select the source lane).  Written as asm so
-        // that all look-ups of a code word are in flight together and ONE lgkmcnt(0) covers them (the
+        // that all look-ups of a code word are in flight together and ONE wait covers them (the
         // compiler would put a wait in front of every use); the "+v" operands tie the wait between
         // the look-ups and their first use.
-        auto lookup = [&](const uint32_t (&w)[NCW], float (&sig)[NK]) {
+        // With the codes in LDS the words of site jn (the next cell) are fetched here as well, INTO w,
+        // right after the look-ups have been issued (they read w at issue): no second register set and
+        // no copy per cell.  LDS operations complete in order, so lgkmcnt(NCW) leaves exactly those
+        // NCW reads in flight; the next call starts by waiting for them.
+        const uint32_t ldsLane = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_codes)) + static_cast<uint32_t>(lane) * 4u;
+        auto lookup = [&](uint32_t (&w)[NCW], float (&sig)[NK], int jn, auto scalarLoadsNearby) {
+          if constexpr (LDSC) {
+#pragma unroll
+            for (int x = 0; x < NCW; x++) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[x]));
+          }
           static_for<NK>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             constexpr int t = k % CPW;
@@ -337,12 +348,21 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
             asm volatile("ds_bpermute_b32 %0, %1, %2" : "=v"(got) : "v"(addr), "v"(lutv));
             sig[k] = got;
           });
-          {   // one wait for everything in flight; operands of the last code word pin its position
+          if constexpr (LDSC) {
+            const uint32_t at = ldsLane + static_cast<uint32_t>(jn) * (NCW * kWave * 4u);
+#pragma unroll
+            for (int x = 0; x < NCW; x++) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(w[x]) : "v"(at), "n"(x * kWave * 4));
+          }
+          {   // one wait for the look-ups; operands of the last code word pin its position
             constexpr int k0 = (NCW - 1) * CPW;
             constexpr int cnt = NK - k0;
             float a0 = sig[k0], a1 = sig[cnt > 1 ? k0 + 1 : k0], a2 = sig[cnt > 2 ? k0 + 2 : k0], a3 = sig[cnt > 3 ? k0 + 3 : k0],
                   a4 = sig[cnt > 4 ? k0 + 4 : k0];
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4));
+            // (scalar loads share the counter and may complete out of order: where the compiler could have one
+            // in flight -- the event cell reads z -- wait for everything)
+            if constexpr (LDSC && !decltype(scalarLoadsNearby)::value)
+              asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4) : "n"(NCW));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4));
             if constexpr (cnt > 1) sig[k0 + 1] = a1;
             if constexpr (cnt > 2) sig[k0 + 2] = a2;
             if constexpr (cnt > 3) sig[k0 + 3] = a3;
@@ -371,9 +391,9 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
           }
         };
         // codon without a frame shift in any sequence (z == 0 for all k, score.c:506-510): straight-line
-        auto fast_cell = [&](const uint32_t (&w)[NCW]) -> float {
+        auto fast_cell = [&](uint32_t (&w)[NCW], int jn) -> float {
           float sig[NK];
-          lookup(w, sig);
+          lookup(w, sig, jn, std::false_type{});
           float sum = 0.0f;
           static_for<NK>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
@@ -389,9 +409,9 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
         // the same before the row has met its first event: states 1 and 2 of EVERY sequence have only
         // ever received "+ omega" from 0, so they all hold the one value w (identical operations on
         // identical operands); MAX3(s0, w, w) = max(s0, w).  w advances once per codon.
-        auto pristine_cell = [&](const uint32_t (&w)[NCW], float &wv) -> float {
+        auto pristine_cell = [&](uint32_t (&w)[NCW], float &wv, int jn) -> float {
           float sig[NK];
-          lookup(w, sig);
+          lookup(w, sig, jn, std::false_type{});
           wv = wv + omega_v;
           float sum = 0.0f;
           static_for<NK>([&](auto kc) {
@@ -404,9 +424,9 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
           return finish(sum);
         };
         // codon where some sequence has z != 0 (score.c:512-533), wave-uniform branch per sequence
-        auto event_cell = [&](const uint32_t (&w)[NCW], int j) -> float {
+        auto event_cell = [&](uint32_t (&w)[NCW], int j, int jn) -> float {
           float sig[NK];
-          lookup(w, sig);
+          lookup(w, sig, jn, std::true_type{});
           const unsigned long long z = zbase[3 * j];
           float sum = 0.0f;
           static_for<NK>([&](auto kc) {
@@ -427,7 +447,9 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
           }
           return end;
         };
-        SampleScan st{0.0f, 0u, 0u, 0u};
+        SampleScan st{0.0f, 0.0f, 0u, 0u};
+        float two_v;
+        asm volatile("v_mov_b32 %0, 2.0" : "=v"(two_v));
         const float negTie = -A.tieThr;
         for (int a = 0; a < sites; a++) {
           sample_scan_row_begin(st, best, static_cast<uint32_t>(a));
@@ -440,17 +462,22 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
           load_words(a, wcur);
           const int jend = (a == sites - 1) ? sites - 1 : sites;   // the frame's final entry is handled below
           int j = a;
+          float j2f = static_cast<float>(2 * a + 1);   // 2j + 1 of the cell being entered
           {   // pristine segment: up to the row's first event
             const int e = next_event(j, jend);
             float wv = 0.0f;
             asm volatile("v_mov_b32 %0, 0" : "=v"(wv));   // keep w a per-lane register (full-rate v_add/v_max operands)
             for (; j < e; j++) {
+              const int jn = j + 1 < sites ? j + 1 : j;
               uint32_t wnext[NCW];
-              load_words(j + 1 < sites ? j + 1 : j, wnext);
-              const float v = pristine_cell(wcur, wv);
-              sample_scan_step(st, v, 2u * static_cast<uint32_t>(j) + 1u, negTie);
+              if constexpr (!LDSC) load_words(jn, wnext);
+              const float v = pristine_cell(wcur, wv, jn);
+              sample_scan_step(st, v, j2f, negTie);
+              asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
+              if constexpr (!LDSC) {
 #pragma unroll
-              for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
+                for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
+              }
             }
             static_for<NK>([&](auto kc) {
               constexpr int k = decltype(kc)::value;
@@ -460,23 +487,35 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
           }
           while (j < jend) {
             if ((zany[j >> 6] >> (j & 63)) & 1ull) {               // event codon
+              const int jn = j + 1 < sites ? j + 1 : j;
               uint32_t wnext[NCW];
-              load_words(j + 1 < sites ? j + 1 : j, wnext);
-              const float v = event_cell(wcur, j);
-              sample_scan_step(st, v, 2u * static_cast<uint32_t>(j) + 1u, negTie);
+              if constexpr (!LDSC) load_words(jn, wnext);
+              const float v = event_cell(wcur, j, jn);
+              sample_scan_step(st, v, j2f, negTie);
+              asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
+              if constexpr (!LDSC) {
 #pragma unroll
-              for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
+                for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
+              }
               j++;
             }
             const int e = next_event(j, jend);
             for (; j < e; j++) {                                   // tight loop: no events
+              const int jn = j + 1 < sites ? j + 1 : j;
               uint32_t wnext[NCW];
-              load_words(j + 1 < sites ? j + 1 : j, wnext);
-              const float v = fast_cell(wcur);
-              sample_scan_step(st, v, 2u * static_cast<uint32_t>(j) + 1u, negTie);
+              if constexpr (!LDSC) load_words(jn, wnext);
+              const float v = fast_cell(wcur, jn);
+              sample_scan_step(st, v, j2f, negTie);
+              asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
+              if constexpr (!LDSC) {
 #pragma unroll
-              for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
+                for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
+              }
             }
+          }
+          if constexpr (LDSC) {   // the last cell's fetch-ahead must have landed before its registers are given away
+#pragma unroll
+            for (int x = 0; x < NCW; x++) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wcur[x]));
           }
           sample_scan_row_end(st, static_cast<uint32_t>(a));
         }
