@@ -58,7 +58,7 @@ struct rc_ctx {
   uint32_t *d_scratch = nullptr;
   size_t scratch_cap = 0;
   unsigned long long *d_clamp = nullptr;
-  unsigned int *d_work = nullptr;   // one item counter per row-count class (k_null pulls work items from it)
+  unsigned int *d_work = nullptr;   // eight item counters (one per XCD queue) per row-count class: k_null pulls work items from them
   float tieThr = 0.0f;
   std::map<std::pair<int, size_t>, int> occ;   // (N-1, LDS bytes) -> resident workgroups per CU of k_null
   size_t ldsMaxBytes = 10240;   // per wavefront: keeps >= 16 wavefronts (4 per SIMD) on a CU
@@ -138,7 +138,7 @@ int rc_ctx_create(int device, rc_ctx **out) {
   HIP_TRY(hipMemcpy(c->d_pair62, c->pt62.pair, 4096, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(c->d_pair90, c->pt90.pair, 4096, hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc(&c->d_clamp, sizeof(unsigned long long)));
-  HIP_TRY(hipMalloc(&c->d_work, sizeof(unsigned int) * (kMaxRows + 1)));
+  HIP_TRY(hipMalloc(&c->d_work, sizeof(unsigned int) * (kMaxRows + 1) * 8));
   c->tieThr = float_threshold_lt(0.0001);
   if (const char *e = std::getenv("RC_LDS_MAX_BYTES")) c->ldsMaxBytes = static_cast<size_t>(std::atol(e));
   if (const char *e = std::getenv("RC_DEBUG_SKIP")) c->debugSkip = std::atoi(e);   // profiling only: results are wrong
@@ -404,7 +404,7 @@ int rc_batch_run(rc_batch *b) {
 
   // ---- null sampling per N-1 class
   HIP_TRY(hipMemsetAsync(c->d_clamp, 0, sizeof(unsigned long long), c->stream));
-  HIP_TRY(hipMemsetAsync(c->d_work, 0, sizeof(unsigned int) * (kMaxRows + 1), c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_work, 0, sizeof(unsigned int) * (kMaxRows + 1) * 8, c->stream));
   // -1.0f everywhere first: skipped blocks report "no HSS" rows
   HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->d_maxima), 0xBF800000u, static_cast<size_t>(n) * sampleN, c->stream));
   HIP_TRY(hipEventRecord(ev[3], c->stream));
@@ -446,7 +446,7 @@ int rc_batch_run(rc_batch *b) {
     a.nClassBlocks = static_cast<int>(kv.second.size()); a.groups = groups; a.sampleN = sampleN; a.Spad = Spad;
     a.U = c->d_U; a.pair = d_pair; a.scratch = c->d_scratch; a.scratchStride = stride;
     a.maxima = b->d_maxima; a.clampCount = c->d_clamp; a.tieThr = c->tieThr; a.debugSkip = c->debugSkip; a.comboSplit = comboSplit;
-    a.workCounter = c->d_work + NK;
+    a.workCounter = c->d_work + NK * 8;
     if (!launch_null(NK, a, grid, ldsBytes, exact, c->stream)) return fail(RC_ERR_UNSUPPORTED, "no null kernel for this number of rows");
     b->nl[2]++;
   }

@@ -25,7 +25,7 @@ struct NullArgs {
   unsigned long long *clampCount;
   float tieThr;               // float form of the 0.0001 tie tolerance (score.c:954)
   int comboSplit;             // 1: items are (block, group, strand x frame); maxima combined by atomic max
-  unsigned int *workCounter;  // zeroed before the launch: next unclaimed work item of this launch
+  unsigned int *workCounter;  // [8], zeroed before the launch: next unclaimed work item of each XCD queue
   int debugSkip;              // profiling only (RC_DEBUG_SKIP): bit0 skip the DP/scan phase, bit1 skip simulation
 };
 

@@ -161,22 +161,32 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
 
   const int lane = threadIdx.x;
   uint32_t *__restrict__ cod = scratch + static_cast<size_t>(blockIdx.x) * A.scratchStride;
-  // comboSplit (small batches): an item is one (block, group, strand x frame) so that 6x more
-  // wavefronts exist; each recomputes phase A and the six partial maxima meet in an atomic max.
-  const int perBlock = A.groups * (A.comboSplit ? 6 : 1);
-  const int nItems = A.nClassBlocks * perBlock;
-
-  // Items are pulled from a shared counter (not strided): blocks of one launch differ in length, and
-  // wavefronts that share a SIMD do not advance at the same pace.
-  for (;;) {
-    int item = 0;
-    if (lane == 0) item = static_cast<int>(atomicAdd(A.workCounter, 1u));
-    item = __builtin_amdgcn_readfirstlane(item);
-    if (item >= nItems) break;
-    const int bi = classBlocks[item / perBlock];
-    const int sub = item % perBlock;
-    const int grp = A.comboSplit ? sub / 6 : sub;
-    const int onlyCombo = A.comboSplit ? sub % 6 : -1;
+  // Work items -- (block, 64-sample group), or with comboSplit (small batches) one strand x frame part
+  // of such an item, so that 6x more wavefronts exist; each part recomputes phase A and the six partial
+  // maxima meet in an atomic max -- are pulled from shared counters, not strided: blocks of one launch
+  // differ in length, and wavefronts that share a SIMD do not advance at the same pace.
+  // There is one queue per XCD, holding the sample groups g with g mod 8 == xcd: a group reads only its
+  // own 64-sample slice of the MT19937 stream, so each XCD's L2 keeps 1/8 of the stream resident instead
+  // of every XCD cycling through all of it.  A workgroup whose own queue is empty steals from the next.
+  unsigned int xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  const int home = static_cast<int>(xcc & 7u);
+  const int parts = A.comboSplit ? 6 : 1;
+  for (int qi = 0; qi < 8;) {
+    const int q = (home + qi) & 7;
+    const int gq = (A.groups - q + 7) >> 3;        // sample groups q, q + 8, ... < groups
+    const int perBlock = gq * parts;
+    const int nq = A.nClassBlocks * perBlock;
+    int t = nq;
+    if (nq > 0) {
+      if (lane == 0) t = static_cast<int>(atomicAdd(A.workCounter + q, 1u));
+      t = __builtin_amdgcn_readfirstlane(t);
+    }
+    if (t >= nq) { qi++; continue; }
+    const int bi = classBlocks[t / perBlock];
+    const int sub = t % perBlock;
+    const int grp = q + 8 * (sub / parts);
+    const int onlyCombo = A.comboSplit ? sub % parts : -1;
     const DevBlock *__restrict__ db = dblocks + bi;
     const int cols = db->cols, L = db->L, nnodes = db->nnodes;
     const float Delta = db->Delta, Omega = db->Omega, omega = db->omega, nkf = db->nkf;
