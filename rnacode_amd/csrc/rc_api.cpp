@@ -61,7 +61,7 @@ struct rc_ctx {
   unsigned int *d_work = nullptr;   // eight item counters (one per XCD queue) per row-count class: k_null pulls work items from them
   float tieThr = 0.0f;
   std::map<std::pair<int, size_t>, int> occ;   // (N-1, LDS bytes) -> resident workgroups per CU of k_null
-  size_t ldsMaxBytes = 10240;   // per wavefront: keeps >= 16 wavefronts (4 per SIMD) on a CU
+  size_t ldsMaxBytes = 13312;   // per wavefront: >= 12 wavefronts per CU; measured crossover against reading the codes from L2 (cols 150: 52.0 vs 54.0 ms, cols 180: 41.5 vs 39.3 ms)
   int debugSkip = 0;
 };
 
