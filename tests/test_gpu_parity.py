@@ -490,3 +490,23 @@ def test_cli_writes_eps_files(tmp_path):
     made = sorted(p.name for p in (tmp_path / "plots").iterdir())
     assert made and all(n.startswith("hss-") and n.endswith(".eps") for n in made)
     assert (tmp_path / "plots" / made[0]).read_text().startswith("%!PS-Adobe-3.0 EPSF-3.0\n")
+
+
+def test_mixed_batch_against_oracle(ctx):
+    """One batch with 3..12 rows and 30..200 columns per block (several row-count classes, blocks of very different
+    length in each, two sample groups so that six of the eight per-XCD queues start empty and steal): per-sample
+    maxima bit-identical to the oracle for every block."""
+    from oracle import binding as ob
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_block
+    rng = np.random.RandomState(2024)
+    blocks = [synth_block(rng, int(rng.randint(3, 13)), int(rng.randint(30, 201)), index=i, gaps=True).upper() for i in range(120)]
+    n, seed = 70, 31337
+    batch = api.Batch(ctx, blocks, api.default_params(sampleN=n, seed_base=seed)).run()
+    for i, b in enumerate(blocks):
+        res = ob.run_block([r.seq for r in b.rows], [r.name for r in b.rows], b.rows[0].start, b.rows[0].length, b.tree, b.kappa,
+                           ob.default_params(n), seed)
+        np.testing.assert_array_equal(batch.maxScores(i), np.float32(res.maxScores), err_msg=f"block {i} ({b.n} x {b.cols})")
+        rc, mu, lam = batch.getExtremeValuePars(i)
+        assert rc == res.evd_rc and (rc != 1 or (close(mu, res.mu) and close(lam, res.lam)))
+    batch.close()
