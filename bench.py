@@ -224,6 +224,9 @@ def main():
                                   "frac": fl / (null_ms * 1e-3) / 1e9 / VALU_PEAK_GOPS,
                                   "algorithmic_flops_per_launch": fl}},
             "device_ms_per_step": {k: v / args.steps for k, v in tk.items()},
+            "device_ms_note": "HIP-event intervals; the native-block kernels run on a second stream beside k_null, so "
+                              "'native' is the interval until they are done (they fill k_null's tail), not their busy time "
+                              "(1.8 ms when run alone, profiles/r01)",
             "host_prep_s": {"generate": t_gen, "models_and_upload": t_prep},
             "sample_alignments_per_s": sa * args.steps / elapsed,
         }

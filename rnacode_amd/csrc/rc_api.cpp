@@ -44,6 +44,7 @@ struct Event {
 struct rc_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;   // native-block kernels: latency-bound, they run beside the null sampling
   int numCU = 0;
   CodeTables ct62{62}, ct90{90};
   PairTable pt62, pt90;
@@ -131,6 +132,7 @@ int rc_ctx_create(int device, rc_ctx **out) {
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   c->numCU = prop.multiProcessorCount;
   HIP_TRY(hipStreamCreate(&c->stream));
+  HIP_TRY(hipStreamCreate(&c->stream2));
   c->pt62.build(c->ct62);
   c->pt90.build(c->ct90);
   HIP_TRY(hipMalloc(&c->d_pair62, 4096));
@@ -156,6 +158,7 @@ void rc_ctx_destroy(rc_ctx *c) {
   if (c->d_clamp) hipFree(c->d_clamp);
   if (c->d_work) hipFree(c->d_work);
   if (c->stream) hipStreamDestroy(c->stream);
+  if (c->stream2) hipStreamDestroy(c->stream2);
   delete c;
 }
 
@@ -385,22 +388,23 @@ int rc_batch_run(rc_batch *b) {
   int rcv = ensure_stream(c, b->par.seed_base, Spad, b->maxDraws, &b->t[1], &b->nl[1]);
   if (rcv) return rcv;
 
-  // ---- native block: sigma -> DP per N-1 class -> scan
-  HIP_TRY(hipEventRecord(ev[1], c->stream));
+  // ---- native block: sigma -> DP per N-1 class -> scan, on the second stream: these kernels are small and
+  // latency-bound, the null sampling below fills the chip beside them; the fit waits for both
+  HIP_TRY(hipEventRecord(ev[1], c->stream2));
   NativeArgs na{};
   na.blob = b->d_blob; na.dblocks = b->d_dblocks; na.blocks = b->d_okBlocks; na.pair = d_pair;
   na.S = b->d_S; na.offS = b->d_offS; na.hss = b->d_hss; na.hssCount = b->d_hssCount; na.hssCap = b->hssCap; na.tieThr = c->tieThr;
-  HIP_TRY(hipMemsetAsync(b->d_hssCount, 0, static_cast<size_t>(n) * 6 * sizeof(int), c->stream));
-  launch_native_sigma(na, static_cast<int>(b->okBlocks.size()), c->stream); b->nl[3]++;
+  HIP_TRY(hipMemsetAsync(b->d_hssCount, 0, static_cast<size_t>(n) * 6 * sizeof(int), c->stream2));
+  launch_native_sigma(na, static_cast<int>(b->okBlocks.size()), c->stream2); b->nl[3]++;
   for (auto &kv : b->classes) {
     NativeArgs nc = na;
     nc.blocks = b->d_classBlocks[kv.first];
-    if (!launch_native_dp(kv.first, nc, static_cast<int>(kv.second.size()), c->stream))
+    if (!launch_native_dp(kv.first, nc, static_cast<int>(kv.second.size()), c->stream2))
       return fail(RC_ERR_UNSUPPORTED, "no native DP kernel for this number of rows");
     b->nl[3]++;
   }
-  launch_native_scan(na, static_cast<int>(b->okBlocks.size()), c->stream); b->nl[3]++;
-  HIP_TRY(hipEventRecord(ev[2], c->stream));
+  launch_native_scan(na, static_cast<int>(b->okBlocks.size()), c->stream2); b->nl[3]++;
+  HIP_TRY(hipEventRecord(ev[2], c->stream2));
 
   // ---- null sampling per N-1 class
   HIP_TRY(hipMemsetAsync(c->d_clamp, 0, sizeof(unsigned long long), c->stream));
@@ -453,6 +457,7 @@ int rc_batch_run(rc_batch *b) {
   HIP_TRY(hipEventRecord(ev[4], c->stream));
 
   // ---- EVD fit
+  HIP_TRY(hipStreamWaitEvent(c->stream, ev[2], 0));   // native HSS of the second stream
   FitArgs fa{};
   fa.dblocks = b->d_dblocks; fa.blocks = b->d_okBlocks; fa.maxima = b->d_maxima; fa.hss = b->d_hss;
   fa.hssCount = b->d_hssCount; fa.hssCap = b->hssCap; fa.out = b->d_fit; fa.sampleN = sampleN; fa.stopEarly = b->par.stopEarly;
