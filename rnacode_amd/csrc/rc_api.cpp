@@ -89,6 +89,8 @@ struct rc_batch {
   size_t S_floats = 0;
   DevHss *d_hss = nullptr;
   int *d_hssCount = nullptr;
+  DevHss *d_hssPacked = nullptr;   // the used records, packed for the copy to the host
+  int *d_hssOffsets = nullptr;     // [n * 6] + 1: start of each slot in d_hssPacked; last entry = total
   FitOut *d_fit = nullptr;
   // host results
   bool ran = false;
@@ -174,6 +176,8 @@ void rc_batch_destroy(rc_batch *b) {
   if (b->d_offS) hipFree(b->d_offS);
   if (b->d_hss) hipFree(b->d_hss);
   if (b->d_hssCount) hipFree(b->d_hssCount);
+  if (b->d_hssPacked) hipFree(b->d_hssPacked);
+  if (b->d_hssOffsets) hipFree(b->d_hssOffsets);
   if (b->d_fit) hipFree(b->d_fit);
   delete b;
 }
@@ -332,6 +336,8 @@ int rc_batch_create(rc_ctx *ctx, const rc_block *blocks, int32_t n_blocks, const
   HIP_TRY(hipMalloc(&b->d_S, std::max<size_t>(b->S_floats, 4) * sizeof(float)));
   HIP_TRY(hipMalloc(&b->d_hss, static_cast<size_t>(std::max(n_blocks, 1)) * 6 * b->hssCap * sizeof(DevHss)));
   HIP_TRY(hipMalloc(&b->d_hssCount, static_cast<size_t>(std::max(n_blocks, 1)) * 6 * sizeof(int)));
+  HIP_TRY(hipMalloc(&b->d_hssPacked, static_cast<size_t>(std::max(n_blocks, 1)) * 6 * b->hssCap * sizeof(DevHss)));
+  HIP_TRY(hipMalloc(&b->d_hssOffsets, (static_cast<size_t>(std::max(n_blocks, 1)) * 6 + 1) * sizeof(int)));
   HIP_TRY(hipMalloc(&b->d_fit, static_cast<size_t>(std::max(n_blocks, 1)) * sizeof(FitOut)));
   *out = guard.release();
   return RC_OK;
@@ -374,7 +380,7 @@ int rc_batch_run(rc_batch *b) {
   const int n = b->n, sampleN = b->par.sampleN;
   const int groups = (sampleN + kWave - 1) / kWave, Spad = groups * kWave;
   b->fit.assign(n, FitOut{0, 0, -1, 0});
-  b->hss.assign(static_cast<size_t>(n) * 6 * b->hssCap, DevHss{0, 0, 0, 0, 0});
+  b->hss.resize(static_cast<size_t>(n) * 6 * b->hssCap);   // entries beyond hssCount[slot] are never read
   b->hssCount.assign(static_cast<size_t>(n) * 6, 0);
   b->clamped = 0;
   if (b->okBlocks.empty()) { b->ran = true; return RC_OK; }
@@ -404,6 +410,9 @@ int rc_batch_run(rc_batch *b) {
     b->nl[3]++;
   }
   launch_native_scan(na, static_cast<int>(b->okBlocks.size()), c->stream2); b->nl[3]++;
+  const int slots = n * 6;
+  HIP_TRY(hipMemsetAsync(b->d_hssOffsets + slots, 0, sizeof(int), c->stream2));
+  launch_hss_pack(b->d_hss, b->d_hssCount, b->hssCap, slots, b->d_hssPacked, b->d_hssOffsets, b->d_hssOffsets + slots, c->stream2);
   HIP_TRY(hipEventRecord(ev[2], c->stream2));
 
   // ---- null sampling per N-1 class
@@ -478,7 +487,15 @@ int rc_batch_run(rc_batch *b) {
     HIP_TRY(hipMemcpy(f.data(), b->d_fit, sizeof(FitOut) * n, hipMemcpyDeviceToHost));
     for (int bi : b->okBlocks) b->fit[bi] = f[bi];
     HIP_TRY(hipMemcpy(b->hssCount.data(), b->d_hssCount, sizeof(int) * b->hssCount.size(), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(b->hss.data(), b->d_hss, sizeof(DevHss) * b->hss.size(), hipMemcpyDeviceToHost));
+    // the used HSS records only (k_hss_pack): offsets + total, then that many records
+    std::vector<int> off(static_cast<size_t>(slots) + 1);
+    HIP_TRY(hipMemcpy(off.data(), b->d_hssOffsets, sizeof(int) * off.size(), hipMemcpyDeviceToHost));
+    std::vector<DevHss> packed(static_cast<size_t>(std::max(off[slots], 0)));
+    if (!packed.empty()) HIP_TRY(hipMemcpy(packed.data(), b->d_hssPacked, sizeof(DevHss) * packed.size(), hipMemcpyDeviceToHost));
+    for (int t = 0; t < slots; t++) {
+      const int cnt = std::min(b->hssCount[t], b->hssCap);
+      for (int i = 0; i < cnt; i++) b->hss[static_cast<size_t>(t) * b->hssCap + i] = packed[static_cast<size_t>(off[t]) + i];
+    }
     HIP_TRY(hipMemcpy(&b->clamped, c->d_clamp, sizeof(unsigned long long), hipMemcpyDeviceToHost));
   }
   b->ran = true;

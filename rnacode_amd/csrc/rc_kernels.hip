@@ -414,6 +414,24 @@ bool launch_native_dp(int NK, const NativeArgs &a, int nblocks, hipStream_t stre
   }
 }
 
+// The HSS records sit in a [block][strand x frame][cap] array of which a few per cent are used: pack the
+// used ones for the copy to the host.  offsets[t] = where the records of slot t start in `packed`.
+__global__ __launch_bounds__(256) void k_hss_pack(const DevHss *__restrict__ hss, const int *__restrict__ count, int cap, int slots,
+                                                  DevHss *__restrict__ packed, int *__restrict__ offsets, int *__restrict__ total) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= slots) return;
+  const int c = min(count[t], cap);
+  const int off = c > 0 ? atomicAdd(total, c) : 0;
+  offsets[t] = off;
+  for (int i = 0; i < c; i++) packed[off + i] = hss[static_cast<size_t>(t) * cap + i];
+}
+
+void launch_hss_pack(const DevHss *hss, const int *count, int cap, int slots, DevHss *packed, int *offsets, int *total,
+                     hipStream_t stream) {
+  if (slots <= 0) return;
+  hipLaunchKernelGGL(k_hss_pack, dim3((slots + 255) / 256), dim3(256), 0, stream, hss, count, cap, slots, packed, offsets, total);
+}
+
 void launch_native_scan(const NativeArgs &a, int nblocks, hipStream_t stream) {
   hipLaunchKernelGGL(k_native_scan, dim3(nblocks * 6), dim3(64), 0, stream, a);
 }

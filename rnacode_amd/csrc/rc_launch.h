@@ -82,6 +82,8 @@ bool launch_null(int NK, const NullArgs &a, int grid, size_t ldsBytes, bool exac
 void launch_native_sigma(const NativeArgs &a, int nblocks, hipStream_t stream);
 bool launch_native_dp(int NK, const NativeArgs &a, int nblocks, hipStream_t stream);
 void launch_native_scan(const NativeArgs &a, int nblocks, hipStream_t stream);
+void launch_hss_pack(const DevHss *hss, const int *count, int cap, int slots, DevHss *packed, int *offsets, int *total,
+                     hipStream_t stream);
 void launch_sk_row(const uint8_t *blob, const DevBlock *dblocks, int bi, int s, int b, int iMax, float *out, int stride,
                    hipStream_t stream);
 void launch_evd_fit(const FitArgs &a, int nblocks, hipStream_t stream);
