@@ -101,9 +101,10 @@ def main():
     ap.add_argument("--samples", type=int, default=1000)
     ap.add_argument("--seed-base", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--exchange", choices=("fits", "maxima"), default="fits",
-                    help="what the ranks all-gather per step: the per-block fit results (16 B per block, default) or "
-                         "the per-sample maxima (4 B x samples per block, written by the kernel into the gathered tensor)")
+    ap.add_argument("--exchange", choices=("maxima", "fits"), default="maxima",
+                    help="what the ranks all-gather per step: the per-sample maxima (north_star's exchange; 4 B x samples per "
+                         "block, written by the kernel straight into the gathered tensor) or only the per-block fit results "
+                         "(16 B per block: enough for p-values, since every rank fits its own blocks on the device)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --blocks per GPU (default); strong: --blocks in total, split across ranks (configs[3])")
     args = ap.parse_args()

@@ -3,10 +3,9 @@ results (RCCL over xGMI when the backend is "nccl"; "gloo" in the CPU tests).
 
 The scoring path has no exchange step inside a block: every (block, sample) unit is independent
 given the block constants, and seeds depend only on the sample index, so any sharding gives the
-same numbers.  The only collective is the final gather of either the fit
-results `[blocks][4]` (evd_rc, mu, lambda, samples above the best native score: all that p-values
-need, 16 B per block) or, if the caller wants the null distributions themselves, of
-`maxima[blocks][sampleN]`."""
+same numbers.  The only collective is the final gather of
+`maxima[blocks][sampleN]` or, for callers that only need p-values, of the fit results `[blocks][4]`
+(evd_rc, mu, lambda, samples above the best native score: 16 B per block)."""
 from __future__ import annotations
 
 from typing import List, Sequence, Tuple

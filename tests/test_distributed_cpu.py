@@ -1,6 +1,6 @@
 """world_size-2 gloo test of the multi-GPU plumbing on CPU: block sharding, the single
-all-gather (of the per-block fit results, bench.py's default exchange, and of the per-sample
-maxima), max-over-ranks timing.  The per-rank maxima come from the CPU
+all-gather (of the per-sample maxima, bench.py's default exchange, and of the per-block fit
+results), max-over-ranks timing.  The per-rank maxima come from the CPU
 oracle (the HIP path cannot run here); what is under test is that sharding + gather reproduces
 the single-process result bit for bit, i.e. the property bench.py --gpus N relies on."""
 import os
