@@ -510,3 +510,28 @@ def test_mixed_batch_against_oracle(ctx):
         rc, mu, lam = batch.getExtremeValuePars(i)
         assert rc == res.evd_rc and (rc != 1 or (close(mu, res.mu) and close(lam, res.lam)))
     batch.close()
+
+
+@pytest.mark.parametrize("pars", [dict(Delta=0.25, Omega=-4.0, omega=-2.0),          # Delta >= 0: MAX3 with Delta matters
+                                  dict(Delta=-10.0, Omega=-4.0, omega=-2.0, stopPenalty_k=-3.0e30),   # outside the proven division range
+                                  dict(Delta=-1.0e-30, Omega=-4.0, omega=-2.0)])
+def test_exact_division_instantiation_against_oracle(ctx, pars):
+    """Parameter sets the fast kernel is not proven for are routed to k_null<.., EXACT = true> (plain '/', MAX3 with
+    Delta kept): same bit-exact bar against the oracle."""
+    from oracle import binding as ob
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_blocks
+    blocks = [b.upper() for b in synth_blocks(3, 5, 75, seed=41) + synth_blocks(2, 9, 60, seed=42)]
+    n, seed = 100, 2718
+    batch = api.Batch(ctx, blocks, api.default_params(sampleN=n, seed_base=seed, **pars)).run()
+    for i, b in enumerate(blocks):
+        p = ob.default_params(n)
+        for k, v in pars.items():
+            setattr(p, k, v)
+        res = ob.run_block([r.seq for r in b.rows], [r.name for r in b.rows], b.rows[0].start, b.rows[0].length, b.tree, b.kappa, p, seed)
+        np.testing.assert_array_equal(batch.maxScores(i), np.float32(res.maxScores), err_msg=f"block {i}")
+        got = sorted(batch.scoreAln(i), key=hss_key)
+        want = sorted(res.hss, key=hss_key)
+        assert [(g["strand"], g["frame"], g["start"], g["end"]) for g in got] == [(w["strand"], w["frame"], w["start"], w["end"]) for w in want]
+        assert all(np.float32(g["score"]) == np.float32(w["score"]) for g, w in zip(got, want))
+    batch.close()
