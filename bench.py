@@ -60,32 +60,37 @@ def measured_traffic():
 
 def cpu_baseline(blocks, sampleN, seed, target_s=12.0):
     """The unmodified reference objects (oracle/_ref/ref_harness, kind "reference") on a bounded
-    sample of the same workload, single thread (the reference has no threading).  Falls back to
-    the oracle restatement (kind "port") only if the harness binary did not travel."""
+    sample of the same workload, single thread (the reference has no threading).  The sample is sized
+    from a two-block probe so that it takes about target_s seconds on whatever host this runs on.
+    Falls back to the oracle restatement (kind "port") only if the harness binary did not travel."""
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
     from rnacode_amd.alnio import write_harness_blocks
-    nblk = max(1, min(len(blocks), int(target_s / 0.55)))   # ~0.54 s per 6x120 block at n=1000 (SURVEY section 6)
-    sub = blocks[:nblk]
-    units = sum(b.cols for b in sub) * sampleN
-    if os.path.exists(harness):
+
+    def run_reference(sub):
         with tempfile.NamedTemporaryFile("w", suffix=".blk", delete=False) as fh:
             path = fh.name
         try:
             write_harness_blocks(sub, path)
             t0 = time.perf_counter()
             subprocess.check_output([harness, path, "--samples", str(sampleN), "--seed", str(seed), "--no-backtrack"])
-            dt = time.perf_counter() - t0
+            return time.perf_counter() - t0
         finally:
             os.unlink(path)
-        kind = "reference"
-    else:
+
+    def run_port(sub):
         from oracle import binding as ob
         t0 = time.perf_counter()
         for b in sub:
             ob.run_block([r.seq for r in b.rows], [r.name for r in b.rows], b.rows[0].start, b.rows[0].length,
                          b.tree, b.kappa, ob.default_params(sampleN), seed)
-        dt = time.perf_counter() - t0
-        kind = "port"
+        return time.perf_counter() - t0
+
+    kind, run = ("reference", run_reference) if os.path.exists(harness) else ("port", run_port)
+    probe = run(blocks[:2]) / 2.0                                    # seconds per block on this host
+    nblk = max(2, min(len(blocks), int(target_s / max(probe, 1e-3))))
+    sub = blocks[:nblk]
+    dt = run(sub)
+    units = sum(b.cols for b in sub) * sampleN
     return dict(value=units / dt, unit="alignment-columns*samples/s", cores=1, kind=kind,
                 sample=f"first {nblk} blocks of the workload at n={sampleN} (tree+kappa given), {dt:.1f} s")
 
