@@ -134,7 +134,8 @@ int rc_ctx_create(int device, rc_ctx **out) {
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   c->numCU = prop.multiProcessorCount;
   HIP_TRY(hipStreamCreate(&c->stream));
-  HIP_TRY(hipStreamCreate(&c->stream2));
+  if (std::getenv("RC_SERIAL_NATIVE")) c->stream2 = c->stream;   // profiling: one kernel at a time, clean per-kernel intervals
+  else HIP_TRY(hipStreamCreate(&c->stream2));
   c->pt62.build(c->ct62);
   c->pt90.build(c->ct90);
   HIP_TRY(hipMalloc(&c->d_pair62, 4096));
@@ -160,7 +161,7 @@ void rc_ctx_destroy(rc_ctx *c) {
   if (c->d_clamp) hipFree(c->d_clamp);
   if (c->d_work) hipFree(c->d_work);
   if (c->stream) hipStreamDestroy(c->stream);
-  if (c->stream2) hipStreamDestroy(c->stream2);
+  if (c->stream2 && c->stream2 != c->stream) hipStreamDestroy(c->stream2);
   delete c;
 }
 
