@@ -828,15 +828,37 @@ int rc_fit_trees_device(rc_ctx *c, const rc_block *blocks, int32_t n_blocks, cha
   }
   const int nj = static_cast<int>(jobs.size());
   if (nj == 0) return 0;
+  // the per-block work areas of one launch share a scratch of at most 8 GiB (RC_TREE_SCRATCH_BYTES): long batches
+  // go in several launches on the one stream, which re-use it
+  size_t capDoubles = (static_cast<size_t>(8) << 30) / sizeof(double);
+  if (const char *e = std::getenv("RC_TREE_SCRATCH_BYTES")) capDoubles = std::max<size_t>(1, static_cast<size_t>(std::atoll(e)) / sizeof(double));
+  std::vector<int> chunkStart{0};
+  size_t maxChunk = 0;
+  {
+    size_t base = 0;
+    for (int q = 0; q < nj; q++) {
+      const size_t end = (q + 1 < nj) ? static_cast<size_t>(jobs[q + 1].off_work) : work_doubles;
+      if (end - base > capDoubles && q > chunkStart.back()) { chunkStart.push_back(q); base = static_cast<size_t>(jobs[q].off_work); }
+      maxChunk = std::max(maxChunk, end - base);
+    }
+    chunkStart.push_back(nj);
+    for (size_t ch = 0; ch + 1 < chunkStart.size(); ch++) {
+      const size_t b0 = static_cast<size_t>(jobs[chunkStart[ch]].off_work);
+      for (int q = chunkStart[ch]; q < chunkStart[ch + 1]; q++) jobs[q].off_work -= b0;
+    }
+  }
   struct DevMem { void *p = nullptr; ~DevMem() { if (p) hipFree(p); } } d_jobs, d_in, d_work, d_out;
   HIP_TRY(hipMalloc(&d_jobs.p, sizeof(TreeJob) * nj));
   HIP_TRY(hipMalloc(&d_in.p, in.size()));
-  HIP_TRY(hipMalloc(&d_work.p, sizeof(double) * work_doubles));
+  HIP_TRY(hipMalloc(&d_work.p, sizeof(double) * maxChunk));
   HIP_TRY(hipMalloc(&d_out.p, sizeof(TreeOut) * nj));
   HIP_TRY(hipMemcpyAsync(d_jobs.p, jobs.data(), sizeof(TreeJob) * nj, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(d_in.p, in.data(), in.size(), hipMemcpyHostToDevice, c->stream));
-  launch_tree_fit(static_cast<const TreeJob *>(d_jobs.p), nj, static_cast<const uint8_t *>(d_in.p), static_cast<double *>(d_work.p),
-                  static_cast<TreeOut *>(d_out.p), c->stream);
+  for (size_t ch = 0; ch + 1 < chunkStart.size(); ch++) {
+    const int q0 = chunkStart[ch], q1 = chunkStart[ch + 1];
+    launch_tree_fit(static_cast<const TreeJob *>(d_jobs.p) + q0, q1 - q0, static_cast<const uint8_t *>(d_in.p), static_cast<double *>(d_work.p),
+                    static_cast<TreeOut *>(d_out.p) + q0, c->stream);
+  }
   HIP_TRY(hipGetLastError());
   std::vector<TreeOut> out(nj);
   HIP_TRY(hipMemcpyAsync(out.data(), d_out.p, sizeof(TreeOut) * nj, hipMemcpyDeviceToHost, c->stream));

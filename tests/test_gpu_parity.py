@@ -535,3 +535,14 @@ def test_exact_division_instantiation_against_oracle(ctx, pars):
         assert [(g["strand"], g["frame"], g["start"], g["end"]) for g in got] == [(w["strand"], w["frame"], w["start"], w["end"]) for w in want]
         assert all(np.float32(g["score"]) == np.float32(w["score"]) for g, w in zip(got, want))
     batch.close()
+
+
+def test_device_tree_fit_in_several_launches(ctx, monkeypatch):
+    """A scratch cap smaller than the batch needs makes rc_fit_trees_device go in several launches: same trees."""
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_blocks
+    blocks = synth_blocks(60, 6, 90, seed=8) + synth_blocks(5, 14, 200, seed=9)
+    whole = api.fit_trees(blocks, ctx=ctx)
+    monkeypatch.setenv("RC_TREE_SCRATCH_BYTES", str(300 * 1024))
+    parts = api.fit_trees(blocks, ctx=ctx)
+    assert parts == whole and all(t is not None for t in whole)
