@@ -84,7 +84,7 @@ int rc_device_count(void);
 
 /* One context per process and GPU (one process per GPU; multi-GPU sharding is done by the
  * caller).  A context owns one HIP stream and the scratch buffers its kernels
- * share: calls that take the same rc_ctx (directly or through one of its batches) must not run
+ * share: calls on one context -- directly or through one of its batches -- must not run
  * concurrently; different contexts are independent.  rc_last_error() is per thread. */
 int rc_ctx_create(int device, rc_ctx **out);
 void rc_ctx_destroy(rc_ctx *ctx);
