@@ -219,7 +219,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"synthetic MAF {args.blocks} blocks x {args.cols} cols x {args.seqs} seqs, "
-                                   f"--num-samples {args.samples}, per GPU (BASELINE.json configs[2]/[3])",
+                                   f"--num-samples {args.samples}, " + ("per GPU" if args.scaling == "weak" else "in total, split across the GPUs")
+                                   + " (BASELINE.json configs[2]/[3])",
                        "blocks_per_gpu": len(blocks), "cols": args.cols, "seqs": args.seqs, "samples": args.samples,
                        "seed_base": args.seed_base, "sharding": f"blocks x{world}",
                        "exchange": ("all-gather of " + args.exchange) if world > 1 else "none"},
