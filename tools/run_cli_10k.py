@@ -1,0 +1,21 @@
+"""End-to-end timing of the stand-alone driver on a synthetic 10k-block MAF (file -> trees -> scores -> listing).
+usage: python tools/run_cli_10k.py [n_blocks]"""
+import os
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, ".")
+from rnacode_amd import cli  # noqa: E402
+from rnacode_amd.synth import synth_blocks, to_maf  # noqa: E402
+
+nb = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+d = tempfile.mkdtemp()
+maf = os.path.join(d, "in.maf")
+with open(maf, "w") as fh:
+    fh.write(to_maf(synth_blocks(nb, 6, 120, seed=1)))
+t = time.time()
+rc = cli.main([maf, "-n", "1000", "-t", "-o", os.path.join(d, "out.tsv")])
+dt = time.time() - t
+print(f"cli rc={rc}: {nb} blocks end to end in {dt:.2f} s ({os.path.getsize(maf) / 1e6:.1f} MB MAF, "
+      f"{sum(1 for _ in open(os.path.join(d, 'out.tsv')))} HSS lines)")
