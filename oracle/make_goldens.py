@@ -201,9 +201,35 @@ def main_eps():
              ["hss-8.eps", "hss-12.eps", "hss-33.eps", "hss-104.eps", "hss-133.eps"])
 
 
+def main_breakmaf():
+    """Input/output pairs of the reference's scripts/breakMAF.pl (run with perl): its own example
+    (examples/genomic.maf -> the shipped examples/genomic-preprocessed.maf) and synthetic long blocks with other
+    parameters."""
+    from rnacode_amd.synth import to_maf
+    script = os.path.join(REF, "scripts", "breakMAF.pl")
+    cases = []
+    with open(os.path.join(REF, "examples", "genomic.maf")) as fh:
+        cases.append(dict(name="genomic.maf", args=[], input=fh.read()))
+    txt = to_maf(synth_blocks(3, 5, 950, seed=3) + synth_blocks(2, 4, 120, seed=4))
+    cases.append(dict(name="synthetic default", args=[], input=txt))
+    cases.append(dict(name="synthetic 300/90", args=["--maxLength", "300", "--desiredLength", "90"], input=txt))
+    for c in cases:
+        c["output"] = subprocess.run(["perl", script, *c["args"]], input=c["input"].encode(), stdout=subprocess.PIPE,
+                                     stderr=subprocess.DEVNULL, check=True).stdout.decode()
+    with open(os.path.join(REF, "examples", "genomic-preprocessed.maf")) as fh:
+        assert cases[0]["output"] == fh.read()      # the reference ships this output
+    out = os.path.join(OUT, "breakmaf_cases.json.gz")
+    with gzip.GzipFile(out, "wb", mtime=0) as fh:
+        fh.write(json.dumps(dict(fixture="breakmaf_cases", cases=cases), separators=(",", ":")).encode())
+    print(f"breakmaf_cases: {len(cases)} cases, {os.path.getsize(out)} bytes")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "eps":
         main_eps()
+    elif len(sys.argv) > 1 and sys.argv[1] == "breakmaf":
+        main_breakmaf()
     else:
         main()
         main_eps()
+        main_breakmaf()

@@ -22,8 +22,8 @@ def load_golden(name):
 
 
 def golden_names():
-    """The scoring fixtures (eps_* hold plots for fixtures listed here and are read by the EPS tests only)."""
-    return sorted(f[:-8] for f in os.listdir(GOLDEN_DIR) if f.endswith(".json.gz") and not f.startswith("eps_"))
+    """The scoring fixtures (eps_* hold plots for fixtures listed here, breakmaf_* the MAF pre-splitting cases)."""
+    return sorted(f[:-8] for f in os.listdir(GOLDEN_DIR) if f.endswith(".json.gz") and not f.startswith(("eps_", "breakmaf_")))
 
 
 def hss_key(h):
