@@ -58,3 +58,15 @@ def test_harness_on_hip_backend_matches_reference(name):
             np.testing.assert_array_equal(np.float32(mg["scores"]), np.float32(mw["scores"]))
         if "backtrack" in w:
             assert g["backtrack"] == w["backtrack"]
+
+
+@pytest.mark.gpu
+def test_c_example_runs(tmp_path):
+    """integration/example_batch.c (plain C against include/rnacode_hip.h): GPU tree fit + batch scoring end to end."""
+    import subprocess
+    from test_host_cpu import _build_c_example
+    exe = str(tmp_path / "example_batch")
+    _build_c_example(exe)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "block 0: tree (" in out.stdout and "block 1: tree (" in out.stdout

@@ -102,3 +102,19 @@ def test_synthetic_generator_is_deterministic_and_well_formed():
     for e, g in zip(doc["blocks"], regen):
         assert [r["seq"] for r in e["input"]["rows"]] == [r.seq for r in g.rows]
         assert e["input"]["tree"] == g.tree
+
+
+def _build_c_example(out_path):
+    import subprocess
+    lib_dir = os.path.join(ROOT, "rnacode_amd")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "integration", "example_batch.c"), "-L" + lib_dir, "-lrnacode_hip",
+           "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-o", out_path]
+    subprocess.check_call(cmd)
+
+
+def test_header_is_plain_c_and_the_example_links(tmp_path):
+    """include/rnacode_hip.h compiles as strict C99 and integration/example_batch.c links against the library."""
+    from rnacode_amd import api
+    api.lib()
+    _build_c_example(str(tmp_path / "example_batch"))
