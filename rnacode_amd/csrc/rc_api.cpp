@@ -45,6 +45,7 @@ struct rc_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // native-block kernels: latency-bound, they run beside the null sampling
+  std::vector<hipStream_t> classStreams;   // k_null launches of different row-count classes, when a batch has several
   int numCU = 0;
   CodeTables ct62{62}, ct90{90};
   PairTable pt62, pt90;
@@ -162,6 +163,7 @@ void rc_ctx_destroy(rc_ctx *c) {
   if (c->d_work) hipFree(c->d_work);
   if (c->stream) hipStreamDestroy(c->stream);
   if (c->stream2 && c->stream2 != c->stream) hipStreamDestroy(c->stream2);
+  for (hipStream_t st : c->classStreams) hipStreamDestroy(st);
   delete c;
 }
 
@@ -433,47 +435,79 @@ int rc_batch_run(rc_batch *b) {
   // -1.0f everywhere first: skipped blocks report "no HSS" rows
   HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->d_maxima), 0xBF800000u, static_cast<size_t>(n) * sampleN, c->stream));
   HIP_TRY(hipEventRecord(ev[3], c->stream));
+  struct Plan { int NK, grid, comboSplit; size_t stride, ldsBytes, need; bool exact; };
+  std::vector<Plan> plans;
+  size_t needSum = 0, needMax = 0;
   for (auto &kv : b->classes) {
-    const int NK = kv.first;
+    Plan p{};
+    p.NK = kv.first;
     int maxLc = 0;
     for (int bi : kv.second) maxLc = std::max(maxLc, b->hb[bi].L);
-    const int NCW = (NK + 4) / 5;   // 5 six-bit sigma codes per word
-    const size_t stride = static_cast<size_t>(2) * (maxLc + 1) * NCW * kWave;
-    // sigma codes of one strand x frame are staged in LDS when that still leaves >= 16 wavefronts per
+    const int NCW = (p.NK + 4) / 5;   // 5 six-bit sigma codes per word
+    p.stride = static_cast<size_t>(2) * (maxLc + 1) * NCW * kWave;
+    // sigma codes of one strand x frame are staged in LDS when that still leaves >= 12 wavefronts per
     // CU (RC_LDS_MAX_BYTES overrides the per-wavefront budget); otherwise they are read from the
     // per-workgroup scratch in global memory.
-    size_t ldsBytes = static_cast<size_t>(maxLc / 3) * NCW * kWave * sizeof(uint32_t);
-    bool exact = false;
-    for (int bi : kv.second) exact = exact || b->hb[bi].exact_div;
-    if (ldsBytes > c->ldsMaxBytes || exact) ldsBytes = 0;
-    else ldsBytes = std::max<size_t>(ldsBytes, kPhaseALds);   // phase A keeps the tree's threshold table and the pair table there
-    const std::pair<int, size_t> key(NK, ldsBytes);
-    if (!c->occ.count(key)) c->occ[key] = null_occupancy(NK, ldsBytes);
-    if (c->occ[key] <= 0 && ldsBytes) { ldsBytes = 0; const std::pair<int, size_t> k2(NK, 0); if (!c->occ.count(k2)) c->occ[k2] = null_occupancy(NK, 0); }
-    const int occ = std::max(1, c->occ[std::pair<int, size_t>(NK, ldsBytes)]);
+    p.ldsBytes = static_cast<size_t>(maxLc / 3) * NCW * kWave * sizeof(uint32_t);
+    for (int bi : kv.second) p.exact = p.exact || b->hb[bi].exact_div;
+    if (p.ldsBytes > c->ldsMaxBytes || p.exact) p.ldsBytes = 0;
+    else p.ldsBytes = std::max<size_t>(p.ldsBytes, kPhaseALds);   // phase A keeps the tree's threshold table and the pair table there
+    const std::pair<int, size_t> key(p.NK, p.ldsBytes);
+    if (!c->occ.count(key)) c->occ[key] = null_occupancy(p.NK, p.ldsBytes);
+    if (c->occ[key] <= 0 && p.ldsBytes) { p.ldsBytes = 0; const std::pair<int, size_t> k2(p.NK, 0); if (!c->occ.count(k2)) c->occ[k2] = null_occupancy(p.NK, 0); }
+    const int occ = std::max(1, c->occ[std::pair<int, size_t>(p.NK, p.ldsBytes)]);
     int items = static_cast<int>(kv.second.size()) * groups;
     // small batches: split every item into its six strand x frame parts to fill the chip
-    const int comboSplit = (items * 2 <= c->numCU * occ) ? 1 : 0;
-    if (comboSplit) items *= 6;
-    int grid = std::min(items, c->numCU * occ);
+    p.comboSplit = (items * 2 <= c->numCU * occ) ? 1 : 0;
+    if (p.comboSplit) items *= 6;
+    p.grid = std::min(items, c->numCU * occ);
     // very long blocks: bound the sigma-code staging area (4 GiB of uint32) by running fewer workgroups
-    grid = static_cast<int>(std::max<size_t>(1, std::min<size_t>(grid, (static_cast<size_t>(1) << 30) / std::max<size_t>(stride, 1))));
-    const size_t need = stride * grid;
-    if (need > c->scratch_cap) {
-      HIP_TRY(hipStreamSynchronize(c->stream));
-      if (c->d_scratch) hipFree(c->d_scratch);
-      c->d_scratch = nullptr; c->scratch_cap = 0;
-      HIP_TRY(hipMalloc(&c->d_scratch, need * sizeof(uint32_t)));
-      c->scratch_cap = need;
+    p.grid = static_cast<int>(std::max<size_t>(1, std::min<size_t>(p.grid, (static_cast<size_t>(1) << 30) / std::max<size_t>(p.stride, 1))));
+    p.need = p.stride * p.grid;
+    needSum += p.need; needMax = std::max(needMax, p.need);
+    plans.push_back(p);
+  }
+  // Several row-count classes: their launches are independent (own work queues, own part of the staging
+  // scratch), so they go on separate streams and share the chip -- a small class no longer waits for the tail
+  // of the previous one.  One class, a scratch that would exceed 4 GiB, or RC_SERIAL_NATIVE: main stream only.
+  const bool concurrent = plans.size() > 1 && needSum <= (static_cast<size_t>(1) << 30) && c->stream2 != c->stream;
+  const size_t need = concurrent ? needSum : needMax;
+  if (need > c->scratch_cap) {
+    HIP_TRY(hipDeviceSynchronize());
+    if (c->d_scratch) hipFree(c->d_scratch);
+    c->d_scratch = nullptr; c->scratch_cap = 0;
+    HIP_TRY(hipMalloc(&c->d_scratch, need * sizeof(uint32_t)));
+    c->scratch_cap = need;
+  }
+  std::vector<Event> classDone(concurrent ? plans.size() : 0);
+  size_t scratchOff = 0;
+  for (size_t pi = 0; pi < plans.size(); pi++) {
+    const Plan &p = plans[pi];
+    const auto &members = b->classes[p.NK];
+    hipStream_t st = c->stream;
+    if (concurrent) {
+      while (c->classStreams.size() < std::min<size_t>(plans.size(), 8)) {
+        hipStream_t ns = nullptr;
+        HIP_TRY(hipStreamCreate(&ns));
+        c->classStreams.push_back(ns);
+      }
+      st = c->classStreams[pi % c->classStreams.size()];
+      HIP_TRY(hipStreamWaitEvent(st, ev[3], 0));   // the memsets above
     }
     NullArgs a{};
-    a.blob = b->d_blob; a.dblocks = b->d_dblocks; a.classBlocks = b->d_classBlocks[NK];
-    a.nClassBlocks = static_cast<int>(kv.second.size()); a.groups = groups; a.sampleN = sampleN; a.Spad = Spad;
-    a.U = c->d_U; a.pair = d_pair; a.scratch = c->d_scratch; a.scratchStride = stride;
-    a.maxima = b->d_maxima; a.clampCount = c->d_clamp; a.tieThr = c->tieThr; a.debugSkip = c->debugSkip; a.comboSplit = comboSplit;
-    a.workCounter = c->d_work + NK * 8;
-    if (!launch_null(NK, a, grid, ldsBytes, exact, c->stream)) return fail(RC_ERR_UNSUPPORTED, "no null kernel for this number of rows");
+    a.blob = b->d_blob; a.dblocks = b->d_dblocks; a.classBlocks = b->d_classBlocks[p.NK];
+    a.nClassBlocks = static_cast<int>(members.size()); a.groups = groups; a.sampleN = sampleN; a.Spad = Spad;
+    a.U = c->d_U; a.pair = d_pair; a.scratch = c->d_scratch + scratchOff; a.scratchStride = p.stride;
+    a.maxima = b->d_maxima; a.clampCount = c->d_clamp; a.tieThr = c->tieThr; a.debugSkip = c->debugSkip; a.comboSplit = p.comboSplit;
+    a.workCounter = c->d_work + p.NK * 8;
+    if (!launch_null(p.NK, a, p.grid, p.ldsBytes, p.exact, st)) return fail(RC_ERR_UNSUPPORTED, "no null kernel for this number of rows");
     b->nl[2]++;
+    if (concurrent) {
+      scratchOff += p.need;
+      HIP_TRY(classDone[pi].create());
+      HIP_TRY(hipEventRecord(classDone[pi], st));
+      HIP_TRY(hipStreamWaitEvent(c->stream, classDone[pi], 0));
+    }
   }
   HIP_TRY(hipEventRecord(ev[4], c->stream));
 
