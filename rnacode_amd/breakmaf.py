@@ -8,7 +8,8 @@ chunks (breakMAF.pl:36-62) with the start/length of every row recomputed from it
 script's formatAln does it ("a score=0", source names cut to "org.chrom", srcSize 0).  The scorer's
 batch path wants this for genome-wide input: it keeps blocks inside the row lengths the sigma-code
 staging in LDS is sized for.  Output is byte-identical to the Perl script's (tests/test_breakmaf_cpu.py:
-examples/genomic.maf -> examples/genomic-preprocessed.maf)."""
+examples/genomic.maf -> examples/genomic-preprocessed.maf), including its quirk: a piece that begins inside a
+gap run of a row starts at the residue before the gap, one position early and one residue long."""
 from __future__ import annotations
 
 import argparse
