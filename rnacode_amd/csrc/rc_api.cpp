@@ -90,6 +90,10 @@ struct rc_batch {
   size_t S_floats = 0;
   DevHss *d_hss = nullptr;
   int *d_hssCount = nullptr;
+  uint8_t *h_stage = nullptr;      // pinned: fit rows, HSS counts and offsets, clamp counter of one run
+  size_t stageBytes = 0;
+  DevHss *h_packed = nullptr;      // pinned: the packed HSS records (grown on demand)
+  size_t packedCap = 0;
   DevHss *d_hssPacked = nullptr;   // the used records, packed for the copy to the host
   int *d_hssOffsets = nullptr;     // [n * 6] + 1: start of each slot in d_hssPacked; last entry = total
   FitOut *d_fit = nullptr;
@@ -180,6 +184,8 @@ void rc_batch_destroy(rc_batch *b) {
   if (b->d_hss) hipFree(b->d_hss);
   if (b->d_hssCount) hipFree(b->d_hssCount);
   if (b->d_hssPacked) hipFree(b->d_hssPacked);
+  if (b->h_stage) hipHostFree(b->h_stage);
+  if (b->h_packed) hipHostFree(b->h_packed);
   if (b->d_hssOffsets) hipFree(b->d_hssOffsets);
   if (b->d_fit) hipFree(b->d_fit);
   delete b;
@@ -519,30 +525,50 @@ int rc_batch_run(rc_batch *b) {
   fa.stopCutoff = static_cast<int>(b->par.cutoff * b->par.sampleN);   // score.c:992
   launch_evd_fit(fa, static_cast<int>(b->okBlocks.size()), c->stream); b->nl[4]++;
   HIP_TRY(hipEventRecord(ev[5], c->stream));
-  HIP_TRY(hipEventSynchronize(ev[5]));
+
+  // small results back to the host: four copies into one pinned staging area behind the fit, one wait
+  const size_t szFit = sizeof(FitOut) * n, szCnt = sizeof(int) * static_cast<size_t>(slots), szOff = sizeof(int) * (static_cast<size_t>(slots) + 1);
+  const size_t oFit = 0, oCnt = (oFit + szFit + 15) & ~static_cast<size_t>(15), oOff = (oCnt + szCnt + 15) & ~static_cast<size_t>(15),
+               oClamp = (oOff + szOff + 15) & ~static_cast<size_t>(15), total = oClamp + 16;
+  if (total > b->stageBytes) {
+    if (b->h_stage) hipHostFree(b->h_stage);
+    b->h_stage = nullptr; b->stageBytes = 0;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_stage), total, hipHostMallocDefault));
+    b->stageBytes = total;
+  }
+  HIP_TRY(hipMemcpyAsync(b->h_stage + oFit, b->d_fit, szFit, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(b->h_stage + oCnt, b->d_hssCount, szCnt, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(b->h_stage + oOff, b->d_hssOffsets, szOff, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(b->h_stage + oClamp, c->d_clamp, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipGetLastError());
   float ms;
   HIP_TRY(hipEventElapsedTime(&ms, ev[1], ev[2])); b->t[3] = ms;
   HIP_TRY(hipEventElapsedTime(&ms, ev[3], ev[4])); b->t[2] = ms;
   HIP_TRY(hipEventElapsedTime(&ms, ev[4], ev[5])); b->t[4] = ms;
   HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[5])); b->t[0] = ms;
-
-  // small results back to the host
   {
-    std::vector<FitOut> f(n);
-    HIP_TRY(hipMemcpy(f.data(), b->d_fit, sizeof(FitOut) * n, hipMemcpyDeviceToHost));
+    const FitOut *f = reinterpret_cast<const FitOut *>(b->h_stage + oFit);
     for (int bi : b->okBlocks) b->fit[bi] = f[bi];
-    HIP_TRY(hipMemcpy(b->hssCount.data(), b->d_hssCount, sizeof(int) * b->hssCount.size(), hipMemcpyDeviceToHost));
-    // the used HSS records only (k_hss_pack): offsets + total, then that many records
-    std::vector<int> off(static_cast<size_t>(slots) + 1);
-    HIP_TRY(hipMemcpy(off.data(), b->d_hssOffsets, sizeof(int) * off.size(), hipMemcpyDeviceToHost));
-    std::vector<DevHss> packed(static_cast<size_t>(std::max(off[slots], 0)));
-    if (!packed.empty()) HIP_TRY(hipMemcpy(packed.data(), b->d_hssPacked, sizeof(DevHss) * packed.size(), hipMemcpyDeviceToHost));
+    std::memcpy(b->hssCount.data(), b->h_stage + oCnt, szCnt);
+    const int *off = reinterpret_cast<const int *>(b->h_stage + oOff);
+    std::memcpy(&b->clamped, b->h_stage + oClamp, sizeof(unsigned long long));
+    // the used HSS records only (k_hss_pack): that many records, second and last wait
+    const size_t nrec = static_cast<size_t>(std::max(off[slots], 0));
+    if (nrec > b->packedCap) {
+      if (b->h_packed) hipHostFree(b->h_packed);
+      b->h_packed = nullptr; b->packedCap = 0;
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_packed), sizeof(DevHss) * (nrec + nrec / 4 + 64), hipHostMallocDefault));
+      b->packedCap = nrec + nrec / 4 + 64;
+    }
+    if (nrec) {
+      HIP_TRY(hipMemcpyAsync(b->h_packed, b->d_hssPacked, sizeof(DevHss) * nrec, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     for (int t = 0; t < slots; t++) {
       const int cnt = std::min(b->hssCount[t], b->hssCap);
-      for (int i = 0; i < cnt; i++) b->hss[static_cast<size_t>(t) * b->hssCap + i] = packed[static_cast<size_t>(off[t]) + i];
+      for (int i = 0; i < cnt; i++) b->hss[static_cast<size_t>(t) * b->hssCap + i] = b->h_packed[static_cast<size_t>(off[t]) + i];
     }
-    HIP_TRY(hipMemcpy(&b->clamped, c->d_clamp, sizeof(unsigned long long), hipMemcpyDeviceToHost));
   }
   b->ran = true;
   return RC_OK;
