@@ -1,0 +1,81 @@
+"""Randomised parity soak: random block shapes, sample counts, seeds and parameters through the HIP path and the
+oracle until the time budget is used up; any difference in per-sample maxima, HSS tables or fit results is printed.
+usage: python tools/soak_parity.py [seconds] [rng_seed]"""
+import re
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+from oracle import binding as ob  # noqa: E402
+from rnacode_amd import api  # noqa: E402
+from rnacode_amd.synth import synth_block  # noqa: E402
+
+
+def key(h):
+    return (-h["score"], h["strand"], h["frame"], h["start"], h["end"])
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    ctx = api.Context(0)
+    t0 = time.time()
+    rounds = blocks_done = bad = 0
+    while time.time() - t0 < budget:
+        rounds += 1
+        n_samples = int(rng.choice([1, 2, 63, 64, 65, 100, 129, 200, 333]))
+        seed = int(rng.randint(1, 2 ** 31 - 1))
+        pars = {}
+        r = rng.rand()
+        if r < 0.15:
+            pars = dict(Delta=float(-rng.uniform(1, 15)), Omega=float(-rng.uniform(1, 8)), omega=float(-rng.uniform(0.5, 4)))
+        elif r < 0.2:
+            pars = dict(Delta=float(rng.uniform(0, 2)))
+        elif r < 0.3:
+            pars = dict(blosum=90)
+        blocks = []
+        for i in range(int(rng.randint(1, 25))):
+            n = int(rng.choice([3, 3, 4, 5, 6, 6, 7, 8, 10, 12, 17, 32]))
+            cols = int(rng.choice([9, 12, 30, 45, 60, 90, 120, 150, 200, 301]))
+            if n * cols > 4000:
+                cols = max(9, 4000 // n)
+            b = synth_block(rng, n, cols, index=i, gaps=bool(rng.rand() < 0.8), mean_branch=float(rng.choice([0.01, 0.1, 0.4]))).upper()
+            if rng.rand() < 0.3:   # common gap stretch (ties) / zero-length branch (degenerate rows)
+                rows = [bytearray(x.seq.encode()) for x in b.rows]
+                ln = int(rng.choice([3, 4, 6, 7])); pos = int(rng.randint(0, max(1, cols - ln)))
+                for q in range(1, n):
+                    rows[q][pos:pos + ln] = b"-" * min(ln, cols - pos)
+                for x, row in zip(b.rows, rows):
+                    x.seq = row.decode(); x.length = sum(ch != "-" for ch in x.seq)
+                m = list(re.finditer(r":[0-9.]+", b.tree))[0]
+                b.tree = b.tree[:m.start()] + ":0.000000" + b.tree[m.end():]
+            blocks.append(b)
+        batch = api.Batch(ctx, blocks, api.default_params(sampleN=n_samples, seed_base=seed, **pars)).run()
+        for i, b in enumerate(blocks):
+            p = ob.default_params(n_samples, blosum=pars.get("blosum", 62))
+            for k, v in pars.items():
+                if k != "blosum":
+                    setattr(p, k, v)
+            if batch.status(i) != 0:
+                continue
+            res = ob.run_block([x.seq for x in b.rows], [x.name for x in b.rows], b.rows[0].start, b.rows[0].length, b.tree, b.kappa, p, seed)
+            ok = np.array_equal(batch.maxScores(i), np.float32(res.maxScores))
+            got, want = sorted(batch.scoreAln(i), key=key), sorted(res.hss, key=key)
+            ok = ok and [(g["strand"], g["frame"], g["start"], g["end"], np.float32(g["score"])) for g in got] == \
+                [(w["strand"], w["frame"], w["start"], w["end"], np.float32(w["score"])) for w in want]
+            rc, mu, lam = batch.getExtremeValuePars(i)
+            ok = ok and rc == res.evd_rc and (rc != 1 or (abs(mu - res.mu) <= 1e-6 * max(1, abs(res.mu)) and abs(lam - res.lam) <= 1e-6 * max(1, abs(res.lam))))
+            blocks_done += 1
+            if not ok:
+                bad += 1
+                print(f"MISMATCH round {rounds} block {i}: {b.n} x {b.cols}, n={n_samples}, seed={seed}, pars={pars}")
+        batch.close()
+    print(f"soak: {rounds} batches, {blocks_done} blocks compared in {time.time() - t0:.0f} s, {bad} mismatches")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
