@@ -120,7 +120,10 @@ def main():
     dist = None
     torch = None
     coll_dev = f"cuda:{local_rank}"
-    if world > 1:
+    # test hook: RC_BENCH_FORCE_DIST=1 takes the multi-rank code path with a world of one, so that a box with a
+    # single GPU still runs init_process_group("nccl"), the all-gather and the reductions through RCCL
+    multi = world > 1 or bool(os.environ.get("RC_BENCH_FORCE_DIST"))
+    if multi:
         import torch
         import torch.distributed as dist
         if os.environ.get("RC_BENCH_TEST_BACKEND") == "gloo":
@@ -156,13 +159,13 @@ def main():
 
     gathered = None
     mine = None
-    if world > 1 and args.exchange == "maxima":
+    if multi and args.exchange == "maxima":
         mine = torch.empty((len(blocks), args.samples), dtype=torch.float32, device=f"cuda:{local_rank}")
         batch.bind_maxima(mine.data_ptr())
 
     def step():
         batch.run()                      # synchronous: kernels done, small results on the host
-        if world > 1:                    # the path's one exchange (RCCL over xGMI): results of all blocks on every rank
+        if multi:                        # the path's one exchange (RCCL over xGMI): results of all blocks on every rank
             nonlocal gathered
             if args.exchange == "maxima":
                 gathered = rd.all_gather_maxima(mine if coll_dev != "cpu" else mine.cpu(), counts)
@@ -171,7 +174,7 @@ def main():
                 gathered = rd.all_gather_fits(fits, counts)
 
     def sync():
-        if world > 1:
+        if multi:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -190,11 +193,11 @@ def main():
         nlaunch = nl
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         elapsed = rd.max_over_ranks(elapsed, device=coll_dev)
 
     sa, cs = batch.work()
-    if world > 1:   # units of all ranks (shards may differ by one block under strong scaling)
+    if multi:   # units of all ranks (shards may differ by one block under strong scaling)
         tot = torch.tensor([float(cs), float(sa)], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tot)
         cs, sa = int(tot[0].item()), int(tot[1].item())
@@ -223,7 +226,7 @@ def main():
                                    + " (BASELINE.json configs[2]/[3])",
                        "blocks_per_gpu": len(blocks), "cols": args.cols, "seqs": args.seqs, "samples": args.samples,
                        "seed_base": args.seed_base, "sharding": f"blocks x{world}",
-                       "exchange": ("all-gather of " + args.exchange) if world > 1 else "none"},
+                       "exchange": ("all-gather of " + args.exchange) if multi else "none"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": measured_traffic() if (args.blocks, args.cols, args.seqs, args.samples) == (10000, 120, 6, 1000) else None, "kernel": "k_null<%d>" % (args.seqs - 1), "kernel_ms": null_ms,
                          "algorithmic_bytes_per_launch": by,
@@ -243,7 +246,7 @@ def main():
         print(json.dumps(out))
     batch.close()
     ctx.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -138,9 +138,15 @@ int rc_ctx_create(int device, rc_ctx **out) {
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   c->numCU = prop.multiProcessorCount;
-  HIP_TRY(hipStreamCreate(&c->stream));
+  // non-blocking streams: no implicit ordering against the legacy default stream that a host framework in
+  // the same process (torch, RCCL) may be using; the second stream gets the higher priority so that the
+  // runtime puts it on a hardware queue of its own (two plain streams can end up sharing one, which
+  // serialises the native-block kernels behind k_null again -- seen under torch.distributed)
+  int prioLow = 0, prioHigh = 0;
+  HIP_TRY(hipDeviceGetStreamPriorityRange(&prioLow, &prioHigh));
+  HIP_TRY(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prioLow));
   if (std::getenv("RC_SERIAL_NATIVE")) c->stream2 = c->stream;   // profiling: one kernel at a time, clean per-kernel intervals
-  else HIP_TRY(hipStreamCreate(&c->stream2));
+  else HIP_TRY(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prioHigh));
   c->pt62.build(c->ct62);
   c->pt90.build(c->ct90);
   HIP_TRY(hipMalloc(&c->d_pair62, 4096));
@@ -494,7 +500,7 @@ int rc_batch_run(rc_batch *b) {
     if (concurrent) {
       while (c->classStreams.size() < std::min<size_t>(plans.size(), 8)) {
         hipStream_t ns = nullptr;
-        HIP_TRY(hipStreamCreate(&ns));
+        HIP_TRY(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
         c->classStreams.push_back(ns);
       }
       st = c->classStreams[pi % c->classStreams.size()];
@@ -744,7 +750,8 @@ int rc_batch_backtrack(const rc_batch *b, int32_t blk, int32_t strand, int32_t o
   HIP_TRY(hipMalloc(&d_out, sizeof(float) * NK * 3 * steps));
   launch_sk_row(b->d_blob, b->d_dblocks, blk, strand, opt_b, opt_i, d_out, steps, c->stream);
   std::vector<float> sk(static_cast<size_t>(NK) * 3 * steps);
-  hipError_t e = hipMemcpy(sk.data(), d_out, sk.size() * sizeof(float), hipMemcpyDeviceToHost);
+  hipError_t e = hipStreamSynchronize(c->stream);   // the streams are non-blocking: a default-stream copy would not wait
+  if (e == hipSuccess) e = hipMemcpy(sk.data(), d_out, sk.size() * sizeof(float), hipMemcpyDeviceToHost);
   hipFree(d_out);
   if (e != hipSuccess) return fail(RC_ERR_DEVICE, hipGetErrorString(e));
   const int pitch = h.cols + 1;
@@ -959,7 +966,8 @@ int rc_evd_fit(rc_ctx *c, const double *x, int32_t n, double *mu, double *lambda
   HIP_TRY(hipMemcpy(d_x, x, sizeof(double) * n, hipMemcpyHostToDevice));
   launch_evd_fit_f64(d_x, n, d_o, c->stream);
   FitOut o;
-  hipError_t e = hipMemcpy(&o, d_o, sizeof o, hipMemcpyDeviceToHost);
+  hipError_t e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = hipMemcpy(&o, d_o, sizeof o, hipMemcpyDeviceToHost);
   hipFree(d_x); hipFree(d_o);
   if (e != hipSuccess) return fail(RC_ERR_DEVICE, hipGetErrorString(e));
   if (mu) *mu = o.mu;
@@ -973,7 +981,8 @@ int rc_mt_stream(rc_ctx *c, uint32_t seed, uint32_t *out, int32_t n) {
   uint32_t *d = nullptr;
   HIP_TRY(hipMalloc(&d, sizeof(uint32_t) * n));
   launch_mt_stream(seed, 1, n, d, c->stream);
-  hipError_t e = hipMemcpy(out, d, sizeof(uint32_t) * n, hipMemcpyDeviceToHost);
+  hipError_t e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = hipMemcpy(out, d, sizeof(uint32_t) * n, hipMemcpyDeviceToHost);
   hipFree(d);
   if (e != hipSuccess) return fail(RC_ERR_DEVICE, hipGetErrorString(e));
   return RC_OK;
