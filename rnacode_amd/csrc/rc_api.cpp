@@ -396,30 +396,20 @@ static int ensure_stream(rc_ctx *c, uint32_t seed, int Spad, int D, float *ms, i
 static bool g_no_stream_cache = false;
 void rc_set_stream_cache(int enabled) { g_no_stream_cache = !enabled; }
 
-int rc_batch_run(rc_batch *b) {
-  if (!b) return fail(RC_ERR_ARG, "null batch");
-  rc_ctx *c = b->ctx;
-  HIP_TRY(hipSetDevice(c->device));
-  std::fill(b->t, b->t + 5, 0.0f);
-  std::fill(b->nl, b->nl + 5, 0);
-  b->ran = false; b->maximaFetched = false;
-  const int n = b->n, sampleN = b->par.sampleN;
-  const int groups = (sampleN + kWave - 1) / kWave, Spad = groups * kWave;
-  b->fit.assign(n, FitOut{0, 0, -1, 0});
-  b->hss.resize(static_cast<size_t>(n) * 6 * b->hssCap);   // entries beyond hssCount[slot] are never read
-  b->hssCount.assign(static_cast<size_t>(n) * 6, 0);
-  b->clamped = 0;
-  if (b->okBlocks.empty()) { b->ran = true; return RC_OK; }
-  const uint8_t *d_pair = (b->par.blosum == 90) ? c->d_pair90 : c->d_pair62;
+// One run's launches, in the order rc_batch_run issues them.  ev[] are the run's timing events:
+// 0 start, 1..2 native block (second stream), 3..4 null sampling, 5 after the fit.
+struct RunEnv {
+  rc_batch *b;
+  rc_ctx *c;
+  int n, sampleN, groups, Spad, slots;
+  const uint8_t *d_pair;
+  Event *ev;
+};
 
-  Event ev[6];
-  for (auto &e : ev) HIP_TRY(e.create());
-  HIP_TRY(hipEventRecord(ev[0], c->stream));
-
-  if (g_no_stream_cache) c->U_valid = false;
-  int rcv = ensure_stream(c, b->par.seed_base, Spad, b->maxDraws, &b->t[1], &b->nl[1]);
-  if (rcv) return rcv;
-
+static int launch_native_block(const RunEnv &R) {
+  rc_batch *b = R.b; rc_ctx *c = R.c; Event *ev = R.ev;
+  const int n = R.n, slots = R.slots;
+  const uint8_t *d_pair = R.d_pair;
   // ---- native block: sigma -> DP per N-1 class -> scan, on the second stream: these kernels are small and
   // latency-bound, the null sampling below fills the chip beside them; the fit waits for both
   HIP_TRY(hipEventRecord(ev[1], c->stream2));
@@ -436,11 +426,17 @@ int rc_batch_run(rc_batch *b) {
     b->nl[3]++;
   }
   launch_native_scan(na, static_cast<int>(b->okBlocks.size()), c->stream2); b->nl[3]++;
-  const int slots = n * 6;
   HIP_TRY(hipMemsetAsync(b->d_hssOffsets + slots, 0, sizeof(int), c->stream2));
   launch_hss_pack(b->d_hss, b->d_hssCount, b->hssCap, slots, b->d_hssPacked, b->d_hssOffsets, b->d_hssOffsets + slots, c->stream2);
   HIP_TRY(hipEventRecord(ev[2], c->stream2));
 
+  return RC_OK;
+}
+
+static int launch_null_sampling(const RunEnv &R) {
+  rc_batch *b = R.b; rc_ctx *c = R.c; Event *ev = R.ev;
+  const int n = R.n, sampleN = R.sampleN, groups = R.groups, Spad = R.Spad;
+  const uint8_t *d_pair = R.d_pair;
   // ---- null sampling per N-1 class
   HIP_TRY(hipMemsetAsync(c->d_clamp, 0, sizeof(unsigned long long), c->stream));
   HIP_TRY(hipMemsetAsync(c->d_work, 0, sizeof(unsigned int) * (kMaxRows + 1) * 8, c->stream));
@@ -522,16 +518,12 @@ int rc_batch_run(rc_batch *b) {
     }
   }
   HIP_TRY(hipEventRecord(ev[4], c->stream));
+  return RC_OK;
+}
 
-  // ---- EVD fit
-  HIP_TRY(hipStreamWaitEvent(c->stream, ev[2], 0));   // native HSS of the second stream
-  FitArgs fa{};
-  fa.dblocks = b->d_dblocks; fa.blocks = b->d_okBlocks; fa.maxima = b->d_maxima; fa.hss = b->d_hss;
-  fa.hssCount = b->d_hssCount; fa.hssCap = b->hssCap; fa.out = b->d_fit; fa.sampleN = sampleN; fa.stopEarly = b->par.stopEarly;
-  fa.stopCutoff = static_cast<int>(b->par.cutoff * b->par.sampleN);   // score.c:992
-  launch_evd_fit(fa, static_cast<int>(b->okBlocks.size()), c->stream); b->nl[4]++;
-  HIP_TRY(hipEventRecord(ev[5], c->stream));
-
+static int fetch_results(const RunEnv &R) {
+  rc_batch *b = R.b; rc_ctx *c = R.c; Event *ev = R.ev;
+  const int n = R.n, slots = R.slots;
   // small results back to the host: four copies into one pinned staging area behind the fit, one wait
   const size_t szFit = sizeof(FitOut) * n, szCnt = sizeof(int) * static_cast<size_t>(slots), szOff = sizeof(int) * (static_cast<size_t>(slots) + 1);
   const size_t oFit = 0, oCnt = (oFit + szFit + 15) & ~static_cast<size_t>(15), oOff = (oCnt + szCnt + 15) & ~static_cast<size_t>(15),
@@ -576,6 +568,47 @@ int rc_batch_run(rc_batch *b) {
       for (int i = 0; i < cnt; i++) b->hss[static_cast<size_t>(t) * b->hssCap + i] = b->h_packed[static_cast<size_t>(off[t]) + i];
     }
   }
+  return RC_OK;
+}
+
+int rc_batch_run(rc_batch *b) {
+  if (!b) return fail(RC_ERR_ARG, "null batch");
+  rc_ctx *c = b->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  std::fill(b->t, b->t + 5, 0.0f);
+  std::fill(b->nl, b->nl + 5, 0);
+  b->ran = false; b->maximaFetched = false;
+  const int n = b->n, sampleN = b->par.sampleN;
+  const int groups = (sampleN + kWave - 1) / kWave, Spad = groups * kWave;
+  b->fit.assign(n, FitOut{0, 0, -1, 0});
+  b->hss.resize(static_cast<size_t>(n) * 6 * b->hssCap);   // entries beyond hssCount[slot] are never read
+  b->hssCount.assign(static_cast<size_t>(n) * 6, 0);
+  b->clamped = 0;
+  if (b->okBlocks.empty()) { b->ran = true; return RC_OK; }
+  const uint8_t *d_pair = (b->par.blosum == 90) ? c->d_pair90 : c->d_pair62;
+
+  Event ev[6];
+  for (auto &e : ev) HIP_TRY(e.create());
+  HIP_TRY(hipEventRecord(ev[0], c->stream));
+
+  if (g_no_stream_cache) c->U_valid = false;
+  int rcv = ensure_stream(c, b->par.seed_base, Spad, b->maxDraws, &b->t[1], &b->nl[1]);
+  if (rcv) return rcv;
+
+  const RunEnv R{b, c, n, sampleN, groups, Spad, n * 6, d_pair, ev};
+  if ((rcv = launch_native_block(R))) return rcv;
+  if ((rcv = launch_null_sampling(R))) return rcv;
+
+  // ---- EVD fit
+  HIP_TRY(hipStreamWaitEvent(c->stream, ev[2], 0));   // native HSS of the second stream
+  FitArgs fa{};
+  fa.dblocks = b->d_dblocks; fa.blocks = b->d_okBlocks; fa.maxima = b->d_maxima; fa.hss = b->d_hss;
+  fa.hssCount = b->d_hssCount; fa.hssCap = b->hssCap; fa.out = b->d_fit; fa.sampleN = sampleN; fa.stopEarly = b->par.stopEarly;
+  fa.stopCutoff = static_cast<int>(b->par.cutoff * b->par.sampleN);   // score.c:992
+  launch_evd_fit(fa, static_cast<int>(b->okBlocks.size()), c->stream); b->nl[4]++;
+  HIP_TRY(hipEventRecord(ev[5], c->stream));
+
+  if ((rcv = fetch_results(R))) return rcv;
   b->ran = true;
   return RC_OK;
 }
