@@ -136,6 +136,10 @@ int rc_batch_fit_all(const rc_batch *b, float *out);
 /* HSS list sorted by score descending as main() does (RNAcode.c:173-176); returns the count
  * (may exceed cap; only cap entries are written) */
 int rc_batch_hss(const rc_batch *b, int32_t blk, rc_hss *out, int32_t cap);
+/* The HSS lists of every block in one call: block i's list (sorted as above) is out[offsets[i] .. offsets[i+1]);
+ * offsets has n_blocks + 1 entries, offsets[n_blocks] is the total, which may exceed cap (only cap records are
+ * written -- call with cap = 0 first to size the buffer).  Blocks that were not scored have empty lists. */
+int rc_batch_hss_all(const rc_batch *b, rc_hss *out, int64_t cap, int64_t *offsets);
 /* draws that fell past the cumulative probability vector (reference reads out of bounds
  * there, seqgen/evolve.c:173; we clamp to state 3 and count) */
 int rc_batch_clamped(const rc_batch *b, int64_t *count);

@@ -53,6 +53,10 @@ class RcHss(C.Structure):
                     score=float(np.float32(self.score)), pvalue=float(np.float32(self.pvalue)))
 
 
+_HSS_DTYPE = np.dtype([(name, "<i4") for name in ("start", "end", "startGenomic", "endGenomic", "startSite", "endSite", "strand", "frame")]
+                      + [("score", "<f4"), ("pvalue", "<f4")])
+
+
 class RcModel(C.Structure):
     _fields_ = [("scores", C.c_float * 4), ("probs", C.c_float * 4), ("kappa", C.c_float), ("dist", C.c_float),
                 ("freqs", C.c_float * 4)]
@@ -102,6 +106,7 @@ def lib():
         l.rc_batch_maxima_all.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         l.rc_batch_fit.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         l.rc_batch_fit_all.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        l.rc_batch_hss_all.argtypes = [C.c_void_p, C.POINTER(RcHss), C.c_int64, C.POINTER(C.c_int64)]
         l.rc_batch_hss.argtypes = [C.c_void_p, C.c_int32, C.POINTER(RcHss), C.c_int32]
         l.rc_batch_clamped.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         l.rc_batch_native_S.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_int32]
@@ -124,7 +129,7 @@ def lib():
 EXPORTED_SYMBOLS = [
     "rc_default_params", "rc_last_error", "rc_device_count", "rc_ctx_create", "rc_ctx_destroy", "rc_batch_create",
     "rc_batch_destroy", "rc_batch_bind_maxima", "rc_batch_run", "rc_set_stream_cache", "rc_batch_work", "rc_batch_timing", "rc_batch_status",
-    "rc_batch_models", "rc_batch_maxima", "rc_batch_maxima_all", "rc_batch_fit", "rc_batch_fit_all", "rc_batch_hss", "rc_batch_clamped",
+    "rc_batch_models", "rc_batch_maxima", "rc_batch_maxima_all", "rc_batch_fit", "rc_batch_fit_all", "rc_batch_hss", "rc_batch_hss_all", "rc_batch_clamped",
     "rc_batch_native_S", "rc_batch_backtrack", "rc_fit_tree", "rc_fit_trees", "rc_fit_trees_device", "rc_tree_lnl", "rc_evd_fit", "rc_mt_stream", "rc_code_tables",
 ]
 
@@ -165,18 +170,41 @@ def fit_tree(block: AlnBlock) -> Tuple[str, float]:
     return buf.value.decode(), float(kappa.value)
 
 
-def fit_trees(blocks: Sequence[AlnBlock], threads: int = 0, cap: int = 1 << 14, ctx: "Optional[Context]" = None,
+class Marshalled:
+    """The rc_block array of a list of AlnBlocks (row and name pointers), built once and shared by the tree fit and
+    the batch: building it is the larger part of both calls' Python time."""
+
+    def __init__(self, blocks: Sequence[AlnBlock]):
+        self.blocks = list(blocks)
+        n = len(self.blocks)
+        self.arr = (RcBlock * max(n, 1))()
+        self.keep = []
+        for i, b in enumerate(self.blocks):
+            rows = (C.c_char_p * b.n)(*[r.seq.encode() for r in b.rows])
+            names = (C.c_char_p * b.n)(*[r.name.encode() for r in b.rows])
+            self.keep.append((rows, names))
+            self.arr[i] = RcBlock(b.n, b.cols, rows, names, b.rows[0].start, b.rows[0].length, None, 0.0)
+
+    def set_trees(self):
+        """Copy tree and kappa of the AlnBlocks into the array (after they were fitted or read from a sidecar)."""
+        self.trees = []
+        for i, b in enumerate(self.blocks):
+            if b.tree is None or b.kappa is None:
+                raise ValueError(f"block {b.block_id}: tree and kappa are required (sidecar or fitted upstream)")
+            t = b.tree.encode()
+            self.trees.append(t)
+            self.arr[i].newick = t
+            self.arr[i].kappa = b.kappa
+
+
+def fit_trees(blocks, threads: int = 0, cap: int = 1 << 14, ctx: "Optional[Context]" = None,
               lnl: Optional[list] = None) -> List[Optional[Tuple[str, float]]]:
-    """Trees + kappas of many blocks; None for blocks the driver skips.  With ctx: rc_fit_trees_device (one wavefront
-    per block on that context's GPU; `lnl`, if a list, receives the log-likelihoods); without: rc_fit_trees on host threads."""
-    n = len(blocks)
-    arr = (RcBlock * max(n, 1))()
-    keep = []
-    for i, b in enumerate(blocks):
-        rows = (C.c_char_p * b.n)(*[r.seq.encode() for r in b.rows])
-        names = (C.c_char_p * b.n)(*[r.name.encode() for r in b.rows])
-        keep.append((rows, names))
-        arr[i] = RcBlock(b.n, b.cols, rows, names, b.rows[0].start, b.rows[0].length, None, 0.0)
+    """Trees + kappas of many blocks (a sequence of AlnBlocks or a Marshalled); None for blocks the driver skips.
+    With ctx: rc_fit_trees_device (one wavefront per block on that context's GPU; `lnl`, if a list, receives the
+    log-likelihoods); without: rc_fit_trees on host threads."""
+    m = blocks if isinstance(blocks, Marshalled) else Marshalled(blocks)
+    n = len(m.blocks)
+    arr = m.arr
     buf = C.create_string_buffer(max(n, 1) * cap)
     kap = (C.c_float * max(n, 1))()
     if ctx is not None:
@@ -250,23 +278,17 @@ class BlockScores:
 class Batch:
     """Alignment blocks resident in HBM (rc_batch)."""
 
-    def __init__(self, ctx: Context, blocks: Sequence[AlnBlock], params: RcParams):
+    def __init__(self, ctx: Context, blocks, params: RcParams):
+        """blocks: a sequence of AlnBlocks with tree and kappa set, or a Marshalled of such blocks."""
         self.ctx = ctx
         self.params = params
-        self.blocks = list(blocks)
+        m = blocks if isinstance(blocks, Marshalled) else Marshalled(blocks)
+        m.set_trees()
+        self._keep = m
+        self.blocks = m.blocks
         n = len(self.blocks)
-        arr = (RcBlock * max(n, 1))()
-        self._keep = []
-        for i, b in enumerate(self.blocks):
-            if b.tree is None or b.kappa is None:
-                raise ValueError(f"block {b.block_id}: tree and kappa are required (sidecar or fitted upstream)")
-            rows = (C.c_char_p * b.n)(*[r.seq.encode() for r in b.rows])
-            names = (C.c_char_p * b.n)(*[r.name.encode() for r in b.rows])
-            tree = b.tree.encode()
-            self._keep.append((rows, names, tree))
-            arr[i] = RcBlock(b.n, b.cols, rows, names, b.rows[0].start, b.rows[0].length, tree, b.kappa)
         self._h = C.c_void_p()
-        _check(lib().rc_batch_create(ctx._h, arr, n, C.byref(params), C.byref(self._h)))
+        _check(lib().rc_batch_create(ctx._h, m.arr, n, C.byref(params), C.byref(self._h)))
         self.n = n
 
     def close(self):
@@ -315,6 +337,21 @@ class Batch:
         out = (RcHss * cap)()
         n = _check(lib().rc_batch_hss(self._h, blk, out, cap))
         return [out[i].as_dict() for i in range(min(n, cap))]
+
+    def scoreAln_all(self) -> List[List[dict]]:
+        """rc_batch_hss_all: the HSS lists of all blocks with two library calls (sizing, then the records)."""
+        offs = (C.c_int64 * (self.n + 1))()
+        _check(lib().rc_batch_hss_all(self._h, None, 0, offs))
+        total = int(offs[self.n])
+        out = (RcHss * max(total, 1))()
+        _check(lib().rc_batch_hss_all(self._h, out, total, offs))
+        a = np.frombuffer(out, dtype=_HSS_DTYPE, count=total)   # columns at once: per-record ctypes access is ~3 us
+        keys = ("strand", "frame", "startSite", "endSite", "start", "end", "startGenomic", "endGenomic", "score", "pvalue")
+        cols = [[chr(v) for v in a["strand"].tolist()]] + [a[k].tolist() for k in keys[1:8]] + \
+               [a["score"].astype(np.float64).tolist(), a["pvalue"].astype(np.float64).tolist()]
+        recs = [dict(zip(keys, vals)) for vals in zip(*cols)]
+        o = list(offs)
+        return [recs[o[i]:o[i + 1]] for i in range(self.n)]
 
     def getExtremeValuePars(self, blk: int) -> Tuple[int, float, float]:
         rc, mu, lam = C.c_int32(), C.c_float(), C.c_float()

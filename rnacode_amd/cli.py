@@ -39,7 +39,7 @@ def read_sidecar(path: str) -> List[Optional[tuple]]:
     return out
 
 
-def fit_trees(blocks: List[AlnBlock], threads: int = 0, ctx: "Optional[api.Context]" = None) -> List[Optional[tuple]]:
+def fit_trees(blocks, threads: int = 0, ctx: "Optional[api.Context]" = None) -> List[Optional[tuple]]:
     """Trees + kappas for every block the driver will score: on ctx's GPU (rc_fit_trees_device) when a
     context is given, else on host threads (rc_fit_trees)."""
     return api.fit_trees(blocks, threads, ctx=ctx)
@@ -85,6 +85,7 @@ def main(argv=None) -> int:
         blocks = read_alignment_file(fh.name)
     blocks = [b.upper() for b in blocks]
     ctx = api.Context(a.device)
+    marshalled = api.Marshalled(blocks)   # one rc_block array for the tree fit and the batch
     if a.trees:
         side = read_sidecar(a.trees)
         if len(side) != len(blocks):
@@ -92,7 +93,7 @@ def main(argv=None) -> int:
             ctx.close()
             return 1
     else:
-        side = fit_trees(blocks, ctx=ctx)
+        side = fit_trees(marshalled, ctx=ctx)
     prepared: List[AlnBlock] = []
     for b, s in zip(blocks, side):
         b.tree, b.kappa = s if s is not None else ("(a:0.1,b:0.1,c:0.1);", 2.0)   # skipped blocks never reach the tree
@@ -101,8 +102,9 @@ def main(argv=None) -> int:
     out = open(a.outfile, "w") if a.outfile else sys.stdout
     fmt = 2 if a.tabular else (1 if a.gtf else 0)
     t0 = time.perf_counter()
-    batch = api.Batch(ctx, prepared, params).run()
+    batch = api.Batch(ctx, marshalled, params).run()   # `prepared` are the marshalled blocks, tree and kappa now set
     st = report.ReportState()
+    all_hss = batch.scoreAln_all()
     for i, b in enumerate(prepared):
         code = batch.status(i)
         if code == api.RC_ERR_SKIP:   # RNAcode.c:142-150
@@ -116,7 +118,7 @@ def main(argv=None) -> int:
                 text = eps.color_aln(b, h, lambda strand, lo, hi: batch.backtrack(i, 0 if strand == "+" else 1, lo, hi), a.blosum)
                 with open(os.path.join(a.eps_dir, f"hss-{counter}.eps"), "w") as fh:
                     fh.write(text)
-        report.print_results(out, fmt, batch.scoreAln(i), b.rows[0].name, st, cutoff=a.cutoff, best_only=a.best_only,
+        report.print_results(out, fmt, all_hss[i], b.rows[0].name, st, cutoff=a.cutoff, best_only=a.best_only,
                              best_region=a.best_region, eps=hook, eps_cutoff=a.eps_cutoff)
     if fmt == 0:
         report.print_footer(out, len(prepared), time.perf_counter() - t0, params.sampleN, params.Delta, params.Omega,

@@ -745,6 +745,26 @@ int rc_batch_hss(const rc_batch *b, int32_t blk, rc_hss *out, int32_t cap) {
   return static_cast<int>(all.size());
 }
 
+int rc_batch_hss_all(const rc_batch *b, rc_hss *out, int64_t cap, int64_t *offsets) {
+  if (!b || !offsets || (!out && cap > 0) || !b->ran) return fail(RC_ERR_ARG, "batch has not been run");
+  int64_t total = 0;
+  std::vector<rc_hss> tmp;
+  for (int blk = 0; blk < b->n; blk++) {
+    offsets[blk] = total;
+    if (b->hb[blk].status != RC_OK) continue;
+    int n = 0;
+    for (int combo = 0; combo < 6; combo++) n += std::min(b->hssCount[static_cast<size_t>(blk) * 6 + combo], b->hssCap);
+    if (n == 0) continue;
+    tmp.resize(n);
+    const int got = rc_batch_hss(b, blk, tmp.data(), n);
+    if (got < 0) return got;
+    for (int i = 0; i < got && i < n; i++) if (total + i < cap) out[total + i] = tmp[i];
+    total += std::min(got, n);
+  }
+  offsets[b->n] = total;
+  return RC_OK;
+}
+
 int rc_batch_clamped(const rc_batch *b, int64_t *count) {
   if (!b || !b->ran) return fail(RC_ERR_ARG, "batch has not been run");
   *count = static_cast<int64_t>(b->clamped);

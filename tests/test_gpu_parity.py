@@ -546,3 +546,16 @@ def test_device_tree_fit_in_several_launches(ctx, monkeypatch):
     monkeypatch.setenv("RC_TREE_SCRATCH_BYTES", str(300 * 1024))
     parts = api.fit_trees(blocks, ctx=ctx)
     assert parts == whole and all(t is not None for t in whole)
+
+
+def test_bulk_hss_fetch_equals_per_block_fetch(ctx):
+    """rc_batch_hss_all against rc_batch_hss block by block (scored, skipped and empty blocks mixed)."""
+    doc = load_golden("genomic_preprocessed_n100")
+    _, blocks, batch = run_golden(ctx, doc)
+    everything = batch.scoreAln_all()
+    assert len(everything) == len(blocks)
+    from rnacode_amd import api
+    for i in range(len(blocks)):
+        want = batch.scoreAln(i) if batch.status(i) == api.RC_OK else []
+        assert everything[i] == want
+    batch.close()
