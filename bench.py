@@ -133,6 +133,10 @@ def main():
             coll_dev = "cpu"
             dist.init_process_group("gloo")
         else:
+            ndev = torch.cuda.device_count()
+            if 0 < ndev <= local_rank:   # a launcher that masks the GPUs per rank (each process sees its own as device 0)
+                local_rank %= ndev
+                coll_dev = f"cuda:{local_rank}"
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
