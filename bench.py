@@ -1,14 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- alignment-columns x samples scored per second on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path (MT19937 streams -> native scoring -> null sampling ->
-EVD fit) over one batch of synthetic alignment blocks already resident in HBM.  Workload at
-N=1: BASELINE.json configs[2], the configuration the north_star target is quoted on
-("10k-block MAF stream at num-samples=1000": 10 000 blocks x 120 cols x 6 seqs, n=1000) --
-configs[1] (genomic-preprocessed.maf, 33 scored blocks) is a parity case (tests/), it cannot
-fill one GPU.  With --gpus N every rank scores its own 10 000-block shard (weak scaling, no
-data-path collective) and the per-sample maxima are exchanged by one RCCL all-gather.
+Workload: BASELINE.json configs[2]/[3], the configuration the north_star target is quoted on: a stream of
+10 000 synthetic MAF blocks x 120 cols x 6 seqs at --num-samples 1000.  (configs[1],
+genomic-preprocessed.maf with 33 scored blocks, is a parity case in tests/: it cannot fill one GPU.)
+`--config c5` switches to a slice of configs[4] (12 seqs x 300 cols, n = 10 000: the long-block stress).
 
+  python bench.py --gpus N --steps K --warmup W
+
+With N > 1 and no torchrun environment this file starts its own N ranks (a fresh
+`python -m torch.distributed.run` child, before anything touches a GPU) and relays rank 0's line; under the
+driver's torchrun it just runs as one rank.  The 10 000 blocks are split across the ranks (strong scaling =
+configs[3]; `--scaling weak` gives every rank its own 10 000), no data-path collective, and every step ends
+with the path's one exchange: an RCCL all-gather of the per-sample maxima.
+
+A step is one pass of the hot path over this rank's blocks.  Two measurements per run, K steps each:
+  * resident (`value`, the contract's definition: inputs in HBM when the timed region starts): MT19937
+    streams -> native scoring -> null sampling -> EVD fit on a resident batch, then the all-gather;
+  * stream (`stream.value`): from host rc_block arrays to fitted results on the host -- block tables prepared
+    by host threads, one pinned copy per sub-batch, the expected-score tables made on the device, kernels,
+    results back -- as a pipeline of sub-batches (rc_stream_*), then the all-gather.  This is SURVEY.md
+    section 8d's "native scoring and fit included" rate; file parsing is not part of it.
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
 """
 from __future__ import annotations
@@ -16,6 +28,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
 import subprocess
 import sys
 import tempfile
@@ -27,6 +40,13 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 VALU_PEAK_GOPS = 78643.2       # 256 CU x 4 SIMD x 64 lanes / 2 cycles x 2.4 GHz (v_add/v_max wave64 = 2 cyc/SIMD)
+PROFILE_ROUND = "r02"
+
+CONFIGS = {
+    # name: (blocks, cols, seqs, samples, description)
+    "c3": (10000, 120, 6, 1000, "BASELINE.json configs[2]/[3]"),
+    "c5": (1000, 300, 12, 10000, "a 1000-block slice of BASELINE.json configs[4] (100k blocks over 8 GPUs = 12 500 per GPU)"),
+}
 
 
 def cells(L: int) -> int:
@@ -44,18 +64,22 @@ def algorithmic_work(blocks, sampleN):
     return by, fl
 
 
-def measured_traffic():
-    """HBM-side bytes per k_null launch from the committed rocprofv3 PMC passes of this same
-    command (profiles/collect.sh -> profiles/r01/k_null_pmc.json): FETCH_SIZE and WRITE_SIZE are in
-    KiB, collected in separate passes; on gfx950 FETCH_SIZE under-reports streaming reads by 2x
+def measured_traffic(config):
+    """HBM-side bytes per k_null launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/collect.sh -> profiles/<round>/k_null_<config>_pmc.json): FETCH_SIZE and WRITE_SIZE are in KiB,
+    collected in separate passes; on gfx950 FETCH_SIZE under-reports streaming reads by 2x
     (MI355X_MICROARCH.md, HBM), so the read side is doubled.  None if no profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01", "k_null_pmc.json")
-    try:
-        with open(path) as fh:
-            d = json.load(fh)
-        return (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
-    except Exception:
-        return None
+    for rnd in (PROFILE_ROUND, "r01"):
+        for name in (f"k_null_{config}_pmc.json", "k_null_pmc.json" if config == "c3" else None):
+            if not name:
+                continue
+            try:
+                with open(os.path.join(ROOT, "profiles", rnd, name)) as fh:
+                    d = json.load(fh)
+                return (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0, f"profiles/{rnd}/{name}"
+            except Exception:
+                continue
+    return None, None
 
 
 def cpu_baseline(blocks, sampleN, seed, target_s=12.0):
@@ -86,37 +110,80 @@ def cpu_baseline(blocks, sampleN, seed, target_s=12.0):
         return time.perf_counter() - t0
 
     kind, run = ("reference", run_reference) if os.path.exists(harness) else ("port", run_port)
-    probe = run(blocks[:2]) / 2.0                                    # seconds per block on this host
-    nblk = max(2, min(len(blocks), int(target_s / max(probe, 1e-3))))
+    probe_n = min(sampleN, 1000)
+    t0 = time.perf_counter()
+    if kind == "reference":   # probe at a bounded sample count (C5: n = 10 000 would take a minute per block)
+        with tempfile.NamedTemporaryFile("w", suffix=".blk", delete=False) as fh:
+            path = fh.name
+        try:
+            write_harness_blocks(blocks[:2], path)
+            subprocess.check_output([harness, path, "--samples", str(probe_n), "--seed", str(seed), "--no-backtrack"])
+        finally:
+            os.unlink(path)
+        probe = (time.perf_counter() - t0) / 2.0 * (sampleN / probe_n)
+    else:
+        probe = run(blocks[:2]) / 2.0
+    nblk = max(1, min(len(blocks), int(target_s / max(probe, 1e-3))))
     sub = blocks[:nblk]
     dt = run(sub)
     units = sum(b.cols for b in sub) * sampleN
     return dict(value=units / dt, unit="alignment-columns*samples/s", cores=1, kind=kind,
-                sample=f"first {nblk} blocks of the workload at n={sampleN} (tree+kappa given), {dt:.1f} s")
+                sample=f"first {nblk} blocks of the workload at n={sampleN}, {dt:.1f} s; tree and kappa given to the harness, "
+                       f"so PhyML's share (1-2 % of the reference's run time, SURVEY.md section 6) is not in it")
 
 
-def main():
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--blocks", type=int, default=10000)
-    ap.add_argument("--cols", type=int, default=120)
-    ap.add_argument("--seqs", type=int, default=6)
-    ap.add_argument("--samples", type=int, default=1000)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
+    ap.add_argument("--blocks", type=int)
+    ap.add_argument("--cols", type=int)
+    ap.add_argument("--seqs", type=int)
+    ap.add_argument("--samples", type=int)
     ap.add_argument("--seed-base", type=int, default=42)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stream", action="store_true", help="skip the host-inclusive stream measurement")
+    ap.add_argument("--sub-batches", type=int, default=8, help="stream mode: sub-batches per rank and pass")
+    ap.add_argument("--depth", type=int, default=3, help="stream mode: batches in flight")
+    ap.add_argument("--host-threads", type=int, default=0, help="block preparation threads per rank (0: this rank's share of the usable CPUs)")
     ap.add_argument("--exchange", choices=("maxima", "fits"), default="maxima",
                     help="what the ranks all-gather per step: the per-sample maxima (north_star's exchange; 4 B x samples per "
                          "block, written by the kernel straight into the gathered tensor) or only the per-block fit results "
                          "(16 B per block: enough for p-values, since every rank fits its own blocks on the device)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="weak: --blocks per GPU (default); strong: --blocks in total, split across ranks (configs[3])")
-    args = ap.parse_args()
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
+                    help="strong (default): --blocks in total, split across the ranks (BASELINE configs[3]); weak: --blocks per GPU")
+    ap.add_argument("--dump-gathered", help="rank 0 writes the gathered per-sample maxima of the last resident step here (.npy; tests)")
+    a = ap.parse_args()
+    blocks, cols, seqs, samples, _ = CONFIGS[a.config]
+    a.blocks = a.blocks or blocks
+    a.cols = a.cols or cols
+    a.seqs = a.seqs or seqs
+    a.samples = a.samples or samples
+    return a
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # start the ranks as a fresh child before this process touches a GPU (never re-exec a process that has)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or without torchrun)")
     dist = None
     torch = None
     coll_dev = f"cuda:{local_rank}"
@@ -140,6 +207,8 @@ def main():
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    import numpy as np
+
     from rnacode_amd import api
     from rnacode_amd import distributed as rd
     from rnacode_amd.synth import synth_blocks
@@ -155,10 +224,15 @@ def main():
     t_gen = time.perf_counter() - t0
 
     ctx = api.Context(local_rank)
+    cpus = api.lib().rc_host_cpus()
+    threads = args.host_threads or max(1, min(32, cpus // max(1, local_world)))
+    ctx.set_host_threads(threads)
     api.lib().rc_set_stream_cache(0)   # the MT19937 streams are part of every step
     params = api.default_params(sampleN=args.samples, seed_base=args.seed_base)
+    marshalled = api.Marshalled(blocks)   # the rc_block arrays a C caller would hold: the stream measurement starts from these
+    marshalled.set_trees()
     t0 = time.perf_counter()
-    batch = api.Batch(ctx, blocks, params)   # host prep (getModels etc.) + upload: inputs now resident in HBM
+    batch = api.Batch(ctx, marshalled, params)   # host prep + upload + table kernels: inputs now resident in HBM
     t_prep = time.perf_counter() - t0
 
     gathered = None
@@ -167,15 +241,35 @@ def main():
         mine = torch.empty((len(blocks), args.samples), dtype=torch.float32, device=f"cuda:{local_rank}")
         batch.bind_maxima(mine.data_ptr())
 
-    def step():
+    def exchange(fit_rows):
+        """The path's one exchange (RCCL over xGMI): results of all blocks on every rank.  Synchronised before it
+        returns: the next step overwrites the gathered buffer's source on the library's own streams."""
+        nonlocal gathered
+        if args.exchange == "maxima":
+            gathered = rd.all_gather_maxima(mine if coll_dev != "cpu" else mine.cpu(), counts)
+        else:
+            fits = torch.from_numpy(fit_rows).to(coll_dev, non_blocking=True)
+            gathered = rd.all_gather_fits(fits, counts)
+        if coll_dev != "cpu":
+            torch.cuda.current_stream().synchronize()
+
+    def resident_step():
         batch.run()                      # synchronous: kernels done, small results on the host
-        if multi:                        # the path's one exchange (RCCL over xGMI): results of all blocks on every rank
-            nonlocal gathered
-            if args.exchange == "maxima":
-                gathered = rd.all_gather_maxima(mine if coll_dev != "cpu" else mine.cpu(), counts)
-            else:
-                fits = torch.from_numpy(batch.fits()).to(coll_dev, non_blocking=True)
-                gathered = rd.all_gather_fits(fits, counts)
+        if multi:
+            exchange(batch.fits() if args.exchange == "fits" else None)
+
+    sub_blocks = max(1, -(-len(blocks) // max(1, args.sub_batches)))
+    stream = None if args.no_stream else api.Stream(ctx, params, args.depth)
+
+    def stream_step():
+        rows = []
+        ptr = mine.data_ptr() if (multi and args.exchange == "maxima") else 0
+        for sb in api.score_stream(ctx, marshalled, params, sub_blocks, stream=stream, maxima_ptr=ptr):
+            rows.append(sb.fits())       # (evd_rc, mu, lambda, better) per block: what a caller needs for p-values
+            sb.close()                   # buffers back to the stream
+        if multi:
+            exchange(np.concatenate(rows) if args.exchange == "fits" else None)
+        return rows
 
     def sync():
         if multi:
@@ -183,22 +277,33 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    tk = {"total": 0.0, "mt_stream": 0.0, "null": 0.0, "native": 0.0, "evd_fit": 0.0}
-    nlaunch = {}
-    for _ in range(args.steps):
-        step()
-        t, nl = batch.timing()
-        for k in tk:
-            tk[k] += t[k]
-        nlaunch = nl
-    sync()
-    elapsed = time.perf_counter() - t0
-    if multi:
-        elapsed = rd.max_over_ranks(elapsed, device=coll_dev)
+    def timed(step, collect_timing):
+        for _ in range(args.warmup):
+            step()
+        sync()
+        t0 = time.perf_counter()
+        tk = {"total": 0.0, "mt_stream": 0.0, "null": 0.0, "native": 0.0, "evd_fit": 0.0}
+        nlaunch = {}
+        for _ in range(args.steps):
+            step()
+            if collect_timing:
+                t, nl = batch.timing()
+                for k in tk:
+                    tk[k] += t[k]
+                nlaunch = nl
+        sync()
+        elapsed = time.perf_counter() - t0
+        if multi:
+            elapsed = rd.max_over_ranks(elapsed, device=coll_dev)
+        return elapsed, tk, nlaunch
+
+    elapsed, tk, nlaunch = timed(resident_step, True)
+    if args.dump_gathered and rank == 0:
+        np.save(args.dump_gathered, gathered.cpu().numpy() if multi else batch.maxScores_all())
+    prep_host_ms, prep_kernels_ms, up_bytes = batch.prep_timing()
+    s_elapsed = None
+    if stream is not None:
+        s_elapsed, _, _ = timed(stream_step, False)
 
     sa, cs = batch.work()
     if multi:   # units of all ranks (shards may differ by one block under strong scaling)
@@ -207,11 +312,14 @@ def main():
         cs, sa = int(tot[0].item()), int(tot[1].item())
     total_units = cs * args.steps
     value = total_units / elapsed
-    out = None
     if rank == 0:
         by, fl = algorithmic_work(blocks, args.samples)
         null_ms = tk["null"] / args.steps / max(1, nlaunch.get("null", 1))   # average duration of one k_null launch
         ach = by / (null_ms * 1e-3) / 1e9
+        traffic, traffic_src = (None, None)
+        if (args.blocks, args.cols, args.seqs, args.samples) == CONFIGS[args.config][:4] and world == 1:
+            traffic, traffic_src = measured_traffic(args.config)
+        desc = CONFIGS[args.config][4]
         out = {
             "metric": "alignment-columns x samples scored /sec",
             "value": value,
@@ -227,27 +335,40 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"synthetic MAF {args.blocks} blocks x {args.cols} cols x {args.seqs} seqs, "
                                    f"--num-samples {args.samples}, " + ("per GPU" if args.scaling == "weak" else "in total, split across the GPUs")
-                                   + " (BASELINE.json configs[2]/[3])",
+                                   + f" ({desc})",
                        "blocks_per_gpu": len(blocks), "cols": args.cols, "seqs": args.seqs, "samples": args.samples,
                        "seed_base": args.seed_base, "sharding": f"blocks x{world}",
                        "exchange": ("all-gather of " + args.exchange) if multi else "none"},
+            "value_definition": "resident: inputs in HBM when the timed region starts (bench contract); the host-inclusive pipeline is stream.value",
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": measured_traffic() if (args.blocks, args.cols, args.seqs, args.samples) == (10000, 120, 6, 1000) else None, "kernel": "k_null<%d>" % (args.seqs - 1), "kernel_ms": null_ms,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_null<%d>" % (args.seqs - 1), "kernel_ms": null_ms,
                          "algorithmic_bytes_per_launch": by,
                          "valu": {"achieved_gops": fl / (null_ms * 1e-3) / 1e9, "peak_gops": VALU_PEAK_GOPS,
                                   "frac": fl / (null_ms * 1e-3) / 1e9 / VALU_PEAK_GOPS,
                                   "algorithmic_flops_per_launch": fl}},
             "device_ms_per_step": {k: v / args.steps for k, v in tk.items()},
             "device_ms_note": "HIP-event intervals; the native-block kernels run on a second stream beside k_null, so "
-                              "'native' is the interval until they are done (they fill k_null's tail), not their busy time "
-                              "(1.8 ms when run alone, profiles/r01)",
-            "host_prep_s": {"generate": t_gen, "models_and_upload": t_prep},
+                              "'native' is the interval until they are done (they fill k_null's tail), not their busy time",
+            "host_prep_s": {"generate": t_gen, "prepare_upload_tables": t_prep, "prepare_host_part": prep_host_ms * 1e-3,
+                            "table_kernels": prep_kernels_ms * 1e-3, "uploaded_bytes": up_bytes, "host_threads": threads,
+                            "usable_cpus": cpus},
             "sample_alignments_per_s": sa * args.steps / elapsed,
         }
+        if s_elapsed is not None:
+            out["stream"] = {
+                "value": total_units / s_elapsed, "unit": "alignment-columns*samples/s", "ms_per_step": s_elapsed / args.steps * 1e3,
+                "frac_of_resident": elapsed / s_elapsed, "sub_batches": -(-len(blocks) // sub_blocks), "blocks_per_sub_batch": sub_blocks,
+                "depth": args.depth, "host_threads": threads, "usable_cpus": cpus,
+                "includes": "block preparation on host threads (getModels inputs, gap tables, tree thresholds), one pinned H2D copy per "
+                            "sub-batch, expected-score tables on the device, MT19937 streams, native scoring, null sampling, EVD fit, "
+                            "fit results back on the host" + (", all-gather" if multi else ""),
+                "excludes": "file parsing and tree fitting (sidecar trees, as for the cpu_baseline)"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(blocks, args.samples, args.seed_base)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
+    if stream is not None:
+        stream.close()
     batch.close()
     ctx.close()
     if multi:

@@ -83,29 +83,71 @@ const char *rc_last_error(void);
 int rc_device_count(void);
 
 /* One context per process and GPU (one process per GPU; multi-GPU sharding is done by the
- * caller).  A context owns one HIP stream and the scratch buffers its kernels
- * share: calls on one context -- directly or through one of its batches -- must not run
- * concurrently; different contexts are independent.  rc_last_error() is per thread. */
+ * caller).  A context owns its HIP streams, the MT19937 stream cache and the host
+ * threads that prepare blocks: calls on one context -- directly or through one of its batches or
+ * streams -- must come from one thread at a time; different contexts are independent.
+ * rc_last_error() is per thread. */
 int rc_ctx_create(int device, rc_ctx **out);
-void rc_ctx_destroy(rc_ctx *ctx);
+void rc_ctx_destroy(rc_ctx *ctx);   /* destroy the context's batches and streams first */
 
-/* getModels x2 (RNAcode.c:164-165) + everything block-constant the kernels need, built on
- * the host and uploaded.  Blocks that the reference driver would skip (N <= 2, L < 3,
- * RNAcode.c:142-150) are kept in the batch with status RC_ERR_SKIP and produce no work. */
+/* Host threads used to prepare blocks (default: the CPUs this process may use -- affinity mask and
+ * cgroup quota, rc_host_cpus() -- capped at 32; RC_HOST_THREADS overrides).  With several ranks per
+ * node give each rank its share. */
+int rc_host_cpus(void);
+int rc_ctx_set_host_threads(rc_ctx *ctx, int32_t threads);
+int rc_ctx_host_threads(const rc_ctx *ctx);
+
+/* getModels x2 (RNAcode.c:164-165) + everything block-constant the kernels need.  The host (threads)
+ * parses the tree, takes base frequencies, tip distances, the HKY85 matrices, the gap pattern and the
+ * integer thresholds of the branch matrices, and writes them straight into one pinned blob; ONE
+ * asynchronous copy moves it; calculateBG's accumulations (score.c:107-193) and the sigma tables are
+ * then made on the device.  Returns when the copy has been queued.
+ * Per-block outcome is in rc_batch_status: RC_OK; RC_ERR_SKIP for blocks the reference driver skips
+ * (N <= 2, L < 3, RNAcode.c:142-150); RC_ERR_ARG / RC_ERR_UNSUPPORTED for blocks that cannot be scored
+ * (no or malformed tree, names that do not match, too many rows) -- those are left out like the
+ * reference's "Skipping alignment" (RNAcode.c:153-156), rc_batch_block_error() has the reason, and
+ * the other blocks of the batch are scored normally. */
 int rc_batch_create(rc_ctx *ctx, const rc_block *blocks, int32_t n_blocks, const rc_params *par, rc_batch **out);
 void rc_batch_destroy(rc_batch *b);
+const char *rc_batch_block_error(const rc_batch *b, int32_t blk);   /* "" if the block was accepted */
+int rc_batch_size(const rc_batch *b);
 
 /* Optional: make the kernels write the per-sample maxima ([n_blocks][sampleN] floats) straight
  * into a caller-owned DEVICE buffer (e.g. a torch tensor handed to an RCCL all-gather).  Must be
- * called before rc_batch_run; the buffer must outlive the batch. */
+ * called before rc_batch_run; the buffer must outlive the batch.  The library writes it on its own
+ * (non-blocking) HIP streams: whoever reads it on another stream -- a collective -- must have finished
+ * before the next rc_batch_run of this batch, which starts by overwriting it. */
 int rc_batch_bind_maxima(rc_batch *b, void *device_ptr);
 
 /* The hot path for the whole batch, all on the device:
  *   scoreAln(native, backtrack=1)      score.c:1067-1147  -> HSS lists
  *   getExtremeValuePars                score.c:976-1064   -> per-sample maxima, mu, lambda
  *   p-values                           RNAcode.c:180-188
- * Synchronous: returns when results are in HBM. */
+ * rc_batch_run is synchronous: it returns when the results are on the host.  rc_batch_run_async queues
+ * every launch and the copies of the small results and returns; rc_batch_wait blocks until they have
+ * arrived.  Several batches of one context may be between run_async and wait at the same time
+ * (consecutive ones go to alternating HIP streams, so the tail of one overlaps the head of the next). */
 int rc_batch_run(rc_batch *b);
+int rc_batch_run_async(rc_batch *b);
+int rc_batch_wait(rc_batch *b);
+
+/* A stream of batches (the reference's unit of work is a stream of blocks, RNAcode.c:115-221): up to
+ * `depth` batches in flight.  rc_stream_submit prepares the blocks on the host threads, queues the copy
+ * and every launch, and returns -- while the GPU scores that batch the caller submits the next one.
+ * rc_stream_next waits for the OLDEST submitted batch and hands it over; read its results with the
+ * rc_batch_* accessors, then give it back with rc_stream_recycle (its pinned and device buffers are
+ * reused by a later submit: the steady state allocates nothing) or keep it and rc_batch_destroy it.
+ * The rc_block arrays only need to live during rc_stream_submit.  Submitting to a full stream is an error. */
+typedef struct rc_stream rc_stream;
+int rc_stream_create(rc_ctx *ctx, const rc_params *par, int32_t depth, rc_stream **out);
+int rc_stream_submit(rc_stream *s, const rc_block *blocks, int32_t n_blocks);
+/* the same, with this batch's per-sample maxima ([n_blocks][sampleN] floats) written into a caller-owned device
+ * buffer (see rc_batch_bind_maxima): e.g. consecutive slices of the tensor a rank hands to the RCCL all-gather */
+int rc_stream_submit_bound(rc_stream *s, const rc_block *blocks, int32_t n_blocks, void *maxima_device_ptr);
+int rc_stream_next(rc_stream *s, rc_batch **out);
+void rc_stream_recycle(rc_stream *s, rc_batch *b);
+int rc_stream_pending(const rc_stream *s);
+void rc_stream_destroy(rc_stream *s);   /* also destroys the batches it still holds */
 
 /* By default the MT19937 output streams (one per sample index, shared by all blocks because
  * seed = seed_base + s) are cached in the context between runs with the same seed_base and
@@ -119,8 +161,11 @@ int rc_batch_work(const rc_batch *b, int64_t *sample_alignments, int64_t *column
  * t[0] total, t[1] MT19937 stream kernel, t[2] null-sampling kernels (simulate+score),
  * t[3] native scoring kernels, t[4] EVD fit kernel.  n_launch[i] = launches behind t[i]. */
 int rc_batch_timing(const rc_batch *b, float t[5], int32_t n_launch[5]);
+/* Preparation of the batch: wall time of the host part (ms), duration of the device kernels that make the
+ * expected-score tables (ms, known after a run), bytes copied to the device. */
+int rc_batch_prep_timing(const rc_batch *b, double *host_ms, float *table_kernels_ms, int64_t *uploaded_bytes);
 
-/* Per-block results (host copies).  status: RC_OK or RC_ERR_SKIP. */
+/* Per-block results (host copies).  status: see rc_batch_create. */
 int rc_batch_status(const rc_batch *b, int32_t blk);
 int rc_batch_models(const rc_batch *b, int32_t blk, rc_model *fwd, rc_model *rev); /* n_rows entries each */
 /* maxScores[] of score.c:1044: sampleN floats (-1 = sample without HSS) */
@@ -183,6 +228,9 @@ int rc_tree_lnl(const rc_block *blk, double *lnl_out);
 
 /* EVDMaxLikelyFit (src/extreme_fit.c:157-251) on the device for n doubles; returns 1 / 0. */
 int rc_evd_fit(rc_ctx *ctx, const double *x, int32_t n, double *mu, double *lambda);
+/* p = 1 - exp(-exp(-lambda (score - mu))) with RNAcode.c:182's float/double promotions (host arithmetic): for callers
+ * that fit gathered maxima themselves (sample-range sharding) */
+float rc_pvalue(float score, float mu, float lambda);
 
 /* First n MT19937 outputs for a seed, generated by the device stream kernel (parity hook
  * for seqgen/twister.c:73-152). */

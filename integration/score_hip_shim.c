@@ -132,9 +132,18 @@ static int is_revcomp_of(const char *s, const char *fwd) {
   return strcmp(s, fwd) != 0;   /* a row equal to its own reverse complement starts a new block */
 }
 
-int **getScoringMatrix(void) {   /* score.c:50-76; only the 24x24 shape matters to callers */
-  int i, **m = (int **)malloc(sizeof(int *) * 24);
-  for (i = 0; i < 24; i++) m[i] = (int *)calloc(24, sizeof(int));
+/* score.c:50-76: a malloc'ed 24x24 copy of BLOSUM62/90 in the amino-acid order of transcode (code.c:28-39).
+ * src/postscript.c:437,527 index it with scoringMatrix[pepA][pepB], pepA/pepB = transcode values (0..19, stops
+ * excluded before the look-up), to pick the colour of a codon pair.  Rows and columns 20..23 (B, Z, X, *) cannot
+ * be reached through transcode; they are zero here. */
+int **getScoringMatrix(void) {
+  int i, j, **m = (int **)malloc(sizeof(int *) * 24);
+  int32_t pep[64], mat[400];
+  if (rc_code_tables(pars.blosum == 90 ? 90 : 62, pep, mat) != RC_OK) die("rc_code_tables");
+  for (i = 0; i < 24; i++) {
+    m[i] = (int *)calloc(24, sizeof(int));
+    if (i < 20) for (j = 0; j < 20; j++) m[i][j] = mat[20 * i + j];
+  }
   return m;
 }
 void freeScoringMatrix(int **m) { int i; for (i = 0; i < 24; i++) free(m[i]); free(m); }

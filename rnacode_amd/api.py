@@ -97,6 +97,23 @@ def lib():
         l.rc_batch_create.argtypes = [C.c_void_p, C.POINTER(RcBlock), C.c_int32, C.POINTER(RcParams), C.POINTER(C.c_void_p)]
         l.rc_batch_destroy.argtypes = [C.c_void_p]
         l.rc_batch_run.argtypes = [C.c_void_p]
+        l.rc_batch_run_async.argtypes = [C.c_void_p]
+        l.rc_batch_wait.argtypes = [C.c_void_p]
+        l.rc_batch_size.argtypes = [C.c_void_p]
+        l.rc_batch_block_error.argtypes = [C.c_void_p, C.c_int32]
+        l.rc_batch_block_error.restype = C.c_char_p
+        l.rc_batch_prep_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int64)]
+        l.rc_ctx_set_host_threads.argtypes = [C.c_void_p, C.c_int32]
+        l.rc_ctx_host_threads.argtypes = [C.c_void_p]
+        l.rc_stream_create.argtypes = [C.c_void_p, C.POINTER(RcParams), C.c_int32, C.POINTER(C.c_void_p)]
+        l.rc_stream_submit.argtypes = [C.c_void_p, C.POINTER(RcBlock), C.c_int32]
+        l.rc_stream_submit_bound.argtypes = [C.c_void_p, C.POINTER(RcBlock), C.c_int32, C.c_void_p]
+        l.rc_stream_next.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        l.rc_stream_recycle.argtypes = [C.c_void_p, C.c_void_p]
+        l.rc_stream_recycle.restype = None
+        l.rc_stream_pending.argtypes = [C.c_void_p]
+        l.rc_stream_destroy.argtypes = [C.c_void_p]
+        l.rc_stream_destroy.restype = None
         l.rc_batch_bind_maxima.argtypes = [C.c_void_p, C.c_void_p]
         l.rc_batch_work.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         l.rc_batch_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
@@ -114,6 +131,8 @@ def lib():
                                          C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         l.rc_evd_fit.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         l.rc_mt_stream.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_int32]
+        l.rc_pvalue.argtypes = [C.c_float, C.c_float, C.c_float]
+        l.rc_pvalue.restype = C.c_float
         l.rc_fit_tree.argtypes = [C.POINTER(RcBlock), C.c_char_p, C.c_int32, C.POINTER(C.c_float)]
         l.rc_fit_trees.argtypes = [C.POINTER(RcBlock), C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_float), C.c_int32]
         l.rc_tree_lnl.argtypes = [C.POINTER(RcBlock), C.POINTER(C.c_double)]
@@ -128,9 +147,11 @@ def lib():
 
 EXPORTED_SYMBOLS = [
     "rc_default_params", "rc_last_error", "rc_device_count", "rc_ctx_create", "rc_ctx_destroy", "rc_batch_create",
-    "rc_batch_destroy", "rc_batch_bind_maxima", "rc_batch_run", "rc_set_stream_cache", "rc_batch_work", "rc_batch_timing", "rc_batch_status",
+    "rc_batch_destroy", "rc_batch_bind_maxima", "rc_batch_run", "rc_batch_run_async", "rc_batch_wait", "rc_batch_size", "rc_batch_block_error",
+    "rc_batch_prep_timing", "rc_host_cpus", "rc_ctx_set_host_threads", "rc_ctx_host_threads", "rc_stream_create", "rc_stream_submit", "rc_stream_submit_bound",
+    "rc_stream_next", "rc_stream_recycle", "rc_stream_pending", "rc_stream_destroy", "rc_set_stream_cache", "rc_batch_work", "rc_batch_timing", "rc_batch_status",
     "rc_batch_models", "rc_batch_maxima", "rc_batch_maxima_all", "rc_batch_fit", "rc_batch_fit_all", "rc_batch_hss", "rc_batch_hss_all", "rc_batch_clamped",
-    "rc_batch_native_S", "rc_batch_backtrack", "rc_fit_tree", "rc_fit_trees", "rc_fit_trees_device", "rc_tree_lnl", "rc_evd_fit", "rc_mt_stream", "rc_code_tables",
+    "rc_batch_native_S", "rc_batch_backtrack", "rc_fit_tree", "rc_fit_trees", "rc_fit_trees_device", "rc_tree_lnl", "rc_evd_fit", "rc_pvalue", "rc_mt_stream", "rc_code_tables",
 ]
 
 
@@ -148,6 +169,11 @@ def default_params(**kw) -> RcParams:
             raise KeyError(k)
         setattr(p, k, v)
     return p
+
+
+def pvalue(score: float, mu: float, lam: float) -> float:
+    """RNAcode.c:182 with its float/double promotions (rc_pvalue)."""
+    return float(lib().rc_pvalue(score, mu, lam))
 
 
 def code_tables(blosum: int = 62) -> Tuple[np.ndarray, np.ndarray]:
@@ -185,12 +211,19 @@ class Marshalled:
             self.keep.append((rows, names))
             self.arr[i] = RcBlock(b.n, b.cols, rows, names, b.rows[0].start, b.rows[0].length, None, 0.0)
 
-    def set_trees(self):
-        """Copy tree and kappa of the AlnBlocks into the array (after they were fitted or read from a sidecar)."""
+    def set_trees(self, strict: bool = True):
+        """Copy tree and kappa of the AlnBlocks into the array (after they were fitted or read from a sidecar).
+        A block without a tree stays without one: the library leaves it out (RC_ERR_ARG, "no tree") like the
+        reference's driver skips a block whose tree fit failed (RNAcode.c:153-156)."""
         self.trees = []
         for i, b in enumerate(self.blocks):
             if b.tree is None or b.kappa is None:
-                raise ValueError(f"block {b.block_id}: tree and kappa are required (sidecar or fitted upstream)")
+                if strict:
+                    raise ValueError(f"block {b.block_id}: tree and kappa are required (sidecar or fitted upstream)")
+                self.trees.append(None)
+                self.arr[i].newick = None
+                self.arr[i].kappa = 0.0
+                continue
             t = b.tree.encode()
             self.trees.append(t)
             self.arr[i].newick = t
@@ -251,6 +284,15 @@ class Context:
         except Exception:
             pass
 
+    def set_host_threads(self, threads: int):
+        """Host threads that prepare blocks (rc_ctx_set_host_threads)."""
+        _check(lib().rc_ctx_set_host_threads(self._h, threads))
+        return self
+
+    @property
+    def host_threads(self) -> int:
+        return lib().rc_ctx_host_threads(self._h)
+
     def evd_fit(self, x) -> Tuple[int, float, float]:
         """EVDMaxLikelyFit (extreme_fit.c:157-251) on the device."""
         arr = np.ascontiguousarray(x, dtype=np.float64)
@@ -282,8 +324,9 @@ class Batch:
         """blocks: a sequence of AlnBlocks with tree and kappa set, or a Marshalled of such blocks."""
         self.ctx = ctx
         self.params = params
+        self._stream = None
         m = blocks if isinstance(blocks, Marshalled) else Marshalled(blocks)
-        m.set_trees()
+        m.set_trees(strict=False)
         self._keep = m
         self.blocks = m.blocks
         n = len(self.blocks)
@@ -291,9 +334,21 @@ class Batch:
         _check(lib().rc_batch_create(ctx._h, m.arr, n, C.byref(params), C.byref(self._h)))
         self.n = n
 
+    @classmethod
+    def _from_stream(cls, stream: "Stream", handle, blocks):
+        b = cls.__new__(cls)
+        b.ctx, b.params, b._stream, b._keep = stream.ctx, stream.params, stream, None
+        b.blocks = blocks
+        b._h = handle
+        b.n = lib().rc_batch_size(handle)
+        return b
+
     def close(self):
         if self._h:
-            lib().rc_batch_destroy(self._h)
+            if self._stream is not None and self._stream._h:
+                lib().rc_stream_recycle(self._stream._h, self._h)   # buffers go back to the stream
+            else:
+                lib().rc_batch_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -310,6 +365,24 @@ class Batch:
     def run(self):
         _check(lib().rc_batch_run(self._h))
         return self
+
+    def run_async(self):
+        _check(lib().rc_batch_run_async(self._h))
+        return self
+
+    def wait(self):
+        _check(lib().rc_batch_wait(self._h))
+        return self
+
+    def block_error(self, blk: int) -> str:
+        """Why a block was left out (status RC_ERR_ARG / RC_ERR_UNSUPPORTED), '' otherwise."""
+        return lib().rc_batch_block_error(self._h, blk).decode()
+
+    def prep_timing(self):
+        """(host preparation ms, device table kernels ms, bytes copied to the device)."""
+        h, k, by = C.c_double(), C.c_float(), C.c_int64()
+        _check(lib().rc_batch_prep_timing(self._h, C.byref(h), C.byref(k), C.byref(by)))
+        return h.value, float(k.value), by.value
 
     def work(self) -> Tuple[int, int]:
         a, c = C.c_int64(), C.c_int64()
@@ -403,13 +476,76 @@ class Batch:
         return BlockScores(st, self.scoreAln(blk), rc, mu, lam, self.maxScores(blk) if with_maxima else None)
 
 
+class Stream:
+    """A stream of batches (rc_stream): submit() prepares a slice of blocks on the host threads and queues its
+    copy and launches; next() hands over the oldest finished batch.  While the GPU scores one batch the caller
+    submits the next, so host preparation, PCIe and kernels overlap (the reference's per-block loop,
+    RNAcode.c:115-221, as a pipeline)."""
+
+    def __init__(self, ctx: Context, params: RcParams, depth: int = 3):
+        self.ctx, self.params, self.depth = ctx, params, depth
+        self._h = C.c_void_p()
+        self._blocks = []   # block lists of the batches in flight, oldest first
+        _check(lib().rc_stream_create(ctx._h, C.byref(params), depth, C.byref(self._h)))
+
+    def submit(self, m: Marshalled, lo: int = 0, hi: Optional[int] = None, maxima_ptr: int = 0):
+        """Submit blocks [lo, hi) of a Marshalled whose trees are set (set_trees).  maxima_ptr: device address that
+        receives this batch's [hi - lo][sampleN] per-sample maxima (rc_stream_submit_bound)."""
+        hi = len(m.blocks) if hi is None else hi
+        arr = C.cast(C.byref(m.arr, lo * C.sizeof(RcBlock)), C.POINTER(RcBlock))
+        _check(lib().rc_stream_submit_bound(self._h, arr, hi - lo, C.c_void_p(maxima_ptr or None)))
+        self._blocks.append(m.blocks[lo:hi])
+
+    @property
+    def pending(self) -> int:
+        return lib().rc_stream_pending(self._h)
+
+    def next(self) -> Batch:
+        h = C.c_void_p()
+        _check(lib().rc_stream_next(self._h, C.byref(h)))
+        return Batch._from_stream(self, h, self._blocks.pop(0))
+
+    def close(self):
+        if self._h:
+            lib().rc_stream_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def score_stream(ctx: Context, m: Marshalled, params: RcParams, sub_blocks: int, depth: int = 3, stream: Optional[Stream] = None,
+                 maxima_ptr: int = 0):
+    """Score the blocks of `m` as a pipeline of sub-batches of `sub_blocks` blocks.  Yields finished Batches in
+    submission order; the consumer closes (recycles) each one.  maxima_ptr: device address of a
+    [len(m.blocks)][sampleN] float32 buffer that receives every block's per-sample maxima."""
+    own = stream is None
+    s = stream or Stream(ctx, params, depth)
+    try:
+        n = len(m.blocks)
+        lo = 0
+        while lo < n or s.pending:
+            while lo < n and s.pending < s.depth:
+                hi = min(n, lo + sub_blocks)
+                s.submit(m, lo, hi, maxima_ptr + 4 * lo * params.sampleN if maxima_ptr else 0)
+                lo = hi
+            yield s.next()
+    finally:
+        if own:
+            s.close()
+
+
 def score_blocks(blocks: Sequence[AlnBlock], device: int = 0, **params) -> List[BlockScores]:
     """Convenience: one context, one batch, everything RNAcode.c:164-188 computes per block."""
     ctx = Context(device)
+    batch = None
     try:
         batch = Batch(ctx, blocks, default_params(**params)).run()
-        out = [batch.results(i, with_maxima=True) for i in range(batch.n)]
-        batch.close()
-        return out
+        return [batch.results(i, with_maxima=True) for i in range(batch.n)]
     finally:
+        if batch is not None:
+            batch.close()   # before the context: a batch must not outlive it
         ctx.close()

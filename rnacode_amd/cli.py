@@ -96,7 +96,9 @@ def main(argv=None) -> int:
         side = fit_trees(marshalled, ctx=ctx)
     prepared: List[AlnBlock] = []
     for b, s in zip(blocks, side):
-        b.tree, b.kappa = s if s is not None else ("(a:0.1,b:0.1,c:0.1);", 2.0)   # skipped blocks never reach the tree
+        # no tree: either a block the driver skips anyway (N <= 2, too short) or one whose tree could not be built;
+        # the library leaves the latter out with a per-block status, the other blocks are scored (RNAcode.c:153-156)
+        b.tree, b.kappa = s if s is not None else (None, None)
         prepared.append(b)
 
     out = open(a.outfile, "w") if a.outfile else sys.stdout
@@ -110,6 +112,9 @@ def main(argv=None) -> int:
         if code == api.RC_ERR_SKIP:   # RNAcode.c:142-150
             msg = "There must be at least three sequences in the alignment." if b.n <= 2 else "Too short."
             print(f"Skipping alignment. {msg}", file=sys.stderr)
+            continue
+        if code != api.RC_OK:         # RNAcode.c:153-156: the reference has no tree for this block either
+            print(f"Skipping alignment. Failed to build ML tree. ({batch.block_error(i) or 'not scored'})", file=sys.stderr)
             continue
         hook = None
         if a.eps:   # misc.c:461-474: hss-<counter>.eps for every listed HSS with p below the plot cutoff

@@ -1,19 +1,31 @@
-// rc_api.cpp -- the C-ABI of include/rnacode_hip.h: contexts, batches resident in HBM, launches.
+// rc_api.cpp -- the C-ABI of include/rnacode_hip.h: contexts, batches resident in HBM, launches, streams of batches.
 //
 // No CPU implementation of the hot path lives here: scoring, sampling, scan and fit are
-// kernels in rc_kernels.hip; this file prepares block constants (rc_host.cpp), moves bytes,
+// kernels in rc_kernels.hip; this file prepares block constants (rc_host.cpp, host threads), moves bytes,
 // launches, and formats results.  Every compute entry point fails with RC_ERR_DEVICE when no
 // HIP device is usable.
+//
+// A batch goes through: prepare (host threads write the block tables straight into one pinned blob) ->
+// upload (ONE asynchronous copy + the kernels that derive the expected-score tables on the device) ->
+// run (all launches asynchronous, results staged into pinned memory) -> wait.  rc_batch_create/rc_batch_run
+// are the synchronous forms; rc_stream_* keeps several batches in flight so that the host prepares batch
+// i+1 while the GPU scores batch i (RNAcode.c:115-221 is a stream of blocks).
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -32,82 +44,230 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
     hipError_t e_ = (expr);                                                                   \
     if (e_ != hipSuccess) return fail(RC_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
+#define RC_TRY(expr) do { int r_ = (expr); if (r_ != RC_OK) return r_; } while (0)
 
-// hipEvent that is destroyed on every exit path
+namespace {
+
+// hipEvent created on first use, destroyed with its owner
 struct Event {
   hipEvent_t e = nullptr;
   ~Event() { if (e) (void)hipEventDestroy(e); }
-  hipError_t create() { return hipEventCreate(&e); }
+  hipError_t record(hipStream_t st) {
+    if (!e) { hipError_t r = hipEventCreate(&e); if (r != hipSuccess) return r; }
+    return hipEventRecord(e, st);
+  }
   operator hipEvent_t() const { return e; }
 };
 
+// device / pinned buffers that only grow (batches of a stream are recycled: steady state allocates nothing)
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  ~DevBuf() { release(); }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap && p) return hipSuccess;
+    release();
+    const size_t want = std::max<size_t>(bytes + bytes / 8, 256);
+    hipError_t r = hipMalloc(&p, want);
+    if (r == hipSuccess) cap = want; else p = nullptr;
+    return r;
+  }
+  template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+struct PinBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  ~PinBuf() { release(); }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap && p) return hipSuccess;
+    release();
+    const size_t want = std::max<size_t>(bytes + bytes / 8, 4096);
+    hipError_t r = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (r == hipSuccess) cap = want; else p = nullptr;
+    return r;
+  }
+  template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
+// CPUs this process may actually use: affinity mask and the cgroup CPU quota (a container sees all cores of the
+// host in hardware_concurrency but is throttled to its quota)
+int effective_cpus() {
+  int n = static_cast<int>(std::thread::hardware_concurrency());
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min(n, CPU_COUNT(&set));
+  if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[64]; long long period = 0;
+    if (std::fscanf(f, "%63s %lld", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0) {
+      const long long quota = std::atoll(q);
+      if (quota > 0) n = std::min<long long>(n, std::max<long long>(1, (quota + period - 1) / period));
+    }
+    std::fclose(f);
+  }
+  return std::max(1, n);
+}
+
+// persistent worker threads for the block preparation: run(n, fn) calls fn(i) for every i in [0, n), the caller
+// takes part, items are handed out one by one (blocks differ in size)
+class Pool {
+  std::vector<std::thread> th_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int)> *job_ = nullptr;
+  std::atomic<int> next_{0};
+  int total_ = 0, busy_ = 0;
+  unsigned long gen_ = 0;
+  bool stop_ = false;
+  void drain() {
+    for (;;) {
+      const int i = next_.fetch_add(1);
+      if (i >= total_) break;
+      (*job_)(i);
+    }
+  }
+  void worker() {
+    unsigned long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+        if (stop_) return;
+        seen = gen_;
+      }
+      drain();
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        if (--busy_ == 0) done_.notify_all();
+      }
+    }
+  }
+
+ public:
+  explicit Pool(int nthreads) { for (int t = 1; t < nthreads; t++) th_.emplace_back([this] { worker(); }); }
+  ~Pool() {
+    { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+    cv_.notify_all();
+    for (auto &t : th_) t.join();
+  }
+  int size() const { return static_cast<int>(th_.size()) + 1; }
+  void run(int n, const std::function<void(int)> &fn) {
+    if (n <= 0) return;
+    if (th_.empty() || n < 4) { for (int i = 0; i < n; i++) fn(i); return; }
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      job_ = &fn; total_ = n; next_.store(0); busy_ = static_cast<int>(th_.size()); gen_++;
+    }
+    cv_.notify_all();
+    drain();
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [&] { return busy_ == 0; });
+    job_ = nullptr;
+  }
+};
+
+size_t al256(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
+
+}  // namespace
+
 struct rc_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
-  hipStream_t stream2 = nullptr;   // native-block kernels: latency-bound, they run beside the null sampling
-  std::vector<hipStream_t> classStreams;   // k_null launches of different row-count classes, when a batch has several
   int numCU = 0;
+  hipStream_t compute[2] = {nullptr, nullptr};   // null sampling + fit; consecutive batches alternate, so the tail of one overlaps the head of the next
+  hipStream_t native = nullptr;    // table preparation and native-block kernels: small and latency-bound, they run beside the null sampling
+  hipStream_t copy = nullptr;      // host -> device blob copies
+  std::vector<hipStream_t> classStreams;   // k_null launches of different row-count classes, when a batch has several
+  unsigned seq = 0;
   CodeTables ct62{62}, ct90{90};
   PairTable pt62, pt90;
-  uint8_t *d_pair62 = nullptr, *d_pair90 = nullptr;
+  DevBuf d_tables;                 // pair tables, genetic code, BLOSUM matrices, code infos (see table_ptrs)
   // MT19937 stream cache
   uint32_t *d_U = nullptr;
   size_t U_cap = 0;
   uint32_t U_seed = 0;
   int U_Spad = 0, U_D = 0;
   bool U_valid = false;
-  // sigma-code staging for the null kernel
-  uint32_t *d_scratch = nullptr;
-  size_t scratch_cap = 0;
-  unsigned long long *d_clamp = nullptr;
-  unsigned int *d_work = nullptr;   // eight item counters (one per XCD queue) per row-count class: k_null pulls work items from them
+  Event U_ready;
   float tieThr = 0.0f;
   std::map<std::pair<int, size_t>, int> occ;   // (N-1, LDS bytes) -> resident workgroups per CU of k_null
   size_t ldsMaxBytes = 13312;   // per wavefront: >= 12 wavefronts per CU; measured crossover against reading the codes from L2 (cols 150: 52.0 vs 54.0 ms, cols 180: 41.5 vs 39.3 ms)
   int debugSkip = 0;
+  int serialNative = 0;
+  int hostThreads = 0;
+  std::unique_ptr<Pool> pool;
+  std::atomic<int> inflight{0};   // batches between run_async and wait
 };
+
+// layout of rc_ctx::d_tables
+struct TablePtrs { const uint8_t *pair; const int *pep; const int *blosum; const CodeInfo *info; };
+static TablePtrs table_ptrs(const rc_ctx *c, int blosum) {
+  const uint8_t *base = c->d_tables.as<uint8_t>();
+  const size_t per = 4096 + 400 * sizeof(int) + 64 * sizeof(CodeInfo);
+  const uint8_t *m = base + 64 * sizeof(int) + (blosum == 90 ? per : 0);
+  return TablePtrs{m, reinterpret_cast<const int *>(base), reinterpret_cast<const int *>(m + 4096),
+                   reinterpret_cast<const CodeInfo *>(m + 4096 + 400 * sizeof(int))};
+}
+
+struct rc_stream;
 
 struct rc_batch {
   rc_ctx *ctx = nullptr;
+  int device = 0;
   rc_params par{};
   int n = 0;
-  std::vector<HostBlock> hb;
-  std::vector<DevBlock> db;
+  enum State { EMPTY, READY, RUNNING, DONE } state = EMPTY;
+  std::vector<BlockMeta> meta;
+  std::vector<DevBlock> db;                  // host copies of the block headers (offsets for the accessors)
+  std::map<int, std::string> errs;           // blocks that were rejected: index -> message
   std::vector<int> okBlocks;                 // batch indices with status RC_OK
   std::map<int, std::vector<int>> classes;   // N-1 -> batch indices
+  int classOff[kMaxRows + 1] = {0};          // start of class NK in the class-ordered lists
   int maxL = 0, maxDraws = 0, hssCap = 8;
-  // device
-  uint8_t *d_blob = nullptr;
-  size_t blobBytes = 0;
-  DevBlock *d_dblocks = nullptr;
-  int *d_okBlocks = nullptr;
-  std::map<int, int *> d_classBlocks;
-  float *d_maxima = nullptr;
-  bool maximaExternal = false;
-  float *d_S = nullptr;
-  size_t *d_offS = nullptr;
-  std::vector<size_t> offS;
+  bool allExact = false;                     // gap parameters outside the fast kernels' range: EXACT instantiation for every block
+  // blob
+  PinBuf hblob;
+  size_t hostCap = 0, hostUsed = 0, devCap = 0;
+  size_t oDblocks = 0, oOk = 0, oClass = 0, oOffS = 0, oPrefix = 0;   // tail arrays inside the host part
+  int nModels = 0;
   size_t S_floats = 0;
-  DevHss *d_hss = nullptr;
-  int *d_hssCount = nullptr;
-  uint8_t *h_stage = nullptr;      // pinned: fit rows, HSS counts and offsets, clamp counter of one run
-  size_t stageBytes = 0;
-  DevHss *h_packed = nullptr;      // pinned: the packed HSS records (grown on demand)
-  size_t packedCap = 0;
-  DevHss *d_hssPacked = nullptr;   // the used records, packed for the copy to the host
-  int *d_hssOffsets = nullptr;     // [n * 6] + 1: start of each slot in d_hssPacked; last entry = total
-  FitOut *d_fit = nullptr;
+  std::vector<uint64_t> offS;
+  // device
+  DevBuf dblob, dmaxima, dS, dhss, dhssCount, dhssPacked, dhssOffsets, dfit, dflags, dexact, dcounters, dscratch;
+  float *maxPtr = nullptr;
+  bool maximaExternal = false;
+  PinBuf hstage, hpacked;
+  Event evUp, evPrep0, evPrep, evStart, evMt0, evMt1, evN0, evN1, evS0, evS1, evMid, evFit, evDone;
+  std::vector<std::unique_ptr<Event>> classDone;
+  bool mtLaunched = false;
   // host results
-  bool ran = false;
   std::vector<float> maxima;
   bool maximaFetched = false;
   std::vector<FitOut> fit;
-  std::vector<DevHss> hss;
-  std::vector<int> hssCount;
+  std::vector<int> hssCount, hssOff;         // per (block, strand x frame) slot: records and where they start in hssRec
+  std::vector<DevHss> hssRec;
   unsigned long long clamped = 0;
-  float t[5] = {0, 0, 0, 0, 0};
-  int nl[5] = {0, 0, 0, 0, 0};
+  float t[6] = {0, 0, 0, 0, 0, 0};
+  int nl[6] = {0, 0, 0, 0, 0, 0};
+  double prepHostMs = 0.0;
+  rc_stream *owner = nullptr;
 };
+
+struct rc_stream {
+  rc_ctx *ctx = nullptr;
+  rc_params par{};
+  int depth = 2;
+  std::deque<rc_batch *> inflight;
+  std::vector<rc_batch *> spare;
+};
+
+// layout of rc_batch::dcounters (uint32 units)
+namespace {
+constexpr size_t kCntExact = 0;                                  // [kMaxRows + 1] int: blocks flagged by k_prep_lut, by NK
+constexpr size_t kCntWork = kMaxRows + 2;                        // [2 phases][2 fast/exact][kMaxRows + 1][8]
+constexpr size_t kCntClamp = kCntWork + 4 * (kMaxRows + 1) * 8;  // one u64 (8-byte aligned: see static_assert)
+constexpr size_t kCntTotal = kCntClamp + 2;
+static_assert((kCntClamp % 2) == 0, "clamp counter alignment");
+}  // namespace
 
 extern "C" {
 
@@ -125,6 +285,21 @@ int rc_device_count(void) {
   return n;
 }
 
+int rc_host_cpus(void) { return effective_cpus(); }
+
+void rc_ctx_destroy(rc_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  c->pool.reset();
+  if (c->d_U) (void)hipFree(c->d_U);
+  for (hipStream_t st : c->compute) if (st) (void)hipStreamDestroy(st);
+  if (c->native) (void)hipStreamDestroy(c->native);
+  if (c->copy) (void)hipStreamDestroy(c->copy);
+  for (hipStream_t st : c->classStreams) (void)hipStreamDestroy(st);
+  delete c;
+}
+
 int rc_ctx_create(int device, rc_ctx **out) {
   if (!out) return fail(RC_ERR_ARG, "null out pointer");
   *out = nullptr;
@@ -133,366 +308,362 @@ int rc_ctx_create(int device, rc_ctx **out) {
     return fail(RC_ERR_DEVICE, "no HIP device available: the scoring path has no CPU fallback");
   if (device < 0 || device >= n) return fail(RC_ERR_ARG, "device index out of range");
   HIP_TRY(hipSetDevice(device));
-  rc_ctx *c = new rc_ctx();
+  std::unique_ptr<rc_ctx, void (*)(rc_ctx *)> guard(new rc_ctx(), rc_ctx_destroy);
+  rc_ctx *c = guard.get();
   c->device = device;
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   c->numCU = prop.multiProcessorCount;
   // non-blocking streams: no implicit ordering against the legacy default stream that a host framework in
-  // the same process (torch, RCCL) may be using; the second stream gets the higher priority so that the
+  // the same process (torch, RCCL) may be using; the native stream gets the higher priority so that the
   // runtime puts it on a hardware queue of its own (two plain streams can end up sharing one, which
   // serialises the native-block kernels behind k_null again -- seen under torch.distributed)
   int prioLow = 0, prioHigh = 0;
   HIP_TRY(hipDeviceGetStreamPriorityRange(&prioLow, &prioHigh));
-  HIP_TRY(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prioLow));
-  if (std::getenv("RC_SERIAL_NATIVE")) c->stream2 = c->stream;   // profiling: one kernel at a time, clean per-kernel intervals
-  else HIP_TRY(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prioHigh));
+  HIP_TRY(hipStreamCreateWithPriority(&c->compute[0], hipStreamNonBlocking, prioLow));
+  HIP_TRY(hipStreamCreateWithPriority(&c->compute[1], hipStreamNonBlocking, prioLow));
+  HIP_TRY(hipStreamCreateWithPriority(&c->native, hipStreamNonBlocking, prioHigh));
+  HIP_TRY(hipStreamCreateWithPriority(&c->copy, hipStreamNonBlocking, prioHigh));
+  c->serialNative = std::getenv("RC_SERIAL_NATIVE") ? 1 : 0;   // profiling: one kernel at a time, clean per-kernel intervals
   c->pt62.build(c->ct62);
   c->pt90.build(c->ct90);
-  HIP_TRY(hipMalloc(&c->d_pair62, 4096));
-  HIP_TRY(hipMalloc(&c->d_pair90, 4096));
-  HIP_TRY(hipMemcpy(c->d_pair62, c->pt62.pair, 4096, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(c->d_pair90, c->pt90.pair, 4096, hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc(&c->d_clamp, sizeof(unsigned long long)));
-  HIP_TRY(hipMalloc(&c->d_work, sizeof(unsigned int) * (kMaxRows + 1) * 8));
+  {   // constant tables: genetic code, then per matrix: pair table, BLOSUM, code infos
+    const size_t per = 4096 + 400 * sizeof(int) + 64 * sizeof(CodeInfo);
+    std::vector<uint8_t> h(64 * sizeof(int) + 2 * per);
+    int *pep = reinterpret_cast<int *>(h.data());
+    for (int i = 0; i < 64; i++) pep[i] = c->ct62.pep[i];
+    for (int w = 0; w < 2; w++) {
+      const PairTable &pt = w ? c->pt90 : c->pt62;
+      const CodeTables &ct = w ? c->ct90 : c->ct62;
+      uint8_t *m = h.data() + 64 * sizeof(int) + w * per;
+      std::memcpy(m, pt.pair, 4096);
+      int *bl = reinterpret_cast<int *>(m + 4096);
+      for (int p = 0; p < 20; p++) for (int q = 0; q < 20; q++) bl[20 * p + q] = ct.blosum[p][q];
+      std::memcpy(m + 4096 + 400 * sizeof(int), pt.info, 64 * sizeof(CodeInfo));
+    }
+    HIP_TRY(c->d_tables.ensure(h.size()));
+    HIP_TRY(hipMemcpy(c->d_tables.p, h.data(), h.size(), hipMemcpyHostToDevice));
+  }
   c->tieThr = float_threshold_lt(0.0001);
   if (const char *e = std::getenv("RC_LDS_MAX_BYTES")) c->ldsMaxBytes = static_cast<size_t>(std::atol(e));
-  if (const char *e = std::getenv("RC_DEBUG_SKIP")) c->debugSkip = std::atoi(e);   // profiling only: results are wrong
-  *out = c;
+  if (kProfiling) if (const char *e = std::getenv("RC_DEBUG_SKIP")) c->debugSkip = std::atoi(e);   // RC_PROFILING builds only: results are wrong
+  c->hostThreads = std::min(effective_cpus(), 32);
+  if (const char *e = std::getenv("RC_HOST_THREADS")) c->hostThreads = std::max(1, std::atoi(e));
+  *out = guard.release();
   return RC_OK;
 }
 
-void rc_ctx_destroy(rc_ctx *c) {
-  if (!c) return;
-  hipSetDevice(c->device);
-  if (c->d_pair62) hipFree(c->d_pair62);
-  if (c->d_pair90) hipFree(c->d_pair90);
-  if (c->d_U) hipFree(c->d_U);
-  if (c->d_scratch) hipFree(c->d_scratch);
-  if (c->d_clamp) hipFree(c->d_clamp);
-  if (c->d_work) hipFree(c->d_work);
-  if (c->stream) hipStreamDestroy(c->stream);
-  if (c->stream2 && c->stream2 != c->stream) hipStreamDestroy(c->stream2);
-  for (hipStream_t st : c->classStreams) hipStreamDestroy(st);
-  delete c;
+int rc_ctx_set_host_threads(rc_ctx *c, int32_t threads) {
+  if (!c || threads < 1) return fail(RC_ERR_ARG, "bad argument");
+  if (c->inflight.load() != 0) return fail(RC_ERR_ARG, "batches are in flight");
+  c->hostThreads = threads;
+  c->pool.reset();
+  return RC_OK;
 }
+
+int rc_ctx_host_threads(const rc_ctx *c) { return c ? c->hostThreads : 0; }
 
 void rc_batch_destroy(rc_batch *b) {
   if (!b) return;
-  hipSetDevice(b->ctx->device);
-  if (b->d_blob) hipFree(b->d_blob);
-  if (b->d_dblocks) hipFree(b->d_dblocks);
-  if (b->d_okBlocks) hipFree(b->d_okBlocks);
-  for (auto &kv : b->d_classBlocks) hipFree(kv.second);
-  if (b->d_maxima && !b->maximaExternal) hipFree(b->d_maxima);
-  if (b->d_S) hipFree(b->d_S);
-  if (b->d_offS) hipFree(b->d_offS);
-  if (b->d_hss) hipFree(b->d_hss);
-  if (b->d_hssCount) hipFree(b->d_hssCount);
-  if (b->d_hssPacked) hipFree(b->d_hssPacked);
-  if (b->h_stage) hipHostFree(b->h_stage);
-  if (b->h_packed) hipHostFree(b->h_packed);
-  if (b->d_hssOffsets) hipFree(b->d_hssOffsets);
-  if (b->d_fit) hipFree(b->d_fit);
+  (void)hipSetDevice(b->device);
+  if (b->state == rc_batch::RUNNING) { if (b->evDone.e) (void)hipEventSynchronize(b->evDone); if (b->ctx) b->ctx->inflight.fetch_sub(1); }
+  else if (b->state == rc_batch::READY && b->evPrep.e) (void)hipEventSynchronize(b->evPrep);   // the upload reads the pinned blob
   delete b;
 }
 
-static size_t align16(size_t x) { return (x + 15) & ~static_cast<size_t>(15); }
+// ------------------------------------------------------------------------------------------ prepare + upload
 
-int rc_batch_create(rc_ctx *ctx, const rc_block *blocks, int32_t n_blocks, const rc_params *par, rc_batch **out) {
-  if (!ctx || !blocks || !par || !out || n_blocks < 0) return fail(RC_ERR_ARG, "bad argument");
+static int batch_prepare(rc_batch *b, const rc_block *blocks, int32_t n_blocks, const rc_params *par) {
+  rc_ctx *ctx = b->ctx;
   if (par->blosum != 62 && par->blosum != 90) return fail(RC_ERR_ARG, "blosum must be 62 or 90");
   if (par->sampleN < 1) return fail(RC_ERR_ARG, "sampleN must be >= 1");
-  *out = nullptr;
-  HIP_TRY(hipSetDevice(ctx->device));
-  rc_batch *b = new rc_batch();
-  b->ctx = ctx; b->par = *par; b->n = n_blocks;
-  std::unique_ptr<rc_batch, void (*)(rc_batch *)> guard(b, rc_batch_destroy);   // released on success only
-  b->hb.resize(n_blocks);
-  const CodeTables &ct = (par->blosum == 90) ? ctx->ct90 : ctx->ct62;
+  const auto t0 = std::chrono::steady_clock::now();
+  b->par = *par; b->n = n_blocks;
+  b->state = rc_batch::EMPTY;
+  b->meta.assign(n_blocks, BlockMeta());
+  b->db.resize(n_blocks);
+  b->errs.clear(); b->okBlocks.clear(); b->classes.clear();
+  b->maxL = 0; b->maxDraws = 0; b->hssCap = 8;
+  b->allExact = !params_in_fast_range(*par);
   const PairTable &pt = (par->blosum == 90) ? ctx->pt90 : ctx->pt62;
+
+  // capacity of the two blob parts from the shapes alone, then one pinned buffer
+  size_t hostSum = 0, devSum = 0;
+  for (int i = 0; i < n_blocks; i++) {
+    size_t h = 0, d = 0;
+    if (blocks[i].n_rows >= 3 && blocks[i].n_rows <= kMaxRows && blocks[i].n_cols >= 3 && blocks[i].n_cols <= 65535)
+      block_footprint(blocks[i].n_rows, blocks[i].n_cols, &h, &d);
+    hostSum += h; devSum += d;
+  }
+  const size_t nn = static_cast<size_t>(std::max(n_blocks, 1));
+  const size_t tail = al256(nn * sizeof(DevBlock)) + 2 * al256(nn * sizeof(int)) + al256(nn * sizeof(uint64_t)) + al256((nn + 1) * sizeof(int));
+  b->hostCap = al256(hostSum) + tail + 256;
+  b->devCap = al256(devSum) + 256;
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(b->hblob.ensure(b->hostCap));
+  BlobArena arena;
+  arena.host = b->hblob.as<uint8_t>();
+  arena.hostCap = b->hostCap;          // the device-only arena starts here in the device blob
+  arena.devCap = b->devCap;
 
   // block-constant preparation, blocks are independent -> host threads
   {
-    std::atomic<int> next{0};
-    std::vector<std::string> errs(n_blocks);
-    unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
-    if (n_blocks < 8) nt = 1;
-    auto work = [&]() {
-      for (;;) {
-        int i = next.fetch_add(1);
-        if (i >= n_blocks) break;
-        prepare_block(blocks[i], *par, ct, pt, b->hb[i], errs[i]);
+    if (!ctx->pool || ctx->pool->size() != ctx->hostThreads) ctx->pool.reset(new Pool(ctx->hostThreads));
+    std::mutex errMu;
+    ctx->pool->run(n_blocks, [&](int i) {
+      std::string err;
+      const int st = prepare_block(blocks[i], *par, pt, arena, static_cast<uint32_t>(i), b->db[i], b->meta[i], err);
+      if (st != RC_OK && st != RC_ERR_SKIP) {
+        std::lock_guard<std::mutex> lk(errMu);
+        b->errs[i] = err;
       }
-    };
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
-    work();
-    for (auto &x : th) x.join();
-    for (int i = 0; i < n_blocks; i++)
-      if (b->hb[i].status != RC_OK && b->hb[i].status != RC_ERR_SKIP) {
-        int st = b->hb[i].status;
-        std::string msg = "block " + std::to_string(i) + ": " + errs[i];
-        return fail(st, msg);
-      }
+    });
   }
 
-  // pack the blob
-  b->db.assign(n_blocks, DevBlock());
-  std::vector<uint8_t> blob;
-  {   // one allocation for the blob instead of repeated doubling (10k blocks: ~150 MB)
-    size_t est = 0;
-    for (int i = 0; i < n_blocks; i++) {
-      const HostBlock &h = b->hb[i];
-      if (h.status != RC_OK) continue;
-      const size_t L1 = static_cast<size_t>(h.L) + 1, ncw = (static_cast<size_t>(h.NK) + 4) / 5;
-      est += h.nodes.size() * sizeof(NodeRec) + kMaxRows + 2 * L1 * (2 + 8 + ncw * 4 + static_cast<size_t>(h.NK) * 4) +
-             2 * static_cast<size_t>(h.NK) * kLutSize * 4 + 2 * static_cast<size_t>(h.N) * h.cols + 6 * ((L1 / 3 + 63) / 64) * 8 + 12 * 16;
-    }
-    blob.reserve(est + est / 16 + 4096);
-  }
+  // lists and per-block result areas
   b->offS.assign(n_blocks, 0);
   size_t sOff = 0;
+  bool sameL = true;
   for (int i = 0; i < n_blocks; i++) {
-    const HostBlock &h = b->hb[i];
-    DevBlock &d = b->db[i];
-    std::memset(&d, 0, sizeof d);
-    d.status = h.status;
-    d.out_index = static_cast<uint32_t>(i);
-    if (h.status != RC_OK) continue;
+    const BlockMeta &m = b->meta[i];
+    if (m.status != RC_OK) continue;
+    if (m.N > kFastRows) {   // TODO(wide kernels)
+      b->meta[i].status = RC_ERR_UNSUPPORTED; b->db[i].status = RC_ERR_UNSUPPORTED;
+      b->errs[i] = "more than 32 rows";
+      continue;
+    }
     b->okBlocks.push_back(i);
-    b->classes[h.NK].push_back(i);
-    b->maxL = std::max(b->maxL, h.L);
-    b->maxDraws = std::max(b->maxDraws, static_cast<int>(h.nodes.size()) * h.cols);
-    d.N = h.N; d.NK = h.NK; d.cols = h.cols; d.L = h.L;
-    d.nnodes = static_cast<int>(h.nodes.size());
-    d.ref_start = h.ref_start; d.ref_length = h.ref_length;
-    d.Delta = par->Delta; d.Omega = par->Omega; d.omega = par->omega;
-    d.nkf = static_cast<float>(h.N - 1);
-    d.stop0 = par->stopPenalty_0; d.stopk = par->stopPenalty_k;
-    d.code_zero = pt.code_zero; d.code_stop0 = pt.code_stop0; d.code_stopk = pt.code_stopk;
-    d.exact_div = h.exact_div;
-    const int L1 = h.L + 1;
-    auto put = [&](const void *p, size_t bytes) {
-      size_t off = align16(blob.size());
-      blob.resize(off + bytes);
-      if (p) std::memcpy(blob.data() + off, p, bytes); else std::memset(blob.data() + off, 0, bytes);
-      return static_cast<uint32_t>(off);
-    };
-    d.off_nodes = put(h.nodes.data(), h.nodes.size() * sizeof(NodeRec));
-    {
-      uint8_t qt[kMaxRows] = {0};   // k_null reads it as 32-bit words
-      std::memcpy(qt, h.qtip.data(), h.qtip.size());
-      d.off_qtip = put(qt, sizeof qt);
-    }
-    {
-      std::vector<uint16_t> rc2(2 * L1);
-      std::memcpy(rc2.data(), h.refcol[0].data(), L1 * 2);
-      std::memcpy(rc2.data() + L1, h.refcol[1].data(), L1 * 2);
-      d.off_refcol = put(rc2.data(), rc2.size() * 2);
-      std::vector<uint64_t> z2(2 * L1);
-      std::memcpy(z2.data(), h.zw[0].data(), L1 * 8);
-      std::memcpy(z2.data() + L1, h.zw[1].data(), L1 * 8);
-      d.off_zw = put(z2.data(), z2.size() * 8);
-      {   // gap masks, five 6-bit fields per word like the sigma codes: [strand][i][word]
-        const int ncw = (h.NK + 4) / 5;
-        std::vector<uint32_t> mw(2 * static_cast<size_t>(L1) * ncw, 0);
-        for (int s = 0; s < 2; s++)
-          for (int k = 0; k < h.NK; k++)
-            for (int p = 0; p < L1; p++)
-              mw[(static_cast<size_t>(s) * L1 + p) * ncw + k / 5] |= static_cast<uint32_t>(h.mask[s][static_cast<size_t>(k) * L1 + p]) << (6 * (k % 5));
-        d.off_mask = put(mw.data(), mw.size() * 4);
-      }
-      std::vector<float> l2(2 * static_cast<size_t>(h.NK) * kLutSize);
-      std::memcpy(l2.data(), h.lut[0].data(), static_cast<size_t>(h.NK) * kLutSize * 4);
-      std::memcpy(l2.data() + static_cast<size_t>(h.NK) * kLutSize, h.lut[1].data(), static_cast<size_t>(h.NK) * kLutSize * 4);
-      d.off_lut = put(l2.data(), l2.size() * 4);
-      std::vector<uint8_t> ch(2 * static_cast<size_t>(h.N) * h.cols);
-      for (int s = 0; s < 2; s++)
-        for (int r = 0; r < h.N; r++) std::memcpy(ch.data() + (static_cast<size_t>(s) * h.N + r) * h.cols, h.rows[s][r].data(), h.cols);
-      d.off_chars = put(ch.data(), ch.size());
-      d.off_sigma = put(nullptr, 2 * static_cast<size_t>(h.NK) * L1 * 4);
-      {
-        const int smax = h.L / 3, zmw = (smax + 63) / 64;
-        std::vector<uint64_t> zm(static_cast<size_t>(6) * zmw, 0);
-        for (int s = 0; s < 2; s++)
-          for (int f = 0; f < 3; f++)
-            for (int j = 0; j < (h.L - f) / 3; j++)
-              if (h.zw[s][3 * j + 3 + f] != 0) zm[static_cast<size_t>(s * 3 + f) * zmw + (j >> 6)] |= 1ull << (j & 63);
-        d.off_zmask = put(zm.data(), zm.size() * 8);
-        d.zm_words = zmw;
-      }
-    }
-    if (blob.size() > 0xFFFFFFF0ull) return fail(RC_ERR_UNSUPPORTED, "batch too large: split it (blob > 4 GiB)");
-    const size_t smax = h.L / 3;
+    auto &cls = b->classes[m.NK];
+    if (!cls.empty() && b->meta[cls.front()].L != m.L) sameL = false;
+    cls.push_back(i);
+    b->maxL = std::max(b->maxL, m.L);
+    b->maxDraws = std::max(b->maxDraws, b->db[i].nnodes * m.cols);
+    const size_t smax = static_cast<size_t>(m.L) / 3;
     b->offS[i] = sOff;
     sOff += 6 * smax * smax;
     b->hssCap = std::max(b->hssCap, static_cast<int>(smax) / 3 + 2);
   }
   b->S_floats = sOff;
-  b->blobBytes = blob.size();
+  // longest blocks first: k_null's workgroups pull items from a shared counter, so the order of the
+  // list is the order of dispatch (longest-processing-time-first keeps the tail short)
+  if (!sameL)
+    for (auto &kv : b->classes) std::stable_sort(kv.second.begin(), kv.second.end(), [&](int x, int y) { return b->meta[x].L > b->meta[y].L; });
 
-  // upload
-  auto up = [&](void **dst, const void *src, size_t bytes) -> int {
-    if (bytes == 0) bytes = 16;
-    HIP_TRY(hipMalloc(dst, bytes));
-    if (src) HIP_TRY(hipMemcpy(*dst, src, std::max<size_t>(bytes, 1), hipMemcpyHostToDevice));
-    return RC_OK;
-  };
-  int rcv;
-  std::vector<uint8_t> pad(16, 0);
-  if ((rcv = up(reinterpret_cast<void **>(&b->d_blob), blob.empty() ? pad.data() : blob.data(), blob.empty() ? 16 : blob.size()))) return rcv;
-  if (n_blocks > 0) {
-    if ((rcv = up(reinterpret_cast<void **>(&b->d_dblocks), b->db.data(), sizeof(DevBlock) * n_blocks))) return rcv;
-    if ((rcv = up(reinterpret_cast<void **>(&b->d_offS), b->offS.data(), sizeof(size_t) * n_blocks))) return rcv;
-  }
-  if (!b->okBlocks.empty()) {
-    if ((rcv = up(reinterpret_cast<void **>(&b->d_okBlocks), b->okBlocks.data(), sizeof(int) * b->okBlocks.size()))) return rcv;
+  // tail of the host part: headers and lists, so that ONE copy moves everything
+  uint8_t *base = arena.host;
+  size_t o = al256(arena.hostUsed.load());
+  auto take = [&](size_t bytes) { const size_t at = o; o += al256(bytes); return at; };
+  b->oDblocks = take(nn * sizeof(DevBlock));
+  b->oOk = take(nn * sizeof(int));
+  b->oClass = take(nn * sizeof(int));
+  b->oOffS = take(nn * sizeof(uint64_t));
+  b->oPrefix = take((nn + 1) * sizeof(int));
+  if (o > b->hostCap) return fail(RC_ERR_ARG, "internal: blob tail does not fit");
+  b->hostUsed = o;
+  if (n_blocks > 0) std::memcpy(base + b->oDblocks, b->db.data(), sizeof(DevBlock) * n_blocks);
+  if (!b->okBlocks.empty()) std::memcpy(base + b->oOk, b->okBlocks.data(), sizeof(int) * b->okBlocks.size());
+  {
+    int *cl = reinterpret_cast<int *>(base + b->oClass);
+    int at = 0;
+    std::fill(b->classOff, b->classOff + kMaxRows + 1, 0);
     for (auto &kv : b->classes) {
-      // longest blocks first: k_null's workgroups pull items from a shared counter, so the order of the
-      // list is the order of dispatch (longest-processing-time-first keeps the tail short)
-      std::stable_sort(kv.second.begin(), kv.second.end(), [&](int x, int y) { return b->hb[x].L > b->hb[y].L; });
-      int *p = nullptr;
-      if ((rcv = up(reinterpret_cast<void **>(&p), kv.second.data(), sizeof(int) * kv.second.size()))) return rcv;
-      b->d_classBlocks[kv.first] = p;
+      b->classOff[kv.first] = at;
+      std::memcpy(cl + at, kv.second.data(), sizeof(int) * kv.second.size());
+      at += static_cast<int>(kv.second.size());
     }
+    if (n_blocks > 0) std::memcpy(base + b->oOffS, b->offS.data(), sizeof(uint64_t) * n_blocks);
+    int *pf = reinterpret_cast<int *>(base + b->oPrefix);
+    int run = 0;
+    for (size_t k = 0; k < b->okBlocks.size(); k++) { pf[k] = run; run += 2 * b->meta[b->okBlocks[k]].N; }
+    pf[b->okBlocks.size()] = run;
+    b->nModels = run;
   }
-  const size_t nm = static_cast<size_t>(std::max(n_blocks, 1)) * par->sampleN;
-  HIP_TRY(hipMalloc(&b->d_maxima, nm * sizeof(float)));
-  HIP_TRY(hipMalloc(&b->d_S, std::max<size_t>(b->S_floats, 4) * sizeof(float)));
-  HIP_TRY(hipMalloc(&b->d_hss, static_cast<size_t>(std::max(n_blocks, 1)) * 6 * b->hssCap * sizeof(DevHss)));
-  HIP_TRY(hipMalloc(&b->d_hssCount, static_cast<size_t>(std::max(n_blocks, 1)) * 6 * sizeof(int)));
-  HIP_TRY(hipMalloc(&b->d_hssPacked, static_cast<size_t>(std::max(n_blocks, 1)) * 6 * b->hssCap * sizeof(DevHss)));
-  HIP_TRY(hipMalloc(&b->d_hssOffsets, (static_cast<size_t>(std::max(n_blocks, 1)) * 6 + 1) * sizeof(int)));
-  HIP_TRY(hipMalloc(&b->d_fit, static_cast<size_t>(std::max(n_blocks, 1)) * sizeof(FitOut)));
+  b->prepHostMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return RC_OK;
+}
+
+// one asynchronous copy of the host part, then the kernels that derive the expected-score tables
+static int batch_upload(rc_batch *b) {
+  rc_ctx *c = b->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  const int n = b->n;
+  const size_t nn = static_cast<size_t>(std::max(n, 1));
+  HIP_TRY(b->dblob.ensure(b->hostCap + b->devCap));
+  if (!b->maximaExternal) { HIP_TRY(b->dmaxima.ensure(nn * b->par.sampleN * sizeof(float))); b->maxPtr = b->dmaxima.as<float>(); }
+  HIP_TRY(b->dS.ensure(std::max<size_t>(b->S_floats, 4) * sizeof(float)));
+  HIP_TRY(b->dhss.ensure(nn * 6 * b->hssCap * sizeof(DevHss)));
+  HIP_TRY(b->dhssCount.ensure(nn * 6 * sizeof(int)));
+  HIP_TRY(b->dhssPacked.ensure(nn * 6 * b->hssCap * sizeof(DevHss)));
+  HIP_TRY(b->dhssOffsets.ensure((nn * 6 + 1) * sizeof(int)));
+  HIP_TRY(b->dfit.ensure(nn * sizeof(FitOut)));
+  HIP_TRY(b->dflags.ensure(nn * sizeof(uint32_t)));
+  HIP_TRY(b->dexact.ensure(nn * sizeof(int)));
+  HIP_TRY(b->dcounters.ensure(kCntTotal * sizeof(uint32_t)));
+  HIP_TRY(hipMemcpyAsync(b->dblob.p, b->hblob.p, b->hostUsed, hipMemcpyHostToDevice, c->copy));
+  HIP_TRY(b->evUp.record(c->copy));
+  HIP_TRY(hipStreamWaitEvent(c->native, b->evUp, 0));
+  HIP_TRY(b->evPrep0.record(c->native));
+  HIP_TRY(hipMemsetAsync(b->dflags.p, 0, nn * sizeof(uint32_t), c->native));
+  HIP_TRY(hipMemsetAsync(b->dcounters.p, 0, kCntTotal * sizeof(uint32_t), c->native));
+  if (!b->okBlocks.empty()) {
+    const TablePtrs tp = table_ptrs(c, b->par.blosum);
+    PrepArgs pa{};
+    uint8_t *blob = b->dblob.as<uint8_t>();
+    pa.blob = blob;
+    pa.dblocks = reinterpret_cast<const DevBlock *>(blob + b->oDblocks);
+    pa.blocks = reinterpret_cast<const int *>(blob + b->oOk);
+    pa.nBlocks = static_cast<int>(b->okBlocks.size());
+    pa.modelPrefix = reinterpret_cast<const int *>(blob + b->oPrefix);
+    pa.nModels = b->nModels;
+    pa.pep = tp.pep; pa.blosum = tp.blosum; pa.codeInfo = tp.info;
+    pa.flags = b->dflags.as<uint32_t>();
+    pa.exactList = b->dexact.as<int>();
+    pa.exactCount = b->dcounters.as<int>() + kCntExact;
+    std::memcpy(pa.classOff, b->classOff, sizeof pa.classOff);
+    launch_prep(pa, c->native);
+  }
+  HIP_TRY(b->evPrep.record(c->native));
+  HIP_TRY(hipGetLastError());
+  b->state = rc_batch::READY;
+  b->maximaFetched = false;
+  return RC_OK;
+}
+
+int rc_batch_create(rc_ctx *ctx, const rc_block *blocks, int32_t n_blocks, const rc_params *par, rc_batch **out) {
+  if (!ctx || (!blocks && n_blocks > 0) || !par || !out || n_blocks < 0) return fail(RC_ERR_ARG, "bad argument");
+  *out = nullptr;
+  std::unique_ptr<rc_batch, void (*)(rc_batch *)> guard(new rc_batch(), rc_batch_destroy);   // released on success only
+  rc_batch *b = guard.get();
+  b->ctx = ctx; b->device = ctx->device;
+  RC_TRY(batch_prepare(b, blocks, n_blocks, par));
+  RC_TRY(batch_upload(b));
   *out = guard.release();
   return RC_OK;
 }
 
-static int ensure_stream(rc_ctx *c, uint32_t seed, int Spad, int D, float *ms, int *launches) {
-  *ms = 0; *launches = 0;
-  if (c->U_valid && c->U_seed == seed && c->U_Spad == Spad && c->U_D >= D) return RC_OK;
-  const size_t need = static_cast<size_t>(Spad) * D;
-  if (need > c->U_cap) {
-    if (c->d_U) hipFree(c->d_U);
-    c->d_U = nullptr; c->U_cap = 0;
-    HIP_TRY(hipMalloc(&c->d_U, need * sizeof(uint32_t)));
-    c->U_cap = need;
-  }
-  Event e0, e1;
-  HIP_TRY(e0.create()); HIP_TRY(e1.create());
-  HIP_TRY(hipEventRecord(e0, c->stream));
-  launch_mt_stream(seed, Spad, D, c->d_U, c->stream);
-  HIP_TRY(hipEventRecord(e1, c->stream));
-  HIP_TRY(hipEventSynchronize(e1));
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventElapsedTime(ms, e0, e1));
-  *launches = 1;
-  c->U_seed = seed; c->U_Spad = Spad; c->U_D = D; c->U_valid = true;
-  return RC_OK;
-}
+// ------------------------------------------------------------------------------------------ run
 
 // When set, the MT19937 stream is regenerated on every run (bench: the stream belongs to a step).
 static bool g_no_stream_cache = false;
 void rc_set_stream_cache(int enabled) { g_no_stream_cache = !enabled; }
 
-// One run's launches, in the order rc_batch_run issues them.  ev[] are the run's timing events:
-// 0 start, 1..2 native block (second stream), 3..4 null sampling, 5 after the fit.
-struct RunEnv {
-  rc_batch *b;
-  rc_ctx *c;
-  int n, sampleN, groups, Spad, slots;
-  const uint8_t *d_pair;
-  Event *ev;
-};
-
-static int launch_native_block(const RunEnv &R) {
-  rc_batch *b = R.b; rc_ctx *c = R.c; Event *ev = R.ev;
-  const int n = R.n, slots = R.slots;
-  const uint8_t *d_pair = R.d_pair;
-  // ---- native block: sigma -> DP per N-1 class -> scan, on the second stream: these kernels are small and
-  // latency-bound, the null sampling below fills the chip beside them; the fit waits for both
-  HIP_TRY(hipEventRecord(ev[1], c->stream2));
-  NativeArgs na{};
-  na.blob = b->d_blob; na.dblocks = b->d_dblocks; na.blocks = b->d_okBlocks; na.pair = d_pair;
-  na.S = b->d_S; na.offS = b->d_offS; na.hss = b->d_hss; na.hssCount = b->d_hssCount; na.hssCap = b->hssCap; na.tieThr = c->tieThr;
-  HIP_TRY(hipMemsetAsync(b->d_hssCount, 0, static_cast<size_t>(n) * 6 * sizeof(int), c->stream2));
-  launch_native_sigma(na, static_cast<int>(b->okBlocks.size()), c->stream2); b->nl[3]++;
-  for (auto &kv : b->classes) {
-    NativeArgs nc = na;
-    nc.blocks = b->d_classBlocks[kv.first];
-    if (!launch_native_dp(kv.first, nc, static_cast<int>(kv.second.size()), c->stream2))
-      return fail(RC_ERR_UNSUPPORTED, "no native DP kernel for this number of rows");
-    b->nl[3]++;
+// U[draw][sample] for seeds seed .. seed + Spad - 1, at least D draws; generated on `st`, other streams order
+// themselves behind U_ready
+static int ensure_mt_stream(rc_ctx *c, rc_batch *b, hipStream_t st, uint32_t seed, int Spad, int D) {
+  b->mtLaunched = false;
+  if (c->U_valid && c->U_seed == seed && c->U_Spad == Spad && c->U_D >= D) {
+    if (c->U_ready.e) HIP_TRY(hipStreamWaitEvent(st, c->U_ready, 0));
+    return RC_OK;
   }
-  launch_native_scan(na, static_cast<int>(b->okBlocks.size()), c->stream2); b->nl[3]++;
-  HIP_TRY(hipMemsetAsync(b->d_hssOffsets + slots, 0, sizeof(int), c->stream2));
-  launch_hss_pack(b->d_hss, b->d_hssCount, b->hssCap, slots, b->d_hssPacked, b->d_hssOffsets, b->d_hssOffsets + slots, c->stream2);
-  HIP_TRY(hipEventRecord(ev[2], c->stream2));
-
+  if (c->inflight.load() > 0) HIP_TRY(hipDeviceSynchronize());   // other batches still read the old stream (rare: a batch with more draws)
+  const size_t need = static_cast<size_t>(Spad) * D;
+  if (need > c->U_cap) {
+    if (c->d_U) (void)hipFree(c->d_U);
+    c->d_U = nullptr; c->U_cap = 0;
+    HIP_TRY(hipMalloc(&c->d_U, need * sizeof(uint32_t)));
+    c->U_cap = need;
+  }
+  HIP_TRY(b->evMt0.record(st));
+  launch_mt_stream(seed, Spad, D, c->d_U, st);
+  HIP_TRY(b->evMt1.record(st));
+  HIP_TRY(c->U_ready.record(st));
+  b->mtLaunched = true;
+  c->U_seed = seed; c->U_Spad = Spad; c->U_D = D; c->U_valid = true;
   return RC_OK;
 }
 
-static int launch_null_sampling(const RunEnv &R) {
-  rc_batch *b = R.b; rc_ctx *c = R.c; Event *ev = R.ev;
-  const int n = R.n, sampleN = R.sampleN, groups = R.groups, Spad = R.Spad;
-  const uint8_t *d_pair = R.d_pair;
-  // ---- null sampling per N-1 class
-  HIP_TRY(hipMemsetAsync(c->d_clamp, 0, sizeof(unsigned long long), c->stream));
-  HIP_TRY(hipMemsetAsync(c->d_work, 0, sizeof(unsigned int) * (kMaxRows + 1) * 8, c->stream));
-  // -1.0f everywhere first: skipped blocks report "no HSS" rows
-  HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->d_maxima), 0xBF800000u, static_cast<size_t>(n) * sampleN, c->stream));
-  HIP_TRY(hipEventRecord(ev[3], c->stream));
-  struct Plan { int NK, grid, comboSplit; size_t stride, ldsBytes, need; bool exact; };
+namespace {
+struct RunEnv {
+  rc_batch *b;
+  rc_ctx *c;
+  hipStream_t cs;     // this run's compute stream
+  int n, sampleN, groups, Spad, slots;
+  TablePtrs tp;
+  const uint8_t *blob;
+  const DevBlock *dblocks;
+  const int *okList, *classList;
+};
+}  // namespace
+
+static int launch_native_block(const RunEnv &R) {
+  rc_batch *b = R.b; rc_ctx *c = R.c;
+  // ---- native block: sigma -> DP per N-1 class -> scan, on the native stream: these kernels are small and
+  // latency-bound, the null sampling fills the chip beside them; the fit waits for both
+  hipStream_t st = c->serialNative ? R.cs : c->native;
+  if (!c->serialNative) HIP_TRY(hipStreamWaitEvent(st, b->evStart, 0));
+  HIP_TRY(b->evN0.record(st));
+  NativeArgs na{};
+  na.blob = b->dblob.as<uint8_t>(); na.dblocks = R.dblocks; na.blocks = R.okList; na.pair = R.tp.pair;
+  na.S = b->dS.as<float>(); na.offS = reinterpret_cast<const uint64_t *>(R.blob + b->oOffS);
+  na.hss = b->dhss.as<DevHss>(); na.hssCount = b->dhssCount.as<int>(); na.hssCap = b->hssCap; na.tieThr = c->tieThr;
+  HIP_TRY(hipMemsetAsync(b->dhssCount.p, 0, static_cast<size_t>(R.n) * 6 * sizeof(int), st));
+  launch_native_sigma(na, static_cast<int>(b->okBlocks.size()), st); b->nl[3]++;
+  for (auto &kv : b->classes) {
+    NativeArgs nc = na;
+    nc.blocks = R.classList + b->classOff[kv.first];
+    if (!launch_native_dp(kv.first, nc, static_cast<int>(kv.second.size()), st))
+      return fail(RC_ERR_UNSUPPORTED, "no native DP kernel for this number of rows");
+    b->nl[3]++;
+  }
+  launch_native_scan(na, static_cast<int>(b->okBlocks.size()), st); b->nl[3]++;
+  HIP_TRY(hipMemsetAsync(b->dhssOffsets.as<int>() + R.slots, 0, sizeof(int), st));
+  launch_hss_pack(b->dhss.as<DevHss>(), b->dhssCount.as<int>(), b->hssCap, R.slots, b->dhssPacked.as<DevHss>(), b->dhssOffsets.as<int>(),
+                  b->dhssOffsets.as<int>() + R.slots, st);
+  HIP_TRY(b->evN1.record(st));
+  return RC_OK;
+}
+
+// null sampling of the sample groups [gLo, gHi) for every class; phase 0 or 1 selects the work counters
+static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t extraSkip) {
+  rc_batch *b = R.b; rc_ctx *c = R.c;
+  const int groupsHere = gHi - gLo;
+  struct Plan { int NK, grid, gridExact, comboSplit; size_t stride, ldsBytes, need; };
   std::vector<Plan> plans;
   size_t needSum = 0, needMax = 0;
   for (auto &kv : b->classes) {
     Plan p{};
     p.NK = kv.first;
     int maxLc = 0;
-    for (int bi : kv.second) maxLc = std::max(maxLc, b->hb[bi].L);
+    for (int bi : kv.second) maxLc = std::max(maxLc, b->meta[bi].L);
     const int NCW = (p.NK + 4) / 5;   // 5 six-bit sigma codes per word
     p.stride = static_cast<size_t>(2) * (maxLc + 1) * NCW * kWave;
     // sigma codes of one strand x frame are staged in LDS when that still leaves >= 12 wavefronts per
     // CU (RC_LDS_MAX_BYTES overrides the per-wavefront budget); otherwise they are read from the
     // per-workgroup scratch in global memory.
     p.ldsBytes = static_cast<size_t>(maxLc / 3) * NCW * kWave * sizeof(uint32_t);
-    for (int bi : kv.second) p.exact = p.exact || b->hb[bi].exact_div;
-    if (p.ldsBytes > c->ldsMaxBytes || p.exact) p.ldsBytes = 0;
+    if (p.ldsBytes > c->ldsMaxBytes || b->allExact) p.ldsBytes = 0;
     else p.ldsBytes = std::max<size_t>(p.ldsBytes, kPhaseALds);   // phase A keeps the tree's threshold table and the pair table there
     const std::pair<int, size_t> key(p.NK, p.ldsBytes);
     if (!c->occ.count(key)) c->occ[key] = null_occupancy(p.NK, p.ldsBytes);
     if (c->occ[key] <= 0 && p.ldsBytes) { p.ldsBytes = 0; const std::pair<int, size_t> k2(p.NK, 0); if (!c->occ.count(k2)) c->occ[k2] = null_occupancy(p.NK, 0); }
     const int occ = std::max(1, c->occ[std::pair<int, size_t>(p.NK, p.ldsBytes)]);
-    int items = static_cast<int>(kv.second.size()) * groups;
+    int items = static_cast<int>(kv.second.size()) * groupsHere;
     // small batches: split every item into its six strand x frame parts to fill the chip
     p.comboSplit = (items * 2 <= c->numCU * occ) ? 1 : 0;
     if (p.comboSplit) items *= 6;
     p.grid = std::min(items, c->numCU * occ);
     // very long blocks: bound the sigma-code staging area (4 GiB of uint32) by running fewer workgroups
     p.grid = static_cast<int>(std::max<size_t>(1, std::min<size_t>(p.grid, (static_cast<size_t>(1) << 30) / std::max<size_t>(p.stride, 1))));
-    p.need = p.stride * p.grid;
+    // blocks flagged by k_prep_lut go through the EXACT instantiation in a second launch on the same stream; their
+    // number is only known on the device, the launch is a few idle workgroups when there are none
+    p.gridExact = b->allExact ? 0 : std::min(p.grid, c->numCU);
+    p.need = p.stride * std::max(p.grid, p.gridExact);
     needSum += p.need; needMax = std::max(needMax, p.need);
     plans.push_back(p);
   }
   // Several row-count classes: their launches are independent (own work queues, own part of the staging
   // scratch), so they go on separate streams and share the chip -- a small class no longer waits for the tail
-  // of the previous one.  One class, a scratch that would exceed 4 GiB, or RC_SERIAL_NATIVE: main stream only.
-  const bool concurrent = plans.size() > 1 && needSum <= (static_cast<size_t>(1) << 30) && c->stream2 != c->stream;
+  // of the previous one.  One class, a scratch that would exceed 4 GiB, or RC_SERIAL_NATIVE: this run's stream only.
+  const bool concurrent = plans.size() > 1 && needSum <= (static_cast<size_t>(1) << 30) && !c->serialNative;
   const size_t need = concurrent ? needSum : needMax;
-  if (need > c->scratch_cap) {
-    HIP_TRY(hipDeviceSynchronize());
-    if (c->d_scratch) hipFree(c->d_scratch);
-    c->d_scratch = nullptr; c->scratch_cap = 0;
-    HIP_TRY(hipMalloc(&c->d_scratch, need * sizeof(uint32_t)));
-    c->scratch_cap = need;
-  }
-  std::vector<Event> classDone(concurrent ? plans.size() : 0);
+  HIP_TRY(b->dscratch.ensure(need * sizeof(uint32_t)));
+  Event &fork = phase ? b->evMid : b->evS0;
   size_t scratchOff = 0;
+  if (concurrent) while (b->classDone.size() < 2 * plans.size()) b->classDone.emplace_back(new Event());
   for (size_t pi = 0; pi < plans.size(); pi++) {
     const Plan &p = plans[pi];
     const auto &members = b->classes[p.NK];
-    hipStream_t st = c->stream;
+    hipStream_t st = R.cs;
     if (concurrent) {
       while (c->classStreams.size() < std::min<size_t>(plans.size(), 8)) {
         hipStream_t ns = nullptr;
@@ -500,170 +671,327 @@ static int launch_null_sampling(const RunEnv &R) {
         c->classStreams.push_back(ns);
       }
       st = c->classStreams[pi % c->classStreams.size()];
-      HIP_TRY(hipStreamWaitEvent(st, ev[3], 0));   // the memsets above
+      HIP_TRY(hipStreamWaitEvent(st, fork, 0));   // the memsets / the stop marks
     }
     NullArgs a{};
-    a.blob = b->d_blob; a.dblocks = b->d_dblocks; a.classBlocks = b->d_classBlocks[p.NK];
-    a.nClassBlocks = static_cast<int>(members.size()); a.groups = groups; a.sampleN = sampleN; a.Spad = Spad;
-    a.U = c->d_U; a.pair = d_pair; a.scratch = c->d_scratch + scratchOff; a.scratchStride = p.stride;
-    a.maxima = b->d_maxima; a.clampCount = c->d_clamp; a.tieThr = c->tieThr; a.debugSkip = c->debugSkip; a.comboSplit = p.comboSplit;
-    a.workCounter = c->d_work + p.NK * 8;
-    if (!launch_null(p.NK, a, p.grid, p.ldsBytes, p.exact, st)) return fail(RC_ERR_UNSUPPORTED, "no null kernel for this number of rows");
-    b->nl[2]++;
+    a.blob = R.blob; a.dblocks = R.dblocks;
+    a.classBlocks = R.classList + b->classOff[p.NK];
+    a.nClassBlocks = static_cast<int>(members.size());
+    a.flags = b->dflags.as<uint32_t>();
+    a.gLo = gLo; a.gHi = gHi; a.sampleN = R.sampleN; a.Spad = R.Spad;
+    a.U = c->d_U; a.pair = R.tp.pair; a.scratch = b->dscratch.as<uint32_t>() + scratchOff; a.scratchStride = p.stride;
+    a.maxima = b->maxPtr; a.clampCount = reinterpret_cast<unsigned long long *>(b->dcounters.as<uint32_t>() + kCntClamp);
+    a.tieThr = c->tieThr; a.debugSkip = c->debugSkip; a.comboSplit = p.comboSplit;
+    unsigned int *work = b->dcounters.as<unsigned int>() + kCntWork + static_cast<size_t>(phase) * 2 * (kMaxRows + 1) * 8;
+    if (b->allExact) {
+      a.skipMask = extraSkip;
+      a.workCounter = work + (kMaxRows + 1) * 8 + p.NK * 8;
+      if (!launch_null(p.NK, a, p.grid, 0, true, st)) return fail(RC_ERR_UNSUPPORTED, "no null kernel for this number of rows");
+      b->nl[2]++;
+    } else {
+      a.skipMask = kFlagExact | extraSkip;
+      a.workCounter = work + p.NK * 8;
+      if (!launch_null(p.NK, a, p.grid, p.ldsBytes, false, st)) return fail(RC_ERR_UNSUPPORTED, "no null kernel for this number of rows");
+      b->nl[2]++;
+      NullArgs e = a;
+      e.classBlocks = b->dexact.as<int>() + b->classOff[p.NK];
+      e.nBlocksPtr = b->dcounters.as<int>() + kCntExact + p.NK;
+      e.nClassBlocks = 0;
+      e.skipMask = extraSkip;
+      e.comboSplit = 0;
+      e.workCounter = work + (kMaxRows + 1) * 8 + p.NK * 8;
+      if (!launch_null(p.NK, e, p.gridExact, 0, true, st)) return fail(RC_ERR_UNSUPPORTED, "no null kernel for this number of rows");
+    }
     if (concurrent) {
       scratchOff += p.need;
-      HIP_TRY(classDone[pi].create());
-      HIP_TRY(hipEventRecord(classDone[pi], st));
-      HIP_TRY(hipStreamWaitEvent(c->stream, classDone[pi], 0));
+      Event &done = *b->classDone[static_cast<size_t>(phase) * plans.size() + pi];
+      HIP_TRY(done.record(st));
+      HIP_TRY(hipStreamWaitEvent(R.cs, done, 0));
     }
   }
-  HIP_TRY(hipEventRecord(ev[4], c->stream));
   return RC_OK;
 }
 
-static int fetch_results(const RunEnv &R) {
-  rc_batch *b = R.b; rc_ctx *c = R.c; Event *ev = R.ev;
-  const int n = R.n, slots = R.slots;
-  // small results back to the host: four copies into one pinned staging area behind the fit, one wait
-  const size_t szFit = sizeof(FitOut) * n, szCnt = sizeof(int) * static_cast<size_t>(slots), szOff = sizeof(int) * (static_cast<size_t>(slots) + 1);
-  const size_t oFit = 0, oCnt = (oFit + szFit + 15) & ~static_cast<size_t>(15), oOff = (oCnt + szCnt + 15) & ~static_cast<size_t>(15),
-               oClamp = (oOff + szOff + 15) & ~static_cast<size_t>(15), total = oClamp + 16;
-  if (total > b->stageBytes) {
-    if (b->h_stage) hipHostFree(b->h_stage);
-    b->h_stage = nullptr; b->stageBytes = 0;
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_stage), total, hipHostMallocDefault));
-    b->stageBytes = total;
+static int batch_run_async(rc_batch *b) {
+  rc_ctx *c = b->ctx;
+  if (b->state != rc_batch::READY && b->state != rc_batch::DONE) return fail(RC_ERR_ARG, "batch is not ready to run");
+  HIP_TRY(hipSetDevice(c->device));
+  std::fill(b->t, b->t + 6, 0.0f);
+  std::fill(b->nl, b->nl + 6, 0);
+  b->maximaFetched = false;
+  const int n = b->n, sampleN = b->par.sampleN;
+  const int groups = (sampleN + kWave - 1) / kWave, Spad = groups * kWave;
+  b->clamped = 0;
+  hipStream_t cs = c->compute[c->seq++ & 1];
+  const uint8_t *blob = b->dblob.as<uint8_t>();
+  const RunEnv R{b, c, cs, n, sampleN, groups, Spad, n * 6, table_ptrs(c, b->par.blosum), blob,
+                 reinterpret_cast<const DevBlock *>(blob + b->oDblocks), reinterpret_cast<const int *>(blob + b->oOk),
+                 reinterpret_cast<const int *>(blob + b->oClass)};
+  HIP_TRY(hipStreamWaitEvent(cs, b->evPrep, 0));   // upload + expected-score tables
+  HIP_TRY(b->evStart.record(cs));
+  if (!b->okBlocks.empty()) {
+    RC_TRY(ensure_mt_stream(c, b, cs, b->par.seed_base, Spad, b->maxDraws));
+    RC_TRY(launch_native_block(R));
+    // ---- null sampling per N-1 class
+    uint32_t *cnt = b->dcounters.as<uint32_t>();
+    HIP_TRY(hipMemsetAsync(cnt + kCntWork, 0, (kCntTotal - kCntWork) * sizeof(uint32_t), cs));   // work queues and the clamp counter
+    // -1.0f everywhere first: skipped blocks report "no HSS" rows
+    HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->maxPtr), 0xBF800000u, static_cast<size_t>(n) * sampleN, cs));
+    HIP_TRY(b->evS0.record(cs));
+    FitArgs fa{};
+    fa.dblocks = R.dblocks; fa.blocks = R.okList; fa.maxima = b->maxPtr; fa.hss = b->dhss.as<DevHss>();
+    fa.hssCount = b->dhssCount.as<int>(); fa.hssCap = b->hssCap; fa.out = b->dfit.as<FitOut>(); fa.flags = b->dflags.as<uint32_t>();
+    fa.sampleN = sampleN; fa.stopEarly = b->par.stopEarly;
+    fa.stopCutoff = static_cast<int>(b->par.cutoff * b->par.sampleN);   // score.c:992
+    // --stop-early: a first round of sample groups for every block, then only the blocks that are still undecided
+    int g1 = groups;
+    if (b->par.stopEarly && fa.stopCutoff >= 0 && fa.stopCutoff < sampleN) g1 = std::min(groups, (fa.stopCutoff + 1 + kWave + kWave - 1) / kWave);
+    RC_TRY(launch_null_groups(R, 0, g1, 0, 0));
+    if (g1 < groups) {
+      if (!c->serialNative) HIP_TRY(hipStreamWaitEvent(cs, b->evN1, 0));   // best native scores
+      fa.firstN = std::min(sampleN, g1 * kWave);
+      launch_stop_mark(fa, static_cast<int>(b->okBlocks.size()), cs);
+      HIP_TRY(b->evMid.record(cs));
+      RC_TRY(launch_null_groups(R, g1, groups, 1, kFlagStopped));
+    }
+    HIP_TRY(b->evS1.record(cs));
+    // ---- EVD fit
+    if (!c->serialNative) HIP_TRY(hipStreamWaitEvent(cs, b->evN1, 0));   // native HSS of the native stream
+    launch_evd_fit(fa, static_cast<int>(b->okBlocks.size()), cs); b->nl[4]++;
   }
-  HIP_TRY(hipMemcpyAsync(b->h_stage + oFit, b->d_fit, szFit, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(b->h_stage + oCnt, b->d_hssCount, szCnt, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(b->h_stage + oOff, b->d_hssOffsets, szOff, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(b->h_stage + oClamp, c->d_clamp, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  HIP_TRY(hipGetLastError());
-  float ms;
-  HIP_TRY(hipEventElapsedTime(&ms, ev[1], ev[2])); b->t[3] = ms;
-  HIP_TRY(hipEventElapsedTime(&ms, ev[3], ev[4])); b->t[2] = ms;
-  HIP_TRY(hipEventElapsedTime(&ms, ev[4], ev[5])); b->t[4] = ms;
-  HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[5])); b->t[0] = ms;
+  HIP_TRY(b->evFit.record(cs));
+  // small results back to the host: four copies into one pinned staging area behind the fit
   {
-    const FitOut *f = reinterpret_cast<const FitOut *>(b->h_stage + oFit);
-    for (int bi : b->okBlocks) b->fit[bi] = f[bi];
-    std::memcpy(b->hssCount.data(), b->h_stage + oCnt, szCnt);
-    const int *off = reinterpret_cast<const int *>(b->h_stage + oOff);
-    std::memcpy(&b->clamped, b->h_stage + oClamp, sizeof(unsigned long long));
-    // the used HSS records only (k_hss_pack): that many records, second and last wait
-    const size_t nrec = static_cast<size_t>(std::max(off[slots], 0));
-    if (nrec > b->packedCap) {
-      if (b->h_packed) hipHostFree(b->h_packed);
-      b->h_packed = nullptr; b->packedCap = 0;
-      HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->h_packed), sizeof(DevHss) * (nrec + nrec / 4 + 64), hipHostMallocDefault));
-      b->packedCap = nrec + nrec / 4 + 64;
-    }
-    if (nrec) {
-      HIP_TRY(hipMemcpyAsync(b->h_packed, b->d_hssPacked, sizeof(DevHss) * nrec, hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(hipStreamSynchronize(c->stream));
-    }
-    for (int t = 0; t < slots; t++) {
-      const int cnt = std::min(b->hssCount[t], b->hssCap);
-      for (int i = 0; i < cnt; i++) b->hss[static_cast<size_t>(t) * b->hssCap + i] = b->h_packed[static_cast<size_t>(off[t]) + i];
+    const int slots = R.slots;
+    const size_t szFit = sizeof(FitOut) * n, szCnt = sizeof(int) * static_cast<size_t>(slots), szOff = sizeof(int) * (static_cast<size_t>(slots) + 1);
+    const size_t oFit = 0, oCnt = al256(oFit + szFit), oOff = al256(oCnt + szCnt), oClamp = al256(oOff + szOff), total = oClamp + 16;
+    HIP_TRY(b->hstage.ensure(total));
+    if (!b->okBlocks.empty()) {
+      uint8_t *hs = b->hstage.as<uint8_t>();
+      HIP_TRY(hipMemcpyAsync(hs + oFit, b->dfit.p, szFit, hipMemcpyDeviceToHost, cs));
+      HIP_TRY(hipMemcpyAsync(hs + oCnt, b->dhssCount.p, szCnt, hipMemcpyDeviceToHost, cs));
+      HIP_TRY(hipMemcpyAsync(hs + oOff, b->dhssOffsets.p, szOff, hipMemcpyDeviceToHost, cs));
+      HIP_TRY(hipMemcpyAsync(hs + oClamp, b->dcounters.as<uint32_t>() + kCntClamp, sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
     }
   }
+  HIP_TRY(b->evDone.record(cs));
+  HIP_TRY(hipGetLastError());
+  b->state = rc_batch::RUNNING;
+  c->inflight.fetch_add(1);
   return RC_OK;
+}
+
+static int batch_wait(rc_batch *b) {
+  if (b->state == rc_batch::DONE) return RC_OK;
+  if (b->state != rc_batch::RUNNING) return fail(RC_ERR_ARG, "batch is not running");
+  rc_ctx *c = b->ctx;
+  HIP_TRY(hipSetDevice(c->device));
+  hipError_t e = hipEventSynchronize(b->evDone);
+  c->inflight.fetch_sub(1);
+  b->state = rc_batch::READY;   // a failed run may be repeated
+  if (e != hipSuccess) return fail(RC_ERR_DEVICE, std::string("hipEventSynchronize: ") + hipGetErrorString(e));
+  HIP_TRY(hipGetLastError());
+  const int n = b->n, slots = n * 6;
+  b->fit.assign(n, FitOut{0, 0, -1, 0});
+  b->hssCount.assign(static_cast<size_t>(slots), 0);
+  b->hssOff.assign(static_cast<size_t>(slots) + 1, 0);
+  b->hssRec.clear();
+  if (!b->okBlocks.empty()) {
+    float ms = 0;
+    if (b->mtLaunched) { HIP_TRY(hipEventElapsedTime(&ms, b->evMt0, b->evMt1)); b->t[1] = ms; b->nl[1] = 1; }
+    HIP_TRY(hipEventElapsedTime(&ms, b->evN0, b->evN1)); b->t[3] = ms;
+    HIP_TRY(hipEventElapsedTime(&ms, b->evS0, b->evS1)); b->t[2] = ms;
+    HIP_TRY(hipEventElapsedTime(&ms, b->evS1, b->evFit)); b->t[4] = ms;
+    HIP_TRY(hipEventElapsedTime(&ms, b->evStart, b->evFit)); b->t[0] = ms;
+    if (b->evPrep0.e && b->evPrep.e) { HIP_TRY(hipEventElapsedTime(&ms, b->evPrep0, b->evPrep)); b->t[5] = ms; b->nl[5] = 2; }
+    const size_t szFit = sizeof(FitOut) * n, szCnt = sizeof(int) * static_cast<size_t>(slots), szOff = sizeof(int) * (static_cast<size_t>(slots) + 1);
+    const size_t oFit = 0, oCnt = al256(oFit + szFit), oOff = al256(oCnt + szCnt), oClamp = al256(oOff + szOff);
+    const uint8_t *hs = b->hstage.as<uint8_t>();
+    const FitOut *f = reinterpret_cast<const FitOut *>(hs + oFit);
+    for (int bi : b->okBlocks) b->fit[bi] = f[bi];
+    std::memcpy(b->hssCount.data(), hs + oCnt, szCnt);
+    std::memcpy(b->hssOff.data(), hs + oOff, szOff);
+    std::memcpy(&b->clamped, hs + oClamp, sizeof(unsigned long long));
+    // the used HSS records only (k_hss_pack): that many records, second and last wait
+    const size_t nrec = static_cast<size_t>(std::max(b->hssOff[slots], 0));
+    if (nrec) {
+      HIP_TRY(b->hpacked.ensure(sizeof(DevHss) * nrec));
+      hipStream_t cs = c->compute[0];
+      HIP_TRY(hipMemcpyAsync(b->hpacked.p, b->dhssPacked.p, sizeof(DevHss) * nrec, hipMemcpyDeviceToHost, cs));
+      HIP_TRY(hipStreamSynchronize(cs));
+      b->hssRec.assign(b->hpacked.as<DevHss>(), b->hpacked.as<DevHss>() + nrec);
+    }
+  }
+  b->state = rc_batch::DONE;
+  return RC_OK;
+}
+
+int rc_batch_run_async(rc_batch *b) {
+  if (!b) return fail(RC_ERR_ARG, "null batch");
+  if (g_no_stream_cache && b->ctx->inflight.load() == 0) b->ctx->U_valid = false;
+  return batch_run_async(b);
+}
+
+int rc_batch_wait(rc_batch *b) {
+  if (!b) return fail(RC_ERR_ARG, "null batch");
+  return batch_wait(b);
 }
 
 int rc_batch_run(rc_batch *b) {
   if (!b) return fail(RC_ERR_ARG, "null batch");
-  rc_ctx *c = b->ctx;
-  HIP_TRY(hipSetDevice(c->device));
-  std::fill(b->t, b->t + 5, 0.0f);
-  std::fill(b->nl, b->nl + 5, 0);
-  b->ran = false; b->maximaFetched = false;
-  const int n = b->n, sampleN = b->par.sampleN;
-  const int groups = (sampleN + kWave - 1) / kWave, Spad = groups * kWave;
-  b->fit.assign(n, FitOut{0, 0, -1, 0});
-  b->hss.resize(static_cast<size_t>(n) * 6 * b->hssCap);   // entries beyond hssCount[slot] are never read
-  b->hssCount.assign(static_cast<size_t>(n) * 6, 0);
-  b->clamped = 0;
-  if (b->okBlocks.empty()) { b->ran = true; return RC_OK; }
-  const uint8_t *d_pair = (b->par.blosum == 90) ? c->d_pair90 : c->d_pair62;
-
-  Event ev[6];
-  for (auto &e : ev) HIP_TRY(e.create());
-  HIP_TRY(hipEventRecord(ev[0], c->stream));
-
-  if (g_no_stream_cache) c->U_valid = false;
-  int rcv = ensure_stream(c, b->par.seed_base, Spad, b->maxDraws, &b->t[1], &b->nl[1]);
-  if (rcv) return rcv;
-
-  const RunEnv R{b, c, n, sampleN, groups, Spad, n * 6, d_pair, ev};
-  if ((rcv = launch_native_block(R))) return rcv;
-  if ((rcv = launch_null_sampling(R))) return rcv;
-
-  // ---- EVD fit
-  HIP_TRY(hipStreamWaitEvent(c->stream, ev[2], 0));   // native HSS of the second stream
-  FitArgs fa{};
-  fa.dblocks = b->d_dblocks; fa.blocks = b->d_okBlocks; fa.maxima = b->d_maxima; fa.hss = b->d_hss;
-  fa.hssCount = b->d_hssCount; fa.hssCap = b->hssCap; fa.out = b->d_fit; fa.sampleN = sampleN; fa.stopEarly = b->par.stopEarly;
-  fa.stopCutoff = static_cast<int>(b->par.cutoff * b->par.sampleN);   // score.c:992
-  launch_evd_fit(fa, static_cast<int>(b->okBlocks.size()), c->stream); b->nl[4]++;
-  HIP_TRY(hipEventRecord(ev[5], c->stream));
-
-  if ((rcv = fetch_results(R))) return rcv;
-  b->ran = true;
-  return RC_OK;
+  RC_TRY(rc_batch_run_async(b));
+  return batch_wait(b);
 }
 
 int rc_batch_bind_maxima(rc_batch *b, void *device_ptr) {
   if (!b || !device_ptr) return fail(RC_ERR_ARG, "bad argument");
-  HIP_TRY(hipSetDevice(b->ctx->device));
-  if (b->d_maxima && !b->maximaExternal) hipFree(b->d_maxima);
-  b->d_maxima = static_cast<float *>(device_ptr);
+  if (b->state == rc_batch::RUNNING) return fail(RC_ERR_ARG, "batch is running");
+  b->dmaxima.release();
+  b->maxPtr = static_cast<float *>(device_ptr);
   b->maximaExternal = true;
-  b->ran = false;
+  if (b->state == rc_batch::DONE) b->state = rc_batch::READY;
   return RC_OK;
 }
+
+// ------------------------------------------------------------------------------------------ streams of batches
+
+int rc_stream_create(rc_ctx *ctx, const rc_params *par, int32_t depth, rc_stream **out) {
+  if (!ctx || !par || !out || depth < 1 || depth > 16) return fail(RC_ERR_ARG, "bad argument");
+  if (par->blosum != 62 && par->blosum != 90) return fail(RC_ERR_ARG, "blosum must be 62 or 90");
+  if (par->sampleN < 1) return fail(RC_ERR_ARG, "sampleN must be >= 1");
+  rc_stream *s = new rc_stream();
+  s->ctx = ctx; s->par = *par; s->depth = depth;
+  *out = s;
+  return RC_OK;
+}
+
+void rc_stream_destroy(rc_stream *s) {
+  if (!s) return;
+  for (rc_batch *b : s->inflight) { b->owner = nullptr; rc_batch_destroy(b); }
+  for (rc_batch *b : s->spare) { b->owner = nullptr; rc_batch_destroy(b); }
+  delete s;
+}
+
+int rc_stream_pending(const rc_stream *s) { return s ? static_cast<int>(s->inflight.size()) : 0; }
+
+int rc_stream_submit_bound(rc_stream *s, const rc_block *blocks, int32_t n_blocks, void *maxima_device_ptr);
+
+int rc_stream_submit(rc_stream *s, const rc_block *blocks, int32_t n_blocks) {
+  return rc_stream_submit_bound(s, blocks, n_blocks, nullptr);
+}
+
+int rc_stream_submit_bound(rc_stream *s, const rc_block *blocks, int32_t n_blocks, void *maxima_device_ptr) {
+  if (!s || (!blocks && n_blocks > 0) || n_blocks < 0) return fail(RC_ERR_ARG, "bad argument");
+  if (static_cast<int>(s->inflight.size()) >= s->depth) return fail(RC_ERR_ARG, "stream is full: take a finished batch with rc_stream_next first");
+  rc_batch *b = nullptr;
+  if (!s->spare.empty()) { b = s->spare.back(); s->spare.pop_back(); }
+  else { b = new rc_batch(); b->ctx = s->ctx; b->device = s->ctx->device; b->owner = s; }
+  if (g_no_stream_cache && s->inflight.empty() && s->ctx->inflight.load() == 0) s->ctx->U_valid = false;   // a new pass over the stream
+  if (maxima_device_ptr) { b->dmaxima.release(); b->maxPtr = static_cast<float *>(maxima_device_ptr); b->maximaExternal = true; }
+  else if (b->maximaExternal) { b->maxPtr = nullptr; b->maximaExternal = false; }
+  int r = batch_prepare(b, blocks, n_blocks, &s->par);
+  if (r == RC_OK) r = batch_upload(b);
+  if (r == RC_OK) r = batch_run_async(b);
+  if (r != RC_OK) { s->spare.push_back(b); return r; }
+  s->inflight.push_back(b);
+  return RC_OK;
+}
+
+int rc_stream_next(rc_stream *s, rc_batch **out) {
+  if (!s || !out) return fail(RC_ERR_ARG, "bad argument");
+  *out = nullptr;
+  if (s->inflight.empty()) return fail(RC_ERR_ARG, "no batch in flight");
+  rc_batch *b = s->inflight.front();
+  s->inflight.pop_front();
+  const int r = batch_wait(b);
+  if (r != RC_OK) { s->spare.push_back(b); return r; }
+  *out = b;
+  return RC_OK;
+}
+
+void rc_stream_recycle(rc_stream *s, rc_batch *b) {
+  if (!b) return;
+  if (!s || b->owner != s || b->state == rc_batch::RUNNING) { rc_batch_destroy(b); return; }
+  s->spare.push_back(b);
+}
+
+// ------------------------------------------------------------------------------------------ results
 
 int rc_batch_work(const rc_batch *b, int64_t *sa, int64_t *cs) {
   if (!b) return fail(RC_ERR_ARG, "null batch");
   int64_t a = 0, c = 0;
-  for (int bi : b->okBlocks) { a += b->par.sampleN; c += static_cast<int64_t>(b->hb[bi].cols) * b->par.sampleN; }
+  for (int bi : b->okBlocks) { a += b->par.sampleN; c += static_cast<int64_t>(b->meta[bi].cols) * b->par.sampleN; }
   if (sa) *sa = a;
   if (cs) *cs = c;
   return RC_OK;
 }
 
+int rc_batch_size(const rc_batch *b) { return b ? b->n : 0; }
+
 int rc_batch_timing(const rc_batch *b, float t[5], int32_t nl[5]) {
-  if (!b || !b->ran) return fail(RC_ERR_ARG, "batch has not been run");
+  if (!b || b->state != rc_batch::DONE) return fail(RC_ERR_ARG, "batch has not been run");
   for (int i = 0; i < 5; i++) { if (t) t[i] = b->t[i]; if (nl) nl[i] = b->nl[i]; }
+  return RC_OK;
+}
+
+int rc_batch_prep_timing(const rc_batch *b, double *host_ms, float *table_kernels_ms, int64_t *uploaded_bytes) {
+  if (!b || b->state == rc_batch::EMPTY) return fail(RC_ERR_ARG, "batch has not been prepared");
+  if (host_ms) *host_ms = b->prepHostMs;
+  if (table_kernels_ms) *table_kernels_ms = b->t[5];
+  if (uploaded_bytes) *uploaded_bytes = static_cast<int64_t>(b->hostUsed);
   return RC_OK;
 }
 
 static int check_blk(const rc_batch *b, int blk, bool needRun) {
   if (!b) return fail(RC_ERR_ARG, "null batch");
   if (blk < 0 || blk >= b->n) return fail(RC_ERR_ARG, "block index out of range");
-  if (needRun && !b->ran) return fail(RC_ERR_ARG, "batch has not been run");
+  if (needRun && b->state != rc_batch::DONE) return fail(RC_ERR_ARG, "batch has not been run");
   return RC_OK;
 }
 
 int rc_batch_status(const rc_batch *b, int32_t blk) {
   int r = check_blk(b, blk, false);
-  return r ? r : b->hb[blk].status;
+  return r ? r : b->meta[blk].status;
+}
+
+const char *rc_batch_block_error(const rc_batch *b, int32_t blk) {
+  if (!b || blk < 0 || blk >= b->n) return "";
+  auto it = b->errs.find(blk);
+  return it == b->errs.end() ? "" : it->second.c_str();
 }
 
 int rc_batch_models(const rc_batch *b, int32_t blk, rc_model *fwd, rc_model *rev) {
   int r = check_blk(b, blk, false);
   if (r) return r;
-  const HostBlock &h = b->hb[blk];
-  if (h.status != RC_OK) return h.status;
-  if (fwd) std::memcpy(fwd, h.models[0].data(), sizeof(rc_model) * h.N);
-  if (rev) std::memcpy(rev, h.models[1].data(), sizeof(rc_model) * h.N);
+  const BlockMeta &m = b->meta[blk];
+  if (m.status != RC_OK) return m.status;
+  if (b->state == rc_batch::EMPTY) return fail(RC_ERR_ARG, "batch has not been uploaded");
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipEventSynchronize(b->evPrep));   // scores and probs are computed on the device (k_prep_models)
+  std::vector<ModelRec> rec(2 * static_cast<size_t>(m.N));
+  HIP_TRY(hipMemcpy(rec.data(), b->dblob.as<uint8_t>() + b->db[blk].off_models, rec.size() * sizeof(ModelRec), hipMemcpyDeviceToHost));
+  for (int s = 0; s < 2; s++) {
+    rc_model *dst = s ? rev : fwd;
+    if (!dst) continue;
+    for (int j = 0; j < m.N; j++) {
+      const ModelRec &q = rec[static_cast<size_t>(s) * m.N + j];
+      std::memcpy(dst[j].scores, q.scores, sizeof q.scores);
+      std::memcpy(dst[j].probs, q.probs, sizeof q.probs);
+      std::memcpy(dst[j].freqs, q.freqs, sizeof q.freqs);
+      dst[j].kappa = q.kappa; dst[j].dist = q.dist;
+    }
+  }
   return RC_OK;
 }
 
 static int fetch_maxima(rc_batch *b) {
   if (b->maximaFetched) return RC_OK;
+  HIP_TRY(hipSetDevice(b->device));
   b->maxima.resize(static_cast<size_t>(b->n) * b->par.sampleN);
-  if (!b->maxima.empty()) HIP_TRY(hipMemcpy(b->maxima.data(), b->d_maxima, b->maxima.size() * sizeof(float), hipMemcpyDeviceToHost));
+  if (!b->maxima.empty()) {
+    if (b->okBlocks.empty()) std::fill(b->maxima.begin(), b->maxima.end(), -1.0f);
+    else HIP_TRY(hipMemcpy(b->maxima.data(), b->maxPtr, b->maxima.size() * sizeof(float), hipMemcpyDeviceToHost));
+  }
   b->maximaFetched = true;
   return RC_OK;
 }
@@ -679,7 +1007,7 @@ int rc_batch_maxima(const rc_batch *bc, int32_t blk, float *out) {
 
 int rc_batch_maxima_all(const rc_batch *bc, float *out) {
   rc_batch *b = const_cast<rc_batch *>(bc);
-  if (!b || !b->ran) return fail(RC_ERR_ARG, "batch has not been run");
+  if (!b || b->state != rc_batch::DONE) return fail(RC_ERR_ARG, "batch has not been run");
   int r = fetch_maxima(b);
   if (r) return r;
   std::memcpy(out, b->maxima.data(), b->maxima.size() * sizeof(float));
@@ -689,7 +1017,7 @@ int rc_batch_maxima_all(const rc_batch *bc, float *out) {
 int rc_batch_fit(const rc_batch *b, int32_t blk, int32_t *evd_rc, float *mu, float *lambda) {
   int r = check_blk(b, blk, true);
   if (r) return r;
-  if (b->hb[blk].status != RC_OK) return b->hb[blk].status;
+  if (b->meta[blk].status != RC_OK) return b->meta[blk].status;
   const FitOut &f = b->fit[blk];
   if (evd_rc) *evd_rc = f.rc;
   if (mu) *mu = static_cast<float>(f.mu);          // *parMu = mu (double -> float), score.c:1051
@@ -698,10 +1026,10 @@ int rc_batch_fit(const rc_batch *b, int32_t blk, int32_t *evd_rc, float *mu, flo
 }
 
 int rc_batch_fit_all(const rc_batch *b, float *out) {
-  if (!b || !out || !b->ran) return fail(RC_ERR_ARG, "batch has not been run");
-  for (size_t i = 0; i < b->hb.size(); i++) {
-    float *o = out + 4 * i;
-    if (b->hb[i].status != RC_OK) { o[0] = static_cast<float>(b->hb[i].status); o[1] = o[2] = o[3] = 0.0f; continue; }
+  if (!b || !out || b->state != rc_batch::DONE) return fail(RC_ERR_ARG, "batch has not been run");
+  for (int i = 0; i < b->n; i++) {
+    float *o = out + 4 * static_cast<size_t>(i);
+    if (b->meta[i].status != RC_OK) { o[0] = static_cast<float>(b->meta[i].status); o[1] = o[2] = o[3] = 0.0f; continue; }
     const FitOut &f = b->fit[i];
     o[0] = static_cast<float>(f.rc); o[1] = static_cast<float>(f.mu); o[2] = static_cast<float>(f.lambda);
     o[3] = static_cast<float>(f.better);
@@ -709,19 +1037,27 @@ int rc_batch_fit_all(const rc_batch *b, float *out) {
   return RC_OK;
 }
 
+// number of HSS records of a block (all six strand x frame lists)
+static int block_hss_count(const rc_batch *b, int blk) {
+  int n = 0;
+  for (int combo = 0; combo < 6; combo++) n += std::min(b->hssCount[static_cast<size_t>(blk) * 6 + combo], b->hssCap);
+  return n;
+}
+
 int rc_batch_hss(const rc_batch *b, int32_t blk, rc_hss *out, int32_t cap) {
   int r = check_blk(b, blk, true);
   if (r) return r;
-  const HostBlock &h = b->hb[blk];
+  const BlockMeta &h = b->meta[blk];
   if (h.status != RC_OK) return h.status;
   const FitOut &f = b->fit[blk];
   const float mu = static_cast<float>(f.mu), lambda = static_cast<float>(f.lambda);
   std::vector<rc_hss> all;
   for (int combo = 0; combo < 6; combo++) {   // '+' hits then '-' hits, frames ascending (score.c:1107-1127)
-    const int cnt = b->hssCount[static_cast<size_t>(blk) * 6 + combo];
+    const size_t slot = static_cast<size_t>(blk) * 6 + combo;
+    const int cnt = b->hssCount[slot];
     if (cnt > b->hssCap) return fail(RC_ERR_UNSUPPORTED, "HSS buffer overflow");
     for (int i = 0; i < cnt; i++) {
-      const DevHss &d = b->hss[(static_cast<size_t>(blk) * 6 + combo) * b->hssCap + i];
+      const DevHss &d = b->hssRec[static_cast<size_t>(b->hssOff[slot]) + i];
       if (!(d.score > 0.0f)) break;           // lists end at the first non-positive score (score.c:1112,1121)
       rc_hss o{};
       o.strand = d.strand ? '-' : '+';
@@ -746,14 +1082,13 @@ int rc_batch_hss(const rc_batch *b, int32_t blk, rc_hss *out, int32_t cap) {
 }
 
 int rc_batch_hss_all(const rc_batch *b, rc_hss *out, int64_t cap, int64_t *offsets) {
-  if (!b || !offsets || (!out && cap > 0) || !b->ran) return fail(RC_ERR_ARG, "batch has not been run");
+  if (!b || !offsets || (!out && cap > 0) || b->state != rc_batch::DONE) return fail(RC_ERR_ARG, "batch has not been run");
   int64_t total = 0;
   std::vector<rc_hss> tmp;
   for (int blk = 0; blk < b->n; blk++) {
     offsets[blk] = total;
-    if (b->hb[blk].status != RC_OK) continue;
-    int n = 0;
-    for (int combo = 0; combo < 6; combo++) n += std::min(b->hssCount[static_cast<size_t>(blk) * 6 + combo], b->hssCap);
+    if (b->meta[blk].status != RC_OK) continue;
+    const int n = block_hss_count(b, blk);
     if (n == 0) continue;
     tmp.resize(n);
     const int got = rc_batch_hss(b, blk, tmp.data(), n);
@@ -766,7 +1101,7 @@ int rc_batch_hss_all(const rc_batch *b, rc_hss *out, int64_t cap, int64_t *offse
 }
 
 int rc_batch_clamped(const rc_batch *b, int64_t *count) {
-  if (!b || !b->ran) return fail(RC_ERR_ARG, "batch has not been run");
+  if (!b || b->state != rc_batch::DONE) return fail(RC_ERR_ARG, "batch has not been run");
   *count = static_cast<int64_t>(b->clamped);
   return RC_OK;
 }
@@ -774,14 +1109,14 @@ int rc_batch_clamped(const rc_batch *b, int64_t *count) {
 int rc_batch_native_S(const rc_batch *b, int32_t blk, int32_t strand, int32_t frame, float *out, int32_t cap) {
   int r = check_blk(b, blk, true);
   if (r) return r;
-  const HostBlock &h = b->hb[blk];
+  const BlockMeta &h = b->meta[blk];
   if (h.status != RC_OK) return h.status;
   if (strand < 0 || strand > 1 || frame < 0 || frame > 2) return fail(RC_ERR_ARG, "bad strand/frame");
   const int sites = (h.L - frame) / 3, smax = h.L / 3;
   if (cap < sites * sites) return fail(RC_ERR_ARG, "output too small");
-  HIP_TRY(hipSetDevice(b->ctx->device));
+  HIP_TRY(hipSetDevice(b->device));
   if (sites > 0)
-    HIP_TRY(hipMemcpy(out, b->d_S + b->offS[blk] + static_cast<size_t>(strand * 3 + frame) * smax * smax,
+    HIP_TRY(hipMemcpy(out, b->dS.as<float>() + b->offS[blk] + static_cast<size_t>(strand * 3 + frame) * smax * smax,
                       sizeof(float) * sites * sites, hipMemcpyDeviceToHost));
   for (int a = 0; a < sites; a++)
     for (int j = 0; j < a; j++) out[a * sites + j] = 0.0f;
@@ -792,20 +1127,24 @@ int rc_batch_backtrack(const rc_batch *b, int32_t blk, int32_t strand, int32_t o
                        int32_t *states, int32_t *zout, int32_t *transitions) {
   int r = check_blk(b, blk, true);
   if (r) return r;
-  const HostBlock &h = b->hb[blk];
+  const BlockMeta &h = b->meta[blk];
   if (h.status != RC_OK) return h.status;
   if (strand < 0 || strand > 1 || opt_b < 1 || opt_i > h.L || opt_i < opt_b + 2 || (opt_i - opt_b - 2) % 3 != 0)
     return fail(RC_ERR_ARG, "bad backtrack range");
   rc_ctx *c = b->ctx;
   HIP_TRY(hipSetDevice(c->device));
   const int steps = (opt_i - (opt_b + 2)) / 3 + 1, NK = h.NK;
-  float *d_out = nullptr;
-  HIP_TRY(hipMalloc(&d_out, sizeof(float) * NK * 3 * steps));
-  launch_sk_row(b->d_blob, b->d_dblocks, blk, strand, opt_b, opt_i, d_out, steps, c->stream);
+  const DevBlock &d = b->db[blk];
+  const int L1 = h.L + 1, zww = d.zw_words;
+  const uint64_t *zw = reinterpret_cast<const uint64_t *>(b->hblob.as<uint8_t>() + d.off_zw) + static_cast<size_t>(strand) * L1 * zww;   // the batch keeps its pinned blob
+  DevBuf d_out;
+  HIP_TRY(d_out.ensure(sizeof(float) * NK * 3 * steps));
+  hipStream_t st = c->compute[0];
+  launch_sk_row(b->dblob.as<uint8_t>(), reinterpret_cast<const DevBlock *>(b->dblob.as<uint8_t>() + b->oDblocks), blk, strand, opt_b, opt_i,
+                d_out.as<float>(), steps, st);
   std::vector<float> sk(static_cast<size_t>(NK) * 3 * steps);
-  hipError_t e = hipStreamSynchronize(c->stream);   // the streams are non-blocking: a default-stream copy would not wait
-  if (e == hipSuccess) e = hipMemcpy(sk.data(), d_out, sk.size() * sizeof(float), hipMemcpyDeviceToHost);
-  hipFree(d_out);
+  hipError_t e = hipStreamSynchronize(st);   // the streams are non-blocking: a default-stream copy would not wait
+  if (e == hipSuccess) e = hipMemcpy(sk.data(), d_out.p, sk.size() * sizeof(float), hipMemcpyDeviceToHost);
   if (e != hipSuccess) return fail(RC_ERR_DEVICE, hipGetErrorString(e));
   const int pitch = h.cols + 1;
   for (int i = 0; i < h.N * pitch; i++) states[i] = zout[i] = transitions[i] = -9;
@@ -817,7 +1156,7 @@ int rc_batch_backtrack(const rc_batch *b, int32_t blk, int32_t strand, int32_t o
     int curr = -1, prev = -1, tr = -9;
     for (int x = 0; x < 3; x++) if (SK(x, steps - 1) > opt) { opt = SK(x, steps - 1); curr = x; }
     for (int t = steps - 1, i = opt_i; t >= 0; t--, i -= 3) {
-      const int zc = static_cast<int>((h.zw[strand][i] >> (2 * (k - 1))) & 3);
+      const int zc = static_cast<int>((zw[static_cast<size_t>(i) * zww + ((k - 1) >> 5)] >> (2 * ((k - 1) & 31))) & 3);
       const int z = zc == 0 ? 0 : (zc == 1 ? 1 : -1);
       const float p0 = SK(0, t - 1), p1 = SK(1, t - 1), p2 = SK(2, t - 1);
       if (z == 0) { prev = curr; tr = 0; }
@@ -972,17 +1311,17 @@ int rc_fit_trees_device(rc_ctx *c, const rc_block *blocks, int32_t n_blocks, cha
   HIP_TRY(hipMalloc(&d_in.p, in.size()));
   HIP_TRY(hipMalloc(&d_work.p, sizeof(double) * maxChunk));
   HIP_TRY(hipMalloc(&d_out.p, sizeof(TreeOut) * nj));
-  HIP_TRY(hipMemcpyAsync(d_jobs.p, jobs.data(), sizeof(TreeJob) * nj, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(d_in.p, in.data(), in.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(d_jobs.p, jobs.data(), sizeof(TreeJob) * nj, hipMemcpyHostToDevice, c->compute[0]));
+  HIP_TRY(hipMemcpyAsync(d_in.p, in.data(), in.size(), hipMemcpyHostToDevice, c->compute[0]));
   for (size_t ch = 0; ch + 1 < chunkStart.size(); ch++) {
     const int q0 = chunkStart[ch], q1 = chunkStart[ch + 1];
     launch_tree_fit(static_cast<const TreeJob *>(d_jobs.p) + q0, q1 - q0, static_cast<const uint8_t *>(d_in.p), static_cast<double *>(d_work.p),
-                    static_cast<TreeOut *>(d_out.p) + q0, c->stream);
+                    static_cast<TreeOut *>(d_out.p) + q0, c->compute[0]);
   }
   HIP_TRY(hipGetLastError());
   std::vector<TreeOut> out(nj);
-  HIP_TRY(hipMemcpyAsync(out.data(), d_out.p, sizeof(TreeOut) * nj, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemcpyAsync(out.data(), d_out.p, sizeof(TreeOut) * nj, hipMemcpyDeviceToHost, c->compute[0]));
+  HIP_TRY(hipStreamSynchronize(c->compute[0]));
   int done = 0;
   for (int q = 0; q < nj; q++) {
     const int i = owner[q];
@@ -1009,6 +1348,8 @@ int rc_tree_lnl(const rc_block *blk, double *lnl_out) {
   return RC_OK;
 }
 
+float rc_pvalue(float score, float mu, float lambda) { return pvalue_of(score, mu, lambda); }
+
 int rc_evd_fit(rc_ctx *c, const double *x, int32_t n, double *mu, double *lambda) {
   if (!c || !x || n < 1) return fail(RC_ERR_ARG, "bad argument");
   HIP_TRY(hipSetDevice(c->device));
@@ -1017,9 +1358,9 @@ int rc_evd_fit(rc_ctx *c, const double *x, int32_t n, double *mu, double *lambda
   HIP_TRY(hipMalloc(&d_x, sizeof(double) * n));
   HIP_TRY(hipMalloc(&d_o, sizeof(FitOut)));
   HIP_TRY(hipMemcpy(d_x, x, sizeof(double) * n, hipMemcpyHostToDevice));
-  launch_evd_fit_f64(d_x, n, d_o, c->stream);
+  launch_evd_fit_f64(d_x, n, d_o, c->compute[0]);
   FitOut o;
-  hipError_t e = hipStreamSynchronize(c->stream);
+  hipError_t e = hipStreamSynchronize(c->compute[0]);
   if (e == hipSuccess) e = hipMemcpy(&o, d_o, sizeof o, hipMemcpyDeviceToHost);
   hipFree(d_x); hipFree(d_o);
   if (e != hipSuccess) return fail(RC_ERR_DEVICE, hipGetErrorString(e));
@@ -1033,8 +1374,8 @@ int rc_mt_stream(rc_ctx *c, uint32_t seed, uint32_t *out, int32_t n) {
   HIP_TRY(hipSetDevice(c->device));
   uint32_t *d = nullptr;
   HIP_TRY(hipMalloc(&d, sizeof(uint32_t) * n));
-  launch_mt_stream(seed, 1, n, d, c->stream);
-  hipError_t e = hipStreamSynchronize(c->stream);
+  launch_mt_stream(seed, 1, n, d, c->compute[0]);
+  hipError_t e = hipStreamSynchronize(c->compute[0]);
   if (e == hipSuccess) e = hipMemcpy(out, d, sizeof(uint32_t) * n, hipMemcpyDeviceToHost);
   hipFree(d);
   if (e != hipSuccess) return fail(RC_ERR_DEVICE, hipGetErrorString(e));

@@ -1,18 +1,23 @@
 // rc_device.h -- data layout shared by the host-side block preparation and the HIP kernels.
 //
 // Everything that is constant for one alignment block (tree, HKY thresholds, gap pattern,
-// expected-score tables) is packed by the host into one byte blob per batch; a DevBlock header
-// per block holds offsets into that blob.  See DESIGN.md "Data layout in HBM".
+// background-model inputs) is packed by the host into one byte blob per batch; a DevBlock header
+// per block holds offsets into that blob.  The blob has two parts: the host-written part, which is
+// the only thing that crosses PCIe (one copy per batch), and a device-only arena behind it for the
+// tables the GPU derives itself (expected-score look-up tables, native sigma).
+// See DESIGN.md "Data layout in HBM".
 #pragma once
 #include <cstdint>
 
 namespace rc {
 
-constexpr int kMaxRows = 32;      // N <= 32 (RC_MAX_ROWS)
+constexpr int kMaxRows = 64;      // N <= 64 (RC_MAX_ROWS)
+constexpr int kFastRows = 32;     // N <= 32: register-resident kernels (k_null<N-1>, k_native_dp<N-1>); above: the wide kernels
 constexpr int kMaxNodes = 2 * kMaxRows;
 constexpr int kWave = 64;         // CDNA wavefront
 constexpr int kLutSize = 64;      // sigma codes are indices into a 64-entry per-(strand,k) table
-constexpr int kPhaseALds = kMaxNodes * 64 + 64 * 64;   // k_null phase A: threshold table + codon-pair table (bytes)
+constexpr int kFastNodes = 2 * kFastRows;
+constexpr int kPhaseALds = kFastNodes * 64 + 64 * 64;   // k_null phase A: threshold table + codon-pair table (bytes)
 
 // One node of the guide tree in Seq-Gen's evolution order (seqgen/evolve.c:400-433: pre-order,
 // branch1, branch2, then branch0 of an unrooted root).  thr[p][j]: integer form of the
@@ -30,27 +35,49 @@ struct alignas(16) NodeRec {
 };
 static_assert(sizeof(NodeRec) == 80, "NodeRec layout");
 
+// Background model of one (strand, row) (bgModel, score.h:34-44).  The host fills the HKY85 matrix
+// P (probHKY needs libm's exp), freqs, kappa and dist; k_prep_models runs calculateBG's two
+// 4096-term accumulations (score.c:107-193) and fills scores and probs.
+struct alignas(16) ModelRec {
+  float P[16];         // P[4*i + j] = probHKY(i, j, dist, freqs, kappa)
+  float scores[4];
+  float probs[4];
+  float kappa, dist;
+  float freqs[4];
+  float pad[2];
+};
+static_assert(sizeof(ModelRec) == 128, "ModelRec layout");
+
 struct DevBlock {
   int32_t N, NK, cols, L;
   int32_t nnodes, status, ref_start, ref_length;
   float Delta, Omega, omega, nkf;          // nkf = (float)(N-1)
   float stop0, stopk;
   int32_t code_zero, code_stop0, code_stopk;         // sigma-code values of the special cases
-  int32_t exact_div;                                 // 1: score tables outside the range proven for div_by_nk -> use '/'
-  // offsets (bytes) into the batch blob
-  uint32_t off_nodes;    // NodeRec[nnodes]
-  uint32_t off_qtip;     // u8[32]       node index of row r's tip (padded: k_null reads words)
-  uint32_t off_refcol;   // u16[2][L+1]  strand s: 0-based column of reference residue i (1..L) in that strand's alignment
-  uint32_t off_zw;       // u64[2][L+1]  2 bits per k (bit 2(k-1)): 0 -> z=0, 1 -> z=+1, 2 -> z=-1
-  uint32_t off_mask;     // u32[2][L+1][ceil(NK/5)] 6-bit AND masks (field k%5 of word k/5) zeroing the codon fields where row k has '-'
-  uint32_t off_lut;      // f32[2][NK][64] sigma value per code
-  uint32_t off_chars;    // u8[2][N][cols] native characters (strand 1 = reverse complement, rnaz_utils.c:316)
-  uint32_t off_sigma;    // f32[2][NK][L+1] native sigma (written by k_native_sigma)
-  uint32_t out_index;    // position of this block in the batch (rows of the maxima matrix)
-  uint32_t off_zmask;    // u64[2][3][zm_words] bit j of (strand, frame): some sequence has z != 0 at codon site j
+  int32_t zw_words;      // 64-bit words per z entry: ceil(NK / 32)
   int32_t zm_words;      // ceil((L/3) / 64)
-  uint32_t pad1[1];
+  uint32_t out_index;    // position of this block in the batch (rows of the maxima matrix)
+  // offsets (bytes) into the batch blob; host-written part
+  uint64_t off_nodes;    // NodeRec[nnodes]
+  uint64_t off_qtip;     // u8[kMaxRows] node index of row r's tip (padded: k_null reads words)
+  uint64_t off_refcol;   // u16[2][L+1]  strand s: 0-based column of reference residue i (1..L) in that strand's alignment
+  uint64_t off_zw;       // u64[2][L+1][zw_words]  2 bits per k (bit 2((k-1)%32) of word (k-1)/32): 0 -> z=0, 1 -> z=+1, 2 -> z=-1
+  uint64_t off_mask;     // u32[2][L+1][ceil(NK/5)] 6-bit AND masks (field k%5 of word k/5) zeroing the codon fields where row k has '-'
+  uint64_t off_chars;    // u8[2][N][cols] native characters (strand 1 = reverse complement, rnaz_utils.c:316)
+  uint64_t off_zmask;    // u64[2][3][zm_words] bit j of (strand, frame): some sequence has z != 0 at codon site j
+  uint64_t off_models;   // ModelRec[2][N]
+  // device-only arena
+  uint64_t off_lut;      // f32[2][NK][64] sigma value per code (k_prep_lut)
+  uint64_t off_sigma;    // f32[2][NK][L+1] native sigma (k_native_sigma)
 };
+
+// per-block flag word (device array next to the DevBlocks)
+constexpr uint32_t kFlagExact = 1u;     // score tables outside the range proven for div_by_nk -> scored by the EXACT instantiation
+constexpr uint32_t kFlagStopped = 2u;   // --stop-early: enough samples beat the native score, the remaining ones are not simulated
+
+// what a sigma code means (PairTable, shared by all blocks of a context): kind 0 unused, 1 score code
+// (value = b - scores[h]), 2 zero, 3 stop in the reference codon, 4 stop in the other codon
+struct CodeInfo { int8_t kind, b, h, pad; };
 
 // HSS record produced by the native scan kernel
 struct DevHss {

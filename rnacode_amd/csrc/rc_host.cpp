@@ -2,7 +2,8 @@
 //
 // What the reference computes once per alignment block before / around the hot loops is
 // restated here from its arithmetic definition and turned into the tables the kernels read:
-//   background models      score.c:107-344 (calculateBG, probHKY, countFreqsMono, getModels)
+//   background models      score.c:204-344 (probHKY, countFreqsMono, getModels; calculateBG's two 4096-term
+//                          accumulations run on the device, k_prep_models)
 //   tip distances          treeSimulate.c:118-251
 //   Newick reader          seqgen/treefile.c:301-530
 //   HKY85 branch matrices  seqgen/nucmodels.c:87-131,187-196,302-362, model.c:116-119
@@ -104,17 +105,22 @@ bool parse_newick(const char *s, Tree &t, std::string &err) {
 
 // ---------------------------------------------------------------------------------- models
 
-// countFreqsMono (score.c:255-280): all rows, '-' skipped, unknown characters count as A
-static void mono_freqs(const std::vector<std::string> &rows, float freqs[4]) {
-  unsigned long cnt[4] = {0, 0, 0, 0}, total = 0;
-  for (const auto &r : rows)
-    for (unsigned char c : r) {
-      if (c == '-') continue;
-      cnt[nt_code(c)]++;
-      total++;
-    }
+// countFreqsMono (score.c:255-280): all rows, '-' skipped, unknown characters count as A.  One pass over the
+// forward rows gives both strands: the reverse complement (rnaz_utils.c:316-348) maps T,U->A, A->T, C<->G and
+// leaves everything else -- which the count files under A -- unchanged.
+static void mono_freqs_both(const uint8_t *chars, size_t nchars, float fwd[4], float rev[4]) {
+  unsigned long cnt[256];
+  std::memset(cnt, 0, sizeof cnt);
+  for (size_t i = 0; i < nchars; i++) cnt[chars[i]]++;
+  const unsigned long total = static_cast<unsigned long>(nchars) - cnt[static_cast<unsigned char>('-')];
+  const unsigned long c = cnt['C'], g = cnt['G'], t = cnt['T'] + cnt['U'], a = cnt['A'];
+  const unsigned long other = total - a - c - g - t;       // N and the rest: index 0 on both strands
+  const unsigned long f[4] = {a + other, c, g, t}, r[4] = {t + other, g, c, a};
   // the reference increments float counters; counts stay far below 2^24 so they are exact
-  for (int i = 0; i < 4; i++) freqs[i] = static_cast<float>(cnt[i]) / static_cast<float>(total);
+  for (int i = 0; i < 4; i++) {
+    fwd[i] = static_cast<float>(f[i]) / static_cast<float>(total);
+    rev[i] = static_cast<float>(r[i]) / static_cast<float>(total);
+  }
 }
 
 // patristic distance row 0 <-> every row, float accumulator += double length (treeSimulate.c:164-182)
@@ -137,7 +143,8 @@ static bool tip_distances(const Tree &t, const std::vector<int> &rowtip, std::ve
 }
 
 // probHKY (score.c:204-244) for all 16 entries at once
-static void hky_probs(float d, const float pi[4], float kappa, float P[4][4]) {
+static void hky_probs(float d, const float pi[4], float kappa, float *Pf) {
+  float (*P)[4] = reinterpret_cast<float (*)[4]>(Pf);
   const float piA = pi[0], piC = pi[1], piG = pi[2], piT = pi[3];
   const float piR = piA + piG;
   const float piY = piT + piC;
@@ -174,42 +181,6 @@ static void hky_probs(float d, const float pi[4], float kappa, float P[4][4]) {
   P[0][3] = P[2][3] = tv(piT);
   P[1][0] = P[3][0] = tv(piA);
   P[1][2] = P[3][2] = tv(piG);
-}
-
-// calculateBG (score.c:107-193): two 4096-term float accumulations in the loop order a1,a2,a3,b1,b2,b3
-static void expected_scores(rc_model &m, const CodeTables &ct) {
-  float P[4][4];
-  hky_probs(m.dist, m.freqs, m.kappa, P);
-  float fA[64], pAB;
-  for (int a = 0; a < 64; a++) fA[a] = m.freqs[a >> 4] * m.freqs[(a >> 2) & 3] * m.freqs[a & 3];
-  float probStop = 0.0f;
-  for (int a = 0; a < 64; a++)
-    for (int b = 0; b < 64; b++) {
-      if (ct.pep[a] != -1 && ct.pep[b] != -1) continue;
-      pAB = P[a >> 4][b >> 4] * P[(a >> 2) & 3][(b >> 2) & 3] * P[a & 3][b & 3];
-      pAB = pAB * fA[a];
-      probStop = probStop + pAB;
-    }
-  float counts[4] = {0, 0, 0, 0}, scores[4] = {0, 0, 0, 0};
-  const float keep = 1.0f - probStop;   // (1 - probStop): int 1 converted to float
-  for (int a = 0; a < 64; a++) {
-    if (ct.pep[a] == -1) continue;
-    for (int b = 0; b < 64; b++) {
-      if (ct.pep[b] == -1) continue;
-      const int x = a ^ b;
-      const int h = ((x & 48) != 0) + ((x & 12) != 0) + ((x & 3) != 0);
-      pAB = P[a >> 4][b >> 4] * P[(a >> 2) & 3][(b >> 2) & 3] * P[a & 3][b & 3];
-      pAB = pAB * fA[a];
-      pAB = pAB / keep;
-      const float sc = static_cast<float>(ct.blosum[ct.pep[a]][ct.pep[b]]);
-      counts[h] = counts[h] + pAB;
-      scores[h] = scores[h] + sc * pAB;
-    }
-  }
-  for (int h = 0; h < 4; h++) {
-    m.scores[h] = scores[h] / counts[h];
-    m.probs[h] = counts[h];
-  }
 }
 
 // ---------------------------------------------------------------------------------- Seq-Gen HKY85
@@ -265,12 +236,12 @@ int64_t threshold_of(double P) {
   const double c = 1.0 / 4294967295.0;
   if (!(0.0 <= P)) return -1;
   if (4294967295.0 * c <= P) return 4294967295LL;
-  int64_t lo = 0, hi = 4294967295LL;   // lo satisfies u*c <= P, hi does not
-  while (hi - lo > 1) {
-    const int64_t mid = lo + (hi - lo) / 2;
-    if (static_cast<double>(static_cast<uint32_t>(mid)) * c <= P) lo = mid; else hi = mid;
-  }
-  return lo;
+  // u -> fl(u * c) is non-decreasing, so the answer is next to P / c: start there and step to the boundary
+  int64_t u = static_cast<int64_t>(P * 4294967295.0);
+  if (u > 4294967295LL) u = 4294967295LL;
+  while (u < 4294967295LL && static_cast<double>(static_cast<uint32_t>(u + 1)) * c <= P) u++;
+  while (u > 0 && static_cast<double>(static_cast<uint32_t>(u)) * c > P) u--;
+  return u;
 }
 
 void pack_thresholds(const double cum[4], U4 *out, uint32_t *base) {
@@ -331,36 +302,53 @@ void PairTable::build(const CodeTables &ct) {
   code_zero = slot[3 * nB]; code_stop0 = slot[3 * nB + 1]; code_stopk = slot[3 * nB + 2];
   for (int a = 0; a < 64; a++)
     for (int b = 0; b < 64; b++) pair[a * 64 + b] = static_cast<uint8_t>(slot[natural(a, b)]);
+  for (int code = 0; code < 64; code++) {
+    CodeInfo &ci = info[code];
+    ci = CodeInfo{0, 0, 0, 0};
+    if (is_score_code(code)) ci = CodeInfo{1, static_cast<int8_t>(b_of_code(code)), static_cast<int8_t>(h_of_code(code)), 0};
+    else if (code == code_zero) ci.kind = 2;
+    else if (code == code_stop0) ci.kind = 3;
+    else if (code == code_stopk) ci.kind = 4;
+  }
 }
 
 // ---------------------------------------------------------------------------------- gap pattern
 
 // getBlock (misc.c:186-246) reduced to what depends on the gap pattern only: z for every
 // reference position i >= 3 and sequence k, and which of the three codon columns are '-' in k.
-static void gap_tables(const std::vector<std::string> &rows, int L, std::vector<uint16_t> &refcol,
-                       std::vector<uint64_t> &zw, std::vector<uint8_t> &mask) {
-  const int N = static_cast<int>(rows.size()), NK = N - 1;
-  const std::string &r0 = rows[0];
-  refcol.assign(L + 1, 0);
-  for (int c = 0, p = 0; c < static_cast<int>(r0.size()); c++)
+// rows: [N][cols] characters of one strand.  gp is scratch: [N][cols+1] prefix counts of '-'.
+static void gap_tables(const uint8_t *rows, int N, int cols, int L, int zwWords, int ncw, uint16_t *refcol, uint64_t *zw,
+                       uint32_t *maskw, std::vector<uint16_t> &gp) {
+  const int NK = N - 1, L1 = L + 1;
+  const uint8_t *r0 = rows;
+  refcol[0] = 0;
+  for (int c = 0, p = 0; c < cols; c++)
     if (r0[c] != '-') { p++; if (p <= L) refcol[p] = static_cast<uint16_t>(c); }
-  zw.assign(L + 1, 0);
-  mask.assign(static_cast<size_t>(NK) * (L + 1), 0);
+  gp.resize(static_cast<size_t>(N) * (cols + 1));
+  for (int r = 0; r < N; r++) {
+    uint16_t *g = gp.data() + static_cast<size_t>(r) * (cols + 1);
+    const uint8_t *row = rows + static_cast<size_t>(r) * cols;
+    uint16_t acc = 0;
+    g[0] = 0;
+    for (int c = 0; c < cols; c++) { acc = static_cast<uint16_t>(acc + (row[c] == '-')); g[c + 1] = acc; }
+  }
+  std::memset(zw, 0, sizeof(uint64_t) * L1 * zwWords);
+  std::memset(maskw, 0, sizeof(uint32_t) * L1 * ncw);
   for (int i = 3; i <= L; i++) {
     const int start = (i > 3) ? refcol[i - 3] + 1 : 0, end = refcol[i];
-    int g0 = 0;
-    for (int c = start; c <= end; c++) g0 += (r0[c] == '-');
-    for (int k = 1; k < N; k++) {
-      const std::string &rk = rows[k];
-      int gk = 0;
-      for (int c = start; c <= end; c++) gk += (rk[c] == '-');
-      const int diff = std::abs(gk - g0) % 3;                     // misc.c:230-244
-      zw[i] |= static_cast<uint64_t>(diff) << (2 * (k - 1));      // 0 -> z=0, 1 -> z=+1, 2 -> z=-1
-      uint8_t m = 0;
-      if (rk[refcol[i - 2]] != '-') m |= 0x30;
-      if (rk[refcol[i - 1]] != '-') m |= 0x0C;
-      if (rk[refcol[i]] != '-') m |= 0x03;
-      mask[static_cast<size_t>(k - 1) * (L + 1) + i] = m;
+    const int g0 = gp[end + 1] - gp[start];
+    const int c2 = refcol[i - 2], c1 = refcol[i - 1], c0 = refcol[i];
+    for (int k = 0; k < NK; k++) {
+      const uint16_t *g = gp.data() + static_cast<size_t>(k + 1) * (cols + 1);
+      const uint8_t *rk = rows + static_cast<size_t>(k + 1) * cols;
+      const int gk = g[end + 1] - g[start];
+      const int diff = std::abs(gk - g0) % 3;                     // misc.c:230-244: 0 -> z=0, 1 -> z=+1, 2 -> z=-1
+      zw[static_cast<size_t>(i) * zwWords + (k >> 5)] |= static_cast<uint64_t>(diff) << (2 * (k & 31));
+      uint32_t m = 0;
+      if (rk[c2] != '-') m |= 0x30;
+      if (rk[c1] != '-') m |= 0x0C;
+      if (rk[c0] != '-') m |= 0x03;
+      maskw[static_cast<size_t>(i) * ncw + k / 5] |= m << (6 * (k % 5));
     }
   }
 }
@@ -372,112 +360,193 @@ static void gap_tables(const std::vector<std::string> &rows, int L, std::vector<
 // sum has |x| >= 2^-99; with fewer than 2^20 terms |x| < 2^60.  That lies inside the range
 // [2^-100, 2^100) in which the kernel's 3-instruction division by N-1 was proven equal to IEEE
 // division by exhaustion (tools/verify_const_div.c).  Anything else (denormal or astronomically
-// large penalties) is scored by the kernel instantiation that uses '/'.
+// large penalties) is scored by the kernel instantiation that uses '/'.  The gap parameters are
+// checked here; the expected-score tables are checked where they are made (k_prep_lut, same test).
 static bool in_div_range(float v) {
   const float a = std::fabs(v);
   return a == 0.0f || (a >= 1.3234889800848443e-23f && a < 1099511627776.0f);
 }
 
-int prepare_block(const rc_block &in, const rc_params &par, const CodeTables &ct, const PairTable &pt,
-                  HostBlock &hb, std::string &err) {
-  hb = HostBlock();
-  const int N = in.n_rows, cols = in.n_cols;
-  if (N < 1 || cols < 1 || !in.rows || !in.names) { err = "empty block"; return hb.status = RC_ERR_ARG; }
-  hb.N = N; hb.NK = N - 1; hb.cols = cols;
-  hb.ref_start = in.ref_start; hb.ref_length = in.ref_length;
-  hb.rows[0].resize(N);
-  for (int r = 0; r < N; r++) {
-    if (!in.rows[r] || static_cast<int>(std::strlen(in.rows[r])) != cols) { err = "Sequences are of unequal length."; return hb.status = RC_ERR_ARG; }
-    hb.rows[0][r].assign(in.rows[r], cols);
-    for (auto &c : hb.rows[0][r]) c = static_cast<char>(std::toupper(static_cast<unsigned char>(c)));  // RNAcode.c:121-128
-  }
-  int L = 0;
-  for (char c : hb.rows[0][0]) L += (c != '-');                   // getSeqLength, misc.c:272-289
-  hb.L = L;
-  if (N <= 2 || L < 3) return hb.status = RC_ERR_SKIP;             // RNAcode.c:142-150
-  if (N > kMaxRows) { err = "more than RC_MAX_ROWS rows"; return hb.status = RC_ERR_UNSUPPORTED; }
-  if (cols > 65535) { err = "more than 65535 columns"; return hb.status = RC_ERR_UNSUPPORTED; }
+bool params_in_fast_range(const rc_params &par) {
+  if (!in_div_range(par.Delta) || !in_div_range(par.Omega) || !in_div_range(par.omega)) return false;
+  if (!in_div_range(par.stopPenalty_0) || !in_div_range(par.stopPenalty_k)) return false;
+  return par.Delta < 0.0f;   // the fast kernel drops MAX3(sum, Delta, Delta): only valid for Delta < 0
+}
 
-  // reverse complement (rnaz_utils.c:316-348): T,U->A  A->T  C<->G, everything else unchanged
-  hb.rows[1].resize(N);
-  for (int r = 0; r < N; r++) {
-    std::string &d = hb.rows[1][r];
-    d.resize(cols);
-    for (int j = 0; j < cols; j++) {
-      char c = hb.rows[0][r][cols - 1 - j];
-      switch (c) { case 'T': case 'U': c = 'A'; break; case 'A': c = 'T'; break; case 'C': c = 'G'; break; case 'G': c = 'C'; break; default: break; }
-      d[j] = c;
-    }
+static inline size_t al16(size_t x) { return (x + 15) & ~static_cast<size_t>(15); }
+
+namespace {
+// section sizes of one block in the two blob parts
+struct Sections {
+  size_t nodes, qtip, refcol, zw, mask, chars, zmask, models, hostTotal;
+  size_t lut, sigma, devTotal;
+  Sections(int N, int cols, int L, int nnodes) {
+    const size_t NK = static_cast<size_t>(N) - 1, L1 = static_cast<size_t>(L) + 1, ncw = (NK + 4) / 5, zww = (NK + 31) / 32;
+    const size_t zmw = (static_cast<size_t>(L) / 3 + 63) / 64;
+    nodes = al16(static_cast<size_t>(nnodes) * sizeof(NodeRec));
+    qtip = al16(kMaxRows);
+    refcol = al16(2 * L1 * 2);
+    zw = al16(2 * L1 * zww * 8);
+    mask = al16(2 * L1 * ncw * 4);
+    chars = al16(2 * static_cast<size_t>(N) * cols);
+    zmask = al16(6 * zmw * 8);
+    models = al16(2 * static_cast<size_t>(N) * sizeof(ModelRec));
+    hostTotal = nodes + qtip + refcol + zw + mask + chars + zmask + models;
+    lut = al16(2 * NK * kLutSize * 4);
+    sigma = al16(2 * NK * L1 * 4);
+    devTotal = lut + sigma;
   }
+};
+}  // namespace
+
+void block_footprint(int N, int cols, size_t *hostBytes, size_t *devBytes) {
+  if (N < 3 || cols < 3) { *hostBytes = 0; *devBytes = 0; return; }
+  const Sections s(N, cols, cols, 2 * N - 1);
+  *hostBytes = s.hostTotal;
+  *devBytes = s.devTotal;
+}
+
+int prepare_block(const rc_block &in, const rc_params &par, const PairTable &pt, BlobArena &arena, uint32_t out_index,
+                  DevBlock &d, BlockMeta &meta, std::string &err) {
+  std::memset(&d, 0, sizeof d);
+  d.out_index = out_index;
+  meta = BlockMeta();
+  auto done = [&](int st) { meta.status = st; d.status = st; return st; };
+  const int N = in.n_rows, cols = in.n_cols;
+  if (N < 1 || cols < 1 || !in.rows || !in.names) { err = "empty block"; return done(RC_ERR_ARG); }
+  meta.N = N; meta.NK = N - 1; meta.cols = cols;
+  meta.ref_start = in.ref_start; meta.ref_length = in.ref_length;
+  for (int r = 0; r < N; r++)
+    if (!in.rows[r] || static_cast<int>(strnlen(in.rows[r], static_cast<size_t>(cols) + 1)) != cols) { err = "Sequences are of unequal length."; return done(RC_ERR_ARG); }
+  int L = 0;
+  for (int c = 0; c < cols; c++) L += (in.rows[0][c] != '-');   // getSeqLength, misc.c:272-289
+  meta.L = L;
+  if (N <= 2 || L < 3) return done(RC_ERR_SKIP);                 // RNAcode.c:142-150
+  if (N > kMaxRows) { err = "more than RC_MAX_ROWS rows"; return done(RC_ERR_UNSUPPORTED); }
+  if (cols > 65535) { err = "more than 65535 columns"; return done(RC_ERR_UNSUPPORTED); }
 
   Tree t;
-  if (!parse_newick(in.newick, t, err)) return hb.status = RC_ERR_ARG;
-  if (static_cast<int>(t.tipname.size()) != N) { err = "tree and alignment differ in the number of sequences"; return hb.status = RC_ERR_ARG; }
-  if (t.nnodes > kMaxNodes) { err = "tree too large"; return hb.status = RC_ERR_UNSUPPORTED; }
-  std::vector<int> rowtip(N, -1);
-  for (int r = 0; r < N; r++) {
-    for (int k = 0; k < N; k++) if (t.tipname[k] == in.names[r]) { rowtip[r] = k; break; }
-    if (rowtip[r] < 0) { err = std::string("row name not found in tree: ") + in.names[r]; return hb.status = RC_ERR_ARG; }
-  }
+  if (!parse_newick(in.newick, t, err)) return done(RC_ERR_ARG);
+  if (static_cast<int>(t.tipname.size()) != N) { err = "tree and alignment differ in the number of sequences"; return done(RC_ERR_ARG); }
+  if (t.nnodes > kMaxNodes) { err = "tree too large"; return done(RC_ERR_UNSUPPORTED); }
+  int rowtip[kMaxRows];
   {
-    std::vector<char> used(N, 0);
-    for (int r = 0; r < N; r++) { if (used[rowtip[r]]) { err = "duplicate row names"; return hb.status = RC_ERR_ARG; } used[rowtip[r]] = 1; }
+    bool used[kMaxRows] = {false};
+    for (int r = 0; r < N; r++) {
+      rowtip[r] = -1;
+      if (!in.names[r]) { err = "row without a name"; return done(RC_ERR_ARG); }
+      for (int k = 0; k < N; k++) if (t.tipname[k] == in.names[r]) { rowtip[r] = k; break; }
+      if (rowtip[r] < 0) { err = std::string("row name not found in tree: ") + in.names[r]; return done(RC_ERR_ARG); }
+      if (used[rowtip[r]]) { err = "duplicate row names"; return done(RC_ERR_ARG); }
+      used[rowtip[r]] = true;
+    }
   }
 
-  // getModels for both strands (RNAcode.c:164-165)
+  // this block's share of the blob
+  const int NK = N - 1, L1 = L + 1, ncw = (NK + 4) / 5, zww = (NK + 31) / 32, zmw = (L / 3 + 63) / 64;
+  const Sections sec(N, cols, L, t.nnodes);
+  const size_t hoff = arena.hostUsed.fetch_add(sec.hostTotal), doff = arena.devUsed.fetch_add(sec.devTotal);
+  if (hoff + sec.hostTotal > arena.hostCap || doff + sec.devTotal > arena.devCap) { err = "internal: blob arena too small"; return done(RC_ERR_ARG); }
+  uint8_t *base = arena.host;
+  size_t o = hoff;
+  d.off_nodes = o; o += sec.nodes;
+  d.off_qtip = o; o += sec.qtip;
+  d.off_refcol = o; o += sec.refcol;
+  d.off_zw = o; o += sec.zw;
+  d.off_mask = o; o += sec.mask;
+  d.off_chars = o; o += sec.chars;
+  d.off_zmask = o; o += sec.zmask;
+  d.off_models = o; o += sec.models;
+  d.off_lut = arena.hostCap + doff;
+  d.off_sigma = d.off_lut + sec.lut;
+
+  d.N = N; d.NK = NK; d.cols = cols; d.L = L;
+  d.nnodes = t.nnodes;
+  d.ref_start = in.ref_start; d.ref_length = in.ref_length;
+  d.Delta = par.Delta; d.Omega = par.Omega; d.omega = par.omega;
+  d.nkf = static_cast<float>(NK);
+  d.stop0 = par.stopPenalty_0; d.stopk = par.stopPenalty_k;
+  d.code_zero = pt.code_zero; d.code_stop0 = pt.code_stop0; d.code_stopk = pt.code_stopk;
+  d.zw_words = zww; d.zm_words = zmw;
+
+  // characters: upper-cased forward rows (RNAcode.c:121-128), then the reverse complement
+  // (rnaz_utils.c:316-348): T,U->A  A->T  C<->G, everything else unchanged
+  uint8_t *chars = base + d.off_chars;
+  for (int r = 0; r < N; r++) {
+    uint8_t *dst = chars + static_cast<size_t>(r) * cols;
+    const char *src = in.rows[r];
+    for (int c = 0; c < cols; c++) dst[c] = static_cast<uint8_t>(std::toupper(static_cast<unsigned char>(src[c])));
+    uint8_t *rv = chars + (static_cast<size_t>(N) + r) * cols;
+    for (int j = 0; j < cols; j++) {
+      uint8_t c = dst[cols - 1 - j];
+      switch (c) { case 'T': case 'U': c = 'A'; break; case 'A': c = 'T'; break; case 'C': c = 'G'; break; case 'G': c = 'C'; break; default: break; }
+      rv[j] = c;
+    }
+  }
+
+  // getModels' inputs for both strands (RNAcode.c:164-165); scores and probs follow on the device
+  std::vector<int> rt(rowtip, rowtip + N);
   std::vector<float> dist;
-  tip_distances(t, rowtip, dist);
-  for (int s = 0; s < 2; s++) {
-    float freqs[4];
-    mono_freqs(hb.rows[s], freqs);
-    hb.models[s].resize(N);
+  tip_distances(t, rt, dist);
+  float freqs[2][4];
+  mono_freqs_both(chars, static_cast<size_t>(N) * cols, freqs[0], freqs[1]);
+  ModelRec *models = reinterpret_cast<ModelRec *>(base + d.off_models);
+  for (int s = 0; s < 2; s++)
     for (int j = 0; j < N; j++) {
-      rc_model &m = hb.models[s][j];
+      ModelRec &m = models[s * N + j];
+      std::memset(&m, 0, sizeof m);
       m.dist = dist[j];
       m.kappa = in.kappa;
-      std::memcpy(m.freqs, freqs, sizeof freqs);
-      expected_scores(m, ct);
+      std::memcpy(m.freqs, freqs[s], sizeof m.freqs);
+      hky_probs(m.dist, m.freqs, m.kappa, m.P);
     }
-    gap_tables(hb.rows[s], L, hb.refcol[s], hb.zw[s], hb.mask[s]);
-    hb.lut[s].assign(static_cast<size_t>(hb.NK) * kLutSize, 0.0f);
-    for (int k = 1; k < N; k++) {
-      float *lut = &hb.lut[s][static_cast<size_t>(k - 1) * kLutSize];
-      for (int code = 0; code < kLutSize; code++) {   // (float)matrix[pepA][pepB] - scores[h], score.c:422-425
-        if (!pt.is_score_code(code)) continue;
-        lut[code] = static_cast<float>(pt.b_of_code(code)) - hb.models[s][k].scores[pt.h_of_code(code)];
-      }
-      lut[pt.code_zero] = 0.0f;
-      lut[pt.code_stop0] = par.stopPenalty_0;
-      lut[pt.code_stopk] = par.stopPenalty_k;
-      for (int code = 0; code < kLutSize; code++) if (!in_div_range(lut[code])) hb.exact_div = 1;
+
+  // gap pattern of both strands
+  {
+    static thread_local std::vector<uint16_t> gp;
+    uint16_t *refcol = reinterpret_cast<uint16_t *>(base + d.off_refcol);
+    uint64_t *zw = reinterpret_cast<uint64_t *>(base + d.off_zw);
+    uint32_t *maskw = reinterpret_cast<uint32_t *>(base + d.off_mask);
+    uint64_t *zm = reinterpret_cast<uint64_t *>(base + d.off_zmask);
+    std::memset(zm, 0, sizeof(uint64_t) * 6 * zmw);
+    for (int s = 0; s < 2; s++) {
+      uint64_t *zws = zw + static_cast<size_t>(s) * L1 * zww;
+      gap_tables(chars + static_cast<size_t>(s) * N * cols, N, cols, L, zww, ncw, refcol + static_cast<size_t>(s) * L1, zws,
+                 maskw + static_cast<size_t>(s) * L1 * ncw, gp);
+      for (int f = 0; f < 3; f++)
+        for (int j = 0; j < (L - f) / 3; j++) {
+          const uint64_t *z = zws + static_cast<size_t>(3 * j + 3 + f) * zww;
+          uint64_t any = 0;
+          for (int w = 0; w < zww; w++) any |= z[w];
+          if (any) zm[static_cast<size_t>(s * 3 + f) * zmw + (j >> 6)] |= 1ull << (j & 63);
+        }
     }
   }
 
   // simulation tables: null alignments use the forward frequencies and kappa (score.c:996-998)
-  SeqGenHky hky(hb.models[0][0].freqs, hb.models[0][0].kappa);
-  hb.nodes.assign(t.nnodes, NodeRec());
+  SeqGenHky hky(freqs[0], in.kappa);
+  NodeRec *nodes = reinterpret_cast<NodeRec *>(base + d.off_nodes);
   for (int q = 0; q < t.nnodes; q++) {
-    NodeRec &nr = hb.nodes[q];
+    NodeRec &nr = nodes[q];
     std::memset(&nr, 0, sizeof nr);
     nr.parent = static_cast<uint8_t>(t.parent[q]);
     nr.tiprow = -1;
     double M[4][4];
     if (q != 0) hky.cumulative(t.length[q], M);                      // evolve.c:404 (scale 1.0), :292
     for (int p = 0; p < 4; p++) {
-      uint32_t base = 0;
-      pack_thresholds(q == 0 ? hky.addFreq : M[p], &nr.thr[p], &base);
-      nr.basepack |= base << (2 * p);
+      uint32_t b = 0;
+      pack_thresholds(q == 0 ? hky.addFreq : M[p], &nr.thr[p], &b);
+      nr.basepack |= b << (2 * p);
     }
   }
-  if (!in_div_range(par.Delta) || !in_div_range(par.Omega) || !in_div_range(par.omega)) hb.exact_div = 1;
-  if (!(par.Delta < 0.0f)) hb.exact_div = 1;   // the fast kernel drops MAX3(sum, Delta, Delta): only valid for Delta < 0
-  hb.qtip.assign(N, 0);
+  uint8_t *qtip = base + d.off_qtip;
+  std::memset(qtip, 0, kMaxRows);
   for (int r = 0; r < N; r++) {
     const int q = t.tipnode[rowtip[r]];
-    hb.qtip[r] = static_cast<uint8_t>(q);
-    hb.nodes[q].tiprow = static_cast<int8_t>(r);
+    qtip[r] = static_cast<uint8_t>(q);
+    nodes[q].tiprow = static_cast<int8_t>(r);
   }
-  return hb.status = RC_OK;
+  return done(RC_OK);
 }
 
 float pvalue_of(float score, float parMu, float parLambda) {   // RNAcode.c:182

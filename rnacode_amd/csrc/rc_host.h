@@ -1,5 +1,6 @@
 // rc_host.h -- host-side, block-constant preparation for the device scoring path.
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -29,30 +30,42 @@ struct PairTable {
   int code_zero = 0, code_stop0 = 0, code_stopk = 0;
   uint8_t pair[64 * 64];      // [codonA][codonB] -> code  (calculateSigma, score.c:406-425, minus the 'N' test)
   int nat_of_slot[64];        // code -> natural number 3*bIdx + (h-1) (or 3nB.. for the specials), -1 = unused
+  CodeInfo info[64];          // the same, in the form k_prep_lut reads
   bool is_score_code(int code) const { return nat_of_slot[code] >= 0 && nat_of_slot[code] < 3 * nB; }
   int h_of_code(int code) const { return nat_of_slot[code] % 3 + 1; }
   int b_of_code(int code) const { return bval[nat_of_slot[code] / 3]; }
   void build(const CodeTables &ct);
 };
 
-struct HostBlock {
+// Where prepare_block writes: the host-written part of a batch blob (a caller-owned buffer, pinned in
+// stream mode) and the device-only arena behind it.  Blocks are prepared by several threads; each takes its
+// share with one atomic add per part.
+struct BlobArena {
+  uint8_t *host = nullptr;
+  size_t hostCap = 0;               // bytes; also the offset of the device-only arena in the device blob
+  std::atomic<size_t> hostUsed{0};
+  size_t devCap = 0;
+  std::atomic<size_t> devUsed{0};
+};
+
+// what the host keeps per block once the tables are in the blob
+struct BlockMeta {
   int status = RC_OK;
   int N = 0, NK = 0, cols = 0, L = 0;
   int ref_start = 0, ref_length = 0;
-  int exact_div = 0;                      // see rc_host.cpp in_div_range
-  std::vector<std::string> rows[2];       // upper-cased forward rows, reverse-complement rows
-  std::vector<rc_model> models[2];        // getModels for both strands
-  std::vector<uint16_t> refcol[2];        // [L+1]
-  std::vector<uint64_t> zw[2];            // [L+1]
-  std::vector<uint8_t> mask[2];           // [NK][L+1]
-  std::vector<float> lut[2];              // [NK][64]
-  std::vector<NodeRec> nodes;
-  std::vector<uint8_t> qtip;              // [N]
 };
 
-// Returns RC_OK, RC_ERR_SKIP (block the reference driver skips) or RC_ERR_ARG / RC_ERR_UNSUPPORTED.
-int prepare_block(const rc_block &in, const rc_params &par, const CodeTables &ct, const PairTable &pt,
-                  HostBlock &out, std::string &err);
+// upper bounds of a block's share of the two blob parts, from its shape alone (L <= cols, nodes <= 2N-1)
+void block_footprint(int N, int cols, size_t *hostBytes, size_t *devBytes);
+
+// getModels' inputs, gap pattern, tree thresholds of one block -> blob + DevBlock header.
+// Returns RC_OK, RC_ERR_SKIP (block the reference driver skips) or RC_ERR_ARG / RC_ERR_UNSUPPORTED; never throws.
+int prepare_block(const rc_block &in, const rc_params &par, const PairTable &pt, BlobArena &arena, uint32_t out_index,
+                  DevBlock &db, BlockMeta &meta, std::string &err);
+
+// true if every gap parameter lies in the range for which the kernels' constant-divisor division was proven
+// (tools/verify_const_div.c) and Delta < 0; otherwise the whole batch is scored by the EXACT instantiation
+bool params_in_fast_range(const rc_params &par);
 
 // tree + kappa estimator (rc_tree.cpp on host threads, rc_tree_kernel.hip on the GPU; both run rc_tree_core.h)
 struct PatternSet {

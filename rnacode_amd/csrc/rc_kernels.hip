@@ -1,6 +1,8 @@
 // rc_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X) of the RNAcode scoring path.
 //
 //   k_mt_stream       MT19937 output streams, one wavefront per seed          (seqgen/twister.c:73-152)
+//   k_prep_models     calculateBG's two 4096-term accumulations per (block, strand, row)  (score.c:107-193)
+//   k_prep_lut        sigma value of every codon-pair code per (block, strand, k)         (score.c:406-425)
 //   k_null<NK>        simulate -> codon-pair codes -> 3-state DP -> HSS scan -> per-sample maximum,
 //                     one LANE per null sample, 64 samples of one block per wavefront
 //                                                                             (score.c:976-1064 loop body)
@@ -63,6 +65,124 @@ __global__ __launch_bounds__(64) void k_mt_stream(uint32_t seedBase, int Spad, i
     }
     __syncthreads();
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// block-constant tables derived on the device
+// ------------------------------------------------------------------------------------------
+
+// calculateBG (score.c:107-193) for one model per lane: two 4096-term float accumulations in the loop
+// order a1,a2,a3,b1,b2,b3, every product and sum a single binary32 operation in the reference's order
+// (SURVEY appendix A.4).  Codon indices, stop tests, Hamming classes and BLOSUM entries are wave-uniform
+// (scalar); the lane's HKY85 matrix and codon frequencies sit in LDS, [entry][lane].
+__global__ __launch_bounds__(64) void k_prep_models(PrepArgs A) {
+  __shared__ float shP[16][kWave];
+  __shared__ float shF[64][kWave];
+  const int lane = threadIdx.x;
+  int t = blockIdx.x * kWave + lane;
+  const bool active = t < A.nModels;
+  if (!active) t = A.nModels - 1;
+  int lo = 0, hi = A.nBlocks;                       // block whose [prefix, next prefix) holds t
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (A.modelPrefix[mid] <= t) lo = mid; else hi = mid;
+  }
+  const DevBlock *db = A.dblocks + A.blocks[lo];
+  ModelRec *m = reinterpret_cast<ModelRec *>(A.blob + db->off_models) + (t - A.modelPrefix[lo]);
+#pragma unroll
+  for (int e = 0; e < 16; e++) shP[e][lane] = m->P[e];
+  const float f0 = m->freqs[0], f1 = m->freqs[1], f2 = m->freqs[2], f3 = m->freqs[3];
+  for (int a = 0; a < 64; a++) {
+    const int a1 = a >> 4, a2 = (a >> 2) & 3, a3 = a & 3;
+    const float x = a1 == 0 ? f0 : a1 == 1 ? f1 : a1 == 2 ? f2 : f3;
+    const float y = a2 == 0 ? f0 : a2 == 1 ? f1 : a2 == 2 ? f2 : f3;
+    const float z = a3 == 0 ? f0 : a3 == 1 ? f1 : a3 == 2 ? f2 : f3;
+    shF[a][lane] = x * y * z;
+  }
+  const int *__restrict__ pep = A.pep;
+  const int *__restrict__ blosum = A.blosum;
+  float probStop = 0.0f;
+  for (int a = 0; a < 64; a++) {
+    const int pa = pep[a];
+    const float fa = shF[a][lane];
+    for (int b = 0; b < 64; b++) {
+      if (pa != -1 && pep[b] != -1) continue;
+      float pAB = shP[(a >> 4) * 4 + (b >> 4)][lane] * shP[((a >> 2) & 3) * 4 + ((b >> 2) & 3)][lane] * shP[(a & 3) * 4 + (b & 3)][lane];
+      pAB = pAB * fa;
+      probStop = probStop + pAB;
+    }
+  }
+  float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f, s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  const float keep = 1.0f - probStop;   // (1 - probStop): int 1 converted to float
+  for (int a = 0; a < 64; a++) {
+    const int pa = pep[a];
+    if (pa == -1) continue;
+    const float fa = shF[a][lane];
+    for (int b = 0; b < 64; b++) {
+      const int pb = pep[b];
+      if (pb == -1) continue;
+      const int x = a ^ b;
+      const int h = ((x & 48) != 0) + ((x & 12) != 0) + ((x & 3) != 0);
+      float pAB = shP[(a >> 4) * 4 + (b >> 4)][lane] * shP[((a >> 2) & 3) * 4 + ((b >> 2) & 3)][lane] * shP[(a & 3) * 4 + (b & 3)][lane];
+      pAB = pAB * fa;
+      pAB = pAB / keep;
+      const float sc = static_cast<float>(blosum[pa * 20 + pb]);
+      const float w = sc * pAB;
+      if (h == 0) { c0 = c0 + pAB; s0 = s0 + w; }
+      else if (h == 1) { c1 = c1 + pAB; s1 = s1 + w; }
+      else if (h == 2) { c2 = c2 + pAB; s2 = s2 + w; }
+      else { c3 = c3 + pAB; s3 = s3 + w; }
+    }
+  }
+  if (active) {
+    m->scores[0] = s0 / c0; m->scores[1] = s1 / c1; m->scores[2] = s2 / c2; m->scores[3] = s3 / c3;
+    m->probs[0] = c0; m->probs[1] = c1; m->probs[2] = c2; m->probs[3] = c3;
+  }
+}
+
+// same test as rc_host.cpp in_div_range: 0, or 2^-76 <= |v| < 2^40
+__device__ __forceinline__ bool in_div_range_dev(float v) {
+  const float a = fabsf(v);
+  return a == 0.0f || (a >= 1.3234889800848443e-23f && a < 1099511627776.0f);
+}
+
+// sigma per code: (float)matrix[pepA][pepB] - scores[h] (score.c:422-425), 0, or a stop penalty.  A block
+// with a value outside the range proven for the constant-divisor division is flagged and appended to its
+// class's list for the EXACT launch.
+__global__ __launch_bounds__(256) void k_prep_lut(PrepArgs A) {
+  __shared__ int bad;
+  const int bi = A.blocks[blockIdx.x];
+  const DevBlock *db = A.dblocks + bi;
+  const int N = db->N, NK = db->NK;
+  if (threadIdx.x == 0) bad = 0;
+  __syncthreads();
+  const ModelRec *models = reinterpret_cast<const ModelRec *>(A.blob + db->off_models);
+  float *lut = reinterpret_cast<float *>(A.blob + db->off_lut);
+  const int total = 2 * NK * kLutSize;
+  bool mine = false;
+  for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+    const int code = idx % kLutSize, k = (idx / kLutSize) % NK, s = idx / (kLutSize * NK);
+    const CodeInfo ci = A.codeInfo[code];
+    float v = 0.0f;
+    if (ci.kind == 1) v = static_cast<float>(ci.b) - models[s * N + k + 1].scores[ci.h];
+    else if (ci.kind == 3) v = db->stop0;
+    else if (ci.kind == 4) v = db->stopk;
+    lut[idx] = v;
+    mine |= !in_div_range_dev(v);
+  }
+  if (mine) bad = 1;
+  __syncthreads();
+  if (threadIdx.x == 0 && bad) {
+    A.flags[bi] |= kFlagExact;
+    const int at = atomicAdd(A.exactCount + NK, 1);
+    A.exactList[A.classOff[NK] + at] = bi;
+  }
+}
+
+void launch_prep(const PrepArgs &a, hipStream_t stream) {
+  if (a.nBlocks <= 0) return;
+  hipLaunchKernelGGL(k_prep_models, dim3((a.nModels + kWave - 1) / kWave), dim3(kWave), 0, stream, a);
+  hipLaunchKernelGGL(k_prep_lut, dim3(a.nBlocks), dim3(256), 0, stream, a);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -286,25 +406,42 @@ __device__ int evd_fit_block(const float *x, int n, double *sh, double *mu_out, 
   return 1;
 }
 
+// best native HSS = results[0].score after the sort, -1 if none (RNAcode.c:176-178)
+__device__ __forceinline__ float best_native(const FitArgs &A, int bi) {
+  float m = -1.0f;
+  for (int c = 0; c < 6; c++) {
+    const int n = min(A.hssCount[static_cast<size_t>(bi) * 6 + c], A.hssCap);
+    const DevHss *h = A.hss + (static_cast<size_t>(bi) * 6 + c) * A.hssCap;
+    for (int i = 0; i < n; i++) if (h[i].score > 0.0f) m = fmaxf(m, h[i].score);
+  }
+  return m;
+}
+
+// --stop-early (score.c:992,1036-1042): the reference leaves the sample loop as soon as more than
+// (int)(cutoff * sampleN) samples beat the best native score.  That count only grows, so a block is decided
+// once the samples simulated so far exceed it; the remaining sample groups are then not run for it.
+__global__ __launch_bounds__(64) void k_stop_mark(FitArgs A) {
+  const int bi = A.blocks[blockIdx.x];
+  const DevBlock *db = A.dblocks + bi;
+  const float *x = A.maxima + static_cast<size_t>(db->out_index) * A.sampleN;
+  const float maxNative = best_native(A, bi);     // every lane: a few records
+  int better = 0;
+  for (int i = threadIdx.x; i < A.firstN; i += kWave) better += (x[i] > maxNative) ? 1 : 0;
+  for (int off = 32; off > 0; off >>= 1) better += __shfl_down(better, off, 64);
+  if (threadIdx.x == 0 && better > A.stopCutoff) A.flags[bi] |= kFlagStopped;
+}
+
 __global__ __launch_bounds__(256) void k_evd_fit(FitArgs A) {
   __shared__ double sh[16];
   __shared__ float maxNativeSh;
   const int bi = A.blocks[blockIdx.x];
   const DevBlock *db = A.dblocks + bi;
   const float *x = A.maxima + static_cast<size_t>(db->out_index) * A.sampleN;
-  if (threadIdx.x == 0) {  // best native HSS = results[0].score after the sort, -1 if none (RNAcode.c:176-178)
-    float m = -1.0f;
-    for (int c = 0; c < 6; c++) {
-      const int n = min(A.hssCount[static_cast<size_t>(bi) * 6 + c], A.hssCap);
-      const DevHss *h = A.hss + (static_cast<size_t>(bi) * 6 + c) * A.hssCap;
-      for (int i = 0; i < n; i++) if (h[i].score > 0.0f) m = fmaxf(m, h[i].score);
-    }
-    maxNativeSh = m;
-  }
+  if (threadIdx.x == 0) maxNativeSh = best_native(A, bi);
   __syncthreads();
   const float maxNative = maxNativeSh;
   double better = 0;
-  for (int i = threadIdx.x; i < A.sampleN; i += blockDim.x) better += (x[i] > maxNative) ? 1.0 : 0.0;
+  for (int i = threadIdx.x; i < A.sampleN; i += blockDim.x) better += (x[i] > maxNative) ? 1.0 : 0.0;   // samples not simulated hold -1
   better = block_sum(better, sh);
   FitOut o;
   o.better = static_cast<int>(better);
@@ -439,6 +576,10 @@ void launch_native_scan(const NativeArgs &a, int nblocks, hipStream_t stream) {
 void launch_sk_row(const uint8_t *blob, const DevBlock *dblocks, int bi, int s, int b, int iMax, float *out, int stride,
                    hipStream_t stream) {
   hipLaunchKernelGGL(k_sk_row, dim3(1), dim3(64), 0, stream, blob, dblocks, bi, s, b, iMax, out, stride);
+}
+
+void launch_stop_mark(const FitArgs &a, int nblocks, hipStream_t stream) {
+  hipLaunchKernelGGL(k_stop_mark, dim3(nblocks), dim3(64), 0, stream, a);
 }
 
 void launch_evd_fit(const FitArgs &a, int nblocks, hipStream_t stream) {

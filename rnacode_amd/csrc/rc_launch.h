@@ -9,14 +9,25 @@
 
 namespace rc {
 
+// -DRC_PROFILING builds (tools/mk_ab.sh) can switch phases of k_null off through RC_DEBUG_SKIP to time them
+// separately; the product library has no such switch.
+#ifdef RC_PROFILING
+constexpr bool kProfiling = true;
+#else
+constexpr bool kProfiling = false;
+#endif
+
 struct NullArgs {
   const uint8_t *blob;
   const DevBlock *dblocks;
-  const int *classBlocks;     // batch indices of the blocks of this N-1 class
+  const int *classBlocks;     // batch indices of the blocks of this launch
   int nClassBlocks;
-  int groups;                 // ceil(sampleN / 64)
+  const int *nBlocksPtr;      // if set: the number of blocks is read from device memory (list built by k_prep_lut)
+  const uint32_t *flags;      // per batch index: kFlagExact, kFlagStopped
+  uint32_t skipMask;          // blocks with (flags & skipMask) != 0 are left out
+  int gLo, gHi;               // sample groups [gLo, gHi) of 64 samples each
   int sampleN;
-  int Spad;                   // groups * 64: row pitch of U
+  int Spad;                   // ceil(sampleN / 64) * 64: row pitch of U
   const uint32_t *U;          // MT19937 streams [draw][Spad]
   const uint8_t *pair;        // [64][64] codon pair -> sigma code
   uint32_t *scratch;          // per-workgroup sigma-code staging
@@ -26,7 +37,7 @@ struct NullArgs {
   float tieThr;               // float form of the 0.0001 tie tolerance (score.c:954)
   int comboSplit;             // 1: items are (block, group, strand x frame); maxima combined by atomic max
   unsigned int *workCounter;  // [8], zeroed before the launch: next unclaimed work item of each XCD queue
-  int debugSkip;              // profiling only (RC_DEBUG_SKIP): bit0 skip the DP/scan phase, bit1 skip simulation
+  int debugSkip;              // RC_PROFILING builds only: bit0 skip the DP/scan phase, bit1 skip simulation
 };
 
 struct NativeArgs {
@@ -35,11 +46,28 @@ struct NativeArgs {
   const int *blocks;          // batch indices handled by this launch
   const uint8_t *pair;
   float *S;                   // native multiple-score matrices
-  const size_t *offS;         // per batch index: offset (floats) of its 6 * (L/3)^2 matrices
+  const uint64_t *offS;       // per batch index: offset (floats) of its 6 * (L/3)^2 matrices
   DevHss *hss;                // [n_blocks][6][kHssCap]
   int *hssCount;              // [n_blocks][6]
   int hssCap;                 // records per (block, strand, frame)
   float tieThr;
+};
+
+// block-constant tables derived on the device (k_prep_models, k_prep_lut)
+struct PrepArgs {
+  uint8_t *blob;
+  const DevBlock *dblocks;
+  const int *blocks;          // batch indices with status RC_OK
+  int nBlocks;
+  const int *modelPrefix;     // [nBlocks + 1] running sum of 2 N over `blocks`: model t belongs to the block whose range holds t
+  int nModels;
+  const int *pep;             // [64] amino-acid index per codon, -1 = stop
+  const int *blosum;          // [20][20]
+  const CodeInfo *codeInfo;   // [64]
+  uint32_t *flags;            // per batch index
+  int *exactList;             // per class: batch indices flagged kFlagExact, at classOff[NK]
+  int *exactCount;            // [kMaxRows + 1] by NK
+  int classOff[kMaxRows + 1]; // by NK
 };
 
 struct FitOut {
@@ -56,7 +84,9 @@ struct FitArgs {
   const int *hssCount;
   int hssCap;
   FitOut *out;                // [n_blocks]
+  uint32_t *flags;            // k_stop_mark sets kFlagStopped
   int sampleN;
+  int firstN;                 // k_stop_mark: number of samples simulated so far
   int stopEarly;
   int stopCutoff;
 };
@@ -77,6 +107,7 @@ struct TreeOut {
 void launch_tree_fit(const TreeJob *jobs, int njobs, const uint8_t *in, double *scratch, TreeOut *out, hipStream_t stream);
 
 void launch_mt_stream(uint32_t seedBase, int Spad, int D, uint32_t *U, hipStream_t stream);
+void launch_prep(const PrepArgs &a, hipStream_t stream);   // k_prep_models, then k_prep_lut
 int null_occupancy(int NK, size_t ldsBytes);   // resident workgroups per CU (0 = cannot launch)
 bool launch_null(int NK, const NullArgs &a, int grid, size_t ldsBytes, bool exact, hipStream_t stream);
 void launch_native_sigma(const NativeArgs &a, int nblocks, hipStream_t stream);
@@ -86,6 +117,7 @@ void launch_hss_pack(const DevHss *hss, const int *count, int cap, int slots, De
                      hipStream_t stream);
 void launch_sk_row(const uint8_t *blob, const DevBlock *dblocks, int bi, int s, int b, int iMax, float *out, int stride,
                    hipStream_t stream);
+void launch_stop_mark(const FitArgs &a, int nblocks, hipStream_t stream);
 void launch_evd_fit(const FitArgs &a, int nblocks, hipStream_t stream);
 void launch_evd_fit_f64(const double *x, int n, FitOut *out, hipStream_t stream);
 

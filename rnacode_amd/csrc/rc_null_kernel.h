@@ -149,7 +149,7 @@ __device__ __forceinline__ void sample_scan_last(const SampleScan &st, float &be
 template <int NK, bool LDSC, bool EXACT>
 __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restrict__ blob,
                                              const DevBlock *__restrict__ dblocks, const int *__restrict__ classBlocks,
-                                             const uint32_t *__restrict__ Ustream, const uint8_t *__restrict__ pairTab,
+                                             const uint32_t *__restrict__ flags, const uint32_t *__restrict__ Ustream, const uint8_t *__restrict__ pairTab,
                                              uint32_t *__restrict__ scratch, float *__restrict__ maxima) {
   constexpr int N = NK + 1;
   constexpr int CPW = 5;                  // 6-bit sigma codes per 32-bit word
@@ -172,11 +172,13 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   const int home = static_cast<int>(xcc & 7u);
   const int parts = A.comboSplit ? 6 : 1;
+  const int nBlocks = A.nBlocksPtr ? *A.nBlocksPtr : A.nClassBlocks;
   for (int qi = 0; qi < 8;) {
     const int q = (home + qi) & 7;
-    const int gq = (A.groups - q + 7) >> 3;        // sample groups q, q + 8, ... < groups
+    const int g0 = A.gLo + ((q - A.gLo) & 7);      // sample groups g0, g0 + 8, ... < gHi: those congruent to q
+    const int gq = g0 < A.gHi ? ((A.gHi - 1 - g0) >> 3) + 1 : 0;
     const int perBlock = gq * parts;
-    const int nq = A.nClassBlocks * perBlock;
+    const int nq = nBlocks * perBlock;
     int t = nq;
     if (nq > 0) {
       if (lane == 0) t = static_cast<int>(atomicAdd(A.workCounter + q, 1u));
@@ -184,8 +186,11 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
     }
     if (t >= nq) { qi++; continue; }
     const int bi = classBlocks[t / perBlock];
+    // blocks another launch takes care of (score tables outside the fast division's range -> the EXACT launch)
+    // or that need no more samples (--stop-early decided)
+    if (A.skipMask && (flags[bi] & A.skipMask)) continue;
     const int sub = t % perBlock;
-    const int grp = q + 8 * (sub / parts);
+    const int grp = g0 + 8 * (sub / parts);
     const int onlyCombo = A.comboSplit ? sub % parts : -1;
     const DevBlock *__restrict__ db = dblocks + bi;
     const int cols = db->cols, L = db->L, nnodes = db->nnodes;
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
     // so that the stream loads and threshold look-ups of independent sites overlap; emit sigma
     // codes for both strands.  Node states of a site are packed 2 bits per node into NODEW
     // registers; the per-branch threshold table sits in LDS (the region phase B reuses for codes).
-    if (!(A.debugSkip & 2)) {
+    if (!kProfiling || !(A.debugSkip & 2)) {
       constexpr int SPI = 4;
       constexpr int NODEW = (2 * N - 1 + 15) / 16;   // 16 nodes per 32-bit word
       U4 *ldsThr = reinterpret_cast<U4 *>(lds_codes);
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
     float omega_v, Delta_v = 0.0f;
     asm volatile("v_mov_b32 %0, %1" : "=v"(omega_v) : "s"(omega));
     if constexpr (EXACT) asm volatile("v_mov_b32 %0, %1" : "=v"(Delta_v) : "s"(Delta));
-    if (!(A.debugSkip & 1))
+    if (!kProfiling || !(A.debugSkip & 1))
     for (int s = 0; s < 2; s++) {
       if (onlyCombo >= 0 && onlyCombo / 3 != s) continue;
       Regs R;
@@ -557,16 +562,16 @@ template <int NK>
 inline void launch_null_one(const NullArgs &a, int grid, size_t ldsBytes, bool exact, hipStream_t stream) {
   if (exact) {
     hipLaunchKernelGGL((k_null<NK, false, true>), dim3(grid), dim3(64), kPhaseALds, stream, a, a.blob, a.dblocks,
-                       a.classBlocks, a.U, a.pair, a.scratch, a.maxima);
+                       a.classBlocks, a.flags, a.U, a.pair, a.scratch, a.maxima);
   } else if (ldsBytes) {
     if (ldsBytes > 48 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_null<NK, true, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsBytes));
     hipLaunchKernelGGL((k_null<NK, true, false>), dim3(grid), dim3(64), ldsBytes, stream, a, a.blob, a.dblocks,
-                       a.classBlocks, a.U, a.pair, a.scratch, a.maxima);
+                       a.classBlocks, a.flags, a.U, a.pair, a.scratch, a.maxima);
   } else {
     hipLaunchKernelGGL((k_null<NK, false, false>), dim3(grid), dim3(64), kPhaseALds, stream, a, a.blob, a.dblocks,
-                       a.classBlocks, a.U, a.pair, a.scratch, a.maxima);
+                       a.classBlocks, a.flags, a.U, a.pair, a.scratch, a.maxima);
   }
 }
 

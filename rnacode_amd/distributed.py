@@ -59,3 +59,81 @@ def max_over_ranks(seconds: float, device=None) -> float:
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# ---------------------------------------------------------------------------------------------------
+# few blocks, many samples (BASELINE configs[0]/[1]): split every block's SAMPLE range across the ranks
+# ---------------------------------------------------------------------------------------------------
+
+def sample_range(n_samples: int, rank: int, world: int, granule: int = 64) -> Tuple[int, int]:
+    """Contiguous [lo, hi) of rank's samples, cut at multiples of `granule` (a wavefront scores 64 samples of one
+    block) so that only the last rank has a ragged group."""
+    groups = -(-n_samples // granule)
+    glo, ghi = shard_range(groups, rank, world)
+    return min(n_samples, glo * granule), min(n_samples, ghi * granule)
+
+
+def score_sample_sharded(score_range, fit, pvalue, gather, n_samples: int, rank: int, world: int, stop_early: bool = False,
+                         cutoff: float = 1.0):
+    """getExtremeValuePars (score.c:976-1064) with the sample loop :1004-1048 split across ranks and the fit :1050 run
+    on the gathered maxima.  Sample s of every block is seeded with seed_base + s whichever rank simulates it, so the
+    gathered row equals the single-process one bit for bit.
+
+      score_range(lo, hi) -> (maxima [n_blocks][hi - lo] float32, native)   this rank's samples of every block and the
+                              native HSS lists (every rank scores the native blocks: 1/1000 of the work)
+      gather(local)       -> [n_blocks][n_samples]                         the path's one all-gather
+      fit(row)            -> (rc, mu, lambda)                              EVDMaxLikelyFit of one block's maxima
+      pvalue(score, mu, lambda)
+
+    Returns a list of (evd_rc, mu, lambda, hss list with p-values) per block.  --stop-early's verdict only needs the
+    gathered row (the count of samples above the best native score only grows along the loop, score.c:1036-1042)."""
+    import numpy as np
+
+    lo, hi = sample_range(n_samples, rank, world)
+    local, native = score_range(lo, hi)
+    full = np.asarray(gather(local))
+    assert full.shape[1] == n_samples
+    out = []
+    for blk, hss in enumerate(native):
+        if hss is None:                       # block the driver skips
+            out.append(None)
+            continue
+        row = full[blk]
+        best = max([h["score"] for h in hss], default=-1.0)
+        rc, mu, lam = -1, 0.0, 0.0
+        stopped = stop_early and int((row > np.float32(best)).sum()) > int(np.float32(cutoff) * np.float32(n_samples))
+        if not stopped:
+            ok, mu, lam = fit(row.astype(np.float64))
+            rc = 1 if ok == 1 else -1
+        mu32, lam32 = float(np.float32(mu)), float(np.float32(lam))    # *parMu = mu, score.c:1051-1052
+        scored = [dict(h, pvalue=(pvalue(h["score"], mu32, lam32) if rc == 1 else 99.0)) for h in hss]
+        out.append((rc, mu32, lam32, scored))
+    return out
+
+
+def all_gather_columns(local, widths: Sequence[int]):
+    """All-gather of per-rank [n_blocks, w_r] sample slices into [n_blocks, sum w_r] (samples are the ragged
+    dimension here): one all_gather_into_tensor on the transposed slices."""
+    t = all_gather_rows(local.t().contiguous(), widths)
+    return t.t().contiguous()
+
+
+def hip_sample_sharded(ctx, blocks, rank: int, world: int, gather, **params):
+    """score_sample_sharded on the HIP path: this rank's sample range as one batch with seed_base + lo."""
+    import numpy as np
+
+    from . import api
+
+    n = params.get("sampleN", 100)
+    base = params.get("seed_base", 42)
+
+    def score_range(lo, hi):
+        kw = dict(params, sampleN=max(1, hi - lo), seed_base=base + lo, stopEarly=0)
+        batch = api.Batch(ctx, blocks, api.default_params(**kw)).run()
+        mx = batch.maxScores_all()[:, :hi - lo]
+        native = [batch.scoreAln(i) if batch.status(i) == api.RC_OK else None for i in range(batch.n)]
+        batch.close()
+        return np.ascontiguousarray(mx), native
+
+    return score_sample_sharded(score_range, ctx.evd_fit, api.pvalue, gather, n, rank, world,
+                                stop_early=bool(params.get("stopEarly", 0)), cutoff=params.get("cutoff", 1.0))

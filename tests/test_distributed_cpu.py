@@ -79,3 +79,77 @@ def test_shard_range_is_a_partition():
             assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in ranges]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _sample_worker(rank, world, port, n, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+
+    from oracle import binding as ob
+    from rnacode_amd import distributed as rd
+    from rnacode_amd.synth import synth_blocks
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    blocks = [b.upper() for b in synth_blocks(3, 4, 36, seed=9)]
+    widths = [rd.sample_range(n, r, world)[1] - rd.sample_range(n, r, world)[0] for r in range(world)]
+
+    def score_range(lo, hi):
+        rows, native = [], []
+        for b in blocks:
+            res = ob.run_block([r.seq for r in b.rows], [r.name for r in b.rows], b.rows[0].start, b.rows[0].length,
+                               b.tree, b.kappa, ob.default_params(max(1, hi - lo)), 42 + lo)
+            rows.append(np.float32(res.maxScores)[:hi - lo])
+            native.append(res.hss)
+        return np.stack(rows), native
+
+    def gather(local):
+        return rd.all_gather_columns(torch.from_numpy(np.ascontiguousarray(local)), widths).numpy()
+
+    res = rd.score_sample_sharded(score_range, ob.evd_fit, ob.pvalue, gather, n, rank, world)
+    if rank == 0:
+        import pickle
+        with open(out_path, "wb") as fh:
+            pickle.dump(res, fh)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [200, 64])   # 200: ranks get 128 + 72 samples; 64: the second rank has none
+def test_sample_range_sharding_equals_single_process(tmp_path, n):
+    """SURVEY section 8e's second partitioning (few blocks, many samples): each rank simulates its own sample range
+    of every block, one all-gather, the fit runs on the gathered maxima."""
+    import pickle
+
+    import torch.multiprocessing as mp
+
+    from oracle import binding as ob
+    from rnacode_amd.synth import synth_blocks
+
+    world = 2
+    out = str(tmp_path / "s.pkl")
+    mp.spawn(_sample_worker, args=(world, _free_port(), n, out), nprocs=world, join=True)
+    with open(out, "rb") as fh:
+        got = pickle.load(fh)
+    blocks = [b.upper() for b in synth_blocks(3, 4, 36, seed=9)]
+    for g, b in zip(got, blocks):
+        res = ob.run_block([r.seq for r in b.rows], [r.name for r in b.rows], b.rows[0].start, b.rows[0].length, b.tree,
+                           b.kappa, ob.default_params(n), 42)
+        rc, mu, lam, hss = g
+        assert rc == res.evd_rc
+        assert np.float32(mu) == np.float32(res.mu) and np.float32(lam) == np.float32(res.lam)
+        assert [(h["strand"], h["frame"], h["start"], h["end"], np.float32(h["score"]), np.float32(h["pvalue"])) for h in hss] == \
+               [(h["strand"], h["frame"], h["start"], h["end"], np.float32(h["score"]), np.float32(h["pvalue"])) for h in res.hss]
+
+
+def test_sample_range_is_a_partition_in_wavefront_groups():
+    from rnacode_amd import distributed as rd
+    for n in (1, 63, 64, 65, 100, 1000, 10000):
+        for world in (1, 2, 3, 8):
+            r = [rd.sample_range(n, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+            assert all(lo % 64 == 0 for lo, _ in r if lo < n)

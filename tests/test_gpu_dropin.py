@@ -70,3 +70,24 @@ def test_c_example_runs(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     assert "block 0: tree (" in out.stdout and "block 1: tree (" in out.stdout
+
+
+@pytest.mark.skipif(not os.path.exists(BIN), reason="oracle/_ref/ref_harness_hip was not built (needs the reference tree)")
+def test_reference_postscript_on_hip_backend_draws_the_reference_plots(tmp_path):
+    """The reference's own colorAln (src/postscript.c, compiled in place) running on the shim: it takes the state paths
+    from backtrack() and the codon-pair colours from getScoringMatrix() (postscript.c:362,437,527), both served by
+    librnacode_hip.so.  The files must be byte-identical with those the unmodified reference wrote."""
+    doc = load_golden("eps_coding_aln_n100")
+    base = load_golden(doc["base"])
+    blocks = [block_from_golden(e) for e in base["blocks"]]
+    path = str(tmp_path / "in.blk")
+    epsdir = str(tmp_path / "eps")
+    write_harness_blocks(blocks, path)
+    subprocess.check_output([BIN, path, "--samples", str(doc["samples"]), "--seed", str(doc["seed_base"]), "--no-backtrack",
+                             "--print-to", str(tmp_path / "list.txt"), "--format", "0", "--eps-dir", epsdir])
+    names = sorted(os.listdir(epsdir), key=lambda s: int(s[4:-4]))
+    assert names == doc["names"]
+    for k, want in doc["files"].items():
+        with open(os.path.join(epsdir, k)) as fh:
+            got = fh.read()
+        assert got == want, k

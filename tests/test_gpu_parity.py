@@ -38,10 +38,7 @@ def run_golden(ctx, doc, max_blocks=None):
     entries = doc["blocks"][:max_blocks] if max_blocks else doc["blocks"]
     blocks = []
     for e in entries:
-        b = block_from_golden(e)
-        if b.tree is None:  # blocks the reference skipped never got a tree; give the parser something
-            b.tree, b.kappa = "(a:0.1,b:0.1,c:0.1);", 2.0
-        blocks.append(b)
+        blocks.append(block_from_golden(e))   # blocks the reference skipped have no tree: they are skipped here as well
     batch = api.Batch(ctx, blocks, api_params(doc)).run()
     return entries, blocks, batch
 
@@ -59,6 +56,8 @@ def check_entry(batch, i, entry):
             assert np.float32(g["dist"]) == np.float32(w["dist"])
             np.testing.assert_array_equal(np.float32(g["freqs"]), np.float32(w["freqs"]))
             np.testing.assert_array_equal(np.float32(g["scores"]), np.float32(w["scores"]))
+            np.testing.assert_array_equal(np.float32(g["probs"]), np.float32(w["probs"]))   # counts[h] of calculateBG, score.c:186-190
+            assert np.float32(g["kappa"]) == np.float32(w["kappa"])
     got = sorted(batch.scoreAln(i), key=hss_key)
     want = sorted(ref["hss"], key=hss_key)
     assert len(got) == len(want)
@@ -160,16 +159,25 @@ def test_errors_and_empty(ctx):
     assert batch.n == 0
     batch.close()
     rows = [AlnRow("a", "ATGGCTAAA"), AlnRow("b", "ATGGCAAAA"), AlnRow("c", "ATGGCTAAG")]
-    with pytest.raises(api.RnacodeError) as ei:
-        api.Batch(ctx, [AlnBlock(rows, "x", "(a:0.1,b:0.1,zzz:0.1);", 2.0)], api.default_params())
-    assert ei.value.code == api.RC_ERR_ARG
-    with pytest.raises(api.RnacodeError):
-        api.Batch(ctx, [AlnBlock(rows, "x", "(a:0.1,b:0.1", 2.0)], api.default_params())
     ragged = [AlnRow("a", "ATGGCTAAA"), AlnRow("b", "ATGGCAAA"), AlnRow("c", "ATGGCTAAG")]
+    good = AlnBlock(rows, "ok", "(a:0.1,b:0.1,c:0.1);", 2.0)
+    # a block that cannot be scored is left out with a status and a reason; the rest of the batch is scored
+    # (the reference's driver prints "Skipping alignment. Failed to build ML tree." and goes on, RNAcode.c:153-156)
+    bad = [AlnBlock(rows, "x", "(a:0.1,b:0.1,zzz:0.1);", 2.0), AlnBlock(rows, "x", "(a:0.1,b:0.1", 2.0),
+           AlnBlock(ragged, "x", "(a:0.1,b:0.1,c:0.1);", 2.0), AlnBlock(rows, "x", None, None)]
+    batch = api.Batch(ctx, [good] + bad + [good], api.default_params(sampleN=64)).run()
+    assert batch.status(0) == api.RC_OK and batch.status(5) == api.RC_OK
+    for i in range(1, 5):
+        assert batch.status(i) == api.RC_ERR_ARG and batch.block_error(i)
+        assert (batch.maxScores(i) == -1.0).all()
+    assert "zzz" in batch.block_error(1) or "not found" in batch.block_error(1)
+    np.testing.assert_array_equal(batch.maxScores(0), batch.maxScores(5))
+    solo = api.Batch(ctx, [good], api.default_params(sampleN=64)).run()
+    np.testing.assert_array_equal(batch.maxScores(0), solo.maxScores(0))
+    assert batch.scoreAln(5) == solo.scoreAln(0)
+    solo.close(); batch.close()
     with pytest.raises(api.RnacodeError):
-        api.Batch(ctx, [AlnBlock(ragged, "x", "(a:0.1,b:0.1,c:0.1);", 2.0)], api.default_params())
-    with pytest.raises(api.RnacodeError):
-        api.Batch(ctx, [AlnBlock(rows, "x", "(a:0.1,b:0.1,c:0.1);", 2.0)], api.default_params(blosum=45))
+        api.Batch(ctx, [good], api.default_params(blosum=45))
 
 
 def test_oracle_parity_on_fresh_seeds(ctx):
@@ -371,8 +379,9 @@ def test_duplicate_row_names_are_rejected(ctx):
     from rnacode_amd import api
     from rnacode_amd.alnio import AlnBlock, AlnRow
     rows = [AlnRow("a", "ATGGCTAAA"), AlnRow("a", "ATGGCAAAA"), AlnRow("c", "ATGGCTAAG")]
-    with pytest.raises(api.RnacodeError):
-        api.Batch(ctx, [AlnBlock(rows, "x", "(a:0.1,a:0.1,c:0.1);", 2.0)], api.default_params())
+    batch = api.Batch(ctx, [AlnBlock(rows, "x", "(a:0.1,a:0.1,c:0.1);", 2.0)], api.default_params())
+    assert batch.status(0) == api.RC_ERR_ARG and "duplicate" in batch.block_error(0)
+    batch.close()
 
 
 def _newick_parts(nwk):

@@ -1,0 +1,282 @@
+"""The asynchronous forms of the hot path (rc_batch_run_async / rc_batch_wait, rc_stream_*): several batches in
+flight on alternating HIP streams, host preparation of one batch overlapping the kernels of another, recycled
+buffers.  Everything they return must equal what one synchronous batch returns, bit for bit -- and, at BASELINE
+configs[2] size (10 000 blocks x 120 cols x 6 seqs, n = 1000), the oracle on a random sub-sample."""
+import numpy as np
+import pytest
+
+from conftest import hss_key
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from rnacode_amd import api
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def mixed_blocks():
+    from rnacode_amd.synth import synth_blocks
+    blocks = (synth_blocks(40, 6, 120, seed=21) + synth_blocks(9, 4, 45, seed=22) + synth_blocks(7, 9, 150, seed=23)
+              + synth_blocks(5, 3, 30, seed=24) + synth_blocks(3, 12, 210, seed=25))
+    rng = np.random.RandomState(5)
+    order = rng.permutation(len(blocks))
+    return [blocks[i].upper() for i in order]
+
+
+def collect(batch):
+    return batch.maxScores_all(), batch.fits(), batch.scoreAln_all(), [batch.status(i) for i in range(batch.n)]
+
+
+def test_stream_of_sub_batches_equals_one_batch(ctx):
+    from rnacode_amd import api
+    blocks = mixed_blocks()
+    p = api.default_params(sampleN=200, seed_base=77)
+    one = api.Batch(ctx, blocks, p).run()
+    want_max, want_fit, want_hss, want_st = collect(one)
+    one.close()
+    m = api.Marshalled(blocks)
+    m.set_trees()
+    for sub, depth in ((7, 3), (16, 2), (64, 1), (1, 4)):
+        stream = api.Stream(ctx, p, depth)
+        for _pass in range(2):   # the second pass runs on recycled batches
+            at = 0
+            for batch in api.score_stream(ctx, m, p, sub, stream=stream):
+                gm, gf, gh, gs = collect(batch)
+                n = batch.n
+                np.testing.assert_array_equal(gm, want_max[at:at + n])
+                np.testing.assert_array_equal(gf[:, :1], want_fit[at:at + n, :1])
+                np.testing.assert_allclose(gf[:, 1:3], want_fit[at:at + n, 1:3], rtol=1e-6)
+                assert gh == want_hss[at:at + n] or all(
+                    [{k: v for k, v in h.items() if k != "pvalue"} for h in a] == [{k: v for k, v in h.items() if k != "pvalue"} for h in b]
+                    for a, b in zip(gh, want_hss[at:at + n]))
+                assert gs == want_st[at:at + n]
+                assert batch.clamped() <= 3   # draws past the cumulative vector: ~1e-7 per root draw
+                at += n
+                batch.close()
+            assert at == len(blocks)
+        stream.close()
+
+
+def test_batches_in_flight_together(ctx):
+    """Three resident batches between run_async and wait at once (alternating compute streams, own scratch and work
+    queues each), twice, against their synchronous results."""
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_blocks
+    p = api.default_params(sampleN=320, seed_base=9)
+    sets = [[b.upper() for b in synth_blocks(30, 6, 120, seed=s)] for s in (31, 32, 33)]
+    want = []
+    for bl in sets:
+        b = api.Batch(ctx, bl, p).run()
+        want.append(collect(b))
+        b.close()
+    batches = [api.Batch(ctx, bl, p) for bl in sets]
+    for _ in range(2):
+        for b in batches:
+            b.run_async()
+        for b, w in zip(batches, want):
+            b.wait()
+            got = collect(b)
+            np.testing.assert_array_equal(got[0], w[0])
+            np.testing.assert_array_equal(got[1][:, 0], w[1][:, 0])
+            assert [[hss_key(h) for h in x] for x in got[2]] == [[hss_key(h) for h in x] for x in w[2]]
+    for b in batches:
+        b.close()
+
+
+def test_stream_with_rejected_and_skipped_blocks(ctx):
+    from rnacode_amd import api
+    from rnacode_amd.alnio import AlnBlock, AlnRow
+    from rnacode_amd.synth import synth_blocks
+    good = [b.upper() for b in synth_blocks(6, 5, 60, seed=3)]
+    short = AlnBlock([AlnRow("a", "AT"), AlnRow("b", "AT"), AlnRow("c", "AT")], "s", None, None)
+    two = AlnBlock([AlnRow("a", "ATGGCTAAA"), AlnRow("b", "ATGGCAAAA")], "t", None, None)
+    notree = AlnBlock([AlnRow("a", "ATGGCTAAA"), AlnRow("b", "ATGGCAAAA"), AlnRow("c", "ATGGCTAAG")], "n", None, None)
+    blocks = [good[0], short, good[1], two, notree, good[2], good[3], notree, good[4], good[5]]
+    p = api.default_params(sampleN=100, seed_base=4)
+    ref = api.Batch(ctx, good, p).run()
+    want = ref.maxScores_all()
+    ref.close()
+    m = api.Marshalled(blocks)
+    m.set_trees(strict=False)
+    rows, status = [], []
+    for batch in api.score_stream(ctx, m, p, 3, depth=2):
+        mx = batch.maxScores_all()
+        for i in range(batch.n):
+            status.append(batch.status(i))
+            if batch.status(i) == api.RC_OK:
+                rows.append(mx[i])
+            else:
+                assert (mx[i] == -1.0).all()
+        batch.close()
+    assert status == [api.RC_OK, api.RC_ERR_SKIP, api.RC_OK, api.RC_ERR_SKIP, api.RC_ERR_ARG, api.RC_OK, api.RC_OK, api.RC_ERR_ARG,
+                      api.RC_OK, api.RC_OK]
+    np.testing.assert_array_equal(np.stack(rows), want)
+
+
+def test_config3_full_size_stream_and_resident_against_oracle(ctx):
+    """BASELINE configs[2] as specified: 10 000 blocks x 120 cols x 6 seqs, n = 1000, once as one resident batch
+    (160 000 work items over the eight XCD queues) and once as a stream of eight sub-batches; both must agree
+    everywhere, and 32 randomly chosen blocks x the first 64 samples must equal the CPU oracle."""
+    from oracle import binding as ob
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_blocks
+    blocks = [b.upper() for b in synth_blocks(10000, 6, 120, seed=1)]
+    p = api.default_params(sampleN=1000, seed_base=42)
+    m = api.Marshalled(blocks)
+    m.set_trees()
+    big = api.Batch(ctx, m, p).run()
+    allmax = big.maxScores_all()
+    fits = big.fits()
+    assert big.clamped() <= 100     # about 1e-7 per root draw
+    assert allmax.shape == (10000, 1000)
+    assert np.isfinite(allmax).all() and ((allmax > 0) | (allmax == -1.0)).all()
+    at = 0
+    for batch in api.score_stream(ctx, m, p, 1250, depth=3):
+        np.testing.assert_array_equal(batch.maxScores_all(), allmax[at:at + batch.n])
+        np.testing.assert_array_equal(batch.fits()[:, 0], fits[at:at + batch.n, 0])
+        np.testing.assert_allclose(batch.fits()[:, 1:3], fits[at:at + batch.n, 1:3], rtol=1e-6)
+        at += batch.n
+        batch.close()
+    assert at == 10000
+    rng = np.random.RandomState(123)
+    picks = sorted(rng.choice(10000, 32, replace=False).tolist())
+    for i in picks:
+        b = blocks[i]
+        res = ob.run_block([r.seq for r in b.rows], [r.name for r in b.rows], b.rows[0].start, b.rows[0].length, b.tree, b.kappa,
+                           ob.default_params(64), 42)
+        np.testing.assert_array_equal(allmax[i, :64], np.float32(res.maxScores))
+        got = sorted(big.scoreAln(i), key=hss_key)
+        want = sorted(res.hss, key=hss_key)
+        assert [(h["strand"], h["frame"], h["start"], h["end"], np.float32(h["score"])) for h in got] == \
+               [(h["strand"], h["frame"], h["start"], h["end"], np.float32(h["score"])) for h in want]
+    # batch-composition invariance: the picked blocks scored alone as one small batch
+    small = api.Batch(ctx, [blocks[i] for i in picks], p).run()
+    np.testing.assert_array_equal(small.maxScores_all(), allmax[picks])
+    small.close()
+    big.close()
+
+
+def test_stop_early_runs_fewer_samples_and_agrees_with_the_oracle(ctx):
+    """--stop-early (score.c:992,1036-1042): blocks whose first samples already beat the native score more often
+    than the cutoff allows are decided (rc = -1) and get no further samples; all others are sampled in full.
+    Decisions, fits and HSS equal the oracle's, which runs the reference's loop literally."""
+    from oracle import binding as ob
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_blocks
+    blocks = [b.upper() for b in synth_blocks(40, 5, 90, seed=8)]
+    n, seed, cutoff = 640, 42, 0.05
+    p = api.default_params(sampleN=n, seed_base=seed, stopEarly=1, cutoff=cutoff)
+    batch = api.Batch(ctx, blocks, p).run()
+    mx = batch.maxScores_all()
+    full = api.Batch(ctx, blocks, api.default_params(sampleN=n, seed_base=seed, cutoff=cutoff)).run()
+    fmx = full.maxScores_all()
+    op = ob.default_params(n)
+    op.stopEarly, op.cutoff = 1, cutoff
+    decided = 0
+    first = ((int(cutoff * n) + 1 + 64 + 63) // 64) * 64
+    for i, b in enumerate(blocks):
+        res = ob.run_block([r.seq for r in b.rows], [r.name for r in b.rows], b.rows[0].start, b.rows[0].length, b.tree, b.kappa, op, seed)
+        rc, mu, lam = batch.getExtremeValuePars(i)
+        assert rc == res.evd_rc
+        np.testing.assert_array_equal(mx[i, :first], fmx[i, :first])
+        if rc == 1:
+            np.testing.assert_array_equal(mx[i], fmx[i])
+            assert abs(mu - res.mu) <= 1e-6 * max(1, abs(res.mu)) and abs(lam - res.lam) <= 1e-6
+        elif (mx[i, first:] == -1.0).all() and (fmx[i, first:] > 0).any():
+            decided += 1
+        assert [hss_key(h)[:5] for h in sorted(batch.scoreAln(i), key=hss_key)] == [hss_key(h)[:5] for h in sorted(full.scoreAln(i), key=hss_key)]
+    assert decided > 0    # random (non-coding) blocks: most are decided after the first round
+    batch.close(); full.close()
+
+
+def test_sample_range_sharding_on_the_hip_path(ctx):
+    """BASELINE configs[1] (genomic-preprocessed.maf, n = 1000): few blocks, so the SAMPLE range is what gets split
+    (SURVEY 8e).  Three 'ranks' run one after the other on the one GPU of the test box, each through
+    hip_sample_sharded with a gather that concatenates their slices; the result must equal the reference's goldens."""
+    from conftest import load_golden
+    from helpers import block_from_golden
+    from rnacode_amd import api
+    from rnacode_amd import distributed as rd
+    doc = load_golden("genomic_preprocessed_n1000")
+    entries = doc["blocks"][:12]
+    blocks = [block_from_golden(e) for e in entries]
+    n, world = doc["samples"], 3
+    slices = {}
+
+    def score_only(rank):
+        def gather(local):
+            slices[rank] = local
+            raise StopIteration
+        try:
+            rd.hip_sample_sharded(ctx, blocks, rank, world, gather, sampleN=n, seed_base=doc["seed_base"])
+        except StopIteration:
+            pass
+
+    for r in range(world):
+        score_only(r)
+    full = np.concatenate([slices[r] for r in range(world)], axis=1)
+    res = rd.hip_sample_sharded(ctx, blocks, 1, world, lambda local: full, sampleN=n, seed_base=doc["seed_base"])
+    for e, got in zip(entries, res):
+        ref = e["ref"]
+        if "skipped" in ref:
+            assert got is None
+            continue
+        rc, mu, lam, hss = got
+        assert rc == ref["evd_rc"]
+        assert abs(mu - ref["mu"]) <= 1e-6 * max(1, abs(ref["mu"])) and abs(lam - ref["lambda"]) <= 1e-6
+        gh, wh = sorted(hss, key=hss_key), sorted(ref["hss"], key=hss_key)
+        assert [hss_key(h)[:5] for h in gh] == [hss_key(h)[:5] for h in wh]
+        for a, b in zip(gh, wh):
+            assert abs(a["pvalue"] - b["pvalue"]) <= 1e-6 * max(1.0, abs(b["pvalue"]))
+    rows = [i for i, e in enumerate(entries) if "skipped" not in e["ref"] and e["ref"]["maxScores"]]
+    for i in rows:
+        np.testing.assert_array_equal(full[i], np.float32(entries[i]["ref"]["maxScores"]))
+
+
+def _bench(tmp_path, gpus, extra=(), env_extra=None):
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+    dump = str(tmp_path / f"g{gpus}.npy")
+    env = dict(os.environ, **(env_extra or {}))
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--blocks", "50", "--samples", "192", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline", "--sub-batches", "3", "--dump-gathered", dump, *extra],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0]), np.load(dump)
+
+
+def test_bench_starts_its_own_ranks_and_two_hip_ranks_gather_the_single_rank_result(tmp_path):
+    """`bench.py --gpus 2` without torchrun launches two ranks itself (before touching the GPU); both run the HIP path
+    on the one GPU of the test box (RC_BENCH_TEST_BACKEND=gloo: the collective goes over gloo, everything else is the
+    production code) and the gathered maxima equal a single rank's."""
+    one, m1 = _bench(tmp_path, 1)
+    two, m2 = _bench(tmp_path, 2, env_extra={"RC_BENCH_TEST_BACKEND": "gloo"})
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
+    assert two["config"]["blocks_per_gpu"] == 25 and "stream" in two and two["stream"]["value"] > 0
+    assert m1.shape == (50, 192)
+    np.testing.assert_array_equal(m1, m2)
+    fits, mf = _bench(tmp_path, 2, extra=("--exchange", "fits"), env_extra={"RC_BENCH_TEST_BACKEND": "gloo"})
+    assert mf.shape == (50, 4) and (mf[:, 0] == 1).all()
+
+
+def test_bench_refuses_a_world_that_does_not_match_gpus(tmp_path):
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--blocks", "8", "--samples", "64", "--steps", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
