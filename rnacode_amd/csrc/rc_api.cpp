@@ -168,6 +168,15 @@ class Pool {
 
 size_t al256(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
 
+// RC_TRACE=1: host-side time stamps of the pipeline stages on stderr (microseconds since the first stamp)
+void trace(const char *what, const void *obj) {
+  static const bool on = std::getenv("RC_TRACE") != nullptr;
+  if (!on) return;
+  static const auto t0 = std::chrono::steady_clock::now();
+  const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  std::fprintf(stderr, "[rc %10.1f us] %-14s %p\n", us, what, obj);
+}
+
 }  // namespace
 
 struct rc_ctx {
@@ -176,6 +185,7 @@ struct rc_ctx {
   hipStream_t compute[2] = {nullptr, nullptr};   // null sampling + fit; consecutive batches alternate, so the tail of one overlaps the head of the next
   hipStream_t native = nullptr;    // table preparation and native-block kernels: small and latency-bound, they run beside the null sampling
   hipStream_t copy = nullptr;      // host -> device blob copies
+  hipStream_t aux = nullptr;       // synchronous helpers (second-stage result copies, backtrack rows, stand-alone fits): never behind queued batches
   std::vector<hipStream_t> classStreams;   // k_null launches of different row-count classes, when a batch has several
   unsigned seq = 0;
   CodeTables ct62{62}, ct90{90};
@@ -239,6 +249,7 @@ struct rc_batch {
   Event evUp, evPrep0, evPrep, evStart, evMt0, evMt1, evN0, evN1, evS0, evS1, evMid, evFit, evDone;
   std::vector<std::unique_ptr<Event>> classDone;
   bool mtLaunched = false;
+  size_t packedAhead = 0;   // HSS records copied to the host together with the counts
   // host results
   std::vector<float> maxima;
   bool maximaFetched = false;
@@ -296,6 +307,7 @@ void rc_ctx_destroy(rc_ctx *c) {
   for (hipStream_t st : c->compute) if (st) (void)hipStreamDestroy(st);
   if (c->native) (void)hipStreamDestroy(c->native);
   if (c->copy) (void)hipStreamDestroy(c->copy);
+  if (c->aux) (void)hipStreamDestroy(c->aux);
   for (hipStream_t st : c->classStreams) (void)hipStreamDestroy(st);
   delete c;
 }
@@ -324,6 +336,7 @@ int rc_ctx_create(int device, rc_ctx **out) {
   HIP_TRY(hipStreamCreateWithPriority(&c->compute[1], hipStreamNonBlocking, prioLow));
   HIP_TRY(hipStreamCreateWithPriority(&c->native, hipStreamNonBlocking, prioHigh));
   HIP_TRY(hipStreamCreateWithPriority(&c->copy, hipStreamNonBlocking, prioHigh));
+  HIP_TRY(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prioHigh));
   c->serialNative = std::getenv("RC_SERIAL_NATIVE") ? 1 : 0;   // profiling: one kernel at a time, clean per-kernel intervals
   c->pt62.build(c->ct62);
   c->pt90.build(c->ct90);
@@ -499,12 +512,13 @@ static int batch_upload(rc_batch *b) {
   HIP_TRY(b->dflags.ensure(nn * sizeof(uint32_t)));
   HIP_TRY(b->dexact.ensure(nn * sizeof(int)));
   HIP_TRY(b->dcounters.ensure(kCntTotal * sizeof(uint32_t)));
-  HIP_TRY(hipMemcpyAsync(b->dblob.p, b->hblob.p, b->hostUsed, hipMemcpyHostToDevice, c->copy));
-  HIP_TRY(b->evUp.record(c->copy));
-  HIP_TRY(hipStreamWaitEvent(c->native, b->evUp, 0));
-  HIP_TRY(b->evPrep0.record(c->native));
-  HIP_TRY(hipMemsetAsync(b->dflags.p, 0, nn * sizeof(uint32_t), c->native));
-  HIP_TRY(hipMemsetAsync(b->dcounters.p, 0, kCntTotal * sizeof(uint32_t), c->native));
+  // copy and table kernels share one stream of their own: batch i+1's tables are made while batch i is being scored
+  hipStream_t ps = c->copy;
+  HIP_TRY(hipMemcpyAsync(b->dblob.p, b->hblob.p, b->hostUsed, hipMemcpyHostToDevice, ps));
+  HIP_TRY(b->evUp.record(ps));
+  HIP_TRY(b->evPrep0.record(ps));
+  HIP_TRY(hipMemsetAsync(b->dflags.p, 0, nn * sizeof(uint32_t), ps));
+  HIP_TRY(hipMemsetAsync(b->dcounters.p, 0, kCntTotal * sizeof(uint32_t), ps));
   if (!b->okBlocks.empty()) {
     const TablePtrs tp = table_ptrs(c, b->par.blosum);
     PrepArgs pa{};
@@ -520,9 +534,9 @@ static int batch_upload(rc_batch *b) {
     pa.exactList = b->dexact.as<int>();
     pa.exactCount = b->dcounters.as<int>() + kCntExact;
     std::memcpy(pa.classOff, b->classOff, sizeof pa.classOff);
-    launch_prep(pa, c->native);
+    launch_prep(pa, ps);
   }
-  HIP_TRY(b->evPrep.record(c->native));
+  HIP_TRY(b->evPrep.record(ps));
   HIP_TRY(hipGetLastError());
   b->state = rc_batch::READY;
   b->maximaFetched = false;
@@ -772,6 +786,11 @@ static int batch_run_async(rc_batch *b) {
       HIP_TRY(hipMemcpyAsync(hs + oCnt, b->dhssCount.p, szCnt, hipMemcpyDeviceToHost, cs));
       HIP_TRY(hipMemcpyAsync(hs + oOff, b->dhssOffsets.p, szOff, hipMemcpyDeviceToHost, cs));
       HIP_TRY(hipMemcpyAsync(hs + oClamp, b->dcounters.as<uint32_t>() + kCntClamp, sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
+      // the packed HSS records: their number is only known on the device, so a generous prefix travels with the
+      // counts (16 per block; 9 on average for random blocks) and rc_batch_wait fetches the rest only if there are more
+      b->packedAhead = std::min(static_cast<size_t>(slots) * b->hssCap, static_cast<size_t>(n) * 16);
+      HIP_TRY(b->hpacked.ensure(sizeof(DevHss) * std::max<size_t>(b->packedAhead, 1)));
+      HIP_TRY(hipMemcpyAsync(b->hpacked.p, b->dhssPacked.p, sizeof(DevHss) * b->packedAhead, hipMemcpyDeviceToHost, cs));
     }
   }
   HIP_TRY(b->evDone.record(cs));
@@ -812,13 +831,16 @@ static int batch_wait(rc_batch *b) {
     std::memcpy(b->hssCount.data(), hs + oCnt, szCnt);
     std::memcpy(b->hssOff.data(), hs + oOff, szOff);
     std::memcpy(&b->clamped, hs + oClamp, sizeof(unsigned long long));
-    // the used HSS records only (k_hss_pack): that many records, second and last wait
+    // the used HSS records only (k_hss_pack); normally all of them came with the first copy
     const size_t nrec = static_cast<size_t>(std::max(b->hssOff[slots], 0));
-    if (nrec) {
-      HIP_TRY(b->hpacked.ensure(sizeof(DevHss) * nrec));
-      hipStream_t cs = c->compute[0];
-      HIP_TRY(hipMemcpyAsync(b->hpacked.p, b->dhssPacked.p, sizeof(DevHss) * nrec, hipMemcpyDeviceToHost, cs));
-      HIP_TRY(hipStreamSynchronize(cs));
+    if (nrec > b->packedAhead) {
+      // on the helper stream: the compute streams may already hold the kernels of later batches
+      PinBuf more;
+      HIP_TRY(more.ensure(sizeof(DevHss) * nrec));
+      HIP_TRY(hipMemcpyAsync(more.p, b->dhssPacked.p, sizeof(DevHss) * nrec, hipMemcpyDeviceToHost, c->aux));
+      HIP_TRY(hipStreamSynchronize(c->aux));
+      b->hssRec.assign(more.as<DevHss>(), more.as<DevHss>() + nrec);
+    } else if (nrec) {
       b->hssRec.assign(b->hpacked.as<DevHss>(), b->hpacked.as<DevHss>() + nrec);
     }
   }
@@ -889,9 +911,13 @@ int rc_stream_submit_bound(rc_stream *s, const rc_block *blocks, int32_t n_block
   if (g_no_stream_cache && s->inflight.empty() && s->ctx->inflight.load() == 0) s->ctx->U_valid = false;   // a new pass over the stream
   if (maxima_device_ptr) { b->dmaxima.release(); b->maxPtr = static_cast<float *>(maxima_device_ptr); b->maximaExternal = true; }
   else if (b->maximaExternal) { b->maxPtr = nullptr; b->maximaExternal = false; }
+  trace("submit", b);
   int r = batch_prepare(b, blocks, n_blocks, &s->par);
+  trace("prepared", b);
   if (r == RC_OK) r = batch_upload(b);
+  trace("uploaded", b);
   if (r == RC_OK) r = batch_run_async(b);
+  trace("queued", b);
   if (r != RC_OK) { s->spare.push_back(b); return r; }
   s->inflight.push_back(b);
   return RC_OK;
@@ -903,7 +929,9 @@ int rc_stream_next(rc_stream *s, rc_batch **out) {
   if (s->inflight.empty()) return fail(RC_ERR_ARG, "no batch in flight");
   rc_batch *b = s->inflight.front();
   s->inflight.pop_front();
+  trace("wait", b);
   const int r = batch_wait(b);
+  trace("done", b);
   if (r != RC_OK) { s->spare.push_back(b); return r; }
   *out = b;
   return RC_OK;
@@ -1129,8 +1157,12 @@ int rc_batch_backtrack(const rc_batch *b, int32_t blk, int32_t strand, int32_t o
   if (r) return r;
   const BlockMeta &h = b->meta[blk];
   if (h.status != RC_OK) return h.status;
-  if (strand < 0 || strand > 1 || opt_b < 1 || opt_i > h.L || opt_i < opt_b + 2 || (opt_i - opt_b - 2) % 3 != 0)
-    return fail(RC_ERR_ARG, "bad backtrack range");
+  if (strand < 0 || strand > 1 || opt_b < 1 || opt_i > h.L) return fail(RC_ERR_ARG, "bad backtrack range");
+  if (opt_i < opt_b + 2) {   // the reference's loop (score.c:629) does not run: nothing is filled in (postscript.c:264-266 asks for such ranges)
+    for (int i = 0; i < h.N * (h.cols + 1); i++) states[i] = zout[i] = transitions[i] = -9;
+    return RC_OK;
+  }
+  if ((opt_i - opt_b - 2) % 3 != 0) return fail(RC_ERR_ARG, "bad backtrack range");
   rc_ctx *c = b->ctx;
   HIP_TRY(hipSetDevice(c->device));
   const int steps = (opt_i - (opt_b + 2)) / 3 + 1, NK = h.NK;
@@ -1139,7 +1171,7 @@ int rc_batch_backtrack(const rc_batch *b, int32_t blk, int32_t strand, int32_t o
   const uint64_t *zw = reinterpret_cast<const uint64_t *>(b->hblob.as<uint8_t>() + d.off_zw) + static_cast<size_t>(strand) * L1 * zww;   // the batch keeps its pinned blob
   DevBuf d_out;
   HIP_TRY(d_out.ensure(sizeof(float) * NK * 3 * steps));
-  hipStream_t st = c->compute[0];
+  hipStream_t st = c->aux;
   launch_sk_row(b->dblob.as<uint8_t>(), reinterpret_cast<const DevBlock *>(b->dblob.as<uint8_t>() + b->oDblocks), blk, strand, opt_b, opt_i,
                 d_out.as<float>(), steps, st);
   std::vector<float> sk(static_cast<size_t>(NK) * 3 * steps);
@@ -1311,17 +1343,17 @@ int rc_fit_trees_device(rc_ctx *c, const rc_block *blocks, int32_t n_blocks, cha
   HIP_TRY(hipMalloc(&d_in.p, in.size()));
   HIP_TRY(hipMalloc(&d_work.p, sizeof(double) * maxChunk));
   HIP_TRY(hipMalloc(&d_out.p, sizeof(TreeOut) * nj));
-  HIP_TRY(hipMemcpyAsync(d_jobs.p, jobs.data(), sizeof(TreeJob) * nj, hipMemcpyHostToDevice, c->compute[0]));
-  HIP_TRY(hipMemcpyAsync(d_in.p, in.data(), in.size(), hipMemcpyHostToDevice, c->compute[0]));
+  HIP_TRY(hipMemcpyAsync(d_jobs.p, jobs.data(), sizeof(TreeJob) * nj, hipMemcpyHostToDevice, c->aux));
+  HIP_TRY(hipMemcpyAsync(d_in.p, in.data(), in.size(), hipMemcpyHostToDevice, c->aux));
   for (size_t ch = 0; ch + 1 < chunkStart.size(); ch++) {
     const int q0 = chunkStart[ch], q1 = chunkStart[ch + 1];
     launch_tree_fit(static_cast<const TreeJob *>(d_jobs.p) + q0, q1 - q0, static_cast<const uint8_t *>(d_in.p), static_cast<double *>(d_work.p),
-                    static_cast<TreeOut *>(d_out.p) + q0, c->compute[0]);
+                    static_cast<TreeOut *>(d_out.p) + q0, c->aux);
   }
   HIP_TRY(hipGetLastError());
   std::vector<TreeOut> out(nj);
-  HIP_TRY(hipMemcpyAsync(out.data(), d_out.p, sizeof(TreeOut) * nj, hipMemcpyDeviceToHost, c->compute[0]));
-  HIP_TRY(hipStreamSynchronize(c->compute[0]));
+  HIP_TRY(hipMemcpyAsync(out.data(), d_out.p, sizeof(TreeOut) * nj, hipMemcpyDeviceToHost, c->aux));
+  HIP_TRY(hipStreamSynchronize(c->aux));
   int done = 0;
   for (int q = 0; q < nj; q++) {
     const int i = owner[q];
@@ -1358,9 +1390,9 @@ int rc_evd_fit(rc_ctx *c, const double *x, int32_t n, double *mu, double *lambda
   HIP_TRY(hipMalloc(&d_x, sizeof(double) * n));
   HIP_TRY(hipMalloc(&d_o, sizeof(FitOut)));
   HIP_TRY(hipMemcpy(d_x, x, sizeof(double) * n, hipMemcpyHostToDevice));
-  launch_evd_fit_f64(d_x, n, d_o, c->compute[0]);
+  launch_evd_fit_f64(d_x, n, d_o, c->aux);
   FitOut o;
-  hipError_t e = hipStreamSynchronize(c->compute[0]);
+  hipError_t e = hipStreamSynchronize(c->aux);
   if (e == hipSuccess) e = hipMemcpy(&o, d_o, sizeof o, hipMemcpyDeviceToHost);
   hipFree(d_x); hipFree(d_o);
   if (e != hipSuccess) return fail(RC_ERR_DEVICE, hipGetErrorString(e));
@@ -1374,8 +1406,8 @@ int rc_mt_stream(rc_ctx *c, uint32_t seed, uint32_t *out, int32_t n) {
   HIP_TRY(hipSetDevice(c->device));
   uint32_t *d = nullptr;
   HIP_TRY(hipMalloc(&d, sizeof(uint32_t) * n));
-  launch_mt_stream(seed, 1, n, d, c->compute[0]);
-  hipError_t e = hipStreamSynchronize(c->compute[0]);
+  launch_mt_stream(seed, 1, n, d, c->aux);
+  hipError_t e = hipStreamSynchronize(c->aux);
   if (e == hipSuccess) e = hipMemcpy(out, d, sizeof(uint32_t) * n, hipMemcpyDeviceToHost);
   hipFree(d);
   if (e != hipSuccess) return fail(RC_ERR_DEVICE, hipGetErrorString(e));

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(64) void k_native_dp(NativeArgs A) {
 }
 
 __global__ __launch_bounds__(64) void k_native_scan(NativeArgs A) {
-  __shared__ float row[kWave];
+  // no LDS: this kernel runs beside k_null, whose workgroups hold all of a CU's LDS
   const int lane = threadIdx.x;
   const int slot = blockIdx.x;            // position in the blocks list
   const int bi = A.blocks[slot / 6];
@@ -273,25 +273,21 @@ __global__ __launch_bounds__(64) void k_native_scan(NativeArgs A) {
   for (int a = 0; a < sites; a++) {
     for (int j0 = a; j0 < sites; j0 += kWave) {
       // the state machine only looks at positive entries and at the frame's final one (score.c:898):
-      // the wave finds them with a ballot, lane 0 walks the set bits in order
+      // the wave finds them with a ballot and walks the set bits in order (every lane the same walk, the
+      // entry's value comes from its lane by a shuffle; lane 0 writes the records)
       const int j = j0 + lane;
       const float v = (j < sites) ? S[static_cast<size_t>(a) * sites + j] : 0.0f;
       const bool last = (a == sites - 1) && (j == sites - 1);
       unsigned long long m = __ballot((j < sites) && (v > 0.0f || last));
-      if (m == 0ull) continue;
-      __syncthreads();
-      row[lane] = v;
-      __syncthreads();
-      if (lane == 0) {
-        while (m) {
-          const int t = __builtin_ctzll(m);
-          m &= m - 1ull;
-          const int jj = j0 + t;
-          scan_step(st, row[t], a, jj, (a == sites - 1) && (jj == sites - 1), A.tieThr, [&](const ScanState &e) {
-            if (n < A.hssCap) out[n] = DevHss{s, f, e.ss, e.se, e.cm};
-            n++;
-          });
-        }
+      while (m) {
+        const int t = __builtin_ctzll(m);
+        m &= m - 1ull;
+        const int jj = j0 + t;
+        const float vt = __shfl(v, t, kWave);
+        scan_step(st, vt, a, jj, (a == sites - 1) && (jj == sites - 1), A.tieThr, [&](const ScanState &e) {
+          if (lane == 0 && n < A.hssCap) out[n] = DevHss{s, f, e.ss, e.se, e.cm};
+          n++;
+        });
       }
     }
   }

@@ -229,7 +229,7 @@ def test_sample_range_sharding_on_the_hip_path(ctx):
         assert rc == ref["evd_rc"]
         assert abs(mu - ref["mu"]) <= 1e-6 * max(1, abs(ref["mu"])) and abs(lam - ref["lambda"]) <= 1e-6
         gh, wh = sorted(hss, key=hss_key), sorted(ref["hss"], key=hss_key)
-        assert [hss_key(h)[:5] for h in gh] == [hss_key(h)[:5] for h in wh]
+        assert [(np.float32(h["score"]),) + hss_key(h)[1:5] for h in gh] == [(np.float32(h["score"]),) + hss_key(h)[1:5] for h in wh]
         for a, b in zip(gh, wh):
             assert abs(a["pvalue"] - b["pvalue"]) <= 1e-6 * max(1.0, abs(b["pvalue"]))
     rows = [i for i, e in enumerate(entries) if "skipped" not in e["ref"] and e["ref"]["maxScores"]]
