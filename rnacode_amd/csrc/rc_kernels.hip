@@ -73,11 +73,21 @@ __global__ __launch_bounds__(64) void k_mt_stream(uint32_t seedBase, int Spad, i
 
 // calculateBG (score.c:107-193) for one model per lane: two 4096-term float accumulations in the loop
 // order a1,a2,a3,b1,b2,b3, every product and sum a single binary32 operation in the reference's order
-// (SURVEY appendix A.4).  Codon indices, stop tests, Hamming classes and BLOSUM entries are wave-uniform
-// (scalar); the lane's HKY85 matrix and codon frequencies sit in LDS, [entry][lane].
+// (SURVEY appendix A.4).  The codon a is a run-time loop (its three HKY85 rows, 12 floats, are re-read per a);
+// the 64 codons b are unrolled, so row entries, stop tests and Hamming classes of b are compile-time and the
+// kernel needs no LDS -- it runs beside k_null, whose workgroups hold all of a CU's LDS.
+__device__ constexpr int kPepOf(int c) {   // genetic code as in rc_tables.h: amino-acid index in "ARNDCQEGHILKMFPSTWYV", -1 = stop
+  constexpr char code[] = "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSS*CWCLFLF";
+  constexpr char order[] = "ARNDCQEGHILKMFPSTWYV";
+  for (int i = 0; i < 20; i++) if (order[i] == code[c]) return i;
+  return -1;
+}
+
+template <int B, typename F> __device__ __forceinline__ void for_codon_b(F &&f) {
+  if constexpr (B < 64) { f(std::integral_constant<int, B>{}); for_codon_b<B + 1>(static_cast<F &&>(f)); }
+}
+
 __global__ __launch_bounds__(64) void k_prep_models(PrepArgs A) {
-  __shared__ float shP[16][kWave];
-  __shared__ float shF[64][kWave];
   const int lane = threadIdx.x;
   int t = blockIdx.x * kWave + lane;
   const bool active = t < A.nModels;
@@ -89,50 +99,58 @@ __global__ __launch_bounds__(64) void k_prep_models(PrepArgs A) {
   }
   const DevBlock *db = A.dblocks + A.blocks[lo];
   ModelRec *m = reinterpret_cast<ModelRec *>(A.blob + db->off_models) + (t - A.modelPrefix[lo]);
-#pragma unroll
-  for (int e = 0; e < 16; e++) shP[e][lane] = m->P[e];
+  const float *__restrict__ P = m->P;
   const float f0 = m->freqs[0], f1 = m->freqs[1], f2 = m->freqs[2], f3 = m->freqs[3];
-  for (int a = 0; a < 64; a++) {
-    const int a1 = a >> 4, a2 = (a >> 2) & 3, a3 = a & 3;
-    const float x = a1 == 0 ? f0 : a1 == 1 ? f1 : a1 == 2 ? f2 : f3;
-    const float y = a2 == 0 ? f0 : a2 == 1 ? f1 : a2 == 2 ? f2 : f3;
-    const float z = a3 == 0 ? f0 : a3 == 1 ? f1 : a3 == 2 ? f2 : f3;
-    shF[a][lane] = x * y * z;
-  }
-  const int *__restrict__ pep = A.pep;
   const int *__restrict__ blosum = A.blosum;
+  auto freq = [&](int x) { return x == 0 ? f0 : x == 1 ? f1 : x == 2 ? f2 : f3; };   // x is wave-uniform
   float probStop = 0.0f;
   for (int a = 0; a < 64; a++) {
-    const int pa = pep[a];
-    const float fa = shF[a][lane];
-    for (int b = 0; b < 64; b++) {
-      if (pa != -1 && pep[b] != -1) continue;
-      float pAB = shP[(a >> 4) * 4 + (b >> 4)][lane] * shP[((a >> 2) & 3) * 4 + ((b >> 2) & 3)][lane] * shP[(a & 3) * 4 + (b & 3)][lane];
-      pAB = pAB * fa;
-      probStop = probStop + pAB;
-    }
+    const int a1 = a >> 4, a2 = (a >> 2) & 3, a3 = a & 3;
+    const bool stopA = A.pep[a] == -1;
+    const float fa = freq(a1) * freq(a2) * freq(a3);
+    float r1[4], r2[4], r3[4];
+#pragma unroll
+    for (int x = 0; x < 4; x++) { r1[x] = P[a1 * 4 + x]; r2[x] = P[a2 * 4 + x]; r3[x] = P[a3 * 4 + x]; }
+    for_codon_b<0>([&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      constexpr bool stopB = kPepOf(b) == -1;
+      if (stopA || stopB) {
+        float pAB = r1[b >> 4] * r2[(b >> 2) & 3] * r3[b & 3];
+        pAB = pAB * fa;
+        probStop = probStop + pAB;
+      }
+    });
   }
   float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f, s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
   const float keep = 1.0f - probStop;   // (1 - probStop): int 1 converted to float
   for (int a = 0; a < 64; a++) {
-    const int pa = pep[a];
+    const int pa = A.pep[a];
     if (pa == -1) continue;
-    const float fa = shF[a][lane];
-    for (int b = 0; b < 64; b++) {
-      const int pb = pep[b];
-      if (pb == -1) continue;
-      const int x = a ^ b;
-      const int h = ((x & 48) != 0) + ((x & 12) != 0) + ((x & 3) != 0);
-      float pAB = shP[(a >> 4) * 4 + (b >> 4)][lane] * shP[((a >> 2) & 3) * 4 + ((b >> 2) & 3)][lane] * shP[(a & 3) * 4 + (b & 3)][lane];
-      pAB = pAB * fa;
-      pAB = pAB / keep;
-      const float sc = static_cast<float>(blosum[pa * 20 + pb]);
-      const float w = sc * pAB;
-      if (h == 0) { c0 = c0 + pAB; s0 = s0 + w; }
-      else if (h == 1) { c1 = c1 + pAB; s1 = s1 + w; }
-      else if (h == 2) { c2 = c2 + pAB; s2 = s2 + w; }
-      else { c3 = c3 + pAB; s3 = s3 + w; }
-    }
+    const int a1 = a >> 4, a2 = (a >> 2) & 3, a3 = a & 3;
+    const float fa = freq(a1) * freq(a2) * freq(a3);
+    float r1[4], r2[4], r3[4];
+#pragma unroll
+    for (int x = 0; x < 4; x++) { r1[x] = P[a1 * 4 + x]; r2[x] = P[a2 * 4 + x]; r3[x] = P[a3 * 4 + x]; }
+    for_codon_b<0>([&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      constexpr int pb = kPepOf(b);
+      if constexpr (pb != -1) {
+        const int x = a ^ b;
+        const int h = ((x & 48) != 0) + ((x & 12) != 0) + ((x & 3) != 0);
+        float pAB = r1[b >> 4] * r2[(b >> 2) & 3] * r3[b & 3];
+        pAB = pAB * fa;
+        pAB = pAB / keep;
+        const float sc = static_cast<float>(blosum[pa * 20 + pb]);
+        // exactly one Hamming class receives the term; the other three add +0, which changes nothing (x + 0 == x
+        // bit for bit for every x these sums can hold: they start at +0).  h is wave-uniform, the selects are cheap;
+        // written as a branch per class the compiler turns the eight accumulators into an array in scratch memory.
+        const float p0 = h == 0 ? pAB : 0.0f, p1 = h == 1 ? pAB : 0.0f, p2 = h == 2 ? pAB : 0.0f, p3 = h == 3 ? pAB : 0.0f;
+        c0 = c0 + p0; s0 = s0 + sc * p0;
+        c1 = c1 + p1; s1 = s1 + sc * p1;
+        c2 = c2 + p2; s2 = s2 + sc * p2;
+        c3 = c3 + p3; s3 = s3 + sc * p3;
+      }
+    });
   }
   if (active) {
     m->scores[0] = s0 / c0; m->scores[1] = s1 / c1; m->scores[2] = s2 / c2; m->scores[3] = s3 / c3;
@@ -331,39 +349,33 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
   return r;
 }
 
-// all four sums of Lawless 4.1.6 in one pass over the workgroup (one barrier pair per evaluation)
-__device__ __forceinline__ void block_sum4(double &a, double &b, double &c, double &d, double *sh) {
-  const int tid = threadIdx.x, nw = static_cast<int>(blockDim.x >> 6);
-  for (int off = 32; off > 0; off >>= 1) {
-    a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64);
-    c += __shfl_down(c, off, 64); d += __shfl_down(d, off, 64);
-  }
-  __syncthreads();
-  if ((tid & 63) == 0) { sh[(tid >> 6) * 4 + 0] = a; sh[(tid >> 6) * 4 + 1] = b; sh[(tid >> 6) * 4 + 2] = c; sh[(tid >> 6) * 4 + 3] = d; }
-  __syncthreads();
-  a = b = c = d = 0.0;
-  for (int w = 0; w < nw; w++) { a += sh[w * 4 + 0]; b += sh[w * 4 + 1]; c += sh[w * 4 + 2]; d += sh[w * 4 + 3]; }
+// The per-block fit runs in ONE wavefront without LDS (it is queued behind k_null, whose workgroups hold all of a
+// CU's LDS, beside the next batch's k_null): sums meet in an xor butterfly, which leaves the same bits on every
+// lane, so the Newton / bisection control flow below is wave-uniform.
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
 }
 
-__device__ void lawless416(const float *x, int n, double lambda, double *sh, double *f, double *df) {
+__device__ void lawless416(const float *x, int n, double lambda, double *f, double *df) {
   double e = 0, xe = 0, xxe = 0, xs = 0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+  for (int i = threadIdx.x; i < n; i += kWave) {
     const double xi = static_cast<double>(x[i]);
     const double ex = exp(-1. * lambda * xi);
     xs += xi; xe += xi * ex; xxe += xi * xi * ex; e += ex;
   }
-  block_sum4(e, xe, xxe, xs, sh);
+  e = wave_sum(e); xe = wave_sum(xe); xxe = wave_sum(xxe); xs = wave_sum(xs);
   const double total = static_cast<double>(n);
   *f = 1. / lambda - xs / total + xe / e;
   *df = ((xe / e) * (xe / e)) - (xxe / e) - (1. / (lambda * lambda));
 }
 
-__device__ int evd_fit_block(const float *x, int n, double *sh, double *mu_out, double *lambda_out) {
+__device__ int evd_fit_block(const float *x, int n, double *mu_out, double *lambda_out) {
   double lambda = 0.2, fx, dfx;
   const double tol = 1e-5;
   int it;
   for (it = 0; it < 100; it++) {
-    lawless416(x, n, lambda, sh, &fx, &dfx);
+    lawless416(x, n, lambda, &fx, &dfx);
     if (fabs(fx) < tol) break;
     lambda = lambda - fx / dfx;
     if (lambda <= 0.) lambda = 0.001;
@@ -371,23 +383,23 @@ __device__ int evd_fit_block(const float *x, int n, double *sh, double *mu_out, 
   if (it == 100) {  // bisection fallback (extreme_fit.c:193-236)
     double left = 0.2, right = 0.2, mid = 0.2;
     lambda = 0.2;
-    lawless416(x, n, lambda, sh, &fx, &dfx);
+    lawless416(x, n, lambda, &fx, &dfx);
     if (fx < 0.) {
       do {
         left -= 0.1;
         if (left < 0.) return 0;
-        lawless416(x, n, left, sh, &fx, &dfx);
+        lawless416(x, n, left, &fx, &dfx);
       } while (fx < 0.);
     } else {
       do {
         right += 0.1;
-        lawless416(x, n, right, sh, &fx, &dfx);
+        lawless416(x, n, right, &fx, &dfx);
         if (right > 100.) return 0;
       } while (fx > 0.);
     }
     for (it = 0; it < 100; it++) {
       mid = (left + right) / 2.;
-      lawless416(x, n, mid, sh, &fx, &dfx);
+      lawless416(x, n, mid, &fx, &dfx);
       if (fabs(fx) < tol) break;
       if (fx > 0.) left = mid; else right = mid;
     }
@@ -395,8 +407,8 @@ __device__ int evd_fit_block(const float *x, int n, double *sh, double *mu_out, 
     lambda = mid;
   }
   double e = 0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) e += exp(-1 * lambda * static_cast<double>(x[i]));
-  e = block_sum(e, sh);
+  for (int i = threadIdx.x; i < n; i += kWave) e += exp(-1 * lambda * static_cast<double>(x[i]));
+  e = wave_sum(e);
   *mu_out = -1. * log(e / static_cast<double>(n)) / lambda;
   *lambda_out = lambda;
   return 1;
@@ -427,25 +439,21 @@ __global__ __launch_bounds__(64) void k_stop_mark(FitArgs A) {
   if (threadIdx.x == 0 && better > A.stopCutoff) A.flags[bi] |= kFlagStopped;
 }
 
-__global__ __launch_bounds__(256) void k_evd_fit(FitArgs A) {
-  __shared__ double sh[16];
-  __shared__ float maxNativeSh;
+__global__ __launch_bounds__(64) void k_evd_fit(FitArgs A) {
   const int bi = A.blocks[blockIdx.x];
   const DevBlock *db = A.dblocks + bi;
   const float *x = A.maxima + static_cast<size_t>(db->out_index) * A.sampleN;
-  if (threadIdx.x == 0) maxNativeSh = best_native(A, bi);
-  __syncthreads();
-  const float maxNative = maxNativeSh;
-  double better = 0;
-  for (int i = threadIdx.x; i < A.sampleN; i += blockDim.x) better += (x[i] > maxNative) ? 1.0 : 0.0;   // samples not simulated hold -1
-  better = block_sum(better, sh);
+  const float maxNative = best_native(A, bi);     // every lane: a few records
+  int better = 0;
+  for (int i = threadIdx.x; i < A.sampleN; i += kWave) better += (x[i] > maxNative) ? 1 : 0;   // samples not simulated hold -1
+  for (int off = 32; off > 0; off >>= 1) better += __shfl_xor(better, off, 64);
   FitOut o;
-  o.better = static_cast<int>(better);
+  o.better = better;
   o.rc = -1; o.mu = 0; o.lambda = 0;
   const bool stopped = A.stopEarly && (o.better > A.stopCutoff);  // score.c:1040-1042
   if (!stopped) {
     double mu, lambda;
-    if (evd_fit_block(x, A.sampleN, sh, &mu, &lambda) == 1) { o.rc = 1; o.mu = mu; o.lambda = lambda; }
+    if (evd_fit_block(x, A.sampleN, &mu, &lambda) == 1) { o.rc = 1; o.mu = mu; o.lambda = lambda; }
   }
   if (threadIdx.x == 0) A.out[db->out_index] = o;
 }
@@ -579,7 +587,7 @@ void launch_stop_mark(const FitArgs &a, int nblocks, hipStream_t stream) {
 }
 
 void launch_evd_fit(const FitArgs &a, int nblocks, hipStream_t stream) {
-  hipLaunchKernelGGL(k_evd_fit, dim3(nblocks), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(k_evd_fit, dim3(nblocks), dim3(64), 0, stream, a);
 }
 
 void launch_evd_fit_f64(const double *x, int n, FitOut *out, hipStream_t stream) {
