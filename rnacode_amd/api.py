@@ -25,7 +25,8 @@ import numpy as np
 from .alnio import AlnBlock
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librnacode_hip.so")
+# RC_LIB_PATH: load another build of the library (tools/ab.sh compares builds without touching the product .so)
+LIB_PATH = os.environ.get("RC_LIB_PATH") or os.path.join(_HERE, "librnacode_hip.so")
 
 RC_OK, RC_ERR_ARG, RC_ERR_DEVICE, RC_ERR_UNSUPPORTED, RC_ERR_SKIP = 0, -1, -2, -3, -4
 

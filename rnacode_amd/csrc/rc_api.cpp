@@ -202,6 +202,7 @@ struct rc_ctx {
   std::map<std::pair<int, size_t>, int> occ;   // (N-1, LDS bytes) -> resident workgroups per CU of k_null
   size_t ldsMaxBytes = 13312;   // per wavefront: >= 12 wavefronts per CU; measured crossover against reading the codes from L2 (cols 150: 52.0 vs 54.0 ms, cols 180: 41.5 vs 39.3 ms)
   int debugSkip = 0;
+  DevBuf d_cellStats;              // RC_PROFILING builds with RC_CELL_STATS=1: k_null's cell counters, printed when the context goes
   int serialNative = 0;
   int hostThreads = 0;
   std::unique_ptr<Pool> pool;
@@ -303,6 +304,12 @@ void rc_ctx_destroy(rc_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   c->pool.reset();
+  if (kProfiling && c->d_cellStats.p) {
+    unsigned long long st[3] = {0, 0, 0};
+    if (hipMemcpy(st, c->d_cellStats.p, sizeof st, hipMemcpyDeviceToHost) == hipSuccess && st[0])
+      std::fprintf(stderr, "[rc cell stats] wavefront-cells %llu, with no positive lane %llu (%.4f %%), positive lane-cells %.2f %%\n", st[0], st[1],
+                   100.0 * st[1] / st[0], 100.0 * st[2] / (64.0 * st[0]));
+  }
   if (c->d_U) (void)hipFree(c->d_U);
   for (hipStream_t st : c->compute) if (st) (void)hipStreamDestroy(st);
   if (c->native) (void)hipStreamDestroy(c->native);
@@ -360,6 +367,10 @@ int rc_ctx_create(int device, rc_ctx **out) {
   c->tieThr = float_threshold_lt(0.0001);
   if (const char *e = std::getenv("RC_LDS_MAX_BYTES")) c->ldsMaxBytes = static_cast<size_t>(std::atol(e));
   if (kProfiling) if (const char *e = std::getenv("RC_DEBUG_SKIP")) c->debugSkip = std::atoi(e);   // RC_PROFILING builds only: results are wrong
+  if (kProfiling && std::getenv("RC_CELL_STATS")) {
+    HIP_TRY(c->d_cellStats.ensure(3 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->d_cellStats.p, 0, 3 * sizeof(unsigned long long)));
+  }
   c->hostThreads = std::min(effective_cpus(), 32);
   if (const char *e = std::getenv("RC_HOST_THREADS")) c->hostThreads = std::max(1, std::atoi(e));
   *out = guard.release();
@@ -440,11 +451,6 @@ static int batch_prepare(rc_batch *b, const rc_block *blocks, int32_t n_blocks, 
   for (int i = 0; i < n_blocks; i++) {
     const BlockMeta &m = b->meta[i];
     if (m.status != RC_OK) continue;
-    if (m.N > kFastRows) {   // TODO(wide kernels)
-      b->meta[i].status = RC_ERR_UNSUPPORTED; b->db[i].status = RC_ERR_UNSUPPORTED;
-      b->errs[i] = "more than 32 rows";
-      continue;
-    }
     b->okBlocks.push_back(i);
     auto &cls = b->classes[m.NK];
     if (!cls.empty() && b->meta[cls.front()].L != m.L) sameL = false;
@@ -645,7 +651,8 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
     // CU (RC_LDS_MAX_BYTES overrides the per-wavefront budget); otherwise they are read from the
     // per-workgroup scratch in global memory.
     p.ldsBytes = static_cast<size_t>(maxLc / 3) * NCW * kWave * sizeof(uint32_t);
-    if (p.ldsBytes > c->ldsMaxBytes || b->allExact) p.ldsBytes = 0;
+    const bool exactOnly = b->allExact || p.NK >= kFastRows;   // wide blocks (N > 32) only have the EXACT instantiation
+    if (p.ldsBytes > c->ldsMaxBytes || exactOnly) p.ldsBytes = 0;
     else p.ldsBytes = std::max<size_t>(p.ldsBytes, kPhaseALds);   // phase A keeps the tree's threshold table and the pair table there
     const std::pair<int, size_t> key(p.NK, p.ldsBytes);
     if (!c->occ.count(key)) c->occ[key] = null_occupancy(p.NK, p.ldsBytes);
@@ -660,7 +667,7 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
     p.grid = static_cast<int>(std::max<size_t>(1, std::min<size_t>(p.grid, (static_cast<size_t>(1) << 30) / std::max<size_t>(p.stride, 1))));
     // blocks flagged by k_prep_lut go through the EXACT instantiation in a second launch on the same stream; their
     // number is only known on the device, the launch is a few idle workgroups when there are none
-    p.gridExact = b->allExact ? 0 : std::min(p.grid, c->numCU);
+    p.gridExact = exactOnly ? 0 : std::min(p.grid, c->numCU);
     p.need = p.stride * std::max(p.grid, p.gridExact);
     needSum += p.need; needMax = std::max(needMax, p.need);
     plans.push_back(p);
@@ -696,8 +703,9 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
     a.U = c->d_U; a.pair = R.tp.pair; a.scratch = b->dscratch.as<uint32_t>() + scratchOff; a.scratchStride = p.stride;
     a.maxima = b->maxPtr; a.clampCount = reinterpret_cast<unsigned long long *>(b->dcounters.as<uint32_t>() + kCntClamp);
     a.tieThr = c->tieThr; a.debugSkip = c->debugSkip; a.comboSplit = p.comboSplit;
+    a.cellStats = c->d_cellStats.as<unsigned long long>();
     unsigned int *work = b->dcounters.as<unsigned int>() + kCntWork + static_cast<size_t>(phase) * 2 * (kMaxRows + 1) * 8;
-    if (b->allExact) {
+    if (b->allExact || p.NK >= kFastRows) {
       a.skipMask = extraSkip;
       a.workCounter = work + (kMaxRows + 1) * 8 + p.NK * 8;
       if (!launch_null(p.NK, a, p.grid, 0, true, st)) return fail(RC_ERR_UNSUPPORTED, "no null kernel for this number of rows");

@@ -260,13 +260,16 @@ __global__ __launch_bounds__(64) void k_native_dp(NativeArgs A) {
     for (int k = 0; k < NK; k++) s0[k] = s1[k] = s2[k] = 0.0f;
     for (int j = a0; j < sites; j++) {
       const int i = 3 * j + 3 + f;
-      const unsigned long long z = zw[s * L1 + i];
+      constexpr int ZW = (NK + 31) / 32;
+      unsigned long long z[ZW];
+#pragma unroll
+      for (int x = 0; x < ZW; x++) z[x] = zw[static_cast<size_t>(s * L1 + i) * ZW + x];
       if (a <= j && a < sites) {
         float sum = 0.0f;
 #pragma unroll
         for (int k = 0; k < NK; k++) {
           const float sig = sigma[(s * NK + k) * L1 + i];
-          pair_step(static_cast<int>((z >> (2 * k)) & 3ull), sig, Delta, Omega, omega, s0[k], s1[k], s2[k]);
+          pair_step(static_cast<int>((z[k >> 5] >> (2 * (k & 31))) & 3ull), sig, Delta, Omega, omega, s0[k], s1[k], s2[k]);
           sum = sum + fmaxf(fmaxf(s0[k], s1[k]), s2[k]);
         }
         S[static_cast<size_t>(a) * sites + j] = fmaxf(sum, Delta) / nkf;
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(64) void k_sk_row(const uint8_t *blob, const DevBlo
   float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
   int t = 0;
   for (int i = b + 2; i <= iMax; i += 3, t++) {
-    const int zc = static_cast<int>((zw[s * L1 + i] >> (2 * k)) & 3ull);
+    const int zc = static_cast<int>((zw[static_cast<size_t>(s * L1 + i) * db->zw_words + (k >> 5)] >> (2 * (k & 31))) & 3ull);
     // lanes follow different k: the branch may diverge here, which is fine for this helper
     pair_step(zc, sigma[(s * db->NK + k) * L1 + i], db->Delta, db->Omega, db->omega, s0, s1, s2);
     out[(k * 3 + 0) * stride + t] = s0;
@@ -519,28 +522,32 @@ void launch_mt_stream(uint32_t seedBase, int Spad, int D, uint32_t *U, hipStream
   hipLaunchKernelGGL(k_mt_stream, dim3(Spad), dim3(64), 0, stream, seedBase, Spad, D, U);
 }
 
-// k_null is instantiated in four units (rc_null_a..d.hip), one per range of N-1
-int null_occupancy_a(int, size_t); int null_occupancy_b(int, size_t); int null_occupancy_c(int, size_t); int null_occupancy_d(int, size_t);
-bool launch_null_a(int, const NullArgs &, int, size_t, bool, hipStream_t);
-bool launch_null_b(int, const NullArgs &, int, size_t, bool, hipStream_t);
-bool launch_null_c(int, const NullArgs &, int, size_t, bool, hipStream_t);
-bool launch_null_d(int, const NullArgs &, int, size_t, bool, hipStream_t);
+// k_null is instantiated in eight units (rc_null_a..h.hip), one per range of N-1; e..h hold the wide blocks (N-1 >= 32)
+#define RC_NULL_UNIT(S) int null_occupancy_##S(int, size_t); bool launch_null_##S(int, const NullArgs &, int, size_t, bool, hipStream_t);
+RC_NULL_UNIT(a) RC_NULL_UNIT(b) RC_NULL_UNIT(c) RC_NULL_UNIT(d) RC_NULL_UNIT(e) RC_NULL_UNIT(f) RC_NULL_UNIT(g) RC_NULL_UNIT(h)
+#undef RC_NULL_UNIT
 
 int null_occupancy(int NK, size_t ldsBytes) {
-  if (NK < 2 || NK > 31) return 0;
+  if (NK < 2 || NK > kMaxRows - 1) return 0;
   return NK <= 6 ? null_occupancy_a(NK, ldsBytes) : NK <= 12 ? null_occupancy_b(NK, ldsBytes)
-       : NK <= 21 ? null_occupancy_c(NK, ldsBytes) : null_occupancy_d(NK, ldsBytes);
+       : NK <= 21 ? null_occupancy_c(NK, ldsBytes) : NK <= 31 ? null_occupancy_d(NK, ldsBytes)
+       : NK <= 39 ? null_occupancy_e(NK, ldsBytes) : NK <= 47 ? null_occupancy_f(NK, ldsBytes)
+       : NK <= 55 ? null_occupancy_g(NK, ldsBytes) : null_occupancy_h(NK, ldsBytes);
 }
 
+// N-1 >= 32: only the EXACT instantiation without code staging exists (ldsBytes and exact are ignored)
 bool launch_null(int NK, const NullArgs &a, int grid, size_t ldsBytes, bool exact, hipStream_t stream) {
-  if (NK < 2 || NK > 31) return false;
+  if (NK < 2 || NK > kMaxRows - 1) return false;
   return NK <= 6 ? launch_null_a(NK, a, grid, ldsBytes, exact, stream) : NK <= 12 ? launch_null_b(NK, a, grid, ldsBytes, exact, stream)
-       : NK <= 21 ? launch_null_c(NK, a, grid, ldsBytes, exact, stream) : launch_null_d(NK, a, grid, ldsBytes, exact, stream);
+       : NK <= 21 ? launch_null_c(NK, a, grid, ldsBytes, exact, stream) : NK <= 31 ? launch_null_d(NK, a, grid, ldsBytes, exact, stream)
+       : NK <= 39 ? launch_null_e(NK, a, grid, ldsBytes, exact, stream) : NK <= 47 ? launch_null_f(NK, a, grid, ldsBytes, exact, stream)
+       : NK <= 55 ? launch_null_g(NK, a, grid, ldsBytes, exact, stream) : launch_null_h(NK, a, grid, ldsBytes, exact, stream);
 }
 
 #define RC_FOR_NK(X) \
   X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) \
-  X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31)
+  X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40) X(41) \
+  X(42) X(43) X(44) X(45) X(46) X(47) X(48) X(49) X(50) X(51) X(52) X(53) X(54) X(55) X(56) X(57) X(58) X(59) X(60) X(61) X(62) X(63)
 
 void launch_native_sigma(const NativeArgs &a, int nblocks, hipStream_t stream) {
   hipLaunchKernelGGL(k_native_sigma, dim3(nblocks), dim3(256), 0, stream, a);

@@ -38,6 +38,7 @@ struct NullArgs {
   int comboSplit;             // 1: items are (block, group, strand x frame); maxima combined by atomic max
   unsigned int *workCounter;  // [8], zeroed before the launch: next unclaimed work item of each XCD queue
   int debugSkip;              // RC_PROFILING builds only: bit0 skip the DP/scan phase, bit1 skip simulation
+  unsigned long long *cellStats;   // RC_PROFILING builds only: [0] wavefront-cells, [1] of those with no lane's sum > 0, [2] lanes with sum > 0
 };
 
 struct NativeArgs {
@@ -100,8 +101,8 @@ struct TreeJob {
 };
 struct TreeOut {
   int root;
-  int parent[63], nchild[63], child[63 * 3], preorder[63];
-  double len[63];
+  int parent[127], nchild[127], child[127 * 3], preorder[127];   // 2 kMaxRows - 1 nodes
+  double len[127];
   double kappa, lnl;
 };
 void launch_tree_fit(const TreeJob *jobs, int njobs, const uint8_t *in, double *scratch, TreeOut *out, hipStream_t stream);

@@ -154,6 +154,7 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
   constexpr int N = NK + 1;
   constexpr int CPW = 5;                  // 6-bit sigma codes per 32-bit word
   constexpr int NCW = (NK + CPW - 1) / CPW;
+  constexpr int ZW = (NK + 31) / 32;      // 64-bit words per z entry (2 bits per sequence)
   using Regs = KRegs<std::make_integer_sequence<int, NK>>;
   // phase A: threshold table of the tree (nnodes x 64 B); phase B with LDSC: [site][NCW][64] sigma codes
   // of the current strand x frame
@@ -306,6 +307,7 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
 
     // ---- phase B: both strands x 3 frames: DP over (start a, end j) + serial HSS scan
     float best = -1.0f;
+    unsigned long long statCells = 0, statNoPos = 0, statPosLanes = 0;   // RC_PROFILING builds only
     // omega and Delta as per-lane values: v_add_f32 with two VGPR operands issues at the full rate,
     // with an SGPR operand at ~60 % of it (tools/microbench.hip)
     float omega_v, Delta_v = 0.0f;
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
         if (sites <= 0) continue;
         if (onlyCombo >= 0 && onlyCombo % 3 != f) continue;
         const uint32_t *__restrict__ cbase = cod + (static_cast<size_t>(s * L1 + 3 + f) * NCW) * kWave + lane;  // site j: + j*3*NCW*64
-        const unsigned long long *__restrict__ zbase = zw + s * L1 + 3 + f;                                       // site j: [3j]
+        const unsigned long long *__restrict__ zbase = zw + static_cast<size_t>(s * L1 + 3 + f) * ZW;               // site j: [3j * ZW + word]
         const unsigned long long *__restrict__ zany = zmask + static_cast<size_t>(s * 3 + f) * zmWords;            // bit j: some z != 0 at site j
         if constexpr (LDSC) {
           for (int idx = 0; idx < sites * NCW; idx++)
@@ -398,6 +400,10 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
         // final entry is never reported), and for Delta < 0 a positive S equals sum/(N-1): the fast
         // instantiation skips the MAX3 with Delta; blocks with Delta >= 0 are routed to EXACT.
         auto finish = [&](float sum) -> float {
+          if constexpr (kProfiling) {   // how often a wave-uniform "no lane has sum > 0" test could skip the division and the scan step
+            const unsigned long long pos = __ballot(sum > 0.0f);
+            statCells++; statNoPos += (pos == 0ull); statPosLanes += __builtin_popcountll(pos);
+          }
           if constexpr (EXACT) {
             const float top = (sum > Delta_v) ? sum : Delta_v;
             return div_by_nk<NK, EXACT>(top, nkf);
@@ -442,12 +448,14 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
         auto event_cell = [&](uint32_t (&w)[NCW], int j, int jn) -> float {
           float sig[NK];
           lookup(w, sig, jn, std::true_type{});
-          const unsigned long long z = zbase[3 * j];
+          unsigned long long z[ZW];
+#pragma unroll
+          for (int x = 0; x < ZW; x++) z[x] = zbase[static_cast<size_t>(3 * j) * ZW + x];
           float sum = 0.0f;
           static_for<NK>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             auto &r = R.template at<k>();
-            pair_step(static_cast<int>((z >> (2 * k)) & 3ull), sig[k], Delta, Omega, omega, r.s0, r.s1, r.s2);
+            pair_step(static_cast<int>((z[k >> 5] >> (2 * (k & 31))) & 3ull), sig[k], Delta, Omega, omega, r.s0, r.s1, r.s2);
             const float m = fmaxf(fmaxf(r.s0, r.s1), r.s2);
             sum = (k == 0) ? m : sum + m;
           });
@@ -537,6 +545,9 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
         sample_scan_last(st, best);   // entry (sites-1, sites-1): its own value can never be reported
       }
     }
+    if constexpr (kProfiling) {
+      if (A.cellStats && lane == 0) { atomicAdd(A.cellStats, statCells); atomicAdd(A.cellStats + 1, statNoPos); atomicAdd(A.cellStats + 2, statPosLanes); }
+    }
     if (sidx < A.sampleN) {
       float *dst = maxima + static_cast<size_t>(db->out_index) * A.sampleN + sidx;
       // scores are positive floats or the -1 sentinel: integer order == float order on that set
@@ -548,11 +559,14 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
 
 
 // launch / occupancy of one N-1 value, used by the range units
+// dynamic LDS of the instantiations that do not stage codes: phase A's threshold table (64 B per node) + pair table
+template <int NK> constexpr size_t phase_a_lds() { return NK < kFastRows ? static_cast<size_t>(kPhaseALds) : static_cast<size_t>(2 * (NK + 1)) * 64 + 64 * 64; }
+
 template <int NK>
 inline int null_occupancy_one(size_t ldsBytes) {
   int nb = 0;
   hipError_t e = ldsBytes ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_null<NK, true, false>, 64, ldsBytes)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_null<NK, false, false>, 64, kPhaseALds);
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_null<NK, false, false>, 64, phase_a_lds<NK>());
   if (e != hipSuccess) return 0;
   return nb;
 }
@@ -561,7 +575,7 @@ inline int null_occupancy_one(size_t ldsBytes) {
 template <int NK>
 inline void launch_null_one(const NullArgs &a, int grid, size_t ldsBytes, bool exact, hipStream_t stream) {
   if (exact) {
-    hipLaunchKernelGGL((k_null<NK, false, true>), dim3(grid), dim3(64), kPhaseALds, stream, a, a.blob, a.dblocks,
+    hipLaunchKernelGGL((k_null<NK, false, true>), dim3(grid), dim3(64), phase_a_lds<NK>(), stream, a, a.blob, a.dblocks,
                        a.classBlocks, a.flags, a.U, a.pair, a.scratch, a.maxima);
   } else if (ldsBytes) {
     if (ldsBytes > 48 * 1024)
@@ -570,7 +584,7 @@ inline void launch_null_one(const NullArgs &a, int grid, size_t ldsBytes, bool e
     hipLaunchKernelGGL((k_null<NK, true, false>), dim3(grid), dim3(64), ldsBytes, stream, a, a.blob, a.dblocks,
                        a.classBlocks, a.flags, a.U, a.pair, a.scratch, a.maxima);
   } else {
-    hipLaunchKernelGGL((k_null<NK, false, false>), dim3(grid), dim3(64), kPhaseALds, stream, a, a.blob, a.dblocks,
+    hipLaunchKernelGGL((k_null<NK, false, false>), dim3(grid), dim3(64), phase_a_lds<NK>(), stream, a, a.blob, a.dblocks,
                        a.classBlocks, a.flags, a.U, a.pair, a.scratch, a.maxima);
   }
 }
@@ -591,6 +605,38 @@ inline void launch_null_one(const NullArgs &a, int grid, size_t ldsBytes, bool e
   int null_occupancy_##SUFFIX(int nk, size_t lds) { return occ_rec_##SUFFIX<LO>(nk, lds); }          \
   bool launch_null_##SUFFIX(int nk, const NullArgs &a, int grid, size_t lds, bool exact, hipStream_t st) { \
     return launch_rec_##SUFFIX<LO>(nk, a, grid, lds, exact, st);                                     \
+  }
+
+
+// Blocks with more than 32 rows (N-1 in [32, 63]): one instantiation per N-1, the EXACT one without code staging -- the 4 N-1
+// per-sequence registers no longer fit the register file (the compiler parks part of them in AGPRs), so this is the slow but
+// complete path for the rare wide block; the reference accepts up to 500 rows (rnaz_utils.h:7).
+#define RC_DEFINE_NULL_WIDE_RANGE(SUFFIX, LO, HI)                                                   \
+  template <int NK> static int occ_rec_##SUFFIX(int nk) {                                            \
+    if constexpr (NK > HI) return 0;                                                                 \
+    else {                                                                                           \
+      if (nk == NK) {                                                                                \
+        int nb = 0;                                                                                  \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_null<NK, false, true>, 64, phase_a_lds<NK>()) != hipSuccess) return 0; \
+        return nb;                                                                                   \
+      }                                                                                              \
+      return occ_rec_##SUFFIX<NK + 1>(nk);                                                           \
+    }                                                                                                \
+  }                                                                                                  \
+  template <int NK> static bool launch_rec_##SUFFIX(int nk, const NullArgs &a, int grid, hipStream_t st) { \
+    if constexpr (NK > HI) return false;                                                             \
+    else {                                                                                           \
+      if (nk == NK) {                                                                                \
+        hipLaunchKernelGGL((k_null<NK, false, true>), dim3(grid), dim3(64), phase_a_lds<NK>(), st, a, a.blob, a.dblocks, a.classBlocks, \
+                           a.flags, a.U, a.pair, a.scratch, a.maxima);                                \
+        return true;                                                                                 \
+      }                                                                                              \
+      return launch_rec_##SUFFIX<NK + 1>(nk, a, grid, st);                                           \
+    }                                                                                                \
+  }                                                                                                  \
+  int null_occupancy_##SUFFIX(int nk, size_t) { return occ_rec_##SUFFIX<LO>(nk); }                   \
+  bool launch_null_##SUFFIX(int nk, const NullArgs &a, int grid, size_t, bool, hipStream_t st) {     \
+    return launch_rec_##SUFFIX<LO>(nk, a, grid, st);                                                 \
   }
 
 }  // namespace rc

@@ -24,7 +24,7 @@ namespace rc {
 namespace treefit {
 
 constexpr double kBlMin = 1e-6, kBlMax = 100.0, kDistMax = 2.0;   // phyml/utilities.h:78,80,88
-constexpr int kMaxTips = 32, kMaxNodes = 2 * kMaxTips - 1;   // a rooted input tree (tree_lnl) has 2N-1 nodes
+constexpr int kMaxTips = 64, kMaxNodes = 2 * kMaxTips - 1;   // a rooted input tree (tree_lnl) has 2N-1 nodes
 
 // allowed-state mask of a character: A=1 C=2 G=4 T=8 (IUPAC as in phyml Get_Base_Freqs); the rest is missing data
 RC_HD inline int state_mask(char c) {

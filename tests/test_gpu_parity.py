@@ -288,10 +288,98 @@ def test_extreme_shapes_against_oracle(ctx):
                [(w["strand"], w["frame"], w["start"], w["end"], np.float32(w["score"])) for w in want]
         batch.close()
     # one row too many for the kernels: a clear per-block status, not a wrong answer
-    big = [b.upper() for b in synth_blocks(1, 33, 30, seed=24)]
+    big = [b.upper() for b in synth_blocks(1, 65, 30, seed=24)]
     batch = api.Batch(ctx, big, api.default_params()).run()
     assert batch.status(0) == api.RC_ERR_UNSUPPORTED and batch.block_error(0)
     batch.close()
+
+
+def test_wide_blocks_against_oracle(ctx):
+    """More than 32 rows (46-/100-way MAFs; the reference takes up to 500, rnaz_utils.h:7): N = 33, 48 and 64 run the
+    wide instantiations (second z word, node states in more words, 13 code words per site).  Same seeds through the HIP
+    path and the oracle: models, native S cell by cell, HSS, per-sample maxima, fit -- alone and mixed with narrow
+    blocks in one batch and one stream."""
+    from oracle import binding as ob
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_blocks
+    wide = [synth_blocks(1, 33, 45, seed=41)[0], synth_blocks(1, 48, 60, seed=42)[0], synth_blocks(1, 64, 36, seed=43)[0]]
+    blocks = [b.upper() for b in wide + synth_blocks(2, 6, 60, seed=44)]
+    n, seed = 70, 11
+    p = api.default_params(sampleN=n, seed_base=seed)
+    batch = api.Batch(ctx, blocks, p).run()
+    results = []
+    for i, b in enumerate(blocks):
+        rows, names = [r.seq for r in b.rows], [r.name for r in b.rows]
+        res = ob.run_block(rows, names, b.rows[0].start, b.rows[0].length, b.tree, b.kappa, ob.default_params(n), seed)
+        results.append(res)
+        assert batch.status(i) == api.RC_OK, batch.block_error(i)
+        np.testing.assert_array_equal(batch.maxScores(i), np.float32(res.maxScores))
+        got = sorted(batch.scoreAln(i), key=hss_key)
+        want = sorted(res.hss, key=hss_key)
+        assert [(g["strand"], g["frame"], g["start"], g["end"], np.float32(g["score"])) for g in got] == \
+               [(w["strand"], w["frame"], w["start"], w["end"], np.float32(w["score"])) for w in want]
+        rc, mu, lam = batch.getExtremeValuePars(i)
+        assert rc == res.evd_rc
+        if rc == 1:
+            assert close(mu, res.mu) and close(lam, res.lam)
+        fwd, _ = batch.getModels(i)
+        want_models = ob.get_models(b.tree, rows, names, b.kappa, 62)
+        for g, w in zip(fwd, want_models):
+            np.testing.assert_array_equal(np.float32(g["scores"]), np.float32(list(w.scores)))
+    # native S of the 48-row block, one frame per strand, cell by cell
+    b = blocks[1]
+    rows, names = [r.seq for r in b.rows], [r.name for r in b.rows]
+    op = ob.default_params(n)
+    for strand, srows in ((0, rows), (1, ob.rev_aln(rows))):
+        models = ob.get_models(b.tree, srows, names, b.kappa, 62)
+        S = ob.score_matrix(srows, models, op)
+        L = b.ref_len
+        got = batch.native_S(1, strand, 1)
+        sites = (L - 1) // 3
+        for a in range(sites):
+            for j in range(a, sites):
+                assert got[a, j] == np.float32(S[3 * a + 1 + 1][3 * j + 3 + 1]), (strand, a, j)
+    assert batch.clamped() == 0
+    batch.close()
+    # the same through a stream of two-block sub-batches
+    m = api.Marshalled(blocks)
+    m.set_trees()
+    at = 0
+    for sb in api.score_stream(ctx, m, p, 2, depth=2):
+        for i in range(sb.n):
+            np.testing.assert_array_equal(sb.maxScores(i), np.float32(results[at + i].maxScores))
+        at += sb.n
+        sb.close()
+    assert at == len(blocks)
+    # backtrack of a wide block (second z word on the host walk)
+    hs = sorted(batch_hss_for_backtrack(ctx, blocks[2], p), key=hss_key)
+    assert hs is not None
+
+
+def batch_hss_for_backtrack(ctx, block, p):
+    """Backtrack the best HSS of `block` on the device and with the oracle; returns the HSS list."""
+    from oracle import binding as ob
+    from rnacode_amd import api
+    batch = api.Batch(ctx, [block], p).run()
+    hss = batch.scoreAln(0)
+    if hss:
+        h = hss[0]
+        strand = 0 if h["strand"] == "+" else 1
+        st, z, tr = batch.backtrack(0, strand, h["start"], h["end"])
+        rows, names = [r.seq for r in block.rows], [r.name for r in block.rows]
+        op = ob.default_params(p.sampleN)
+        m = ob.get_models(block.tree, rows, names, block.kappa, 62)
+        rrows = ob.rev_aln(rows)
+        mr = ob.get_models(block.tree, rrows, names, block.kappa, 62)
+        _, skf, skr = ob.score_aln(rows, block.rows[0].start, block.rows[0].length, m, mr, op, want_sk=True)
+        want = ob.backtrack(h["start"], h["end"], skf if strand == 0 else skr, rows if strand == 0 else rrows, op)
+        ws, wz, wt = want
+        idx = list(range(h["end"], h["start"] + 1, -3))
+        assert len(idx) >= 3
+        for k in range(1, block.n):
+            assert list(st[k, idx]) == list(ws[k, idx]) and list(z[k, idx]) == list(wz[k, idx]) and list(tr[k, idx]) == list(wt[k, idx])
+    batch.close()
+    return hss
 
 
 def test_built_in_trees_give_the_same_calls_as_phyml_trees(ctx):
