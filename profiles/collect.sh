@@ -1,14 +1,15 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence behind bench.py's numbers on the GPU box (run through gpurun).
-#   profiles/collect.sh <tag>      -> gpurun_out/prof_<tag>/{stats,pmc_*}
+#   profiles/collect.sh <tag> [bench args]     -> gpurun_out/prof_<tag>/{stats,pmc_*}     (e.g. collect.sh r02_c5 --config c5)
 # Kernel trace/stats and each PMC group are separate passes (MI355X_MICROARCH.md, rocprofv3 PMC slots).
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
+shift || true
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-stream $*"
 # one kernel at a time while profiling: by default the native-block kernels run on a second stream beside k_null and
 # their trace intervals then span its whole duration
 export RC_SERIAL_NATIVE=1

@@ -167,18 +167,15 @@ __device__ __forceinline__ bool in_div_range_dev(float v) {
 // sigma per code: (float)matrix[pepA][pepB] - scores[h] (score.c:422-425), 0, or a stop penalty.  A block
 // with a value outside the range proven for the constant-divisor division is flagged and appended to its
 // class's list for the EXACT launch.
-__global__ __launch_bounds__(256) void k_prep_lut(PrepArgs A) {
-  __shared__ int bad;
+__global__ __launch_bounds__(64) void k_prep_lut(PrepArgs A) {   // one wavefront per block, no LDS (it runs beside k_null)
   const int bi = A.blocks[blockIdx.x];
   const DevBlock *db = A.dblocks + bi;
   const int N = db->N, NK = db->NK;
-  if (threadIdx.x == 0) bad = 0;
-  __syncthreads();
   const ModelRec *models = reinterpret_cast<const ModelRec *>(A.blob + db->off_models);
   float *lut = reinterpret_cast<float *>(A.blob + db->off_lut);
   const int total = 2 * NK * kLutSize;
   bool mine = false;
-  for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+  for (int idx = threadIdx.x; idx < total; idx += kWave) {
     const int code = idx % kLutSize, k = (idx / kLutSize) % NK, s = idx / (kLutSize * NK);
     const CodeInfo ci = A.codeInfo[code];
     float v = 0.0f;
@@ -188,8 +185,7 @@ __global__ __launch_bounds__(256) void k_prep_lut(PrepArgs A) {
     lut[idx] = v;
     mine |= !in_div_range_dev(v);
   }
-  if (mine) bad = 1;
-  __syncthreads();
+  const bool bad = __ballot(mine) != 0ull;
   if (threadIdx.x == 0 && bad) {
     A.flags[bi] |= kFlagExact;
     const int at = atomicAdd(A.exactCount + NK, 1);
@@ -200,7 +196,7 @@ __global__ __launch_bounds__(256) void k_prep_lut(PrepArgs A) {
 void launch_prep(const PrepArgs &a, hipStream_t stream) {
   if (a.nBlocks <= 0) return;
   hipLaunchKernelGGL(k_prep_models, dim3((a.nModels + kWave - 1) / kWave), dim3(kWave), 0, stream, a);
-  hipLaunchKernelGGL(k_prep_lut, dim3(a.nBlocks), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(k_prep_lut, dim3(a.nBlocks), dim3(kWave), 0, stream, a);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -214,11 +214,21 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
     if (!kProfiling || !(A.debugSkip & 2)) {
       constexpr int SPI = 4;
       constexpr int NODEW = (2 * N - 1 + 15) / 16;   // 16 nodes per 32-bit word
-      U4 *ldsThr = reinterpret_cast<U4 *>(lds_codes);
-      // behind it the 64 x 64 codon-pair -> sigma-code table (4 KB): the 2 NK gathers per site are LDS
-      // byte reads instead of global ones
-      const uint8_t *ldsPair = reinterpret_cast<const uint8_t *>(lds_codes + nnodes * 16);
-      {
+      // The EXACT instantiation uses no LDS at all and reads both tables from global memory (L1/L2): its launches are
+      // mostly empty (blocks flagged on the device) and must not wait for LDS that another batch's k_null holds.
+      const U4 *thrTab;
+      const uint8_t *pairLut;
+      int thrStride;   // U4 per node
+      if constexpr (EXACT) {
+        thrTab = reinterpret_cast<const U4 *>(nodes);
+        thrStride = sizeof(NodeRec) / sizeof(U4);
+        pairLut = pairTab;
+      } else {
+        thrTab = reinterpret_cast<const U4 *>(lds_codes);
+        thrStride = 4;
+        // behind it the 64 x 64 codon-pair -> sigma-code table (4 KB): the 2 NK gathers per site are LDS
+        // byte reads instead of global ones
+        pairLut = reinterpret_cast<const uint8_t *>(lds_codes + nnodes * 16);
         const uint32_t *src = reinterpret_cast<const uint32_t *>(nodes);
         for (int idx = lane; idx < nnodes * 16; idx += kWave) lds_codes[idx] = src[(idx >> 4) * (sizeof(NodeRec) / 4) + (idx & 15)];
         const uint32_t *psrc = reinterpret_cast<const uint32_t *>(pairTab);
@@ -258,7 +268,7 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
 #pragma unroll
             for (int t = 0; t < SPI; t++) {
               const uint32_t ps = (q == 0) ? 0u : get_state(ns[t], pq);
-              const U4 th = ldsThr[q * 4 + ps];
+              const U4 th = thrTab[q * thrStride + ps];
               uint32_t st = (u[t] > th.x) + (u[t] > th.y) + (u[t] > th.z);
               if constexpr (decltype(withBase)::value) st += (bp >> (2 * ps)) & 3u;
               clamped += (u[t] > th.w);
@@ -291,8 +301,8 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
                     const uint32_t bF = win[k + 1] & ((mF >> (6 * c)) & 63u);
                     const uint32_t bR = (codon_flip(win[k + 1]) ^ 63u) & ((mR >> (6 * c)) & 63u);
                     // field c sits at bits [6c+7 : 6c+2]: shifted down by 6c it is a ds_bpermute address
-                    wf |= static_cast<uint32_t>(ldsPair[aF * 64 + bF]) << (6 * c + 2);
-                    wr |= static_cast<uint32_t>(ldsPair[aR * 64 + bR]) << (6 * c + 2);
+                    wf |= static_cast<uint32_t>(pairLut[aF * 64 + bF]) << (6 * c + 2);
+                    wr |= static_cast<uint32_t>(pairLut[aR * 64 + bR]) << (6 * c + 2);
                   }
                 }
                 cod[(static_cast<size_t>(0 * L1 + i) * NCW + w) * kWave + lane] = wf;
@@ -575,7 +585,7 @@ inline int null_occupancy_one(size_t ldsBytes) {
 template <int NK>
 inline void launch_null_one(const NullArgs &a, int grid, size_t ldsBytes, bool exact, hipStream_t stream) {
   if (exact) {
-    hipLaunchKernelGGL((k_null<NK, false, true>), dim3(grid), dim3(64), phase_a_lds<NK>(), stream, a, a.blob, a.dblocks,
+    hipLaunchKernelGGL((k_null<NK, false, true>), dim3(grid), dim3(64), 0, stream, a, a.blob, a.dblocks,
                        a.classBlocks, a.flags, a.U, a.pair, a.scratch, a.maxima);
   } else if (ldsBytes) {
     if (ldsBytes > 48 * 1024)
@@ -617,7 +627,7 @@ inline void launch_null_one(const NullArgs &a, int grid, size_t ldsBytes, bool e
     else {                                                                                           \
       if (nk == NK) {                                                                                \
         int nb = 0;                                                                                  \
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_null<NK, false, true>, 64, phase_a_lds<NK>()) != hipSuccess) return 0; \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_null<NK, false, true>, 64, 0) != hipSuccess) return 0; \
         return nb;                                                                                   \
       }                                                                                              \
       return occ_rec_##SUFFIX<NK + 1>(nk);                                                           \
@@ -627,7 +637,7 @@ inline void launch_null_one(const NullArgs &a, int grid, size_t ldsBytes, bool e
     if constexpr (NK > HI) return false;                                                             \
     else {                                                                                           \
       if (nk == NK) {                                                                                \
-        hipLaunchKernelGGL((k_null<NK, false, true>), dim3(grid), dim3(64), phase_a_lds<NK>(), st, a, a.blob, a.dblocks, a.classBlocks, \
+        hipLaunchKernelGGL((k_null<NK, false, true>), dim3(grid), dim3(64), 0, st, a, a.blob, a.dblocks, a.classBlocks, \
                            a.flags, a.U, a.pair, a.scratch, a.maxima);                                \
         return true;                                                                                 \
       }                                                                                              \

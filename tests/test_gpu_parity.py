@@ -481,13 +481,14 @@ def test_device_tree_fit_matches_the_host_fit(ctx):
     """rc_fit_trees_device (one wavefront per block) runs the same estimator as rc_fit_trees (host
     threads) -- rc_tree_core.h -- so topologies are identical and lengths / kappa / lnL agree to the
     optimiser's tolerance; checked on the real-data goldens (IUPAC codes, gaps, 3..~12 rows), on
-    synthetic blocks, on the widest shape (32 rows) and on blocks the driver skips."""
+    synthetic blocks, on wide shapes (32, 48 and 64 rows) and on blocks the driver skips."""
     from rnacode_amd import api
     from rnacode_amd.synth import synth_blocks
     blocks = []
     for name in ("genomic_preprocessed_n100", "coding_maf_n100", "noncoding_maf_n100", "edge_cases_n50"):
         blocks += [block_from_golden(e) for e in load_golden(name)["blocks"]]
     blocks += synth_blocks(40, 6, 120, seed=3) + synth_blocks(3, 32, 90, seed=4) + synth_blocks(2, 3, 30, seed=5) + synth_blocks(2, 12, 600, seed=6)
+    blocks += synth_blocks(1, 48, 90, seed=7) + synth_blocks(1, 64, 60, seed=8)   # wide blocks: up to RC_MAX_ROWS tips
     lnl = []
     dev = api.fit_trees(blocks, ctx=ctx, lnl=lnl)
     host = api.fit_trees(blocks)
