@@ -204,6 +204,8 @@ struct rc_ctx {
   int debugSkip = 0;
   DevBuf d_cellStats;              // RC_PROFILING builds with RC_CELL_STATS=1: k_null's cell counters, printed when the context goes
   int serialNative = 0;
+  int stopRounds = 6;                    // at most this many rounds (RC_STOP_ROUNDS; <= kMaxRounds)
+  long long stopTwoRoundsMinItems = 0;   // --stop-early runs two rounds of sample groups only for batches with at least this many (block, group) items
   int hostThreads = 0;
   std::unique_ptr<Pool> pool;
   std::atomic<int> inflight{0};   // batches between run_async and wait
@@ -275,8 +277,9 @@ struct rc_stream {
 // layout of rc_batch::dcounters (uint32 units)
 namespace {
 constexpr size_t kCntExact = 0;                                  // [kMaxRows + 1] int: blocks flagged by k_prep_lut, by NK
-constexpr size_t kCntWork = kMaxRows + 2;                        // [2 phases][2 fast/exact][kMaxRows + 1][8]
-constexpr size_t kCntClamp = kCntWork + 4 * (kMaxRows + 1) * 8;  // one u64 (8-byte aligned: see static_assert)
+constexpr int kMaxRounds = 6;                                    // --stop-early: rounds of sample groups (each doubles the samples simulated so far)
+constexpr size_t kCntWork = kMaxRows + 2;                        // [kMaxRounds][2 fast/exact][kMaxRows + 1][8]
+constexpr size_t kCntClamp = kCntWork + static_cast<size_t>(kMaxRounds) * 2 * (kMaxRows + 1) * 8;  // one u64 (8-byte aligned: see static_assert)
 constexpr size_t kCntTotal = kCntClamp + 2;
 static_assert((kCntClamp % 2) == 0, "clamp counter alignment");
 }  // namespace
@@ -345,6 +348,9 @@ int rc_ctx_create(int device, rc_ctx **out) {
   HIP_TRY(hipStreamCreateWithPriority(&c->copy, hipStreamNonBlocking, prioHigh));
   HIP_TRY(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prioHigh));
   c->serialNative = std::getenv("RC_SERIAL_NATIVE") ? 1 : 0;   // profiling: one kernel at a time, clean per-kernel intervals
+  c->stopTwoRoundsMinItems = 4LL * c->numCU * 16;   // the chip filled four times over
+  if (const char *e = std::getenv("RC_STOP_MIN_ITEMS")) c->stopTwoRoundsMinItems = std::atoll(e);
+  if (const char *e = std::getenv("RC_STOP_ROUNDS")) c->stopRounds = std::max(2, std::min(kMaxRounds, std::atoi(e)));
   c->pt62.build(c->ct62);
   c->pt90.build(c->ct90);
   {   // constant tables: genetic code, then per matrix: pair table, BLOSUM, code infos
@@ -634,7 +640,8 @@ static int launch_native_block(const RunEnv &R) {
 }
 
 // null sampling of the sample groups [gLo, gHi) for every class; phase 0 or 1 selects the work counters
-static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t extraSkip) {
+// sizeOnly: no launch, *sizeOnly = uint32 of staging scratch this round needs (the rounds of a run share one allocation made up front)
+static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t extraSkip, size_t *sizeOnly = nullptr) {
   rc_batch *b = R.b; rc_ctx *c = R.c;
   const int groupsHere = gHi - gLo;
   struct Plan { int NK, grid, gridExact, comboSplit; size_t stride, ldsBytes, need; };
@@ -677,10 +684,11 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
   // of the previous one.  One class, a scratch that would exceed 4 GiB, or RC_SERIAL_NATIVE: this run's stream only.
   const bool concurrent = plans.size() > 1 && needSum <= (static_cast<size_t>(1) << 30) && !c->serialNative;
   const size_t need = concurrent ? needSum : needMax;
-  HIP_TRY(b->dscratch.ensure(need * sizeof(uint32_t)));
+  if (sizeOnly) { *sizeOnly = need; return RC_OK; }
+  if (need * sizeof(uint32_t) > b->dscratch.cap) return fail(RC_ERR_ARG, "internal: staging scratch was not sized for this round");
   Event &fork = phase ? b->evMid : b->evS0;
   size_t scratchOff = 0;
-  if (concurrent) while (b->classDone.size() < 2 * plans.size()) b->classDone.emplace_back(new Event());
+  if (concurrent) while (b->classDone.size() < static_cast<size_t>(kMaxRounds) * plans.size()) b->classDone.emplace_back(new Event());
   for (size_t pi = 0; pi < plans.size(); pi++) {
     const Plan &p = plans[pi];
     const auto &members = b->classes[p.NK];
@@ -765,16 +773,36 @@ static int batch_run_async(rc_batch *b) {
     fa.hssCount = b->dhssCount.as<int>(); fa.hssCap = b->hssCap; fa.out = b->dfit.as<FitOut>(); fa.flags = b->dflags.as<uint32_t>();
     fa.sampleN = sampleN; fa.stopEarly = b->par.stopEarly;
     fa.stopCutoff = static_cast<int>(b->par.cutoff * b->par.sampleN);   // score.c:992
-    // --stop-early: a first round of sample groups for every block, then only the blocks that are still undecided
+    // --stop-early: a first round of sample groups for every block, then -- doubling the samples each round -- only the blocks
+    // that are still undecided (k_stop_mark between the rounds)
+    // (only when the batch fills the chip several times over: two rounds of a small batch are two under-filled launches in a
+    // row -- genomic-preprocessed.maf, 33 blocks: 3.1 ms in one round, 5.0 ms in two)
     int g1 = groups;
-    if (b->par.stopEarly && fa.stopCutoff >= 0 && fa.stopCutoff < sampleN) g1 = std::min(groups, (fa.stopCutoff + 1 + kWave + kWave - 1) / kWave);
-    RC_TRY(launch_null_groups(R, 0, g1, 0, 0));
-    if (g1 < groups) {
-      if (!c->serialNative) HIP_TRY(hipStreamWaitEvent(cs, b->evN1, 0));   // best native scores
-      fa.firstN = std::min(sampleN, g1 * kWave);
-      launch_stop_mark(fa, static_cast<int>(b->okBlocks.size()), cs);
-      HIP_TRY(b->evMid.record(cs));
-      RC_TRY(launch_null_groups(R, g1, groups, 1, kFlagStopped));
+    if (b->par.stopEarly && fa.stopCutoff >= 0 && fa.stopCutoff < sampleN && static_cast<long long>(b->okBlocks.size()) * groups >= c->stopTwoRoundsMinItems)
+      g1 = std::min(groups, (fa.stopCutoff + 1 + kWave + kWave - 1) / kWave);
+    {   // one staging scratch for all rounds
+      size_t need = 0, most = 0;
+      int r = 0;
+      for (int lo = 0, hi = g1; lo < groups; r++) {
+        if (r == c->stopRounds - 1) hi = groups;
+        RC_TRY(launch_null_groups(R, lo, hi, r, 0, &need));
+        most = std::max(most, need);
+        lo = hi; hi = std::min(groups, hi * 2);
+      }
+      HIP_TRY(b->dscratch.ensure(most * sizeof(uint32_t)));
+    }
+    int round = 0;
+    for (int lo = 0, hi = g1; lo < groups; round++) {
+      if (round == c->stopRounds - 1) hi = groups;
+      if (lo > 0) {
+        if (!c->serialNative && lo == g1) HIP_TRY(hipStreamWaitEvent(cs, b->evN1, 0));   // best native scores
+        fa.firstN = std::min(sampleN, lo * kWave);
+        launch_stop_mark(fa, static_cast<int>(b->okBlocks.size()), cs);
+        HIP_TRY(b->evMid.record(cs));
+      }
+      RC_TRY(launch_null_groups(R, lo, hi, round, lo > 0 ? kFlagStopped : 0));
+      lo = hi;
+      hi = std::min(groups, hi * 2);
     }
     HIP_TRY(b->evS1.record(cs));
     // ---- EVD fit

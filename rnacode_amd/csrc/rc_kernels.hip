@@ -435,7 +435,9 @@ __global__ __launch_bounds__(64) void k_stop_mark(FitArgs A) {
   int better = 0;
   for (int i = threadIdx.x; i < A.firstN; i += kWave) better += (x[i] > maxNative) ? 1 : 0;
   for (int off = 32; off > 0; off >>= 1) better += __shfl_down(better, off, 64);
-  if (threadIdx.x == 0 && better > A.stopCutoff) A.flags[bi] |= kFlagStopped;
+  // written either way: the bit of an earlier run of this batch must not survive (a block decided late in that run would otherwise
+  // be left out from the second round on and be fitted on too few samples)
+  if (threadIdx.x == 0) A.flags[bi] = (A.flags[bi] & ~kFlagStopped) | (better > A.stopCutoff ? kFlagStopped : 0u);
 }
 
 __global__ __launch_bounds__(64) void k_evd_fit(FitArgs A) {

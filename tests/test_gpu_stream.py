@@ -160,17 +160,23 @@ def test_config3_full_size_stream_and_resident_against_oracle(ctx):
     big.close()
 
 
-def test_stop_early_runs_fewer_samples_and_agrees_with_the_oracle(ctx):
+def test_stop_early_runs_fewer_samples_and_agrees_with_the_oracle(monkeypatch):
     """--stop-early (score.c:992,1036-1042): blocks whose first samples already beat the native score more often
     than the cutoff allows are decided (rc = -1) and get no further samples; all others are sampled in full.
     Decisions, fits and HSS equal the oracle's, which runs the reference's loop literally."""
     from oracle import binding as ob
     from rnacode_amd import api
     from rnacode_amd.synth import synth_blocks
+    # the two-round schedule is only used for batches that fill the chip several times; let this small one take it
+    monkeypatch.setenv("RC_STOP_MIN_ITEMS", "1")
+    ctx = api.Context(0)
     blocks = [b.upper() for b in synth_blocks(40, 5, 90, seed=8)]
     n, seed, cutoff = 640, 42, 0.05
     p = api.default_params(sampleN=n, seed_base=seed, stopEarly=1, cutoff=cutoff)
     batch = api.Batch(ctx, blocks, p).run()
+    first_fits = batch.fits()
+    batch.run()      # a second run of the same batch starts from clean stop marks
+    np.testing.assert_array_equal(batch.fits(), first_fits)
     mx = batch.maxScores_all()
     full = api.Batch(ctx, blocks, api.default_params(sampleN=n, seed_base=seed, cutoff=cutoff)).run()
     fmx = full.maxScores_all()
@@ -191,6 +197,7 @@ def test_stop_early_runs_fewer_samples_and_agrees_with_the_oracle(ctx):
         assert [hss_key(h)[:5] for h in sorted(batch.scoreAln(i), key=hss_key)] == [hss_key(h)[:5] for h in sorted(full.scoreAln(i), key=hss_key)]
     assert decided > 0    # random (non-coding) blocks: most are decided after the first round
     batch.close(); full.close()
+    ctx.close()
 
 
 def test_sample_range_sharding_on_the_hip_path(ctx):
