@@ -160,6 +160,7 @@ def parse_args():
                          "(16 B per block: enough for p-values, since every rank fits its own blocks on the device)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
                     help="strong (default): --blocks in total, split across the ranks (BASELINE configs[3]); weak: --blocks per GPU")
+    ap.add_argument("--no-weak", action="store_true", help="N > 1, strong scaling: skip the extra weak-scaling measurement")
     ap.add_argument("--dump-gathered", help="rank 0 writes the gathered per-sample maxima of the last resident step here (.npy; tests)")
     a = ap.parse_args()
     blocks, cols, seqs, samples, _ = CONFIGS[a.config]
@@ -277,6 +278,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if multi:   # RCCL's first collective builds its rings: keep that out of the timed steps even with --warmup 0
+        probe = torch.zeros((1, 4), dtype=torch.float32, device=coll_dev)
+        rd.all_gather_rows(probe, [1] * world)
+        sync()
+
     def timed(step, collect_timing):
         for _ in range(args.warmup):
             step()
@@ -304,6 +310,36 @@ def main():
     s_elapsed = None
     if stream is not None:
         s_elapsed, _, _ = timed(stream_step, False)
+
+    # N > 1 under strong scaling: also the weak-scaling figure (every rank its own --blocks blocks, generator seed 1 + rank),
+    # as an extra key: the per-GPU work then equals the N = 1 run's, which is what separates kernel scaling from shard size
+    weak = None
+    if world > 1 and args.scaling == "strong" and not args.no_weak:
+        wblocks = [b.upper() for b in synth_blocks(args.blocks, args.seqs, args.cols, seed=1 + rank)]
+        wm = api.Marshalled(wblocks)
+        wm.set_trees()
+        wbatch = api.Batch(ctx, wm, params)
+        wmine = None
+        if args.exchange == "maxima":
+            wmine = torch.empty((len(wblocks), args.samples), dtype=torch.float32, device=f"cuda:{local_rank}")
+            wbatch.bind_maxima(wmine.data_ptr())
+        wcounts = [args.blocks] * world
+
+        def weak_step():
+            wbatch.run()
+            if args.exchange == "maxima":
+                rd.all_gather_maxima(wmine if coll_dev != "cpu" else wmine.cpu(), wcounts)
+            else:
+                rd.all_gather_fits(torch.from_numpy(wbatch.fits()).to(coll_dev), wcounts)
+            if coll_dev != "cpu":
+                torch.cuda.current_stream().synchronize()
+
+        w_elapsed, _, _ = timed(weak_step, False)
+        _, wcs = wbatch.work()
+        weak = {"value": wcs * world * args.steps / w_elapsed, "unit": "alignment-columns*samples/s", "ms_per_step": w_elapsed / args.steps * 1e3,
+                "blocks_per_gpu": len(wblocks), "scaling": "weak"}
+        wbatch.close()
+        del wmine
 
     sa, cs = batch.work()
     if multi:   # units of all ranks (shards may differ by one block under strong scaling)
@@ -363,6 +399,8 @@ def main():
                             "sub-batch, expected-score tables on the device, MT19937 streams, native scoring, null sampling, EVD fit, "
                             "fit results back on the host" + (", all-gather" if multi else ""),
                 "excludes": "file parsing and tree fitting (sidecar trees, as for the cpu_baseline)"}
+        if weak is not None:
+            out["weak_scaling"] = weak
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(blocks, args.samples, args.seed_base)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]

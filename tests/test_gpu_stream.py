@@ -271,6 +271,7 @@ def test_bench_starts_its_own_ranks_and_two_hip_ranks_gather_the_single_rank_res
     two, m2 = _bench(tmp_path, 2, env_extra={"RC_BENCH_TEST_BACKEND": "gloo"})
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
     assert two["config"]["blocks_per_gpu"] == 25 and "stream" in two and two["stream"]["value"] > 0
+    assert two["weak_scaling"]["blocks_per_gpu"] == 50 and two["weak_scaling"]["value"] > 0
     assert m1.shape == (50, 192)
     np.testing.assert_array_equal(m1, m2)
     fits, mf = _bench(tmp_path, 2, extra=("--exchange", "fits"), env_extra={"RC_BENCH_TEST_BACKEND": "gloo"})
