@@ -454,6 +454,24 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
           });
           return finish(sum);
         };
+        // the same after the row's LAST event: states 1 and 2 only ever receive "+ omega" from here to the end of the
+        // row and are never read individually again, so one value per sequence, t = max(s1, s2), stands for both:
+        // fl(max(s1, s2) + omega) == max(fl(s1 + omega), fl(s2 + omega)) because x -> fl(x + omega) is monotone, and
+        // MAX3(s0, s1, s2) == max(s0, t).  The caller folds s2 into s1 first; one add per sequence and codon less.
+        auto tail_cell = [&](uint32_t (&w)[NCW], int jn) -> float {
+          float sig[NK];
+          lookup(w, sig, jn, std::false_type{});
+          float sum = 0.0f;
+          static_for<NK>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            auto &r = R.template at<k>();
+            r.s0 = r.s0 + sig[k];
+            r.s1 = r.s1 + omega_v;
+            const float m = fmaxf(r.s0, r.s1);
+            sum = (k == 0) ? m : sum + m;
+          });
+          return finish(sum);
+        };
         // codon where some sequence has z != 0 (score.c:512-533), wave-uniform branch per sequence
         auto event_cell = [&](uint32_t (&w)[NCW], int j, int jn) -> float {
           float sig[NK];
@@ -533,6 +551,25 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
               j++;
             }
             const int e = next_event(j, jend);
+            if (e == jend) {                                       // no further event in this row: the tail
+              static_for<NK>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                auto &r = R.template at<k>();
+                r.s1 = fmaxf(r.s1, r.s2);
+              });
+              for (; j < e; j++) {
+                const int jn = j + 1 < sites ? j + 1 : j;
+                uint32_t wnext[NCW];
+                if constexpr (!LDSC) load_words(jn, wnext);
+                const float v = tail_cell(wcur, jn);
+                sample_scan_step(st, v, j2f, negTie);
+                asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
+                if constexpr (!LDSC) {
+#pragma unroll
+                  for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
+                }
+              }
+            }
             for (; j < e; j++) {                                   // tight loop: no events
               const int jn = j + 1 < sites ? j + 1 : j;
               uint32_t wnext[NCW];
