@@ -390,7 +390,9 @@ def main():
                             "usable_cpus": cpus},
             "sample_alignments_per_s": sa * args.steps / elapsed,
         }
+        out["value_resident"] = value
         if s_elapsed is not None:
+            out["value_stream"] = total_units / s_elapsed
             out["stream"] = {
                 "value": total_units / s_elapsed, "unit": "alignment-columns*samples/s", "ms_per_step": s_elapsed / args.steps * 1e3,
                 "frac_of_resident": elapsed / s_elapsed, "sub_batches": -(-len(blocks) // sub_blocks), "blocks_per_sub_batch": sub_blocks,
