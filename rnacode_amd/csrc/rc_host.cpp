@@ -324,31 +324,36 @@ static void gap_tables(const uint8_t *rows, int N, int cols, int L, int zwWords,
   refcol[0] = 0;
   for (int c = 0, p = 0; c < cols; c++)
     if (r0[c] != '-') { p++; if (p <= L) refcol[p] = static_cast<uint16_t>(c); }
-  gp.resize(static_cast<size_t>(N) * (cols + 1));
-  for (int r = 0; r < N; r++) {
-    uint16_t *g = gp.data() + static_cast<size_t>(r) * (cols + 1);
-    const uint8_t *row = rows + static_cast<size_t>(r) * cols;
+  // scratch: [0, cols]: prefix counts of '-' of the current row; then per reference position the window's
+  // bounds [lo, hi) as prefix indices, the reference's own gap count in it, and the row's "not a gap" flag there
+  gp.resize(static_cast<size_t>(cols + 1) + 4 * static_cast<size_t>(L1));
+  uint16_t *g = gp.data(), *lo = g + cols + 1, *hi = lo + L1, *g0 = hi + L1, *ng = g0 + L1;
+  auto prefix = [&](const uint8_t *row) {
     uint16_t acc = 0;
     g[0] = 0;
     for (int c = 0; c < cols; c++) { acc = static_cast<uint16_t>(acc + (row[c] == '-')); g[c + 1] = acc; }
+  };
+  prefix(r0);
+  for (int i = 3; i <= L; i++) {
+    lo[i] = static_cast<uint16_t>((i > 3) ? refcol[i - 3] + 1 : 0);
+    hi[i] = static_cast<uint16_t>(refcol[i] + 1);
+    g0[i] = static_cast<uint16_t>(g[hi[i]] - g[lo[i]]);
   }
   std::memset(zw, 0, sizeof(uint64_t) * L1 * zwWords);
   std::memset(maskw, 0, sizeof(uint32_t) * L1 * ncw);
-  for (int i = 3; i <= L; i++) {
-    const int start = (i > 3) ? refcol[i - 3] + 1 : 0, end = refcol[i];
-    const int g0 = gp[end + 1] - gp[start];
-    const int c2 = refcol[i - 2], c1 = refcol[i - 1], c0 = refcol[i];
-    for (int k = 0; k < NK; k++) {
-      const uint16_t *g = gp.data() + static_cast<size_t>(k + 1) * (cols + 1);
-      const uint8_t *rk = rows + static_cast<size_t>(k + 1) * cols;
-      const int gk = g[end + 1] - g[start];
-      const int diff = std::abs(gk - g0) % 3;                     // misc.c:230-244: 0 -> z=0, 1 -> z=+1, 2 -> z=-1
-      zw[static_cast<size_t>(i) * zwWords + (k >> 5)] |= static_cast<uint64_t>(diff) << (2 * (k & 31));
-      uint32_t m = 0;
-      if (rk[c2] != '-') m |= 0x30;
-      if (rk[c1] != '-') m |= 0x0C;
-      if (rk[c0] != '-') m |= 0x03;
-      maskw[static_cast<size_t>(i) * ncw + k / 5] |= m << (6 * (k % 5));
+  for (int k = 0; k < NK; k++) {
+    const uint8_t *rk = rows + static_cast<size_t>(k + 1) * cols;
+    prefix(rk);
+    for (int i = 1; i <= L; i++) ng[i] = rk[refcol[i]] != '-';
+    uint64_t *zk = zw + (k >> 5);
+    uint32_t *mk = maskw + k / 5;
+    const int zs = 2 * (k & 31), ms = 6 * (k % 5);
+    for (int i = 3; i <= L; i++) {
+      const int gk = g[hi[i]] - g[lo[i]];
+      const int diff = std::abs(gk - static_cast<int>(g0[i])) % 3;        // misc.c:230-244: 0 -> z=0, 1 -> z=+1, 2 -> z=-1
+      zk[static_cast<size_t>(i) * zwWords] |= static_cast<uint64_t>(diff) << zs;
+      const uint32_t m = ng[i - 2] * 0x30u | ng[i - 1] * 0x0Cu | ng[i] * 0x03u;
+      mk[static_cast<size_t>(i) * ncw] |= m << ms;
     }
   }
 }
@@ -472,16 +477,18 @@ int prepare_block(const rc_block &in, const rc_params &par, const PairTable &pt,
   // characters: upper-cased forward rows (RNAcode.c:121-128), then the reverse complement
   // (rnaz_utils.c:316-348): T,U->A  A->T  C<->G, everything else unchanged
   uint8_t *chars = base + d.off_chars;
+  static const struct Luts {
+    uint8_t up[256], rc[256];
+    Luts() {
+      for (int c = 0; c < 256; c++) { up[c] = static_cast<uint8_t>((c >= 'a' && c <= 'z') ? c - 32 : c); rc[c] = static_cast<uint8_t>(c); }
+      rc['T'] = rc['U'] = 'A'; rc['A'] = 'T'; rc['C'] = 'G'; rc['G'] = 'C';
+    }
+  } luts;
   for (int r = 0; r < N; r++) {
     uint8_t *dst = chars + static_cast<size_t>(r) * cols;
-    const char *src = in.rows[r];
-    for (int c = 0; c < cols; c++) dst[c] = static_cast<uint8_t>(std::toupper(static_cast<unsigned char>(src[c])));
+    const uint8_t *src = reinterpret_cast<const uint8_t *>(in.rows[r]);
     uint8_t *rv = chars + (static_cast<size_t>(N) + r) * cols;
-    for (int j = 0; j < cols; j++) {
-      uint8_t c = dst[cols - 1 - j];
-      switch (c) { case 'T': case 'U': c = 'A'; break; case 'A': c = 'T'; break; case 'C': c = 'G'; break; case 'G': c = 'C'; break; default: break; }
-      rv[j] = c;
-    }
+    for (int c = 0; c < cols; c++) { const uint8_t u = luts.up[src[c]]; dst[c] = u; rv[cols - 1 - c] = luts.rc[u]; }
   }
 
   // getModels' inputs for both strands (RNAcode.c:164-165); scores and probs follow on the device
