@@ -9,7 +9,7 @@ options that concern the scoring path and the listings:
 Tree + kappa per block (PhyML in the reference, RNAcode.c:153) come either from a sidecar
 (`--trees`: one `<newick> TAB <kappa>` line per alignment block, in file order; `-` for blocks the
 driver skips) or, without it, from the built-in estimator (rc_fit_trees_device, one wavefront per
-block).  All blocks of the file are scored as ONE batch on the GPU.  -e writes the reference's colored
+block).  The blocks are scored on the GPU as a stream of sub-batches (--sub-blocks, rc_stream_*).  -e writes the reference's colored
 alignment plots (src/postscript.c) as <DIR>/hss-<n>.eps.
 Quirk kept from the reference: the 4th value of --pars goes to stopPenalty_0 (RNAcode.c:318)."""
 from __future__ import annotations
@@ -62,6 +62,7 @@ def main(argv=None) -> int:
     ap.add_argument("-i", "--eps-cutoff", type=float, default=0.05, help="Create plots only if p better than this cutoff")
     ap.add_argument("-d", "--eps-dir", default="eps", help="Directory to put eps-files")
     ap.add_argument("--trees", help="sidecar: one '<newick>\\t<kappa>' line per block (default: fit them)")
+    ap.add_argument("--sub-blocks", type=int, default=2048, help="alignment blocks per sub-batch of the GPU stream")
     ap.add_argument("--seed-base", type=int, default=42)
     ap.add_argument("--device", type=int, default=0)
     a = ap.parse_args(argv)
@@ -104,31 +105,37 @@ def main(argv=None) -> int:
     out = open(a.outfile, "w") if a.outfile else sys.stdout
     fmt = 2 if a.tabular else (1 if a.gtf else 0)
     t0 = time.perf_counter()
-    batch = api.Batch(ctx, marshalled, params).run()   # `prepared` are the marshalled blocks, tree and kappa now set
+    # the blocks go through the GPU as a stream of sub-batches (rc_stream_*): while one is being scored the next is prepared
+    # on the host threads, and the listing of a finished one is written meanwhile (the reference's loop, RNAcode.c:115-221)
+    marshalled.set_trees(strict=False)
     st = report.ReportState()
-    all_hss = batch.scoreAln_all()
-    for i, b in enumerate(prepared):
-        code = batch.status(i)
-        if code == api.RC_ERR_SKIP:   # RNAcode.c:142-150
-            msg = "There must be at least three sequences in the alignment." if b.n <= 2 else "Too short."
-            print(f"Skipping alignment. {msg}", file=sys.stderr)
-            continue
-        if code != api.RC_OK:         # RNAcode.c:153-156: the reference has no tree for this block either
-            print(f"Skipping alignment. Failed to build ML tree. ({batch.block_error(i) or 'not scored'})", file=sys.stderr)
-            continue
-        hook = None
-        if a.eps:   # misc.c:461-474: hss-<counter>.eps for every listed HSS with p below the plot cutoff
-            def hook(counter, h, i=i, b=b):
-                os.makedirs(a.eps_dir, exist_ok=True)
-                text = eps.color_aln(b, h, lambda strand, lo, hi: batch.backtrack(i, 0 if strand == "+" else 1, lo, hi), a.blosum)
-                with open(os.path.join(a.eps_dir, f"hss-{counter}.eps"), "w") as fh:
-                    fh.write(text)
-        report.print_results(out, fmt, all_hss[i], b.rows[0].name, st, cutoff=a.cutoff, best_only=a.best_only,
-                             best_region=a.best_region, eps=hook, eps_cutoff=a.eps_cutoff)
+    base = 0
+    for batch in api.score_stream(ctx, marshalled, params, max(1, a.sub_blocks), depth=3):
+        all_hss = batch.scoreAln_all()
+        for i in range(batch.n):
+            b = prepared[base + i]
+            code = batch.status(i)
+            if code == api.RC_ERR_SKIP:   # RNAcode.c:142-150
+                msg = "There must be at least three sequences in the alignment." if b.n <= 2 else "Too short."
+                print(f"Skipping alignment. {msg}", file=sys.stderr)
+                continue
+            if code != api.RC_OK:         # RNAcode.c:153-156: the reference has no tree for this block either
+                print(f"Skipping alignment. Failed to build ML tree. ({batch.block_error(i) or 'not scored'})", file=sys.stderr)
+                continue
+            hook = None
+            if a.eps:   # misc.c:461-474: hss-<counter>.eps for every listed HSS with p below the plot cutoff
+                def hook(counter, h, i=i, b=b, batch=batch):
+                    os.makedirs(a.eps_dir, exist_ok=True)
+                    text = eps.color_aln(b, h, lambda strand, lo, hi: batch.backtrack(i, 0 if strand == "+" else 1, lo, hi), a.blosum)
+                    with open(os.path.join(a.eps_dir, f"hss-{counter}.eps"), "w") as fh:
+                        fh.write(text)
+            report.print_results(out, fmt, all_hss[i], b.rows[0].name, st, cutoff=a.cutoff, best_only=a.best_only,
+                                 best_region=a.best_region, eps=hook, eps_cutoff=a.eps_cutoff)
+        base += batch.n
+        batch.close()
     if fmt == 0:
         report.print_footer(out, len(prepared), time.perf_counter() - t0, params.sampleN, params.Delta, params.Omega,
                             params.omega, params.stopPenalty_k)
-    batch.close()
     ctx.close()
     if a.outfile:
         out.close()

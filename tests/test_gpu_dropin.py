@@ -72,6 +72,18 @@ def test_c_example_runs(tmp_path):
     assert "block 0: tree (" in out.stdout and "block 1: tree (" in out.stdout
 
 
+@pytest.mark.gpu
+def test_c_stream_example_runs(tmp_path):
+    """integration/example_stream.c: rc_stream_* from plain C, sub-batches in flight, results equal to one batch."""
+    import subprocess
+    from test_host_cpu import _build_c_example
+    exe = str(tmp_path / "example_stream")
+    _build_c_example(exe, "example_stream.c")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert "stream ok: 72 blocks" in out.stdout and "48 scored, 24 skipped" in out.stdout
+
+
 @pytest.mark.skipif(not os.path.exists(BIN), reason="oracle/_ref/ref_harness_hip was not built (needs the reference tree)")
 def test_reference_postscript_on_hip_backend_draws_the_reference_plots(tmp_path):
     """The reference's own colorAln (src/postscript.c, compiled in place) running on the shim: it takes the state paths

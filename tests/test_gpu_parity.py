@@ -246,12 +246,13 @@ def test_full_size_properties(ctx):
 
 
 def test_cli_end_to_end_matches_reference_listing(tmp_path):
-    """File in, listing out (section 8f-1): MAF/ClustalW reader -> one GPU batch -> printResults
+    """File in, listing out (section 8f-1): MAF/ClustalW reader -> stream of GPU sub-batches -> printResults
     formats, against the reference's own printResults output for the same seeds."""
     from rnacode_amd import cli
     from rnacode_amd.synth import to_maf
     for name, variant, flags in (("genomic_preprocessed_n100", "tabular", ["-t"]),
-                                 ("genomic_preprocessed_n100", "tabular_best_region", ["-t", "-r"]),
+                                 ("genomic_preprocessed_n100", "tabular", ["-t", "--sub-blocks", "5"]),   # seven sub-batches through the stream
+                                 ("genomic_preprocessed_n100", "tabular_best_region", ["-t", "-r", "--sub-blocks", "1"]),
                                  ("coding_maf_n100", "gtf", ["-g"])):
         doc = load_golden(name)
         blocks = [block_from_golden(e) for e in doc["blocks"]]

@@ -104,17 +104,18 @@ def test_synthetic_generator_is_deterministic_and_well_formed():
         assert e["input"]["tree"] == g.tree
 
 
-def _build_c_example(out_path):
+def _build_c_example(out_path, source="example_batch.c"):
     import subprocess
     lib_dir = os.path.join(ROOT, "rnacode_amd")
     cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "integration", "example_batch.c"), "-L" + lib_dir, "-lrnacode_hip",
+           os.path.join(ROOT, "integration", source), "-L" + lib_dir, "-lrnacode_hip",
            "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-o", out_path]
     subprocess.check_call(cmd)
 
 
 def test_header_is_plain_c_and_the_example_links(tmp_path):
-    """include/rnacode_hip.h compiles as strict C99 and integration/example_batch.c links against the library."""
+    """include/rnacode_hip.h compiles as strict C99 and integration/example_batch.c / example_stream.c link against the library."""
     from rnacode_amd import api
     api.lib()
     _build_c_example(str(tmp_path / "example_batch"))
+    _build_c_example(str(tmp_path / "example_stream"), "example_stream.c")
