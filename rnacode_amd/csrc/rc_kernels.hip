@@ -348,33 +348,52 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
   return r;
 }
 
-// The per-block fit runs in ONE wavefront without LDS (it is queued behind k_null, whose workgroups hold all of a
-// CU's LDS, beside the next batch's k_null): sums meet in an xor butterfly, which leaves the same bits on every
-// lane, so the Newton / bisection control flow below is wave-uniform.
+// The per-block fit comes in two shapes.  THREADS = 64: ONE wavefront without LDS -- in a large batch it is queued behind k_null,
+// whose workgroups hold all of a CU's LDS, beside the next batch's k_null, and must not wait for LDS.  THREADS = 256: four
+// wavefronts that meet through 128 bytes of LDS -- for small batches, where nothing competes for LDS and the latency of the
+// slowest block's fit (up to 300 evaluations of the four sums when Newton's method needs the bisection fallback) is the run time.
+// Either way the sums end as identical bits on every thread (xor butterfly, then a fixed-order sum of the wavefronts' values), so
+// the Newton / bisection control flow below is uniform.
 __device__ __forceinline__ double wave_sum(double v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
 
-__device__ void lawless416(const float *x, int n, double lambda, double *f, double *df) {
+template <int THREADS>
+__device__ __forceinline__ void fit_sum4(double &a, double &b, double &c, double &d, double *sh) {
+  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); d = wave_sum(d);
+  if constexpr (THREADS > kWave) {
+    constexpr int NW = THREADS / kWave;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { double *w = sh + (threadIdx.x >> 6) * 4; w[0] = a; w[1] = b; w[2] = c; w[3] = d; }
+    __syncthreads();
+    a = b = c = d = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) { a += sh[w * 4 + 0]; b += sh[w * 4 + 1]; c += sh[w * 4 + 2]; d += sh[w * 4 + 3]; }
+  }
+}
+
+template <int THREADS>
+__device__ void lawless416(const float *x, int n, double lambda, double *sh, double *f, double *df) {
   double e = 0, xe = 0, xxe = 0, xs = 0;
-  for (int i = threadIdx.x; i < n; i += kWave) {
+  for (int i = threadIdx.x; i < n; i += THREADS) {
     const double xi = static_cast<double>(x[i]);
     const double ex = exp(-1. * lambda * xi);
     xs += xi; xe += xi * ex; xxe += xi * xi * ex; e += ex;
   }
-  e = wave_sum(e); xe = wave_sum(xe); xxe = wave_sum(xxe); xs = wave_sum(xs);
+  fit_sum4<THREADS>(e, xe, xxe, xs, sh);
   const double total = static_cast<double>(n);
   *f = 1. / lambda - xs / total + xe / e;
   *df = ((xe / e) * (xe / e)) - (xxe / e) - (1. / (lambda * lambda));
 }
 
-__device__ int evd_fit_block(const float *x, int n, double *mu_out, double *lambda_out) {
+template <int THREADS>
+__device__ int evd_fit_block(const float *x, int n, double *sh, double *mu_out, double *lambda_out) {
   double lambda = 0.2, fx, dfx;
   const double tol = 1e-5;
   int it;
   for (it = 0; it < 100; it++) {
-    lawless416(x, n, lambda, &fx, &dfx);
+    lawless416<THREADS>(x, n, lambda, sh, &fx, &dfx);
     if (fabs(fx) < tol) break;
     lambda = lambda - fx / dfx;
     if (lambda <= 0.) lambda = 0.001;
@@ -382,32 +401,32 @@ __device__ int evd_fit_block(const float *x, int n, double *mu_out, double *lamb
   if (it == 100) {  // bisection fallback (extreme_fit.c:193-236)
     double left = 0.2, right = 0.2, mid = 0.2;
     lambda = 0.2;
-    lawless416(x, n, lambda, &fx, &dfx);
+    lawless416<THREADS>(x, n, lambda, sh, &fx, &dfx);
     if (fx < 0.) {
       do {
         left -= 0.1;
         if (left < 0.) return 0;
-        lawless416(x, n, left, &fx, &dfx);
+        lawless416<THREADS>(x, n, left, sh, &fx, &dfx);
       } while (fx < 0.);
     } else {
       do {
         right += 0.1;
-        lawless416(x, n, right, &fx, &dfx);
+        lawless416<THREADS>(x, n, right, sh, &fx, &dfx);
         if (right > 100.) return 0;
       } while (fx > 0.);
     }
     for (it = 0; it < 100; it++) {
       mid = (left + right) / 2.;
-      lawless416(x, n, mid, &fx, &dfx);
+      lawless416<THREADS>(x, n, mid, sh, &fx, &dfx);
       if (fabs(fx) < tol) break;
       if (fx > 0.) left = mid; else right = mid;
     }
     if (it == 100) return 0;
     lambda = mid;
   }
-  double e = 0;
-  for (int i = threadIdx.x; i < n; i += kWave) e += exp(-1 * lambda * static_cast<double>(x[i]));
-  e = wave_sum(e);
+  double e = 0, z0 = 0, z1 = 0, z2 = 0;
+  for (int i = threadIdx.x; i < n; i += THREADS) e += exp(-1 * lambda * static_cast<double>(x[i]));
+  fit_sum4<THREADS>(e, z0, z1, z2, sh);
   *mu_out = -1. * log(e / static_cast<double>(n)) / lambda;
   *lambda_out = lambda;
   return 1;
@@ -440,21 +459,23 @@ __global__ __launch_bounds__(64) void k_stop_mark(FitArgs A) {
   if (threadIdx.x == 0) A.flags[bi] = (A.flags[bi] & ~kFlagStopped) | (better > A.stopCutoff ? kFlagStopped : 0u);
 }
 
-__global__ __launch_bounds__(64) void k_evd_fit(FitArgs A) {
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_evd_fit(FitArgs A) {
+  __shared__ double sh[THREADS > kWave ? (THREADS / kWave) * 4 : 1];   // not referenced (and not allocated) for THREADS = 64
   const int bi = A.blocks[blockIdx.x];
   const DevBlock *db = A.dblocks + bi;
   const float *x = A.maxima + static_cast<size_t>(db->out_index) * A.sampleN;
-  const float maxNative = best_native(A, bi);     // every lane: a few records
-  int better = 0;
-  for (int i = threadIdx.x; i < A.sampleN; i += kWave) better += (x[i] > maxNative) ? 1 : 0;   // samples not simulated hold -1
-  for (int off = 32; off > 0; off >>= 1) better += __shfl_xor(better, off, 64);
+  const float maxNative = best_native(A, bi);     // every thread: a few records
+  double better = 0, z0 = 0, z1 = 0, z2 = 0;
+  for (int i = threadIdx.x; i < A.sampleN; i += THREADS) better += (x[i] > maxNative) ? 1.0 : 0.0;   // samples not simulated hold -1
+  fit_sum4<THREADS>(better, z0, z1, z2, sh);
   FitOut o;
-  o.better = better;
+  o.better = static_cast<int>(better);
   o.rc = -1; o.mu = 0; o.lambda = 0;
   const bool stopped = A.stopEarly && (o.better > A.stopCutoff);  // score.c:1040-1042
   if (!stopped) {
     double mu, lambda;
-    if (evd_fit_block(x, A.sampleN, &mu, &lambda) == 1) { o.rc = 1; o.mu = mu; o.lambda = lambda; }
+    if (evd_fit_block<THREADS>(x, A.sampleN, sh, &mu, &lambda) == 1) { o.rc = 1; o.mu = mu; o.lambda = lambda; }
   }
   if (threadIdx.x == 0) A.out[db->out_index] = o;
 }
@@ -592,7 +613,9 @@ void launch_stop_mark(const FitArgs &a, int nblocks, hipStream_t stream) {
 }
 
 void launch_evd_fit(const FitArgs &a, int nblocks, hipStream_t stream) {
-  hipLaunchKernelGGL(k_evd_fit, dim3(nblocks), dim3(64), 0, stream, a);
+  // few blocks: four wavefronts per block (latency); many: one LDS-free wavefront per block (see fit_sum4)
+  if (nblocks <= 2048) hipLaunchKernelGGL(k_evd_fit<256>, dim3(nblocks), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(k_evd_fit<64>, dim3(nblocks), dim3(64), 0, stream, a);
 }
 
 void launch_evd_fit_f64(const double *x, int n, FitOut *out, hipStream_t stream) {
