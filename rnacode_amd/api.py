@@ -519,18 +519,25 @@ class Stream:
 
 
 def score_stream(ctx: Context, m: Marshalled, params: RcParams, sub_blocks: int, depth: int = 3, stream: Optional[Stream] = None,
-                 maxima_ptr: int = 0):
+                 maxima_ptr: int = 0, ramp: bool = True):
     """Score the blocks of `m` as a pipeline of sub-batches of `sub_blocks` blocks.  Yields finished Batches in
     submission order; the consumer closes (recycles) each one.  maxima_ptr: device address of a
-    [len(m.blocks)][sampleN] float32 buffer that receives every block's per-sample maxima."""
+    [len(m.blocks)][sampleN] float32 buffer that receives every block's per-sample maxima.  ramp: the first two
+    sub-batches are a quarter and a half of sub_blocks, so that the GPU gets its first kernels after a quarter of the
+    preparation time (the pipeline's fill is the one part of a pass that nothing overlaps)."""
     own = stream is None
     s = stream or Stream(ctx, params, depth)
     try:
         n = len(m.blocks)
         lo = 0
+        sent = 0
         while lo < n or s.pending:
             while lo < n and s.pending < s.depth:
-                hi = min(n, lo + sub_blocks)
+                size = sub_blocks
+                if ramp and sent < 2 and sub_blocks >= 256:
+                    size = sub_blocks // (4 >> sent)
+                sent += 1
+                hi = min(n, lo + size)
                 s.submit(m, lo, hi, maxima_ptr + 4 * lo * params.sampleN if maxima_ptr else 0)
                 lo = hi
             yield s.next()
