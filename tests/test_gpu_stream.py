@@ -288,3 +288,32 @@ def test_bench_refuses_a_world_that_does_not_match_gpus(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--blocks", "8", "--samples", "64", "--steps", "1",
                         "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_bench_under_torchrun_goes_through_rccl(tmp_path):
+    """The driver's launch line (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`) with the one GPU a test
+    box has: RC_BENCH_FORCE_DIST=1 takes the multi-rank path with a world of one, so init_process_group("nccl"), the all-gather
+    of the kernel-written tensor (resident and stream mode), the reductions and the barriers all run through RCCL."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dump = str(tmp_path / "g.npy")
+    env = dict(os.environ, RC_BENCH_FORCE_DIST="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--blocks", "40", "--samples", "128",
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--sub-batches", "2", "--dump-gathered", dump],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["config"]["exchange"] == "all-gather of maxima" and line["n_gpus"] == 1 and line["stream"]["value"] > 0
+    one, m1 = _bench(tmp_path, 1, extra=("--blocks", "40", "--samples", "128"))
+    np.testing.assert_array_equal(np.load(dump), m1)
