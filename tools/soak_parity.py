@@ -38,10 +38,12 @@ def main():
             pars = dict(blosum=90)
         blocks = []
         for i in range(int(rng.randint(1, 25))):
-            n = int(rng.choice([3, 3, 4, 5, 6, 6, 7, 8, 10, 12, 17, 32]))
+            n = int(rng.choice([3, 3, 4, 5, 6, 6, 7, 8, 10, 12, 17, 32, 33, 40, 64]))
             cols = int(rng.choice([9, 12, 30, 45, 60, 90, 120, 150, 200, 301]))
             if n * cols > 4000:
                 cols = max(9, 4000 // n)
+            if n > 32:
+                cols = min(cols, 45)
             b = synth_block(rng, n, cols, index=i, gaps=bool(rng.rand() < 0.8), mean_branch=float(rng.choice([0.01, 0.1, 0.4]))).upper()
             if rng.rand() < 0.3:   # common gap stretch (ties) / zero-length branch (degenerate rows)
                 rows = [bytearray(x.seq.encode()) for x in b.rows]
@@ -53,8 +55,19 @@ def main():
                 m = list(re.finditer(r":[0-9.]+", b.tree))[0]
                 b.tree = b.tree[:m.start()] + ":0.000000" + b.tree[m.end():]
             blocks.append(b)
-        batch = api.Batch(ctx, blocks, api.default_params(sampleN=n_samples, seed_base=seed, **pars)).run()
-        for i, b in enumerate(blocks):
+        stop = rng.rand() < 0.2
+        if stop:
+            pars.update(stopEarly=1, cutoff=float(rng.choice([0.05, 0.2, 0.5])))
+        hp = api.default_params(sampleN=n_samples, seed_base=seed, **pars)
+        # a third of the rounds go through a stream of sub-batches (rc_stream_*) instead of one batch
+        if rng.rand() < 0.33:
+            m = api.Marshalled(blocks)
+            m.set_trees()
+            parts = list(api.score_stream(ctx, m, hp, int(rng.randint(1, 8)), depth=int(rng.randint(1, 4))))
+        else:
+            parts = [api.Batch(ctx, blocks, hp).run()]
+        where = [(pb, i) for pb in parts for i in range(pb.n)]
+        for (batch, i), b in zip(where, blocks):
             p = ob.default_params(n_samples, blosum=pars.get("blosum", 62))
             for k, v in pars.items():
                 if k != "blosum":
@@ -62,7 +75,9 @@ def main():
             if batch.status(i) != 0:
                 continue
             res = ob.run_block([x.seq for x in b.rows], [x.name for x in b.rows], b.rows[0].start, b.rows[0].length, b.tree, b.kappa, p, seed)
-            ok = np.array_equal(batch.maxScores(i), np.float32(res.maxScores))
+            rc0 = batch.getExtremeValuePars(i)[0]
+            # --stop-early: a decided block (rc -1) may have fewer samples simulated here than the reference had when it left its loop
+            ok = np.array_equal(batch.maxScores(i), np.float32(res.maxScores)) or (stop and rc0 == -1 and res.evd_rc == -1)
             got, want = sorted(batch.scoreAln(i), key=key), sorted(res.hss, key=key)
             ok = ok and [(g["strand"], g["frame"], g["start"], g["end"], np.float32(g["score"])) for g in got] == \
                 [(w["strand"], w["frame"], w["start"], w["end"], np.float32(w["score"])) for w in want]
@@ -72,7 +87,8 @@ def main():
             if not ok:
                 bad += 1
                 print(f"MISMATCH round {rounds} block {i}: {b.n} x {b.cols}, n={n_samples}, seed={seed}, pars={pars}")
-        batch.close()
+        for pb in parts:
+            pb.close()
     print(f"soak: {rounds} batches, {blocks_done} blocks compared in {time.time() - t0:.0f} s, {bad} mismatches")
     return 1 if bad else 0
 
