@@ -807,7 +807,7 @@ static int batch_run_async(rc_batch *b) {
     HIP_TRY(b->evS1.record(cs));
     // ---- EVD fit
     if (!c->serialNative) HIP_TRY(hipStreamWaitEvent(cs, b->evN1, 0));   // native HSS of the native stream
-    launch_evd_fit(fa, static_cast<int>(b->okBlocks.size()), cs); b->nl[4]++;
+    launch_evd_fit(fa, static_cast<int>(b->okBlocks.size()), c->inflight.load() == 0, cs); b->nl[4]++;
   }
   HIP_TRY(b->evFit.record(cs));
   // small results back to the host: four copies into one pinned staging area behind the fit

@@ -612,9 +612,10 @@ void launch_stop_mark(const FitArgs &a, int nblocks, hipStream_t stream) {
   hipLaunchKernelGGL(k_stop_mark, dim3(nblocks), dim3(64), 0, stream, a);
 }
 
-void launch_evd_fit(const FitArgs &a, int nblocks, hipStream_t stream) {
-  // few blocks: four wavefronts per block (latency); many: one LDS-free wavefront per block (see fit_sum4)
-  if (nblocks <= 2048) hipLaunchKernelGGL(k_evd_fit<256>, dim3(nblocks), dim3(256), 0, stream, a);
+void launch_evd_fit(const FitArgs &a, int nblocks, bool latency, hipStream_t stream) {
+  // a small batch with the chip to itself: four wavefronts per block (latency); otherwise one LDS-free wavefront per block
+  // (see fit_sum4: beside another batch's k_null the LDS variant waits milliseconds for its 128 bytes)
+  if (latency && nblocks <= 2048) hipLaunchKernelGGL(k_evd_fit<256>, dim3(nblocks), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(k_evd_fit<64>, dim3(nblocks), dim3(64), 0, stream, a);
 }
 

@@ -119,7 +119,7 @@ void launch_hss_pack(const DevHss *hss, const int *count, int cap, int slots, De
 void launch_sk_row(const uint8_t *blob, const DevBlock *dblocks, int bi, int s, int b, int iMax, float *out, int stride,
                    hipStream_t stream);
 void launch_stop_mark(const FitArgs &a, int nblocks, hipStream_t stream);
-void launch_evd_fit(const FitArgs &a, int nblocks, hipStream_t stream);
+void launch_evd_fit(const FitArgs &a, int nblocks, bool latency, hipStream_t stream);   // latency: no other batch is in flight
 void launch_evd_fit_f64(const double *x, int n, FitOut *out, hipStream_t stream);
 
 }  // namespace rc
