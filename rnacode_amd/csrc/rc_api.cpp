@@ -308,10 +308,12 @@ void rc_ctx_destroy(rc_ctx *c) {
   (void)hipDeviceSynchronize();
   c->pool.reset();
   if (kProfiling && c->d_cellStats.p) {
-    unsigned long long st[3] = {0, 0, 0};
+    unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
     if (hipMemcpy(st, c->d_cellStats.p, sizeof st, hipMemcpyDeviceToHost) == hipSuccess && st[0])
       std::fprintf(stderr, "[rc cell stats] wavefront-cells %llu, with no positive lane %llu (%.4f %%), positive lane-cells %.2f %%\n", st[0], st[1],
-                   100.0 * st[1] / st[0], 100.0 * st[2] / (64.0 * st[0]));
+                   100.0 * st[1] / st[0], 100.0 * st[2] / (64.0 * st[0])),
+      std::fprintf(stderr, "[rc cell stats] before the row's first event %.1f %%, event codons %.1f %%, after its last event %.1f %%, between events %.1f %%\n",
+                   100.0 * st[3] / st[0], 100.0 * st[4] / st[0], 100.0 * st[5] / st[0], 100.0 * (st[0] - st[3] - st[4] - st[5]) / st[0]);
   }
   if (c->d_U) (void)hipFree(c->d_U);
   for (hipStream_t st : c->compute) if (st) (void)hipStreamDestroy(st);
@@ -374,8 +376,8 @@ int rc_ctx_create(int device, rc_ctx **out) {
   if (const char *e = std::getenv("RC_LDS_MAX_BYTES")) c->ldsMaxBytes = static_cast<size_t>(std::atol(e));
   if (kProfiling) if (const char *e = std::getenv("RC_DEBUG_SKIP")) c->debugSkip = std::atoi(e);   // RC_PROFILING builds only: results are wrong
   if (kProfiling && std::getenv("RC_CELL_STATS")) {
-    HIP_TRY(c->d_cellStats.ensure(3 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(c->d_cellStats.p, 0, 3 * sizeof(unsigned long long)));
+    HIP_TRY(c->d_cellStats.ensure(6 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->d_cellStats.p, 0, 6 * sizeof(unsigned long long)));
   }
   c->hostThreads = std::min(effective_cpus(), 32);
   if (const char *e = std::getenv("RC_HOST_THREADS")) c->hostThreads = std::max(1, std::atoi(e));

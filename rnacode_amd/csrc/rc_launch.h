@@ -38,7 +38,7 @@ struct NullArgs {
   int comboSplit;             // 1: items are (block, group, strand x frame); maxima combined by atomic max
   unsigned int *workCounter;  // [8], zeroed before the launch: next unclaimed work item of each XCD queue
   int debugSkip;              // RC_PROFILING builds only: bit0 skip the DP/scan phase, bit1 skip simulation
-  unsigned long long *cellStats;   // RC_PROFILING builds only: [0] wavefront-cells, [1] of those with no lane's sum > 0, [2] lanes with sum > 0
+  unsigned long long *cellStats;   // RC_PROFILING builds only: [0] wavefront-cells, [1] of those with no lane's sum > 0, [2] lanes with sum > 0, [3..5] cells before the row's first event / at events / after its last
 };
 
 struct NativeArgs {

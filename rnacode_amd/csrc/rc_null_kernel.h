@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
 
     // ---- phase B: both strands x 3 frames: DP over (start a, end j) + serial HSS scan
     float best = -1.0f;
-    unsigned long long statCells = 0, statNoPos = 0, statPosLanes = 0;   // RC_PROFILING builds only
+    unsigned long long statCells = 0, statNoPos = 0, statPosLanes = 0, statPristine = 0, statEvent = 0, statTail = 0;   // RC_PROFILING builds only
     // omega and Delta as per-lane values: v_add_f32 with two VGPR operands issues at the full rate,
     // with an SGPR operand at ~60 % of it (tools/microbench.hip)
     float omega_v, Delta_v = 0.0f;
@@ -522,6 +522,7 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
               const int jn = j + 1 < sites ? j + 1 : j;
               uint32_t wnext[NCW];
               if constexpr (!LDSC) load_words(jn, wnext);
+              if constexpr (kProfiling) statPristine++;
               const float v = pristine_cell(wcur, wv, jn);
               sample_scan_step(st, v, j2f, negTie);
               asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
@@ -541,6 +542,7 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
               const int jn = j + 1 < sites ? j + 1 : j;
               uint32_t wnext[NCW];
               if constexpr (!LDSC) load_words(jn, wnext);
+              if constexpr (kProfiling) statEvent++;
               const float v = event_cell(wcur, j, jn);
               sample_scan_step(st, v, j2f, negTie);
               asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
@@ -561,6 +563,7 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
                 const int jn = j + 1 < sites ? j + 1 : j;
                 uint32_t wnext[NCW];
                 if constexpr (!LDSC) load_words(jn, wnext);
+                if constexpr (kProfiling) statTail++;
                 const float v = tail_cell(wcur, jn);
                 sample_scan_step(st, v, j2f, negTie);
                 asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
@@ -593,7 +596,10 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
       }
     }
     if constexpr (kProfiling) {
-      if (A.cellStats && lane == 0) { atomicAdd(A.cellStats, statCells); atomicAdd(A.cellStats + 1, statNoPos); atomicAdd(A.cellStats + 2, statPosLanes); }
+      if (A.cellStats && lane == 0) {
+        atomicAdd(A.cellStats, statCells); atomicAdd(A.cellStats + 1, statNoPos); atomicAdd(A.cellStats + 2, statPosLanes);
+        atomicAdd(A.cellStats + 3, statPristine); atomicAdd(A.cellStats + 4, statEvent); atomicAdd(A.cellStats + 5, statTail);
+      }
     }
     if (sidx < A.sampleN) {
       float *dst = maxima + static_cast<size_t>(db->out_index) * A.sampleN + sidx;
