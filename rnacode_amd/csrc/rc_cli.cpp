@@ -1,0 +1,327 @@
+// rc_cli.cpp -- rnacode_hip: a native stand-alone driver around the scoring path.
+//
+// The reference's driver (src/RNAcode.c:52-231) reads alignment blocks, gets a tree and kappa per block from PhyML, scores
+// the block and prints its high-scoring segments.  This one does the same on top of the public C-ABI only
+// (include/rnacode_hip.h): MAF / ClustalW readers (src/rnaz_utils.c:44-234), trees from a sidecar or fitted on the GPU
+// (rc_fit_trees_device), scoring as a stream of sub-batches (rc_stream_*), listings in the reference's three formats
+// (src/misc.c:392-552 printResults, footer RNAcode.c:223-228) byte for byte.  Same options as `python -m rnacode_amd.cli`
+// (which additionally draws the EPS plots):
+//
+//   rnacode_hip [-n N] [-p CUTOFF] [-g | -t] [-b] [-r] [-s] [-m 62|90] [-c D,O,o,S] [-o OUT] [--trees SIDECAR]
+//               [--seed-base S] [--device D] [--sub-blocks B] [FILE]
+//
+// Quirk kept from the reference: the 4th value of --pars goes to stopPenalty_0 (RNAcode.c:318).
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/rnacode_hip.h"
+
+namespace {
+
+struct Row {
+  std::string name, seq;
+  int start = 0, length = 0;
+  char strand = '?';
+};
+struct Block {
+  std::vector<Row> rows;
+  std::string tree;     // empty: none
+  float kappa = 0.0f;
+};
+
+[[noreturn]] void die(const std::string &msg) {
+  std::fprintf(stderr, "ERROR: %s\n", msg.c_str());
+  std::exit(1);
+}
+
+std::vector<std::string> fields(const std::string &line) {
+  std::vector<std::string> f;
+  std::istringstream is(line);
+  std::string w;
+  while (is >> w) f.push_back(w);
+  return f;
+}
+
+void check_equal(const Block &b) {
+  for (const Row &r : b.rows)
+    if (r.seq.size() != b.rows[0].seq.size()) die("Sequences are of unequal length.");
+}
+
+// Blocks of a MAF stream: 's' lines need exactly 7 fields; 'i', 'e', 'q' and comment lines are skipped; a block ends at the
+// next 'a' line (rnaz_utils.c:132-234)
+std::vector<Block> read_maf(const std::vector<std::string> &lines) {
+  std::vector<Block> out;
+  Block cur;
+  for (const std::string &line : lines) {
+    const std::vector<std::string> f = fields(line);
+    if (f.empty() || f[0][0] == '#') continue;
+    if (f[0] == "i" || f[0] == "e" || f[0] == "q") continue;
+    if (f[0] == "s") {
+      if (f.size() != 7) die("Invalid MAF format (number of fields in 's' line not correct)");
+      if (f[4][0] != '+' && f[4][0] != '-') die("Invalid MAF format (strand)");
+      Row r;
+      r.name = f[1]; r.seq = f[6]; r.start = std::atoi(f[2].c_str()); r.length = std::atoi(f[3].c_str()); r.strand = f[4][0];
+      cur.rows.push_back(r);
+      continue;
+    }
+    if (f[0] == "a") {
+      if (!cur.rows.empty()) { check_equal(cur); out.push_back(cur); }
+      cur = Block();
+    }
+  }
+  if (!cur.rows.empty()) { check_equal(cur); out.push_back(cur); }
+  return out;
+}
+
+// A ClustalW file holds one block; rows get start = length = 0 (rnaz_utils.c:44-117)
+std::vector<Block> read_clustal(const std::vector<std::string> &lines) {
+  std::vector<std::string> names, seqs;
+  size_t nn = 0;
+  for (const std::string &raw : lines) {
+    std::string line = raw;
+    while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
+    if (line.compare(0, 7, "CLUSTAL") == 0) {
+      if (!names.empty()) break;
+      continue;
+    }
+    if (line.size() < 4 || std::isspace(static_cast<unsigned char>(line[0]))) { nn = 0; continue; }
+    const std::vector<std::string> f = fields(line);
+    if (f.size() < 2) continue;
+    const std::string name = f[0].substr(0, 99);
+    if (nn == names.size()) { names.push_back(name); seqs.push_back(f[1]); }
+    else {
+      if (names[nn] != name) die("Inconsistent sequence names in CLUSTAL file");
+      seqs[nn] += f[1];
+    }
+    nn++;
+  }
+  std::vector<Block> out;
+  if (!names.empty()) {
+    Block b;
+    for (size_t i = 0; i < names.size(); i++) { Row r; r.name = names[i]; r.seq = seqs[i]; b.rows.push_back(r); }
+    check_equal(b);
+    out.push_back(b);
+  }
+  return out;
+}
+
+std::vector<Block> read_alignment(std::istream &in) {
+  std::vector<std::string> lines;
+  std::string line;
+  while (std::getline(in, line)) lines.push_back(line);
+  for (const std::string &l : lines) {
+    if (l.find_first_not_of(" \t\r\n") == std::string::npos) continue;
+    if (l.compare(0, 7, "CLUSTAL") == 0) return read_clustal(lines);
+    break;
+  }
+  return read_maf(lines);
+}
+
+// printResults (misc.c:392-552); the HSS counter runs across blocks and is not advanced after a --best-only break
+struct Listing {
+  FILE *out = stdout;
+  int fmt = 0;          // 0 default table, 1 GTF, 2 tabular
+  float cutoff = 1.0f;
+  bool bestOnly = false, bestRegion = false;
+  int hitCounter = 0;
+
+  void block(std::vector<rc_hss> res, const std::string &refName) {
+    res.erase(std::remove_if(res.begin(), res.end(), [](const rc_hss &h) { return !(h.score > 0.0f); }), res.end());
+    std::vector<char> hide(res.size(), 0);
+    if (bestRegion) {   // misc.c:408-433: sort by start codon, hide the weaker of two overlapping HSS
+      std::stable_sort(res.begin(), res.end(), [](const rc_hss &a, const rc_hss &b) { return a.startSite < b.startSite; });
+      size_t curr = 0;
+      for (size_t nxt = 1; nxt < res.size(); nxt++) {
+        if (!(res[curr].endSite <= res[nxt].startSite)) {
+          if (res[curr].score > res[nxt].score) hide[nxt] = 1;
+          else { hide[curr] = 1; curr = nxt; }
+        } else curr = nxt;
+      }
+    }
+    std::vector<size_t> order(res.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return res[a].score > res[b].score; });
+    if (res.empty() || res[order[0]].pvalue > cutoff) {
+      if (fmt == 0) std::fprintf(out, "\nNo significant coding regions found.\n");
+      return;
+    }
+    if (fmt == 0) {
+      std::fprintf(out, "\n%6s%5s%7s%6s%6s%12s%12s%12s%9s%9s\n", " HSS # ", "Frame", "Length", "From", "To", "Name", "Start", "End", "Score", "P");
+      std::fprintf(out, "======================================================================================\n");
+    }
+    for (size_t idx : order) {
+      const rc_hss &h = res[idx];
+      const double p = static_cast<double>(h.pvalue);
+      if (!(h.pvalue < cutoff)) break;
+      if (hide[idx]) continue;
+      const int length = h.endSite - h.startSite + 1;
+      const char strand[2] = {static_cast<char>(h.strand), 0};
+      if (fmt == 0) {
+        std::fprintf(out, "%6i %4s%i%7i%6i%6i%12s%12i%12i%9.2f", hitCounter, strand, h.frame + 1, length, h.startSite + 1, h.endSite + 1,
+                     refName.c_str(), h.startGenomic, h.endGenomic, static_cast<double>(h.score));
+        if (p < 0.001) {
+          if (p < 10e-16) std::fprintf(out, "   <1e-16\n"); else std::fprintf(out, "% 9.1e\n", p);
+        } else std::fprintf(out, "% 9.3f\n", p);
+      } else if (fmt == 1) {
+        const size_t k = refName.find('.');
+        const std::string name = k == std::string::npos ? refName : refName.substr(k + 1);
+        std::fprintf(out, "%s\t%s\t%s\t%i\t%i\t%.2f|%.2e\t%s\t%s\t%s%i%s\n", name.c_str(), "RNAcode", "CDS", h.startGenomic + 1, h.endGenomic + 1,
+                     static_cast<double>(h.score), p, strand, ".", "gene_id \"Gene", hitCounter, "\"; transcript_id \"transcript 0\";");
+      } else {
+        std::fprintf(out, "%i\t%s\t%i\t%i\t%i\t%i\t%s\t%i\t%i\t%7.3f\t", hitCounter, strand, h.frame + 1, length, h.startSite + 1, h.endSite + 1,
+                     refName.c_str(), h.startGenomic, h.endGenomic, static_cast<double>(h.score));
+        if (p < 0.001) std::fprintf(out, "% 9.3e\n", p); else std::fprintf(out, "% 9.3f\n", p);
+      }
+      if (bestOnly) break;
+      hitCounter++;
+    }
+  }
+};
+
+void usage() {
+  std::fprintf(stderr, "usage: rnacode_hip [-n N] [-p CUTOFF] [-g | -t] [-b] [-r] [-s] [-m 62|90] [-c D,O,o,S] [-o OUT] [--trees SIDECAR]\n"
+                       "                   [--seed-base S] [--device D] [--sub-blocks B] [FILE]\n");
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  rc_params par;
+  rc_default_params(&par);
+  Listing list;
+  std::string file, outfile, trees;
+  int device = 0, subBlocks = 2048;
+  for (int a = 1; a < argc; a++) {
+    const std::string o = argv[a];
+    auto val = [&]() -> const char * { if (a + 1 >= argc) { usage(); std::exit(2); } return argv[++a]; };
+    if (o == "-o" || o == "--outfile") outfile = val();
+    else if (o == "-g" || o == "--gtf") list.fmt = 1;
+    else if (o == "-t" || o == "--tabular") list.fmt = 2;
+    else if (o == "-b" || o == "--best-only") list.bestOnly = true;
+    else if (o == "-r" || o == "--best-region") list.bestRegion = true;
+    else if (o == "-s" || o == "--stop-early") par.stopEarly = 1;
+    else if (o == "-n" || o == "--num-samples") par.sampleN = std::atoi(val());
+    else if (o == "-p" || o == "--cutoff") par.cutoff = static_cast<float>(std::atof(val()));
+    else if (o == "-m" || o == "--blosum") par.blosum = std::atoi(val());
+    else if (o == "-c" || o == "--pars") {
+      float *dst[4] = {&par.Delta, &par.Omega, &par.omega, &par.stopPenalty_0};
+      std::stringstream ss(val());
+      std::string item;
+      for (int i = 0; i < 4 && std::getline(ss, item, ','); i++) *dst[i] = static_cast<float>(std::atof(item.c_str()));
+    } else if (o == "--trees") trees = val();
+    else if (o == "--seed-base") par.seed_base = static_cast<uint32_t>(std::strtoul(val(), nullptr, 10));
+    else if (o == "--device") device = std::atoi(val());
+    else if (o == "--sub-blocks") subBlocks = std::max(1, std::atoi(val()));
+    else if (o == "-h" || o == "--help") { usage(); return 0; }
+    else if (o == "-e" || o == "--eps") die("EPS plots are drawn by `python -m rnacode_amd.cli -e`");
+    else if (!o.empty() && o[0] == '-' && o != "-") { usage(); return 2; }
+    else file = o;
+  }
+  if (par.blosum != 62 && par.blosum != 90) die("Currently only BLOSUM62 and BLOSUM90 are supported.");
+  list.cutoff = par.cutoff;
+
+  std::vector<Block> blocks;
+  if (file.empty() || file == "-") blocks = read_alignment(std::cin);
+  else {
+    std::ifstream in(file);
+    if (!in) die("Could not open input file " + file);
+    blocks = read_alignment(in);
+  }
+  const int n = static_cast<int>(blocks.size());
+  if (!trees.empty()) {   // one '<newick> TAB <kappa>' line per block, '-' for blocks without a tree
+    std::ifstream in(trees);
+    if (!in) die("Could not open " + trees);
+    std::string line;
+    int i = 0;
+    while (std::getline(in, line)) {
+      if (line.find_first_not_of(" \t\r\n") == std::string::npos) continue;
+      if (i >= n) { i++; continue; }
+      const size_t tab = line.find('\t');
+      if (tab != std::string::npos) { blocks[i].tree = line.substr(0, tab); blocks[i].kappa = static_cast<float>(std::atof(line.c_str() + tab + 1)); }
+      i++;
+    }
+    if (i != n) die(std::to_string(n) + " alignment blocks but " + std::to_string(i) + " sidecar entries");
+  }
+
+  if (!outfile.empty()) { list.out = std::fopen(outfile.c_str(), "w"); if (!list.out) die("Could not open " + outfile); }
+  rc_ctx *ctx = nullptr;
+  if (rc_ctx_create(device, &ctx) != RC_OK) die(rc_last_error());
+  const auto t0 = std::chrono::steady_clock::now();
+
+  // rc_block views of the blocks
+  std::vector<std::vector<const char *>> rowPtr(n), namePtr(n);
+  std::vector<rc_block> rb(n);
+  for (int i = 0; i < n; i++) {
+    for (const Row &r : blocks[i].rows) { rowPtr[i].push_back(r.seq.c_str()); namePtr[i].push_back(r.name.c_str()); }
+    rc_block &b = rb[i];
+    std::memset(&b, 0, sizeof b);
+    b.n_rows = static_cast<int>(blocks[i].rows.size());
+    b.n_cols = static_cast<int>(blocks[i].rows[0].seq.size());
+    b.rows = rowPtr[i].data(); b.names = namePtr[i].data();
+    b.ref_start = blocks[i].rows[0].start; b.ref_length = blocks[i].rows[0].length;
+  }
+
+  rc_stream *stream = nullptr;
+  if (rc_stream_create(ctx, &par, 3, &stream) != RC_OK) die(rc_last_error());
+  const int cap = 1 << 14;
+  std::vector<char> nwk;
+  std::vector<float> kap;
+  int next = 0, base = 0;
+  std::vector<rc_hss> hss;
+  std::vector<int64_t> offs;
+  while (next < n || rc_stream_pending(stream) > 0) {
+    while (next < n && rc_stream_pending(stream) < 3) {
+      const int m = std::min(subBlocks, n - next);
+      if (trees.empty()) {   // what treeML() hands over (RNAcode.c:153): tree + kappa, fitted on the GPU, all blocks of the sub-batch at once
+        nwk.assign(static_cast<size_t>(m) * cap, 0);
+        kap.assign(m, 0.0f);
+        if (rc_fit_trees_device(ctx, rb.data() + next, m, nwk.data(), cap, kap.data(), nullptr) < 0) die(rc_last_error());
+        for (int i = 0; i < m; i++) { blocks[next + i].tree = nwk.data() + static_cast<size_t>(i) * cap; blocks[next + i].kappa = kap[i]; }
+      }
+      for (int i = next; i < next + m; i++) { rb[i].newick = blocks[i].tree.empty() ? nullptr : blocks[i].tree.c_str(); rb[i].kappa = blocks[i].kappa; }
+      if (rc_stream_submit(stream, rb.data() + next, m) != RC_OK) die(rc_last_error());
+      next += m;
+    }
+    rc_batch *b = nullptr;
+    if (rc_stream_next(stream, &b) != RC_OK) die(rc_last_error());
+    const int m = rc_batch_size(b);
+    offs.assign(static_cast<size_t>(m) + 1, 0);
+    if (rc_batch_hss_all(b, nullptr, 0, offs.data()) != RC_OK) die(rc_last_error());
+    hss.resize(static_cast<size_t>(std::max<int64_t>(offs[m], 1)));
+    if (rc_batch_hss_all(b, hss.data(), offs[m], offs.data()) != RC_OK) die(rc_last_error());
+    for (int i = 0; i < m; i++) {
+      const int st = rc_batch_status(b, i);
+      const Block &blk = blocks[base + i];
+      if (st == RC_ERR_SKIP) {   // RNAcode.c:142-150
+        std::fprintf(stderr, "Skipping alignment. %s\n", blk.rows.size() <= 2 ? "There must be at least three sequences in the alignment." : "Too short.");
+        continue;
+      }
+      if (st != RC_OK) {         // RNAcode.c:153-156
+        const char *why = rc_batch_block_error(b, i);
+        std::fprintf(stderr, "Skipping alignment. Failed to build ML tree. (%s)\n", (why && *why) ? why : "not scored");
+        continue;
+      }
+      list.block(std::vector<rc_hss>(hss.begin() + offs[i], hss.begin() + offs[i + 1]), blk.rows[0].name);
+    }
+    base += m;
+    rc_stream_recycle(stream, b);
+  }
+  rc_stream_destroy(stream);
+  if (list.fmt == 0) {   // RNAcode.c:223-228
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::fprintf(list.out, "\n%i alignment(s) scored in %.2f seconds. Parameters used:\nN=%i, Delta=%.2f, Omega=%.2f, omega=%.2f, stop penalty=%.2f\n\n",
+                 n, secs, par.sampleN, static_cast<double>(par.Delta), static_cast<double>(par.Omega), static_cast<double>(par.omega),
+                 static_cast<double>(par.stopPenalty_k));
+  }
+  rc_ctx_destroy(ctx);
+  if (list.out != stdout) std::fclose(list.out);
+  return 0;
+}

@@ -268,6 +268,52 @@ def test_cli_end_to_end_matches_reference_listing(tmp_path):
         assert outp.read_text() == doc["print"][variant]
 
 
+def test_native_cli_matches_reference_listing_and_python_cli(tmp_path):
+    """rnacode_amd/rnacode_hip (rc_cli.cpp: C++ on the public C-ABI only -- readers, GPU tree fit, rc_stream_*, printResults):
+    the reference's own listings byte for byte, and the default table equal to the Python driver's (footer timing aside)."""
+    import os
+    import subprocess
+
+    from conftest import ROOT
+    from rnacode_amd import cli
+    from rnacode_amd.synth import to_maf
+    exe = os.path.join(ROOT, "rnacode_amd", "rnacode_hip")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    for name, variant, flags in (("genomic_preprocessed_n100", "tabular", ["-t"]),
+                                 ("genomic_preprocessed_n100", "tabular", ["-t", "--sub-blocks", "5"]),
+                                 ("genomic_preprocessed_n100", "tabular_best_region", ["-t", "-r", "--sub-blocks", "1"]),
+                                 ("coding_maf_n100", "gtf", ["-g"]),
+                                 ("genomic_preprocessed_n100", None, [])):
+        doc = load_golden(name)
+        blocks = [block_from_golden(e) for e in doc["blocks"]]
+        maf = tmp_path / "in.maf"
+        maf.write_text(to_maf(blocks))
+        side = tmp_path / "trees.tsv"
+        side.write_text("".join("-\n" if "skipped" in e["ref"] else f"{e['ref']['tree']}\t{e['ref']['kappa']!r}\n"
+                                for e in doc["blocks"]))
+        outp = tmp_path / "out.txt"
+        common = [str(maf), "--trees", str(side), "-n", str(doc["samples"]), "--seed-base", str(doc["seed_base"])]
+        r = subprocess.run([exe, *common, "-o", str(outp), *flags], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        if variant is not None:
+            assert outp.read_text() == doc["print"][variant]
+        else:   # default table: against the Python driver, without the footer's seconds
+            pyo = tmp_path / "py.txt"
+            assert cli.main([*common, "-o", str(pyo)]) == 0
+            strip = lambda t: [l for l in t.splitlines() if "alignment(s) scored in" not in l]
+            assert strip(outp.read_text()) == strip(pyo.read_text())
+            assert "Skipping alignment. Too short." in r.stderr
+    # ClustalW input, trees fitted on the GPU by the driver itself
+    doc = load_golden("coding_aln_n100")
+    b = block_from_golden(doc["blocks"][0])
+    aln = tmp_path / "in.aln"
+    aln.write_text("CLUSTAL W (1.83) multiple sequence alignment\n\n" + "".join(f"{r.name:<40s}{r.seq}\n" for r in b.rows) + "\n")
+    r = subprocess.run([exe, str(aln), "-n", "100", "-t"], capture_output=True, text=True, timeout=300)
+    pyo = tmp_path / "py2.txt"
+    assert r.returncode == 0 and cli.main([str(aln), "-n", "100", "-t", "-o", str(pyo)]) == 0
+    assert r.stdout == pyo.read_text() and r.stdout.count("\n") >= 2
+
+
 def test_extreme_shapes_against_oracle(ctx):
     """Maximum row count of the kernels (N = 32), a long block (1500 columns) and the smallest
     legal block, same seeds through the HIP path and the oracle."""

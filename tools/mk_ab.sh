@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 ROOT=$(pwd)
-build() { make -s -C rnacode_amd/csrc -j6 OUT=$ROOT/tools/ab_$1.so OBJDIR=$ROOT/tools/build_ab_$1 EXTRA=-DRC_PROFILING > /dev/null; }
+build() { make -s -C rnacode_amd/csrc -j6 OUT=$ROOT/tools/ab_$1.so OBJDIR=$ROOT/tools/build_ab_$1 EXTRA=-DRC_PROFILING lib > /dev/null; }
 git stash -q
 build A
 git stash pop -q

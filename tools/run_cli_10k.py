@@ -19,3 +19,12 @@ rc = cli.main([maf, "-n", "1000", "-t", "-o", os.path.join(d, "out.tsv")])
 dt = time.time() - t
 print(f"cli rc={rc}: {nb} blocks end to end in {dt:.2f} s ({os.path.getsize(maf) / 1e6:.1f} MB MAF, "
       f"{sum(1 for _ in open(os.path.join(d, 'out.tsv')))} HSS lines)")
+# the native driver (rc_cli.cpp), a fresh process each time: library load and context creation included
+import subprocess  # noqa: E402
+exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rnacode_amd", "rnacode_hip")
+for _ in range(2):
+    t = time.time()
+    r = subprocess.run([exe, maf, "-n", "1000", "-t", "-o", os.path.join(d, "out_native.tsv")], capture_output=True, text=True)
+    dt = time.time() - t
+    same = open(os.path.join(d, "out_native.tsv")).read() == open(os.path.join(d, "out.tsv")).read()
+    print(f"native rc={r.returncode}: {nb} blocks end to end in {dt:.2f} s, listing identical to the Python driver's: {same}")
