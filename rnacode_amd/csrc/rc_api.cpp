@@ -1273,7 +1273,7 @@ int rc_fit_tree(const rc_block *blk, char *newick_out, int32_t cap, float *kappa
 int rc_fit_trees(const rc_block *blocks, int32_t n_blocks, char *newick_out, int32_t cap, float *kappa_out, int32_t threads) {
   if (!blocks || !newick_out || !kappa_out || n_blocks < 0 || cap < 8) return fail(RC_ERR_ARG, "bad argument");
   std::atomic<int> next{0}, done{0};
-  unsigned nt = threads > 0 ? static_cast<unsigned>(threads) : std::max(1u, std::thread::hardware_concurrency());
+  unsigned nt = threads > 0 ? static_cast<unsigned>(threads) : static_cast<unsigned>(std::min(effective_cpus(), 32));   // the CPUs this process may use, not the host's
   nt = std::min<unsigned>(nt, static_cast<unsigned>(std::max(1, n_blocks)));
   auto work = [&]() {
     for (;;) {
@@ -1313,7 +1313,7 @@ int rc_fit_trees_device(rc_ctx *c, const rc_block *blocks, int32_t n_blocks, cha
   std::vector<char> ok(n_blocks, 0);
   {
     std::atomic<int> next{0};
-    const unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), static_cast<unsigned>(std::max(1, n_blocks)));
+    const unsigned nt = std::min<unsigned>(static_cast<unsigned>(c->hostThreads), static_cast<unsigned>(std::max(1, n_blocks)));
     auto work = [&]() {
       for (;;) {
         const int i = next.fetch_add(1);

@@ -228,6 +228,8 @@ int main(int argc, char **argv) {
   if (par.blosum != 62 && par.blosum != 90) die("Currently only BLOSUM62 and BLOSUM90 are supported.");
   list.cutoff = par.cutoff;
 
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tRead = now(), tCtx = 0, tTrees = 0, tSubmit = 0, tWait = 0, tList = 0;
   std::vector<Block> blocks;
   if (file.empty() || file == "-") blocks = read_alignment(std::cin);
   else {
@@ -252,8 +254,11 @@ int main(int argc, char **argv) {
   }
 
   if (!outfile.empty()) { list.out = std::fopen(outfile.c_str(), "w"); if (!list.out) die("Could not open " + outfile); }
+  tRead = now() - tRead;
   rc_ctx *ctx = nullptr;
+  tCtx = now();
   if (rc_ctx_create(device, &ctx) != RC_OK) die(rc_last_error());
+  tCtx = now() - tCtx;
   const auto t0 = std::chrono::steady_clock::now();
 
   // rc_block views of the blocks
@@ -274,24 +279,36 @@ int main(int argc, char **argv) {
   const int cap = 1 << 14;
   std::vector<char> nwk;
   std::vector<float> kap;
-  int next = 0, base = 0;
+  int next = 0, base = 0, fitted = 0;
   std::vector<rc_hss> hss;
   std::vector<int64_t> offs;
   while (next < n || rc_stream_pending(stream) > 0) {
     while (next < n && rc_stream_pending(stream) < 3) {
       const int m = std::min(subBlocks, n - next);
-      if (trees.empty()) {   // what treeML() hands over (RNAcode.c:153): tree + kappa, fitted on the GPU, all blocks of the sub-batch at once
-        nwk.assign(static_cast<size_t>(m) * cap, 0);
-        kap.assign(m, 0.0f);
-        if (rc_fit_trees_device(ctx, rb.data() + next, m, nwk.data(), cap, kap.data(), nullptr) < 0) die(rc_last_error());
-        for (int i = 0; i < m; i++) { blocks[next + i].tree = nwk.data() + static_cast<size_t>(i) * cap; blocks[next + i].kappa = kap[i]; }
+      if (trees.empty() && next + m > fitted) {
+        // what treeML() hands over (RNAcode.c:153): tree + kappa, fitted on the GPU.  One wavefront per block, latency-bound:
+        // a call costs about the same for 100 blocks as for 2048 (the wavefronts the chip holds at once), so the fits
+        // run ahead of the scoring in chunks of 8192 blocks
+        const int mf = std::min(std::max(subBlocks, 8192), n - fitted);
+        nwk.assign(static_cast<size_t>(mf) * cap, 0);
+        kap.assign(mf, 0.0f);
+        const double t = now();
+        if (rc_fit_trees_device(ctx, rb.data() + fitted, mf, nwk.data(), cap, kap.data(), nullptr) < 0) die(rc_last_error());
+        tTrees += now() - t;
+        for (int i = 0; i < mf; i++) { blocks[fitted + i].tree = nwk.data() + static_cast<size_t>(i) * cap; blocks[fitted + i].kappa = kap[i]; }
+        fitted += mf;
       }
       for (int i = next; i < next + m; i++) { rb[i].newick = blocks[i].tree.empty() ? nullptr : blocks[i].tree.c_str(); rb[i].kappa = blocks[i].kappa; }
+      const double t = now();
       if (rc_stream_submit(stream, rb.data() + next, m) != RC_OK) die(rc_last_error());
+      tSubmit += now() - t;
       next += m;
     }
     rc_batch *b = nullptr;
+    double t = now();
     if (rc_stream_next(stream, &b) != RC_OK) die(rc_last_error());
+    tWait += now() - t;
+    t = now();
     const int m = rc_batch_size(b);
     offs.assign(static_cast<size_t>(m) + 1, 0);
     if (rc_batch_hss_all(b, nullptr, 0, offs.data()) != RC_OK) die(rc_last_error());
@@ -312,9 +329,12 @@ int main(int argc, char **argv) {
       list.block(std::vector<rc_hss>(hss.begin() + offs[i], hss.begin() + offs[i + 1]), blk.rows[0].name);
     }
     base += m;
+    tList += now() - t;
     rc_stream_recycle(stream, b);
   }
   rc_stream_destroy(stream);
+  if (std::getenv("RC_CLI_TIMES"))
+    std::fprintf(stderr, "[rnacode_hip] read %.3f s, context %.3f s, trees %.3f s, submit %.3f s, wait %.3f s, listing %.3f s\n", tRead, tCtx, tTrees, tSubmit, tWait, tList);
   if (list.fmt == 0) {   // RNAcode.c:223-228
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::fprintf(list.out, "\n%i alignment(s) scored in %.2f seconds. Parameters used:\nN=%i, Delta=%.2f, Omega=%.2f, omega=%.2f, stop penalty=%.2f\n\n",

@@ -24,7 +24,9 @@ import subprocess  # noqa: E402
 exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rnacode_amd", "rnacode_hip")
 for _ in range(2):
     t = time.time()
-    r = subprocess.run([exe, maf, "-n", "1000", "-t", "-o", os.path.join(d, "out_native.tsv")], capture_output=True, text=True)
+    r = subprocess.run([exe, maf, "-n", "1000", "-t", "-o", os.path.join(d, "out_native.tsv")], capture_output=True, text=True,
+                       env=dict(os.environ, RC_CLI_TIMES="1"))
+    print(r.stderr.strip().splitlines()[-1] if r.stderr.strip() else "")
     dt = time.time() - t
     same = open(os.path.join(d, "out_native.tsv")).read() == open(os.path.join(d, "out.tsv")).read()
     print(f"native rc={r.returncode}: {nb} blocks end to end in {dt:.2f} s, listing identical to the Python driver's: {same}")
