@@ -119,3 +119,25 @@ def test_header_is_plain_c_and_the_example_links(tmp_path):
     api.lib()
     _build_c_example(str(tmp_path / "example_batch"))
     _build_c_example(str(tmp_path / "example_stream"), "example_stream.c")
+
+
+def test_native_driver_is_built_and_fails_loudly_without_a_gpu(tmp_path):
+    """rnacode_amd/rnacode_hip (rc_cli.cpp) is built next to the library; without a HIP device it says so instead of scoring
+    anything on the CPU (this test runs in the GPU-less container; on a GPU box the device exists and it scores)."""
+    import subprocess
+    exe = os.path.join(ROOT, "rnacode_amd", "rnacode_hip")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    r = subprocess.run([exe, "--help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "usage: rnacode_hip" in r.stderr
+    maf = tmp_path / "in.maf"
+    maf.write_text("a score=0\ns a.chr1 0 9 + 100 ATGGCTAAA\ns b.chr1 0 9 + 100 ATGGCAAAA\ns c.chr1 0 9 + 100 ATGGCTAAG\n\n")
+    from rnacode_amd import api
+    r = subprocess.run([exe, str(maf), "-n", "64", "-t"], capture_output=True, text=True)
+    if api.lib().rc_device_count() == 0:
+        assert r.returncode != 0 and "no HIP device" in r.stderr and r.stdout == ""
+    else:
+        assert r.returncode == 0
+    bad = tmp_path / "bad.maf"
+    bad.write_text("a score=0\ns a.chr1 0 9 + 100\n")
+    r = subprocess.run([exe, str(bad)], capture_output=True, text=True)
+    assert r.returncode != 0 and "Invalid MAF format" in r.stderr
