@@ -23,8 +23,10 @@ extern "C" {
 #define RC_ERR_UNSUPPORTED (-3) /* shape outside the built kernels (N > RC_MAX_ROWS) */
 #define RC_ERR_SKIP (-4)        /* block the reference driver skips (RNAcode.c:142-150) */
 
-#define RC_MAX_ROWS 64          /* rows per block handled by the device kernels; N <= 32 runs the register-resident kernels,
-                                   33..64 a slower instantiation of the same code (the reference's own limit is 500, rnaz_utils.h:7) */
+#define RC_MAX_ROWS 500         /* rows per block, the reference's own limit (MAX_NUM_NAMES, rnaz_utils.h:7).  N <= 32 runs the
+                                   register-resident kernels, 33..64 a slower instantiation of the same code, 65..500 generic kernels
+                                   with their per-sequence states in global memory (slow, complete); the built-in tree estimator
+                                   (rc_fit_tree*) takes up to 64 rows, wider blocks need their tree from the caller */
 
 /* Scoring parameters: the members of `parameters pars` (src/RNAcode.h:29-54) that the
  * scoring path reads (score.c:415,419,508-533,842,992,1040), plus the seed base that

@@ -204,6 +204,7 @@ struct rc_ctx {
   int debugSkip = 0;
   DevBuf d_cellStats;              // RC_PROFILING builds with RC_CELL_STATS=1: k_null's cell counters, printed when the context goes
   int serialNative = 0;
+  int genericMinRows = kTemplRows + 1;   // blocks with at least this many rows take the generic kernels (RC_GENERIC_MIN_ROWS: tests run everything through them)
   int stopRounds = 6;                    // at most this many rounds (RC_STOP_ROUNDS; <= kMaxRounds)
   long long stopTwoRoundsMinItems = 0;   // --stop-early runs two rounds of sample groups only for batches with at least this many (block, group) items
   int hostThreads = 0;
@@ -233,8 +234,8 @@ struct rc_batch {
   std::vector<DevBlock> db;                  // host copies of the block headers (offsets for the accessors)
   std::map<int, std::string> errs;           // blocks that were rejected: index -> message
   std::vector<int> okBlocks;                 // batch indices with status RC_OK
-  std::map<int, std::vector<int>> classes;   // N-1 -> batch indices
-  int classOff[kMaxRows + 1] = {0};          // start of class NK in the class-ordered lists
+  std::map<int, std::vector<int>> classes;   // class (N-1, or kGenericClass for blocks of more than 64 rows) -> batch indices
+  int classOff[kClassSlots] = {0};           // start of a class in the class-ordered lists
   int maxL = 0, maxDraws = 0, hssCap = 8;
   bool allExact = false;                     // gap parameters outside the fast kernels' range: EXACT instantiation for every block
   // blob
@@ -245,7 +246,7 @@ struct rc_batch {
   size_t S_floats = 0;
   std::vector<uint64_t> offS;
   // device
-  DevBuf dblob, dmaxima, dS, dhss, dhssCount, dhssPacked, dhssOffsets, dfit, dflags, dexact, dcounters, dscratch;
+  DevBuf dblob, dmaxima, dS, dhss, dhssCount, dhssPacked, dhssOffsets, dfit, dflags, dexact, dcounters, dscratch, dnativeScratch;
   float *maxPtr = nullptr;
   bool maximaExternal = false;
   PinBuf hstage, hpacked;
@@ -276,10 +277,10 @@ struct rc_stream {
 
 // layout of rc_batch::dcounters (uint32 units)
 namespace {
-constexpr size_t kCntExact = 0;                                  // [kMaxRows + 1] int: blocks flagged by k_prep_lut, by NK
+constexpr size_t kCntExact = 0;                                  // [kClassSlots] int: blocks flagged by k_prep_lut, by class
 constexpr int kMaxRounds = 6;                                    // --stop-early: rounds of sample groups (each doubles the samples simulated so far)
-constexpr size_t kCntWork = kMaxRows + 2;                        // [kMaxRounds][2 fast/exact][kMaxRows + 1][8]
-constexpr size_t kCntClamp = kCntWork + static_cast<size_t>(kMaxRounds) * 2 * (kMaxRows + 1) * 8;  // one u64 (8-byte aligned: see static_assert)
+constexpr size_t kCntWork = kClassSlots + 1;                     // [kMaxRounds][2 fast/exact][kClassSlots][8]
+constexpr size_t kCntClamp = kCntWork + static_cast<size_t>(kMaxRounds) * 2 * kClassSlots * 8;  // one u64 (8-byte aligned: see static_assert)
 constexpr size_t kCntTotal = kCntClamp + 2;
 static_assert((kCntClamp % 2) == 0, "clamp counter alignment");
 }  // namespace
@@ -352,6 +353,7 @@ int rc_ctx_create(int device, rc_ctx **out) {
   c->serialNative = std::getenv("RC_SERIAL_NATIVE") ? 1 : 0;   // profiling: one kernel at a time, clean per-kernel intervals
   c->stopTwoRoundsMinItems = 4LL * c->numCU * 16;   // the chip filled four times over
   if (const char *e = std::getenv("RC_STOP_MIN_ITEMS")) c->stopTwoRoundsMinItems = std::atoll(e);
+  if (const char *e = std::getenv("RC_GENERIC_MIN_ROWS")) c->genericMinRows = std::max(3, std::min(kTemplRows + 1, std::atoi(e)));
   if (const char *e = std::getenv("RC_STOP_ROUNDS")) c->stopRounds = std::max(2, std::min(kMaxRounds, std::atoi(e)));
   c->pt62.build(c->ct62);
   c->pt90.build(c->ct90);
@@ -460,7 +462,7 @@ static int batch_prepare(rc_batch *b, const rc_block *blocks, int32_t n_blocks, 
     const BlockMeta &m = b->meta[i];
     if (m.status != RC_OK) continue;
     b->okBlocks.push_back(i);
-    auto &cls = b->classes[m.NK];
+    auto &cls = b->classes[m.N < ctx->genericMinRows ? m.NK : kGenericClass];
     if (!cls.empty() && b->meta[cls.front()].L != m.L) sameL = false;
     cls.push_back(i);
     b->maxL = std::max(b->maxL, m.L);
@@ -492,7 +494,7 @@ static int batch_prepare(rc_batch *b, const rc_block *blocks, int32_t n_blocks, 
   {
     int *cl = reinterpret_cast<int *>(base + b->oClass);
     int at = 0;
-    std::fill(b->classOff, b->classOff + kMaxRows + 1, 0);
+    std::fill(b->classOff, b->classOff + kClassSlots, 0);
     for (auto &kv : b->classes) {
       b->classOff[kv.first] = at;
       std::memcpy(cl + at, kv.second.data(), sizeof(int) * kv.second.size());
@@ -548,6 +550,7 @@ static int batch_upload(rc_batch *b) {
     pa.exactList = b->dexact.as<int>();
     pa.exactCount = b->dcounters.as<int>() + kCntExact;
     std::memcpy(pa.classOff, b->classOff, sizeof pa.classOff);
+    pa.genericMinRows = c->genericMinRows;
     launch_prep(pa, ps);
   }
   HIP_TRY(b->evPrep.record(ps));
@@ -629,6 +632,20 @@ static int launch_native_block(const RunEnv &R) {
   for (auto &kv : b->classes) {
     NativeArgs nc = na;
     nc.blocks = R.classList + b->classOff[kv.first];
+    if (kv.first == kGenericClass) {   // more than 64 rows: states in a scratch, at most 256 blocks per launch share it
+      int maxNK = 0;
+      for (int bi : kv.second) maxNK = std::max(maxNK, b->meta[bi].NK);
+      const size_t stride = static_cast<size_t>(3) * maxNK * kWave;
+      const int chunk = 256;
+      HIP_TRY(b->dnativeScratch.ensure(stride * 6 * std::min<size_t>(chunk, kv.second.size()) * sizeof(float)));
+      for (size_t at = 0; at < kv.second.size(); at += chunk) {
+        NativeArgs ng = nc;
+        ng.blocks = nc.blocks + at;
+        launch_native_dp_generic(ng, static_cast<int>(std::min<size_t>(chunk, kv.second.size() - at)), b->dnativeScratch.as<float>(), stride, st);
+        b->nl[3]++;
+      }
+      continue;
+    }
     if (!launch_native_dp(kv.first, nc, static_cast<int>(kv.second.size()), st))
       return fail(RC_ERR_UNSUPPORTED, "no native DP kernel for this number of rows");
     b->nl[3]++;
@@ -654,6 +671,20 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
     p.NK = kv.first;
     int maxLc = 0;
     for (int bi : kv.second) maxLc = std::max(maxLc, b->meta[bi].L);
+    if (kv.first == kGenericClass) {   // k_null_generic: one launch for every block of more than 64 rows, whatever its N
+      int maxN = 0, maxNodes = 0;
+      for (int bi : kv.second) { maxN = std::max(maxN, b->meta[bi].N); maxNodes = std::max(maxNodes, b->db[bi].nnodes); }
+      p.stride = (null_generic_scratch_bytes(maxN, maxLc, maxNodes) + 3) / 4;   // in uint32 like the others
+      const std::pair<int, size_t> key(kGenericClass, 0);
+      if (!c->occ.count(key)) c->occ[key] = null_generic_occupancy();
+      const int occ = std::max(1, c->occ[key]);
+      p.grid = static_cast<int>(std::min<long long>(static_cast<long long>(kv.second.size()) * groupsHere, static_cast<long long>(c->numCU) * occ));
+      p.grid = static_cast<int>(std::max<size_t>(1, std::min<size_t>(p.grid, (static_cast<size_t>(1) << 30) / std::max<size_t>(p.stride, 1))));
+      p.need = p.stride * p.grid;
+      needSum += p.need; needMax = std::max(needMax, p.need);
+      plans.push_back(p);
+      continue;
+    }
     const int NCW = (p.NK + 4) / 5;   // 5 six-bit sigma codes per word
     p.stride = static_cast<size_t>(2) * (maxLc + 1) * NCW * kWave;
     // sigma codes of one strand x frame are staged in LDS when that still leaves >= 12 wavefronts per
@@ -714,10 +745,17 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
     a.maxima = b->maxPtr; a.clampCount = reinterpret_cast<unsigned long long *>(b->dcounters.as<uint32_t>() + kCntClamp);
     a.tieThr = c->tieThr; a.debugSkip = c->debugSkip; a.comboSplit = p.comboSplit;
     a.cellStats = c->d_cellStats.as<unsigned long long>();
-    unsigned int *work = b->dcounters.as<unsigned int>() + kCntWork + static_cast<size_t>(phase) * 2 * (kMaxRows + 1) * 8;
-    if (b->allExact || p.NK >= kFastRows) {
+    unsigned int *work = b->dcounters.as<unsigned int>() + kCntWork + static_cast<size_t>(phase) * 2 * kClassSlots * 8;
+    if (p.NK == kGenericClass) {
       a.skipMask = extraSkip;
-      a.workCounter = work + (kMaxRows + 1) * 8 + p.NK * 8;
+      a.comboSplit = 0;
+      a.scratchStride = p.stride * sizeof(uint32_t);   // bytes for this kernel
+      a.workCounter = work + p.NK * 8;
+      launch_null_generic(a, p.grid, reinterpret_cast<uint8_t *>(a.scratch), st);
+      b->nl[2]++;
+    } else if (b->allExact || p.NK >= kFastRows) {
+      a.skipMask = extraSkip;
+      a.workCounter = work + kClassSlots * 8 + p.NK * 8;
       if (!launch_null(p.NK, a, p.grid, 0, true, st)) return fail(RC_ERR_UNSUPPORTED, "no null kernel for this number of rows");
       b->nl[2]++;
     } else {
@@ -731,7 +769,7 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
       e.nClassBlocks = 0;
       e.skipMask = extraSkip;
       e.comboSplit = 0;
-      e.workCounter = work + (kMaxRows + 1) * 8 + p.NK * 8;
+      e.workCounter = work + kClassSlots * 8 + p.NK * 8;
       if (!launch_null(p.NK, e, p.gridExact, 0, true, st)) return fail(RC_ERR_UNSUPPORTED, "no null kernel for this number of rows");
     }
     if (concurrent) {

@@ -11,8 +11,11 @@
 
 namespace rc {
 
-constexpr int kMaxRows = 64;      // N <= 64 (RC_MAX_ROWS)
-constexpr int kFastRows = 32;     // N <= 32: register-resident kernels (k_null<N-1>, k_native_dp<N-1>); above: the wide kernels
+constexpr int kMaxRows = 500;     // N <= 500 (RC_MAX_ROWS, the reference's MAX_NUM_NAMES, rnaz_utils.h:7)
+constexpr int kTemplRows = 64;    // N <= 64: kernels instantiated per N-1 (k_null<N-1>, k_native_dp<N-1>); above: k_null_generic
+constexpr int kFastRows = 32;     // N <= 32: register-resident fast instantiations; 33..64 the EXACT instantiation only
+constexpr int kGenericClass = kTemplRows;   // row-count classes are indexed by N-1 (2..63); all wider blocks share this one
+constexpr int kClassSlots = kTemplRows + 1;
 constexpr int kMaxNodes = 2 * kMaxRows;
 constexpr int kWave = 64;         // CDNA wavefront
 constexpr int kLutSize = 64;      // sigma codes are indices into a 64-entry per-(strand,k) table
@@ -29,9 +32,9 @@ struct alignas(16) U4 { uint32_t x, y, z, w; };
 struct alignas(16) NodeRec {
   U4 thr[4];        // thr[p] = {t0, t1, t2, t3} for parent state p
   uint32_t basepack;   // base[p] in bits 2p..2p+1 (non-zero only for degenerate cumulative rows)
-  uint8_t parent;      // index of the parent node in this order (root: 0)
-  int8_t tiprow;       // alignment row of this tip, -1 for internal nodes
-  uint8_t pad[10];
+  uint16_t parent;     // index of the parent node in this order (root: 0); the instantiated kernels (< 256 nodes) read its low byte
+  int16_t tiprow;      // alignment row of this tip, -1 for internal nodes
+  uint8_t pad[8];
 };
 static_assert(sizeof(NodeRec) == 80, "NodeRec layout");
 
@@ -59,7 +62,8 @@ struct DevBlock {
   uint32_t out_index;    // position of this block in the batch (rows of the maxima matrix)
   // offsets (bytes) into the batch blob; host-written part
   uint64_t off_nodes;    // NodeRec[nnodes]
-  uint64_t off_qtip;     // u8[kMaxRows] node index of row r's tip (padded: k_null reads words)
+  uint64_t off_qtip;     // u8[N padded to 16] node index of row r's tip (k_null reads words); meaningful for N <= 64 (fewer than 256 nodes)
+  uint64_t off_qtip16;   // u16[N] the same for any N (k_null_generic)
   uint64_t off_refcol;   // u16[2][L+1]  strand s: 0-based column of reference residue i (1..L) in that strand's alignment
   uint64_t off_zw;       // u64[2][L+1][zw_words]  2 bits per k (bit 2((k-1)%32) of word (k-1)/32): 0 -> z=0, 1 -> z=+1, 2 -> z=-1
   uint64_t off_mask;     // u32[2][L+1][ceil(NK/5)] 6-bit AND masks (field k%5 of word k/5) zeroing the codon fields where row k has '-'

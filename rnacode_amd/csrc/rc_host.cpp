@@ -383,20 +383,21 @@ static inline size_t al16(size_t x) { return (x + 15) & ~static_cast<size_t>(15)
 namespace {
 // section sizes of one block in the two blob parts
 struct Sections {
-  size_t nodes, qtip, refcol, zw, mask, chars, zmask, models, hostTotal;
+  size_t nodes, qtip, qtip16, refcol, zw, mask, chars, zmask, models, hostTotal;
   size_t lut, sigma, devTotal;
   Sections(int N, int cols, int L, int nnodes) {
     const size_t NK = static_cast<size_t>(N) - 1, L1 = static_cast<size_t>(L) + 1, ncw = (NK + 4) / 5, zww = (NK + 31) / 32;
     const size_t zmw = (static_cast<size_t>(L) / 3 + 63) / 64;
     nodes = al16(static_cast<size_t>(nnodes) * sizeof(NodeRec));
-    qtip = al16(kMaxRows);
+    qtip = al16(static_cast<size_t>(N));
+    qtip16 = al16(2 * static_cast<size_t>(N));
     refcol = al16(2 * L1 * 2);
     zw = al16(2 * L1 * zww * 8);
     mask = al16(2 * L1 * ncw * 4);
     chars = al16(2 * static_cast<size_t>(N) * cols);
     zmask = al16(6 * zmw * 8);
     models = al16(2 * static_cast<size_t>(N) * sizeof(ModelRec));
-    hostTotal = nodes + qtip + refcol + zw + mask + chars + zmask + models;
+    hostTotal = nodes + qtip + qtip16 + refcol + zw + mask + chars + zmask + models;
     lut = al16(2 * NK * kLutSize * 4);
     sigma = al16(2 * NK * L1 * 4);
     devTotal = lut + sigma;
@@ -434,9 +435,10 @@ int prepare_block(const rc_block &in, const rc_params &par, const PairTable &pt,
   if (!parse_newick(in.newick, t, err)) return done(RC_ERR_ARG);
   if (static_cast<int>(t.tipname.size()) != N) { err = "tree and alignment differ in the number of sequences"; return done(RC_ERR_ARG); }
   if (t.nnodes > kMaxNodes) { err = "tree too large"; return done(RC_ERR_UNSUPPORTED); }
-  int rowtip[kMaxRows];
+  std::vector<int> rowtipv(N, -1);
+  int *rowtip = rowtipv.data();
   {
-    bool used[kMaxRows] = {false};
+    std::vector<char> used(N, 0);
     for (int r = 0; r < N; r++) {
       rowtip[r] = -1;
       if (!in.names[r]) { err = "row without a name"; return done(RC_ERR_ARG); }
@@ -456,6 +458,7 @@ int prepare_block(const rc_block &in, const rc_params &par, const PairTable &pt,
   size_t o = hoff;
   d.off_nodes = o; o += sec.nodes;
   d.off_qtip = o; o += sec.qtip;
+  d.off_qtip16 = o; o += sec.qtip16;
   d.off_refcol = o; o += sec.refcol;
   d.off_zw = o; o += sec.zw;
   d.off_mask = o; o += sec.mask;
@@ -492,9 +495,8 @@ int prepare_block(const rc_block &in, const rc_params &par, const PairTable &pt,
   }
 
   // getModels' inputs for both strands (RNAcode.c:164-165); scores and probs follow on the device
-  std::vector<int> rt(rowtip, rowtip + N);
   std::vector<float> dist;
-  tip_distances(t, rt, dist);
+  tip_distances(t, rowtipv, dist);
   float freqs[2][4];
   mono_freqs_both(chars, static_cast<size_t>(N) * cols, freqs[0], freqs[1]);
   ModelRec *models = reinterpret_cast<ModelRec *>(base + d.off_models);
@@ -536,7 +538,7 @@ int prepare_block(const rc_block &in, const rc_params &par, const PairTable &pt,
   for (int q = 0; q < t.nnodes; q++) {
     NodeRec &nr = nodes[q];
     std::memset(&nr, 0, sizeof nr);
-    nr.parent = static_cast<uint8_t>(t.parent[q]);
+    nr.parent = static_cast<uint16_t>(t.parent[q]);
     nr.tiprow = -1;
     double M[4][4];
     if (q != 0) hky.cumulative(t.length[q], M);                      // evolve.c:404 (scale 1.0), :292
@@ -547,11 +549,13 @@ int prepare_block(const rc_block &in, const rc_params &par, const PairTable &pt,
     }
   }
   uint8_t *qtip = base + d.off_qtip;
-  std::memset(qtip, 0, kMaxRows);
+  uint16_t *qtip16 = reinterpret_cast<uint16_t *>(base + d.off_qtip16);
+  std::memset(qtip, 0, sec.qtip);
   for (int r = 0; r < N; r++) {
     const int q = t.tipnode[rowtip[r]];
     qtip[r] = static_cast<uint8_t>(q);
-    nodes[q].tiprow = static_cast<int8_t>(r);
+    qtip16[r] = static_cast<uint16_t>(q);
+    nodes[q].tiprow = static_cast<int16_t>(r);
   }
   return done(RC_OK);
 }

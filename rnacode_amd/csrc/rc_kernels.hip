@@ -16,6 +16,7 @@
 // Numerics: every add/max of the DP is a single IEEE binary32 operation in the reference's
 // order; compile with -ffp-contract=off; float division is hipcc's correctly rounded default.
 #include "rc_null_kernel.h"
+#include "rc_null_generic.h"
 
 namespace rc {
 
@@ -188,8 +189,9 @@ __global__ __launch_bounds__(64) void k_prep_lut(PrepArgs A) {   // one wavefron
   const bool bad = __ballot(mine) != 0ull;
   if (threadIdx.x == 0 && bad) {
     A.flags[bi] |= kFlagExact;
-    const int at = atomicAdd(A.exactCount + NK, 1);
-    A.exactList[A.classOff[NK] + at] = bi;
+    const int cls = A.genericMinRows > N ? NK : kGenericClass;
+    const int at = atomicAdd(A.exactCount + cls, 1);
+    A.exactList[A.classOff[cls] + at] = bi;
   }
 }
 
@@ -315,20 +317,20 @@ __global__ __launch_bounds__(64) void k_native_scan(NativeArgs A) {
 __global__ __launch_bounds__(64) void k_sk_row(const uint8_t *blob, const DevBlock *dblocks, int bi, int s, int b, int iMax,
                                                float *out, int stride) {
   const DevBlock *db = dblocks + bi;
-  const int k = threadIdx.x;
-  if (k >= db->NK) return;
   const int L1 = db->L + 1;
   const unsigned long long *zw = reinterpret_cast<const unsigned long long *>(blob + db->off_zw);
   const float *sigma = reinterpret_cast<const float *>(blob + db->off_sigma);
-  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
-  int t = 0;
-  for (int i = b + 2; i <= iMax; i += 3, t++) {
-    const int zc = static_cast<int>((zw[static_cast<size_t>(s * L1 + i) * db->zw_words + (k >> 5)] >> (2 * (k & 31))) & 3ull);
-    // lanes follow different k: the branch may diverge here, which is fine for this helper
-    pair_step(zc, sigma[(s * db->NK + k) * L1 + i], db->Delta, db->Omega, db->omega, s0, s1, s2);
-    out[(k * 3 + 0) * stride + t] = s0;
-    out[(k * 3 + 1) * stride + t] = s1;
-    out[(k * 3 + 2) * stride + t] = s2;
+  for (int k = threadIdx.x; k < db->NK; k += kWave) {
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    int t = 0;
+    for (int i = b + 2; i <= iMax; i += 3, t++) {
+      const int zc = static_cast<int>((zw[static_cast<size_t>(s * L1 + i) * db->zw_words + (k >> 5)] >> (2 * (k & 31))) & 3ull);
+      // lanes follow different k: the branch may diverge here, which is fine for this helper
+      pair_step(zc, sigma[(static_cast<size_t>(s) * db->NK + k) * L1 + i], db->Delta, db->Omega, db->omega, s0, s1, s2);
+      out[(static_cast<size_t>(k) * 3 + 0) * stride + t] = s0;
+      out[(static_cast<size_t>(k) * 3 + 1) * stride + t] = s1;
+      out[(static_cast<size_t>(k) * 3 + 2) * stride + t] = s2;
+    }
   }
 }
 
@@ -547,7 +549,7 @@ RC_NULL_UNIT(a) RC_NULL_UNIT(b) RC_NULL_UNIT(c) RC_NULL_UNIT(d) RC_NULL_UNIT(e) 
 #undef RC_NULL_UNIT
 
 int null_occupancy(int NK, size_t ldsBytes) {
-  if (NK < 2 || NK > kMaxRows - 1) return 0;
+  if (NK < 2 || NK > kTemplRows - 1) return 0;
   return NK <= 6 ? null_occupancy_a(NK, ldsBytes) : NK <= 12 ? null_occupancy_b(NK, ldsBytes)
        : NK <= 21 ? null_occupancy_c(NK, ldsBytes) : NK <= 31 ? null_occupancy_d(NK, ldsBytes)
        : NK <= 39 ? null_occupancy_e(NK, ldsBytes) : NK <= 47 ? null_occupancy_f(NK, ldsBytes)
@@ -556,7 +558,7 @@ int null_occupancy(int NK, size_t ldsBytes) {
 
 // N-1 >= 32: only the EXACT instantiation without code staging exists (ldsBytes and exact are ignored)
 bool launch_null(int NK, const NullArgs &a, int grid, size_t ldsBytes, bool exact, hipStream_t stream) {
-  if (NK < 2 || NK > kMaxRows - 1) return false;
+  if (NK < 2 || NK > kTemplRows - 1) return false;
   return NK <= 6 ? launch_null_a(NK, a, grid, ldsBytes, exact, stream) : NK <= 12 ? launch_null_b(NK, a, grid, ldsBytes, exact, stream)
        : NK <= 21 ? launch_null_c(NK, a, grid, ldsBytes, exact, stream) : NK <= 31 ? launch_null_d(NK, a, grid, ldsBytes, exact, stream)
        : NK <= 39 ? launch_null_e(NK, a, grid, ldsBytes, exact, stream) : NK <= 47 ? launch_null_f(NK, a, grid, ldsBytes, exact, stream)
@@ -606,6 +608,22 @@ void launch_native_scan(const NativeArgs &a, int nblocks, hipStream_t stream) {
 void launch_sk_row(const uint8_t *blob, const DevBlock *dblocks, int bi, int s, int b, int iMax, float *out, int stride,
                    hipStream_t stream) {
   hipLaunchKernelGGL(k_sk_row, dim3(1), dim3(64), 0, stream, blob, dblocks, bi, s, b, iMax, out, stride);
+}
+
+size_t null_generic_scratch_bytes(int N, int L, int nnodes) { return GenericLayout(N, L, nnodes).total; }
+
+int null_generic_occupancy() {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_null_generic, 64, 0) != hipSuccess) return 0;
+  return nb;
+}
+
+void launch_null_generic(const NullArgs &a, int grid, uint8_t *scratchBytes, hipStream_t stream) {
+  hipLaunchKernelGGL(k_null_generic, dim3(grid), dim3(64), 0, stream, a, a.blob, a.dblocks, a.classBlocks, a.flags, a.U, a.pair, scratchBytes, a.maxima);
+}
+
+void launch_native_dp_generic(const NativeArgs &a, int nblocks, float *scratch, size_t scratchStride, hipStream_t stream) {
+  hipLaunchKernelGGL(k_native_dp_generic, dim3(nblocks * 6), dim3(64), 0, stream, a, scratch, scratchStride);
 }
 
 void launch_stop_mark(const FitArgs &a, int nblocks, hipStream_t stream) {

@@ -67,8 +67,9 @@ struct PrepArgs {
   const CodeInfo *codeInfo;   // [64]
   uint32_t *flags;            // per batch index
   int *exactList;             // per class: batch indices flagged kFlagExact, at classOff[NK]
-  int *exactCount;            // [kMaxRows + 1] by NK
-  int classOff[kMaxRows + 1]; // by NK
+  int *exactCount;            // [kClassSlots] by class
+  int classOff[kClassSlots];  // by class (N-1 for the instantiated kernels, kGenericClass for wider blocks)
+  int genericMinRows;         // blocks with at least this many rows are in the generic class
 };
 
 struct FitOut {
@@ -118,6 +119,11 @@ void launch_hss_pack(const DevHss *hss, const int *count, int cap, int slots, De
                      hipStream_t stream);
 void launch_sk_row(const uint8_t *blob, const DevBlock *dblocks, int bi, int s, int b, int iMax, float *out, int stride,
                    hipStream_t stream);
+// wider blocks (N > 64): generic kernels with their states in a global scratch (rc_null_generic.h)
+size_t null_generic_scratch_bytes(int N, int L, int nnodes);
+int null_generic_occupancy();
+void launch_null_generic(const NullArgs &a, int grid, uint8_t *scratchBytes, hipStream_t stream);
+void launch_native_dp_generic(const NativeArgs &a, int nblocks, float *scratch, size_t scratchStride, hipStream_t stream);
 void launch_stop_mark(const FitArgs &a, int nblocks, hipStream_t stream);
 void launch_evd_fit(const FitArgs &a, int nblocks, bool latency, hipStream_t stream);   // latency: no other batch is in flight
 void launch_evd_fit_f64(const double *x, int n, FitOut *out, hipStream_t stream);

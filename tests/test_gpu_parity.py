@@ -335,7 +335,7 @@ def test_extreme_shapes_against_oracle(ctx):
                [(w["strand"], w["frame"], w["start"], w["end"], np.float32(w["score"])) for w in want]
         batch.close()
     # one row too many for the kernels: a clear per-block status, not a wrong answer
-    big = [b.upper() for b in synth_blocks(1, 65, 30, seed=24)]
+    big = [b.upper() for b in synth_blocks(1, 501, 12, seed=24, gaps=False)]
     batch = api.Batch(ctx, big, api.default_params()).run()
     assert batch.status(0) == api.RC_ERR_UNSUPPORTED and batch.block_error(0)
     batch.close()
@@ -401,6 +401,52 @@ def test_wide_blocks_against_oracle(ctx):
     # backtrack of a wide block (second z word on the host walk)
     hs = sorted(batch_hss_for_backtrack(ctx, blocks[2], p), key=hss_key)
     assert hs is not None
+
+
+def test_blocks_beyond_64_rows_against_oracle(ctx):
+    """65..500 rows (the reference's own limit, rnaz_utils.h:7; 100-way genome alignments): k_null_generic and
+    k_native_dp_generic keep the per-sequence states in global memory instead of registers.  Same seeds through the HIP
+    path and the oracle, blocks of different widths in ONE launch (they share the generic class), mixed with narrow ones,
+    as one batch, as a stream and with --stop-early; backtrack of a wide block."""
+    from oracle import binding as ob
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_blocks
+    shapes = [(65, 36, 51), (100, 45, 52), (200, 24, 53), (500, 12, 54)]
+    wide = [synth_blocks(1, n, cols, seed=sd, gaps=(n < 500))[0] for n, cols, sd in shapes]
+    blocks = [b.upper() for b in [wide[0]] + synth_blocks(2, 6, 60, seed=55) + wide[1:] + synth_blocks(1, 40, 30, seed=56)]
+    n, seed = 70, 13
+    p = api.default_params(sampleN=n, seed_base=seed)
+    batch = api.Batch(ctx, blocks, p).run()
+    results = []
+    for i, b in enumerate(blocks):
+        rows, names = [r.seq for r in b.rows], [r.name for r in b.rows]
+        res = ob.run_block(rows, names, b.rows[0].start, b.rows[0].length, b.tree, b.kappa, ob.default_params(n), seed)
+        results.append(res)
+        assert batch.status(i) == api.RC_OK, batch.block_error(i)
+        np.testing.assert_array_equal(batch.maxScores(i), np.float32(res.maxScores))
+        got = sorted(batch.scoreAln(i), key=hss_key)
+        want = sorted(res.hss, key=hss_key)
+        assert [(g["strand"], g["frame"], g["start"], g["end"], np.float32(g["score"])) for g in got] == \
+               [(w["strand"], w["frame"], w["start"], w["end"], np.float32(w["score"])) for w in want]
+        rc, mu, lam = batch.getExtremeValuePars(i)
+        assert rc == res.evd_rc
+        if rc == 1:
+            assert close(mu, res.mu) and close(lam, res.lam)
+    assert batch.clamped() == 0
+    batch.close()
+    m = api.Marshalled(blocks)
+    m.set_trees()
+    at = 0
+    for sb in api.score_stream(ctx, m, p, 3, depth=2):
+        for i in range(sb.n):
+            np.testing.assert_array_equal(sb.maxScores(i), np.float32(results[at + i].maxScores))
+        at += sb.n
+        sb.close()
+    assert at == len(blocks)
+    assert batch_hss_for_backtrack(ctx, blocks[3], p) is not None     # 100 rows: four z words on the host walk
+    # the built-in tree estimator stops at 64 rows: such a block then has no tree and is left out, the others are scored
+    fits = api.fit_trees(blocks, ctx=ctx)
+    assert fits[0] is None and fits[1] is not None
 
 
 def batch_hss_for_backtrack(ctx, block, p):

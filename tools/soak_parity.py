@@ -38,7 +38,7 @@ def main():
             pars = dict(blosum=90)
         blocks = []
         for i in range(int(rng.randint(1, 25))):
-            n = int(rng.choice([3, 3, 4, 5, 6, 6, 7, 8, 10, 12, 17, 32, 33, 40, 64]))
+            n = int(rng.choice([3, 3, 4, 5, 6, 6, 7, 8, 10, 12, 17, 32, 33, 40, 64, 65, 90, 130]))
             cols = int(rng.choice([9, 12, 30, 45, 60, 90, 120, 150, 200, 301]))
             if n * cols > 4000:
                 cols = max(9, 4000 // n)
