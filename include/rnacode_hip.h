@@ -26,7 +26,7 @@ extern "C" {
 #define RC_MAX_ROWS 500         /* rows per block, the reference's own limit (MAX_NUM_NAMES, rnaz_utils.h:7).  N <= 32 runs the
                                    register-resident kernels, 33..64 a slower instantiation of the same code, 65..500 generic kernels
                                    with their per-sequence states in global memory (slow, complete); the built-in tree estimator
-                                   (rc_fit_tree*) takes up to 64 rows, wider blocks need their tree from the caller */
+                                   runs on the GPU for up to 64 rows and on host threads for wider blocks */
 
 /* Scoring parameters: the members of `parameters pars` (src/RNAcode.h:29-54) that the
  * scoring path reads (score.c:415,419,508-533,842,992,1040), plus the seed base that
@@ -221,7 +221,8 @@ int rc_fit_trees(const rc_block *blocks, int32_t n_blocks, char *newick_out, int
 /* The same estimator on the GPU of `ctx`, one wavefront per block, all blocks concurrently (the host
  * only compresses site patterns and writes the Newick text).  Same algorithm as rc_fit_trees; the
  * per-site sums are taken in a different order, so branch lengths agree to ~1e-6, not bitwise.
- * lnl_out (may be NULL) receives the log-likelihoods.  Returns the number of fitted blocks or a
+ * lnl_out (may be NULL) receives the log-likelihoods.  Blocks with more than 64 rows are fitted by the host estimator
+ * inside the same call (the kernel keeps BIONJ's tables per lane).  Returns the number of fitted blocks or a
  * negative error code. */
 int rc_fit_trees_device(rc_ctx *ctx, const rc_block *blocks, int32_t n_blocks, char *newick_out, int32_t cap, float *kappa_out,
                         double *lnl_out);

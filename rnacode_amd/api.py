@@ -231,7 +231,7 @@ class Marshalled:
             self.arr[i].kappa = b.kappa
 
 
-def fit_trees(blocks, threads: int = 0, cap: int = 1 << 14, ctx: "Optional[Context]" = None,
+def fit_trees(blocks, threads: int = 0, cap: int = 0, ctx: "Optional[Context]" = None,
               lnl: Optional[list] = None) -> List[Optional[Tuple[str, float]]]:
     """Trees + kappas of many blocks (a sequence of AlnBlocks or a Marshalled); None for blocks the driver skips.
     With ctx: rc_fit_trees_device (one wavefront per block on that context's GPU; `lnl`, if a list, receives the
@@ -239,6 +239,8 @@ def fit_trees(blocks, threads: int = 0, cap: int = 1 << 14, ctx: "Optional[Conte
     m = blocks if isinstance(blocks, Marshalled) else Marshalled(blocks)
     n = len(m.blocks)
     arr = m.arr
+    if cap <= 0:   # room for the widest block's Newick text (name + ":0.123456" + brackets per node)
+        cap = max(1 << 14, 96 * max((b.n for b in m.blocks), default=0))
     buf = C.create_string_buffer(max(n, 1) * cap)
     kap = (C.c_float * max(n, 1))()
     if ctx is not None:

@@ -1343,6 +1343,8 @@ int rc_fit_trees(const rc_block *blocks, int32_t n_blocks, char *newick_out, int
 
 // The same fits on the GPU, one wavefront per block (rc_tree_kernel.hip).  Host work: pattern
 // compression (threads) and writing the Newick text.
+static constexpr int kTreeDeviceTips = 64;   // treefit::kMaxTipsDevice (rc_tree_core.h)
+
 int rc_fit_trees_device(rc_ctx *c, const rc_block *blocks, int32_t n_blocks, char *newick_out, int32_t cap, float *kappa_out,
                         double *lnl_out) {
   if (!c || !blocks || !newick_out || !kappa_out || n_blocks < 0 || cap < 8) return fail(RC_ERR_ARG, "bad argument");
@@ -1361,6 +1363,21 @@ int rc_fit_trees_device(rc_ctx *c, const rc_block *blocks, int32_t n_blocks, cha
         int L = 0;
         for (const char *p = b.rows[0]; *p; p++) L += (*p != '-');
         if (L < 3) continue;
+        if (b.n_rows > kTreeDeviceTips) {   // more tips than the kernel's per-lane tables hold: the host estimator, here on this thread
+          std::vector<std::string> rows(b.n_rows), names(b.n_rows);
+          for (int r = 0; r < b.n_rows; r++) { rows[r] = b.rows[r]; names[r] = b.names[r]; }
+          std::string nwk, err;
+          float kappa = 0;
+          double lnl = 0;
+          char *dst = newick_out + static_cast<size_t>(i) * cap;
+          if (fit_tree(rows, names, nwk, kappa, &lnl, err) && static_cast<int>(nwk.size()) + 1 <= cap) {
+            std::memcpy(dst, nwk.c_str(), nwk.size() + 1);
+            kappa_out[i] = kappa;
+            if (lnl_out) lnl_out[i] = lnl;
+            ok[i] = 2;
+          }
+          continue;
+        }
         std::vector<std::string> rows(b.n_rows);
         for (int r = 0; r < b.n_rows; r++) rows[r] = b.rows[r];
         std::string err;
@@ -1376,7 +1393,9 @@ int rc_fit_trees_device(rc_ctx *c, const rc_block *blocks, int32_t n_blocks, cha
   std::vector<int> owner;
   std::vector<uint8_t> in;
   size_t work_doubles = 0;
+  int hostDone = 0;
   for (int i = 0; i < n_blocks; i++) {
+    if (ok[i] == 2) { hostDone++; continue; }   // fitted on the host above
     newick_out[static_cast<size_t>(i) * cap] = 0; kappa_out[i] = 0.0f;
     if (lnl_out) lnl_out[i] = 0.0;
     if (!ok[i]) continue;
@@ -1394,7 +1413,7 @@ int rc_fit_trees_device(rc_ctx *c, const rc_block *blocks, int32_t n_blocks, cha
     owner.push_back(i);
   }
   const int nj = static_cast<int>(jobs.size());
-  if (nj == 0) return 0;
+  if (nj == 0) return hostDone;
   // the per-block work areas of one launch share a scratch of at most 8 GiB (RC_TREE_SCRATCH_BYTES): long batches
   // go in several launches on the one stream, which re-use it
   size_t capDoubles = (static_cast<size_t>(8) << 30) / sizeof(double);
@@ -1444,7 +1463,7 @@ int rc_fit_trees_device(rc_ctx *c, const rc_block *blocks, int32_t n_blocks, cha
     if (lnl_out) lnl_out[i] = o.lnl;
     done++;
   }
-  return done;
+  return done + hostDone;
 }
 
 int rc_tree_lnl(const rc_block *blk, double *lnl_out) {

@@ -276,7 +276,8 @@ int main(int argc, char **argv) {
 
   rc_stream *stream = nullptr;
   if (rc_stream_create(ctx, &par, 3, &stream) != RC_OK) die(rc_last_error());
-  const int cap = 1 << 14;
+  int cap = 1 << 14;   // per block: room for the widest block's Newick text
+  for (const Block &b : blocks) cap = std::max(cap, 96 * static_cast<int>(b.rows.size()));
   std::vector<char> nwk;
   std::vector<float> kap;
   int next = 0, base = 0, fitted = 0;

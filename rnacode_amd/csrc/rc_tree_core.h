@@ -24,7 +24,15 @@ namespace rc {
 namespace treefit {
 
 constexpr double kBlMin = 1e-6, kBlMax = 100.0, kDistMax = 2.0;   // phyml/utilities.h:78,80,88
-constexpr int kMaxTips = 64, kMaxNodes = 2 * kMaxTips - 1;   // a rooted input tree (tree_lnl) has 2N-1 nodes
+// The kernel keeps BIONJ's bookkeeping in per-lane arrays, so on the device the estimator stops at 64 tips; host code
+// (rc_fit_tree, rc_tree_lnl, and the wider blocks that rc_fit_trees_device hands to host threads) goes up to the library's 500 rows.
+constexpr int kMaxTipsDevice = 64;
+#if defined(__HIP_DEVICE_COMPILE__)
+constexpr int kMaxTips = kMaxTipsDevice;
+#else
+constexpr int kMaxTips = 512;
+#endif
+constexpr int kMaxNodes = 2 * kMaxTips - 1;   // a rooted input tree (tree_lnl) has 2N-1 nodes
 
 // allowed-state mask of a character: A=1 C=2 G=4 T=8 (IUPAC as in phyml Get_Base_Freqs); the rest is missing data
 RC_HD inline int state_mask(char c) {

@@ -444,9 +444,22 @@ def test_blocks_beyond_64_rows_against_oracle(ctx):
         sb.close()
     assert at == len(blocks)
     assert batch_hss_for_backtrack(ctx, blocks[3], p) is not None     # 100 rows: four z words on the host walk
-    # the built-in tree estimator stops at 64 rows: such a block then has no tree and is left out, the others are scored
-    fits = api.fit_trees(blocks, ctx=ctx)
-    assert fits[0] is None and fits[1] is not None
+    # the built-in tree estimator: up to 64 tips on the GPU, wider blocks on host threads inside the same call
+    lnl = []
+    sub = [blocks[0], blocks[1], blocks[3]]          # 65 rows, 6 rows, 100 rows
+    fits = api.fit_trees(sub, ctx=ctx, lnl=lnl)
+    assert all(f is not None for f in fits)
+    for b, (nwk, kappa), l in zip(sub, fits, lnl):
+        assert nwk.count(",") == b.n - 1 and 0.5 < kappa < 20
+        assert abs(l - api.tree_lnl(b, nwk, kappa)) < 0.05 + 1e-4 * abs(l)   # lnL of the printed (%f-rounded) tree, host evaluation
+    host = api.fit_trees(sub)
+    assert [_newick_parts(h[0])[0] for h in host] == [_newick_parts(f[0])[0] for f in fits]
+    refit = [b for b in sub]
+    for b, f in zip(refit, fits):
+        b.tree, b.kappa = f
+    again = api.Batch(ctx, refit, p).run()
+    assert [again.status(i) for i in range(3)] == [api.RC_OK] * 3
+    again.close()
 
 
 def batch_hss_for_backtrack(ctx, block, p):
