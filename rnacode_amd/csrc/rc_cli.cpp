@@ -188,7 +188,7 @@ struct Listing {
 
 void usage() {
   std::fprintf(stderr, "usage: rnacode_hip [-n N] [-p CUTOFF] [-g | -t] [-b] [-r] [-s] [-m 62|90] [-c D,O,o,S] [-o OUT] [--trees SIDECAR]\n"
-                       "                   [--seed-base S] [--device D] [--sub-blocks B] [FILE]\n");
+                       "                   [--seed-base S] [--device D] [--sub-blocks B] [--dump-blocks] [FILE]\n");
 }
 
 }  // namespace
@@ -199,6 +199,7 @@ int main(int argc, char **argv) {
   Listing list;
   std::string file, outfile, trees;
   int device = 0, subBlocks = 2048;
+  bool dumpBlocks = false;
   for (int a = 1; a < argc; a++) {
     const std::string o = argv[a];
     auto val = [&]() -> const char * { if (a + 1 >= argc) { usage(); std::exit(2); } return argv[++a]; };
@@ -220,6 +221,7 @@ int main(int argc, char **argv) {
     else if (o == "--seed-base") par.seed_base = static_cast<uint32_t>(std::strtoul(val(), nullptr, 10));
     else if (o == "--device") device = std::atoi(val());
     else if (o == "--sub-blocks") subBlocks = std::max(1, std::atoi(val()));
+    else if (o == "--dump-blocks") dumpBlocks = true;
     else if (o == "-h" || o == "--help") { usage(); return 0; }
     else if (o == "-e" || o == "--eps") die("EPS plots are drawn by `python -m rnacode_amd.cli -e`");
     else if (!o.empty() && o[0] == '-' && o != "-") { usage(); return 2; }
@@ -238,6 +240,14 @@ int main(int argc, char **argv) {
     blocks = read_alignment(in);
   }
   const int n = static_cast<int>(blocks.size());
+  if (dumpBlocks) {   // reader check (tests): what was parsed, one record per row, no device needed
+    for (int i = 0; i < n; i++) {
+      std::printf("B %d\n", i);
+      for (const Row &r : blocks[i].rows) std::printf("S %s %d %d %c %s\n", r.name.c_str(), r.start, r.length, r.strand, r.seq.c_str());
+      std::printf("E\n");
+    }
+    return 0;
+  }
   if (!trees.empty()) {   // one '<newick> TAB <kappa>' line per block, '-' for blocks without a tree
     std::ifstream in(trees);
     if (!in) die("Could not open " + trees);

@@ -141,3 +141,82 @@ def test_native_driver_is_built_and_fails_loudly_without_a_gpu(tmp_path):
     bad.write_text("a score=0\ns a.chr1 0 9 + 100\n")
     r = subprocess.run([exe, str(bad)], capture_output=True, text=True)
     assert r.returncode != 0 and "Invalid MAF format" in r.stderr
+
+
+def _native_dump(path):
+    import subprocess
+    exe = os.path.join(ROOT, "rnacode_amd", "rnacode_hip")
+    r = subprocess.run([exe, "--dump-blocks", str(path)], capture_output=True, text=True)
+    if r.returncode != 0:
+        return r.stderr.strip()
+    blocks, cur = [], None
+    for line in r.stdout.splitlines():
+        f = line.split(" ")
+        if f[0] == "B":
+            cur = []
+        elif f[0] == "S":
+            cur.append((f[1], int(f[2]), int(f[3]), f[4], f[5]))
+        elif f[0] == "E":
+            blocks.append(cur)
+    return blocks
+
+
+def _python_dump(path):
+    from rnacode_amd import alnio
+    try:
+        return [[(r.name, r.start, r.length, r.strand, r.seq) for r in b.rows] for b in alnio.read_alignment_file(str(path))]
+    except ValueError as e:
+        return "ERROR: " + str(e)
+
+
+def test_native_reader_parses_what_the_python_reader_parses(tmp_path):
+    """The two drivers share no reader code (rc_cli.cpp read_maf/read_clustal, alnio.py): random MAF and ClustalW texts with the
+    things rnaz_utils.c:44-234 has to cope with -- i/e/q and comment lines, blank lines, tabs, CRLF, blocks without 's' lines,
+    wrapped ClustalW blocks with conservation lines -- must come out of both as the same blocks, and the malformed ones
+    (wrong field count, unequal lengths, inconsistent names) must be refused by both with the same message."""
+    import numpy as np
+    rng = np.random.RandomState(5)
+    alpha = np.array(list("ACGTacgtNn-"))
+    cases = 0
+    for it in range(60):
+        if it % 3 != 2:   # MAF
+            out = ["##maf version=1\n"] if rng.rand() < 0.5 else []
+            for b in range(rng.randint(0, 6)):
+                out.append("a score=%d\n" % rng.randint(0, 1000) if rng.rand() < 0.8 else "a\n")
+                cols = int(rng.randint(1, 80))
+                bad_len = it % 10 == 7 and b == 1
+                for r in range(rng.randint(0, 7)):
+                    seq = "".join(rng.choice(alpha, cols - (1 if bad_len and r == 1 else 0)))
+                    sep = "\t" if rng.rand() < 0.3 else " " * int(rng.randint(1, 4))
+                    f = ["s", "sp%d.chr%d" % (r, rng.randint(1, 23)), str(rng.randint(0, 10 ** 6)), str(cols), "+-"[rng.randint(2)], str(10 ** 7), seq]
+                    if it % 10 == 9 and b == 0 and r == 0:
+                        f = f[:6]          # field count
+                    out.append(sep.join(f) + ("\r\n" if rng.rand() < 0.2 else "\n"))
+                    if rng.rand() < 0.3:
+                        out.append("i sp%d.chr1 C 0 C 0\n" % r)
+                    if rng.rand() < 0.1:
+                        out.append("q sp%d.chr1 %s\n" % (r, "9" * cols))
+                if rng.rand() < 0.3:
+                    out.append("e sp9.chr2 100 20 + 5000 I\n")
+                if rng.rand() < 0.2:
+                    out.append("# a comment\n")
+                out.append("\n" if rng.rand() < 0.9 else "")
+            text = "".join(out)
+        else:             # ClustalW, wrapped at 60 columns
+            n, cols = int(rng.randint(1, 8)), int(rng.randint(1, 200))
+            names = ["seq_%d" % i for i in range(n)]
+            seqs = ["".join(rng.choice(alpha, cols)) for _ in range(n)]
+            out = ["CLUSTAL W (1.83) multiple sequence alignment\n", "\n", "\n"]
+            for at in range(0, cols, 60):
+                for i in range(n):
+                    name = names[i] if not (it % 12 == 5 and at > 0 and i == 0) else "other"
+                    out.append("%-16s%s%s\n" % (name, seqs[i][at:at + 60], " %d" % min(cols, at + 60) if rng.rand() < 0.3 else ""))
+                out.append(" " * 16 + "".join(rng.choice(list(" *"), min(60, cols - at))) + "\n")
+                out.append("\r\n" if rng.rand() < 0.2 else "\n")
+            text = "".join(out)
+        p = tmp_path / ("case%d.txt" % it)
+        p.write_bytes(text.encode())
+        got, want = _native_dump(p), _python_dump(p)
+        assert got == want, (it, text[:400])
+        cases += 1
+    assert cases == 60
