@@ -61,6 +61,7 @@ def main(argv=None) -> int:
     ap.add_argument("-e", "--eps", action="store_true", help="Create colored plots in EPS format")
     ap.add_argument("-i", "--eps-cutoff", type=float, default=0.05, help="Create plots only if p better than this cutoff")
     ap.add_argument("-d", "--eps-dir", default="eps", help="Directory to put eps-files")
+    ap.add_argument("-l", "--limit", help="limit to species: keep the rows whose name starts with one of these comma-separated strings")
     ap.add_argument("--trees", help="sidecar: one '<newick>\\t<kappa>' line per block (default: fit them)")
     ap.add_argument("--sub-blocks", type=int, default=2048, help="alignment blocks per sub-batch of the GPU stream")
     ap.add_argument("--seed-base", type=int, default=42)
@@ -85,6 +86,17 @@ def main(argv=None) -> int:
             fh.write(sys.stdin.read())
         blocks = read_alignment_file(fh.name)
     blocks = [b.upper() for b in blocks]
+    n_read = len(blocks)
+    if a.limit:   # pruneAln (rnaz_utils.c:724-752, called at RNAcode.c:130-132): rows only, the columns stay
+        keep = [x for x in a.limit.split(",") if x]
+        kept = []
+        for b in blocks:
+            rows = [r for r in b.rows if any(r.name.startswith(x) for x in keep)]
+            if not rows:   # (the reference dereferences the missing first row here)
+                print("Skipping alignment. There must be at least three sequences in the alignment.", file=sys.stderr)
+                continue
+            kept.append(AlnBlock(rows, b.block_id, b.tree, b.kappa))
+        blocks = kept
     ctx = api.Context(a.device)
     marshalled = api.Marshalled(blocks)   # one rc_block array for the tree fit and the batch
     if a.trees:
@@ -134,7 +146,7 @@ def main(argv=None) -> int:
         base += batch.n
         batch.close()
     if fmt == 0:
-        report.print_footer(out, len(prepared), time.perf_counter() - t0, params.sampleN, params.Delta, params.Omega,
+        report.print_footer(out, n_read, time.perf_counter() - t0, params.sampleN, params.Delta, params.Omega,
                             params.omega, params.stopPenalty_k)
     ctx.close()
     if a.outfile:

@@ -7,7 +7,7 @@
 // (src/misc.c:392-552 printResults, footer RNAcode.c:223-228) byte for byte.  Same options as `python -m rnacode_amd.cli`
 // (which additionally draws the EPS plots):
 //
-//   rnacode_hip [-n N] [-p CUTOFF] [-g | -t] [-b] [-r] [-s] [-m 62|90] [-c D,O,o,S] [-o OUT] [--trees SIDECAR]
+//   rnacode_hip [-n N] [-p CUTOFF] [-g | -t] [-b] [-r] [-s] [-m 62|90] [-c D,O,o,S] [-o OUT] [-l SPECIES,...] [--trees SIDECAR]
 //               [--seed-base S] [--device D] [--sub-blocks B] [FILE]
 //
 // Quirk kept from the reference: the 4th value of --pars goes to stopPenalty_0 (RNAcode.c:318).
@@ -187,7 +187,7 @@ struct Listing {
 };
 
 void usage() {
-  std::fprintf(stderr, "usage: rnacode_hip [-n N] [-p CUTOFF] [-g | -t] [-b] [-r] [-s] [-m 62|90] [-c D,O,o,S] [-o OUT] [--trees SIDECAR]\n"
+  std::fprintf(stderr, "usage: rnacode_hip [-n N] [-p CUTOFF] [-g | -t] [-b] [-r] [-s] [-m 62|90] [-c D,O,o,S] [-o OUT] [-l SPECIES,...] [--trees SIDECAR]\n"
                        "                   [--seed-base S] [--device D] [--sub-blocks B] [--dump-blocks] [FILE]\n");
 }
 
@@ -197,7 +197,7 @@ int main(int argc, char **argv) {
   rc_params par;
   rc_default_params(&par);
   Listing list;
-  std::string file, outfile, trees;
+  std::string file, outfile, trees, limit;
   int device = 0, subBlocks = 2048;
   bool dumpBlocks = false;
   for (int a = 1; a < argc; a++) {
@@ -217,7 +217,8 @@ int main(int argc, char **argv) {
       std::stringstream ss(val());
       std::string item;
       for (int i = 0; i < 4 && std::getline(ss, item, ','); i++) *dst[i] = static_cast<float>(std::atof(item.c_str()));
-    } else if (o == "--trees") trees = val();
+    } else if (o == "-l" || o == "--limit") limit = val();
+    else if (o == "--trees") trees = val();
     else if (o == "--seed-base") par.seed_base = static_cast<uint32_t>(std::strtoul(val(), nullptr, 10));
     else if (o == "--device") device = std::atoi(val());
     else if (o == "--sub-blocks") subBlocks = std::max(1, std::atoi(val()));
@@ -238,6 +239,26 @@ int main(int argc, char **argv) {
     std::ifstream in(file);
     if (!in) die("Could not open input file " + file);
     blocks = read_alignment(in);
+  }
+  const int nRead = static_cast<int>(blocks.size());
+  if (!limit.empty()) {   // pruneAln (rnaz_utils.c:724-752, RNAcode.c:130-132): rows whose name starts with a listed string stay
+    std::vector<std::string> keep;
+    std::stringstream ss(limit);
+    std::string item;
+    while (std::getline(ss, item, ',')) if (!item.empty()) keep.push_back(item);
+    std::vector<Block> kept;
+    for (Block &b : blocks) {
+      Block nb;
+      nb.tree = b.tree; nb.kappa = b.kappa;
+      for (const Row &r : b.rows)
+        if (std::any_of(keep.begin(), keep.end(), [&](const std::string &x) { return r.name.compare(0, x.size(), x) == 0; })) nb.rows.push_back(r);
+      if (nb.rows.empty()) {   // (the reference dereferences the missing first row here)
+        std::fprintf(stderr, "Skipping alignment. There must be at least three sequences in the alignment.\n");
+        continue;
+      }
+      kept.push_back(std::move(nb));
+    }
+    blocks.swap(kept);
   }
   const int n = static_cast<int>(blocks.size());
   if (dumpBlocks) {   // reader check (tests): what was parsed, one record per row, no device needed
@@ -349,7 +370,7 @@ int main(int argc, char **argv) {
   if (list.fmt == 0) {   // RNAcode.c:223-228
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::fprintf(list.out, "\n%i alignment(s) scored in %.2f seconds. Parameters used:\nN=%i, Delta=%.2f, Omega=%.2f, omega=%.2f, stop penalty=%.2f\n\n",
-                 n, secs, par.sampleN, static_cast<double>(par.Delta), static_cast<double>(par.Omega), static_cast<double>(par.omega),
+                 nRead, secs, par.sampleN, static_cast<double>(par.Delta), static_cast<double>(par.Omega), static_cast<double>(par.omega),
                  static_cast<double>(par.stopPenalty_k));
   }
   rc_ctx_destroy(ctx);

@@ -312,6 +312,31 @@ def test_native_cli_matches_reference_listing_and_python_cli(tmp_path):
     pyo = tmp_path / "py2.txt"
     assert r.returncode == 0 and cli.main([str(aln), "-n", "100", "-t", "-o", str(pyo)]) == 0
     assert r.stdout == pyo.read_text() and r.stdout.count("\n") >= 2
+    # --limit (pruneAln): both drivers drop the rows first and fit the trees on what is left -- same listing as for a file
+    # that never held the other rows
+    doc = load_golden("genomic_preprocessed_n100")
+    blocks = [block_from_golden(e) for e in doc["blocks"]]
+    names = sorted({r.name.split(".")[0] for b in blocks for r in b.rows})
+    keep = names[: max(4, len(names) - 2)]
+    maf = tmp_path / "all.maf"
+    maf.write_text(to_maf(blocks))
+    import copy
+    pruned = []
+    for b in blocks:
+        rows = [r for r in b.rows if any(r.name.startswith(k) for k in keep)]
+        if rows:
+            nb = copy.copy(b)
+            nb.rows = rows
+            pruned.append(nb)
+    pm = tmp_path / "pruned.maf"
+    pm.write_text(to_maf(pruned))
+    got = subprocess.run([exe, str(maf), "-l", ",".join(keep), "-n", "100", "-t"], capture_output=True, text=True, timeout=300)
+    want = subprocess.run([exe, str(pm), "-n", "100", "-t"], capture_output=True, text=True, timeout=300)
+    assert got.returncode == 0 and want.returncode == 0, got.stderr + want.stderr
+    assert got.stdout == want.stdout and got.stdout.count("\n") >= 2
+    pyo = tmp_path / "py3.txt"
+    assert cli.main([str(maf), "--limit", ",".join(keep), "-n", "100", "-t", "-o", str(pyo)]) == 0
+    assert pyo.read_text() == got.stdout
 
 
 def test_extreme_shapes_against_oracle(ctx):

@@ -220,3 +220,18 @@ def test_native_reader_parses_what_the_python_reader_parses(tmp_path):
         assert got == want, (it, text[:400])
         cases += 1
     assert cases == 60
+
+
+def test_native_driver_limit_prunes_rows_like_prune_aln(tmp_path):
+    """--limit (pruneAln, rnaz_utils.c:724-752): a row stays if its name STARTS with one of the listed strings; columns are untouched."""
+    maf = tmp_path / "in.maf"
+    maf.write_text("a score=0\ns hg18.chr1 0 9 + 100 ATGGCTAAA\ns mm9.chr1 0 9 + 100 ATGGCAAAA\ns hg18b.chr1 0 9 + 100 ATGGCTAAG\ns canFam2.chr3 0 9 + 100 ATG---AAG\n\n"
+                   "a score=1\ns mm9.chr2 5 3 + 100 ATG\ns rn4.chr2 5 3 + 100 ATG\n\n"
+                   "a score=2\ns rn4.chr2 5 3 + 100 ATG\n\n")
+    import subprocess
+    exe = os.path.join(ROOT, "rnacode_amd", "rnacode_hip")
+    r = subprocess.run([exe, "--dump-blocks", "--limit", "hg18,canFam,mm", str(maf)], capture_output=True, text=True)
+    assert r.returncode == 0
+    assert r.stdout == ("B 0\nS hg18.chr1 0 9 + ATGGCTAAA\nS mm9.chr1 0 9 + ATGGCAAAA\nS hg18b.chr1 0 9 + ATGGCTAAG\nS canFam2.chr3 0 9 + ATG---AAG\nE\n"
+                        "B 1\nS mm9.chr2 5 3 + ATG\nE\n")
+    assert r.stderr.count("Skipping alignment.") == 1   # the block that lost every row
