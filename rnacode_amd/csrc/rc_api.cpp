@@ -182,6 +182,7 @@ void trace(const char *what, const void *obj) {
 struct rc_ctx {
   int device = 0;
   int numCU = 0;
+  size_t genericScratchWords = static_cast<size_t>(1) << 30;   // uint32 of staging scratch one k_null_generic launch may take: a twelfth of the device memory (24 GB of 288)
   hipStream_t compute[2] = {nullptr, nullptr};   // null sampling + fit; consecutive batches alternate, so the tail of one overlaps the head of the next
   hipStream_t native = nullptr;    // table preparation and native-block kernels: small and latency-bound, they run beside the null sampling
   hipStream_t copy = nullptr;      // host -> device blob copies
@@ -339,6 +340,8 @@ int rc_ctx_create(int device, rc_ctx **out) {
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   c->numCU = prop.multiProcessorCount;
+  c->genericScratchWords = std::max<size_t>(static_cast<size_t>(1) << 30, prop.totalGlobalMem / 12 / sizeof(uint32_t));
+  if (const char *e = std::getenv("RC_GENERIC_SCRATCH_MB")) c->genericScratchWords = std::max<size_t>(1, static_cast<size_t>(std::atoll(e))) * (1u << 20) / sizeof(uint32_t);
   // non-blocking streams: no implicit ordering against the legacy default stream that a host framework in
   // the same process (torch, RCCL) may be using; the native stream gets the higher priority so that the
   // runtime puts it on a hardware queue of its own (two plain streams can end up sharing one, which
@@ -675,11 +678,16 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
       int maxN = 0, maxNodes = 0;
       for (int bi : kv.second) { maxN = std::max(maxN, b->meta[bi].N); maxNodes = std::max(maxNodes, b->db[bi].nnodes); }
       p.stride = (null_generic_scratch_bytes(maxN, maxLc, maxNodes) + 3) / 4;   // in uint32 like the others
-      const std::pair<int, size_t> key(kGenericClass, 0);
-      if (!c->occ.count(key)) c->occ[key] = null_generic_occupancy();
+      p.ldsBytes = null_generic_lds_bytes(maxN, maxNodes);
+      const std::pair<int, size_t> key(kGenericClass, p.ldsBytes);
+      if (!c->occ.count(key)) c->occ[key] = null_generic_occupancy(p.ldsBytes);
       const int occ = std::max(1, c->occ[key]);
-      p.grid = static_cast<int>(std::min<long long>(static_cast<long long>(kv.second.size()) * groupsHere, static_cast<long long>(c->numCU) * occ));
-      p.grid = static_cast<int>(std::max<size_t>(1, std::min<size_t>(p.grid, (static_cast<size_t>(1) << 30) / std::max<size_t>(p.stride, 1))));
+      long long items = static_cast<long long>(kv.second.size()) * groupsHere;
+      p.comboSplit = (items * 2 <= static_cast<long long>(c->numCU) * occ) ? 1 : 0;
+      if (p.comboSplit) items *= 6;
+      p.grid = static_cast<int>(std::min<long long>(items, static_cast<long long>(c->numCU) * occ));
+      // every wavefront keeps the sigma codes of its 64 samples (N x L x 2 bytes per sample): the scratch, not the registers, bounds the occupancy
+      p.grid = static_cast<int>(std::max<size_t>(1, std::min<size_t>(p.grid, c->genericScratchWords / std::max<size_t>(p.stride, 1))));
       p.need = p.stride * p.grid;
       needSum += p.need; needMax = std::max(needMax, p.need);
       plans.push_back(p);
@@ -748,10 +756,9 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
     unsigned int *work = b->dcounters.as<unsigned int>() + kCntWork + static_cast<size_t>(phase) * 2 * kClassSlots * 8;
     if (p.NK == kGenericClass) {
       a.skipMask = extraSkip;
-      a.comboSplit = 0;
       a.scratchStride = p.stride * sizeof(uint32_t);   // bytes for this kernel
       a.workCounter = work + p.NK * 8;
-      launch_null_generic(a, p.grid, reinterpret_cast<uint8_t *>(a.scratch), st);
+      launch_null_generic(a, p.grid, p.ldsBytes, reinterpret_cast<uint8_t *>(a.scratch), st);
       b->nl[2]++;
     } else if (b->allExact || p.NK >= kFastRows) {
       a.skipMask = extraSkip;

@@ -611,15 +611,16 @@ void launch_sk_row(const uint8_t *blob, const DevBlock *dblocks, int bi, int s, 
 }
 
 size_t null_generic_scratch_bytes(int N, int L, int nnodes) { return GenericLayout(N, L, nnodes).total; }
+size_t null_generic_lds_bytes(int N, int nnodes) { return generic_lds_bytes(N, nnodes); }
 
-int null_generic_occupancy() {
+int null_generic_occupancy(size_t ldsBytes) {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_null_generic, 64, 0) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_null_generic, 64, ldsBytes) != hipSuccess) return 0;
   return nb;
 }
 
-void launch_null_generic(const NullArgs &a, int grid, uint8_t *scratchBytes, hipStream_t stream) {
-  hipLaunchKernelGGL(k_null_generic, dim3(grid), dim3(64), 0, stream, a, a.blob, a.dblocks, a.classBlocks, a.flags, a.U, a.pair, scratchBytes, a.maxima);
+void launch_null_generic(const NullArgs &a, int grid, size_t ldsBytes, uint8_t *scratchBytes, hipStream_t stream) {
+  hipLaunchKernelGGL(k_null_generic, dim3(grid), dim3(64), ldsBytes, stream, a, a.blob, a.dblocks, a.classBlocks, a.flags, a.U, a.pair, scratchBytes, a.maxima);
 }
 
 void launch_native_dp_generic(const NativeArgs &a, int nblocks, float *scratch, size_t scratchStride, hipStream_t stream) {

@@ -121,8 +121,9 @@ void launch_sk_row(const uint8_t *blob, const DevBlock *dblocks, int bi, int s, 
                    hipStream_t stream);
 // wider blocks (N > 64): generic kernels with their states in a global scratch (rc_null_generic.h)
 size_t null_generic_scratch_bytes(int N, int L, int nnodes);
-int null_generic_occupancy();
-void launch_null_generic(const NullArgs &a, int grid, uint8_t *scratchBytes, hipStream_t stream);
+size_t null_generic_lds_bytes(int N, int nnodes);   // packed node states + codon windows of the widest block of the launch
+int null_generic_occupancy(size_t ldsBytes);
+void launch_null_generic(const NullArgs &a, int grid, size_t ldsBytes, uint8_t *scratchBytes, hipStream_t stream);
 void launch_native_dp_generic(const NativeArgs &a, int nblocks, float *scratch, size_t scratchStride, hipStream_t stream);
 void launch_stop_mark(const FitArgs &a, int nblocks, hipStream_t stream);
 void launch_evd_fit(const FitArgs &a, int nblocks, bool latency, hipStream_t stream);   // latency: no other batch is in flight
