@@ -38,7 +38,7 @@ __host__ __device__ inline size_t generic_lds_bytes(int N, int nn) {
   return (static_cast<size_t>((nn + 15) >> 4) * sizeof(uint32_t) + static_cast<size_t>(N)) * kWave;
 }
 
-__global__ __launch_bounds__(64) void k_null_generic(NullArgs A, const uint8_t *__restrict__ blob, const DevBlock *__restrict__ dblocks,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_null_generic(NullArgs A, const uint8_t *__restrict__ blob, const DevBlock *__restrict__ dblocks,
                                                      const int *__restrict__ classBlocks, const uint32_t *__restrict__ flags,
                                                      const uint32_t *__restrict__ Ustream, const uint8_t *__restrict__ pairTab,
                                                      uint8_t *__restrict__ scratch, float *__restrict__ maxima) {
