@@ -192,6 +192,25 @@ def emit_eps(name, base_fixture, blocks, samples, keep):
     print(f"{name}: {len(names)} plots, {len(files)} kept, {os.path.getsize(out)} bytes")
 
 
+def main_chars():
+    """Ambiguity codes / N / U / lower case sprinkled over synthetic blocks, and blocks wider than the register-resident kernels
+    take (33..64 rows: the EXACT instantiations, > 64 rows: the generic kernels) -- all scored by the reference itself."""
+    import numpy as np
+    rng = np.random.RandomState(11)
+    blocks = synth_blocks(6, 5, 60, seed=6)
+    for b in blocks:
+        for x in b.rows:
+            row = bytearray(x.seq.encode())
+            for q in np.flatnonzero(rng.rand(len(row)) < 0.06):
+                if row[q] != ord("-"):
+                    row[q] = ord(str(rng.choice(list("NNNRYKMSWBDHVUacgtn"))))
+            x.seq = row.decode()
+    emit("synth_iupac_5x60_n50", blocks, 50, note="6 % of the residues replaced by ambiguity codes, N, U or lower case")
+    emit("synth_wide_40x90_n30", synth_blocks(1, 40, 90, seed=7), 30, note="40 rows: the EXACT instantiations for 33..64 rows")
+    emit("synth_wide_70x120_n20", synth_blocks(1, 70, 120, seed=8) + synth_blocks(1, 130, 60, seed=9), 20,
+         note="70 and 130 rows: the generic kernels for more than 64 rows (one tile and several tiles per DP row)")
+
+
 def main_eps():
     ex = os.path.join(REF, "examples")
     emit_eps("eps_coding_aln_n100", "coding_aln_n100", read_alignment_file(os.path.join(ex, "coding.aln")), 100,
@@ -229,7 +248,10 @@ if __name__ == "__main__":
         main_eps()
     elif len(sys.argv) > 1 and sys.argv[1] == "breakmaf":
         main_breakmaf()
+    elif len(sys.argv) > 1 and sys.argv[1] == "chars":
+        main_chars()
     else:
         main()
+        main_chars()
         main_eps()
         main_breakmaf()

@@ -54,6 +54,13 @@ def main():
                     x.seq = row.decode(); x.length = sum(ch != "-" for ch in x.seq)
                 m = list(re.finditer(r":[0-9.]+", b.tree))[0]
                 b.tree = b.tree[:m.start()] + ":0.000000" + b.tree[m.end():]
+            if rng.rand() < 0.2:   # ambiguity codes, N and U among the residues (score.c:255-280 counts them as index 0, :389-392 scores N codons as 0)
+                for x in b.rows:
+                    row = bytearray(x.seq.encode())
+                    for q in np.flatnonzero(rng.rand(len(row)) < 0.04):
+                        if row[q] != ord("-"):
+                            row[q] = ord(str(rng.choice(list("NNNRYKMSWBDHVU"))))
+                    x.seq = row.decode()
             blocks.append(b)
         stop = rng.rand() < 0.2
         if stop:
