@@ -206,6 +206,8 @@ def main_chars():
                     row[q] = ord(str(rng.choice(list("NNNRYKMSWBDHVUacgtn"))))
             x.seq = row.decode()
     emit("synth_iupac_5x60_n50", blocks, 50, note="6 % of the residues replaced by ambiguity codes, N, U or lower case")
+    emit("synth_5x60_delta_pos_n100", synth_blocks(4, 5, 60, seed=3), 100, params=dict(Delta=0.25, Omega=-4.0, omega=-2.0, stopPenalty_k=-8.0),
+         extra=("--pars", "0.25", "-4.0", "-2.0", "-8.0"), note="Delta >= 0: the MAX3 with Delta decides cells (the EXACT instantiations)")
     emit("synth_wide_40x90_n30", synth_blocks(1, 40, 90, seed=7), 30, note="40 rows: the EXACT instantiations for 33..64 rows")
     emit("synth_wide_70x120_n20", synth_blocks(1, 70, 120, seed=8) + synth_blocks(1, 130, 60, seed=9), 20,
          note="70 and 130 rows: the generic kernels for more than 64 rows (one tile and several tiles per DP row)")
