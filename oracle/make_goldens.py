@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import gzip
 import json
+import re
 import os
 import subprocess
 import sys
@@ -39,7 +40,8 @@ def run_harness(blocks, samples, extra=()):
         out = subprocess.check_output([HARNESS, path, "--samples", str(samples), "--seed", str(SEED), *extra])
     finally:
         os.unlink(path)
-    return [json.loads(l) for l in out.decode().splitlines() if l.strip()]
+    # (printf writes "-nan" for the self-pair model's expected scores when a zero distance makes its probabilities exactly 1, 0, 0, 0)
+    return [json.loads(re.sub(r"-?nan", "NaN", l)) for l in out.decode().splitlines() if l.strip()]
 
 
 def block_json(b: AlnBlock):
@@ -206,6 +208,31 @@ def main_chars():
                     row[q] = ord(str(rng.choice(list("NNNRYKMSWBDHVUacgtn"))))
             x.seq = row.decode()
     emit("synth_iupac_5x60_n50", blocks, 50, note="6 % of the residues replaced by ambiguity codes, N, U or lower case")
+    # stretches where every non-reference row is gapped (sigma = 0: equal consecutive scores, getHSS's 'equal score, longer segment'
+    # rule decides, score.c:953-954), frame-shifting gap lengths, zero-length branches (degenerate cumulative rows, evolve.c:292)
+    import re
+    from rnacode_amd.synth import synth_block
+    rng = np.random.RandomState(77)
+    ties = []
+    for i in range(12):
+        n = int(rng.randint(3, 7))
+        cols = int(rng.randint(45, 121))
+        b = synth_block(rng, n, cols, index=i, gaps=bool(i % 2), mean_branch=(0.02, 0.1, 0.3)[i % 3]).upper()
+        rows = [bytearray(r.seq.encode()) for r in b.rows]
+        for _ in range(int(rng.randint(1, 4))):
+            length = int((3, 6, 9, 12, 4, 7)[rng.randint(6)])
+            pos = int(rng.randint(0, cols - length))
+            for r in range(1, n):
+                rows[r][pos:pos + length] = b"-" * length
+        for r, row in zip(b.rows, rows):
+            r.seq = row.decode()
+            r.length = sum(1 for ch in r.seq if ch != "-")
+        if i % 2 == 0:
+            lens = list(re.finditer(r":[0-9.]+", b.tree))
+            for m in [lens[j] for j in rng.choice(len(lens), size=min(2, len(lens)), replace=False)]:
+                b.tree = b.tree[:m.start()] + ":0.000000" + b.tree[m.end():]
+        ties.append(b)
+    emit("synth_ties_zero_branches_n60", ties, 60, note="common gap stretches (score ties), frame-shifting gaps, zero-length branches")
     emit("synth_5x60_delta_pos_n100", synth_blocks(4, 5, 60, seed=3), 100, params=dict(Delta=0.25, Omega=-4.0, omega=-2.0, stopPenalty_k=-8.0),
          extra=("--pars", "0.25", "-4.0", "-2.0", "-8.0"), note="Delta >= 0: the MAX3 with Delta decides cells (the EXACT instantiations)")
     emit("synth_wide_40x90_n30", synth_blocks(1, 40, 90, seed=7), 30, note="40 rows: the EXACT instantiations for 33..64 rows")
