@@ -235,6 +235,9 @@ def main_chars():
     emit("synth_ties_zero_branches_n60", ties, 60, note="common gap stretches (score ties), frame-shifting gaps, zero-length branches")
     emit("synth_5x60_delta_pos_n100", synth_blocks(4, 5, 60, seed=3), 100, params=dict(Delta=0.25, Omega=-4.0, omega=-2.0, stopPenalty_k=-8.0),
          extra=("--pars", "0.25", "-4.0", "-2.0", "-8.0"), note="Delta >= 0: the MAX3 with Delta decides cells (the EXACT instantiations)")
+    emit("synth_long_5x900_n20", synth_blocks(1, 5, 900, seed=12) + synth_blocks(1, 4, 1500, seed=13), 20,
+         note="long blocks: the sigma codes no longer fit in LDS (read from the staging scratch)")
+    emit("synth_5x60_n5", synth_blocks(3, 5, 60, seed=14), 5, note="five samples only: the Gumbel fit on next to nothing")
     emit("synth_wide_40x90_n30", synth_blocks(1, 40, 90, seed=7), 30, note="40 rows: the EXACT instantiations for 33..64 rows")
     emit("synth_wide_70x120_n20", synth_blocks(1, 70, 120, seed=8) + synth_blocks(1, 130, 60, seed=9), 20,
          note="70 and 130 rows: the generic kernels for more than 64 rows (one tile and several tiles per DP row)")

@@ -21,7 +21,8 @@ BIN = os.path.join(ROOT, "oracle", "_ref", "ref_harness_hip")
 
 @pytest.mark.skipif(not os.path.exists(BIN), reason="oracle/_ref/ref_harness_hip was not built (needs the reference tree)")
 @pytest.mark.parametrize("name", ["coding_aln_n100", "noncoding_maf_n100", "synth_6x120_n200", "edge_cases_n50", "synth_iupac_5x60_n50",
-                                  "synth_wide_40x90_n30", "synth_wide_70x120_n20", "synth_5x60_delta_pos_n100", "synth_ties_zero_branches_n60"])
+                                  "synth_wide_40x90_n30", "synth_wide_70x120_n20", "synth_5x60_delta_pos_n100", "synth_ties_zero_branches_n60",
+                                  "synth_long_5x900_n20", "synth_5x60_n5"])
 def test_harness_on_hip_backend_matches_reference(name):
     doc = load_golden(name)
     blocks = []
