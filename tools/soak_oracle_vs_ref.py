@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Randomised pin of the oracle: random blocks (shapes, gaps, ambiguity codes, score ties, zero-length branches, parameter sets)
+through oracle/_ref/ref_harness -- the unmodified reference objects, only where /root/reference exists -- and through the oracle;
+per-sample maxima, HSS tables and fit results must be identical.   usage: tools/soak_oracle_vs_ref.py [seconds] [rng_seed]"""
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from oracle import binding as ob  # noqa: E402
+from rnacode_amd.alnio import write_harness_blocks  # noqa: E402
+from rnacode_amd.synth import synth_block  # noqa: E402
+
+HARNESS = os.path.join("oracle", "_ref", "ref_harness")
+
+
+def key(h):
+    return (-h["score"], h["strand"], h["frame"], h["start"], h["end"])
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    t0 = time.time()
+    rounds = done = bad = 0
+    while time.time() - t0 < budget:
+        rounds += 1
+        n_samples = int(rng.choice([1, 2, 5, 20, 64, 65, 100]))
+        seed = int(rng.randint(1, 2 ** 31 - 1))
+        pars, extra = {}, []
+        r = rng.rand()
+        if r < 0.2:
+            pars = dict(Delta=float(np.float32(-rng.uniform(1, 15))), Omega=float(np.float32(-rng.uniform(1, 8))), omega=float(np.float32(-rng.uniform(0.5, 4))),
+                        stopPenalty_k=float(np.float32(-rng.uniform(2, 12))))
+        elif r < 0.3:
+            pars = dict(Delta=float(np.float32(rng.uniform(0, 2))), Omega=-4.0, omega=-2.0, stopPenalty_k=-8.0)
+        if pars:
+            extra += ["--pars"] + [repr(pars[k]) for k in ("Delta", "Omega", "omega", "stopPenalty_k")]
+        blosum = 90 if rng.rand() < 0.15 else 62
+        if blosum == 90:
+            extra += ["--blosum", "90"]
+        blocks = []
+        for i in range(int(rng.randint(1, 6))):
+            n = int(rng.choice([3, 3, 4, 5, 6, 8, 12, 20, 40, 70]))
+            cols = int(rng.choice([9, 12, 30, 45, 60, 90, 120, 200, 400]))
+            if n * cols > 3000:
+                cols = max(9, 3000 // n)
+            b = synth_block(rng, n, cols, index=i, gaps=bool(rng.rand() < 0.8), mean_branch=float(rng.choice([0.01, 0.1, 0.4]))).upper()
+            rows = [bytearray(x.seq.encode()) for x in b.rows]
+            if rng.rand() < 0.3:
+                ln = int(rng.choice([3, 4, 6, 7])); pos = int(rng.randint(0, max(1, cols - ln)))
+                for q in range(1, n):
+                    rows[q][pos:pos + ln] = b"-" * min(ln, cols - pos)
+                m = list(re.finditer(r":[0-9.]+", b.tree))[int(rng.randint(0, 3))]
+                b.tree = b.tree[:m.start()] + ":0.000000" + b.tree[m.end():]
+            if rng.rand() < 0.3:
+                for row in rows:
+                    for q in np.flatnonzero(rng.rand(len(row)) < 0.04):
+                        if row[q] != ord("-"):
+                            row[q] = ord(str(rng.choice(list("NNNRYKMSWBDHVUacgt"))))
+            for x, row in zip(b.rows, rows):
+                x.seq = row.decode(); x.length = sum(ch != "-" for ch in x.seq)
+            blocks.append(b)
+        with tempfile.NamedTemporaryFile("w", suffix=".blk", delete=False) as fh:
+            path = fh.name
+        try:
+            write_harness_blocks(blocks, path)
+            out = subprocess.run([HARNESS, path, "--samples", str(n_samples), "--seed", str(seed), "--no-backtrack", *extra], capture_output=True)
+        finally:
+            os.unlink(path)
+        if out.returncode != 0:
+            print(f"harness failed (rc {out.returncode}) in round {rounds}: {out.stderr.decode()[:200]}")
+            bad += 1
+            continue
+        refs = [json.loads(re.sub(r"-?nan", "NaN", l)) for l in out.stdout.decode().splitlines() if l.strip()]
+        for b, ref in zip(blocks, refs):
+            if "skipped" in ref:
+                continue
+            p = ob.default_params(n_samples, blosum=blosum)
+            for k, v in pars.items():
+                setattr(p, k, v)
+            res = ob.run_block([x.seq.upper() for x in b.rows], [x.name for x in b.rows], b.rows[0].start, b.rows[0].length, b.tree, b.kappa, p, seed)
+            ok = np.array_equal(np.float32(res.maxScores), np.float32(ref["maxScores"])) and res.evd_rc == ref["evd_rc"]
+            got, want = sorted(res.hss, key=key), sorted(ref["hss"], key=key)
+            ok = ok and [(g["strand"], g["frame"], g["start"], g["end"], np.float32(g["score"])) for g in got] == \
+                [(w["strand"], w["frame"], w["start"], w["end"], np.float32(w["score"])) for w in want]
+            if ok and ref["evd_rc"] == 1:
+                ok = np.float32(res.mu) == np.float32(ref["mu"]) and np.float32(res.lam) == np.float32(ref["lambda"])
+            done += 1
+            if not ok:
+                bad += 1
+                print(f"MISMATCH round {rounds}: {b.n} x {b.cols}, n={n_samples}, seed={seed}, pars={pars}, blosum={blosum}")
+    print(f"oracle vs reference: {rounds} harness runs, {done} blocks compared in {time.time() - t0:.0f} s, {bad} mismatches")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
