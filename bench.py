@@ -392,6 +392,9 @@ def main():
                             "table_kernels": prep_kernels_ms * 1e-3, "uploaded_bytes": up_bytes, "host_threads": threads,
                             "usable_cpus": cpus},
             "sample_alignments_per_s": sa * args.steps / elapsed,
+            # draws beyond the last cumulative frequency (float frequencies need not sum to 1): the reference reads out of bounds there
+            # (seqgen/evolve.c:173), this path clamps to state 3 and counts -- the one documented divergence
+            "reference_ub_draws_per_step": {"count": int(batch.clamped()), "of_draws": int(sum(int(b.cols) * (2 * int(b.n) - 2) for b in blocks)) * int(params.sampleN)},
         }
         out["value_resident"] = value
         if s_elapsed is not None:

@@ -235,7 +235,7 @@ int main(int argc, char **argv) {
   int haveKappa = 0;
   float userKappa = 0;
   char blockId[256] = "";
-  int want_bt = 1, want_digest = 1;
+  int want_bt = 1, want_digest = 1, dump_sample = -1;
   FILE *printTo = NULL;   /* --print-to: also run the reference's printResults (misc.c:392-552) into this file */
 
   pars.Delta = -10.0; pars.Omega = -4.0; pars.omega = -2.0;
@@ -252,6 +252,7 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[a], "--stop-early")) pars.stopEarly = 1;
     else if (!strcmp(argv[a], "--cutoff") && a + 1 < argc) pars.cutoff = (float)atof(argv[++a]);
     else if (!strcmp(argv[a], "--no-backtrack")) want_bt = 0;
+    else if (!strcmp(argv[a], "--dump-sample") && a + 1 < argc) dump_sample = atoi(argv[++a]);
     else if (!strcmp(argv[a], "--no-digest")) want_digest = 0;
     else if (!strcmp(argv[a], "--print-to") && a + 1 < argc) printTo = fopen(argv[++a], "w");
     else if (!strcmp(argv[a], "--format") && a + 1 < argc) pars.outputFormat = atoi(argv[++a]);
@@ -346,6 +347,21 @@ int main(int argc, char **argv) {
           dump_backtrack("backtrack", results[0].start, results[0].end, Sk_native_rev, (const struct aln **)inputAlnRev, N);
       }
 
+      if (dump_sample >= 0) {   /* debugging aid: one null sample as getExtremeValuePars draws and scores it (score.c:1005-1031) */
+        struct aln *sampledAln[MAX_NUM_NAMES];
+        segmentStats *sr;
+        int x;
+        g_seed_counter = (unsigned long)dump_sample;
+        simulateTree(tree, models[0].freqs, models[0].kappa, (int)strlen(inputAln[0]->seq));
+        tree2aln(tree, sampledAln);
+        sortAln((const struct aln **)inputAln, sampledAln);
+        reintroduceGaps((const struct aln **)inputAln, sampledAln);
+        fprintf(stderr, "sample %d\n", dump_sample);
+        for (x = 0; sampledAln[x] != NULL; x++) fprintf(stderr, "R %s %s\n", sampledAln[x]->name, sampledAln[x]->seq);
+        sr = scoreAln((const struct aln **)sampledAln, tree, kappa, 0);
+        for (x = 0; sr[x].score >= 0; x++)
+          fprintf(stderr, "H %c %d %d %d %.9g\n", sr[x].strand, sr[x].frame, sr[x].startSite, sr[x].endSite, (double)sr[x].score);
+      }
       g_seed_counter = 0; g_max_n = 0; g_fit_rc = -2;
       rc = getExtremeValuePars(tree, (const struct aln **)inputAln, pars.sampleN, maxScore, &parMu, &parLambda);
       for (i = 0; i < hssCount; i++) {

@@ -7,7 +7,11 @@
 // is cut into tiles of kGenericTile end codons; within a tile the loop runs sequence by sequence -- the three states of the
 // current sequence in registers (parked in the scratch between tiles), its 64-entry sigma table spread over the lanes and read
 // with ds_bpermute like in k_null -- and adds each sequence's max3 to the tile's sums, which stay in registers, in the reference's
-// order k = 0, 1, ...; the HSS scan then walks the tile.  No LDS, few registers: many wavefronts per SIMD hide the code loads.
+// order k = 0, 1, ...; the HSS scan then walks the tile.
+// Tried on top of this and dropped (tools/time_wide.py, 1024 blocks of 100 x 300: 1.60 s): unguarded steps with the row's last
+// tile computed in full (35 % more steps at this length: 1.68 s), groups of eight steps skipped past the row end (2.1 s: the
+// branches cost more than the steps), the next sequence's loads issued during the current one's steps (1.7-2.2 s: 13 more live
+// registers, and the pass is issue-bound, not latency-bound), tiles of 16 or 24 end codons, 3 or 5 wavefronts per SIMD.
 // It is the slow, complete path for rare inputs; the division is the plain '/'.
 #pragma once
 #include "rc_null_kernel.h"
@@ -204,10 +208,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             }
 #pragma unroll
             for (int u = 0; u < kGenericTile; u++) {
-              const int j = j0 + u;
-              if (j < jend) {
+              if ((valid >> u) & 1u) {   // a <= j0 + u < jend
                 const float v = fmaxf(sum[u], Delta) / nkf;
-                sample_scan_step(st, v, static_cast<float>(2 * j + 1), negTie);
+                sample_scan_step(st, v, static_cast<float>(2 * (j0 + u) + 1), negTie);
               }
             }
           }

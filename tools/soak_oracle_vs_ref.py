@@ -27,8 +27,9 @@ def key(h):
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    only = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # replay: do the work of this round only (the generator is advanced through the others)
     t0 = time.time()
-    rounds = done = bad = 0
+    rounds = done = bad = ub = 0
     while time.time() - t0 < budget:
         rounds += 1
         n_samples = int(rng.choice([1, 2, 5, 20, 64, 65, 100]))
@@ -67,8 +68,15 @@ def main():
             for x, row in zip(b.rows, rows):
                 x.seq = row.decode(); x.length = sum(ch != "-" for ch in x.seq)
             blocks.append(b)
+        if only and rounds != only:
+            if rounds > only:
+                break
+            continue
         with tempfile.NamedTemporaryFile("w", suffix=".blk", delete=False) as fh:
             path = fh.name
+        if only:
+            write_harness_blocks(blocks, "/tmp/replay.blk")
+            print("replay: /tmp/replay.blk", "--samples", n_samples, "--seed", seed, extra)
         try:
             write_harness_blocks(blocks, path)
             out = subprocess.run([HARNESS, path, "--samples", str(n_samples), "--seed", str(seed), "--no-backtrack", *extra], capture_output=True)
@@ -93,10 +101,23 @@ def main():
             if ok and ref["evd_rc"] == 1:
                 ok = np.float32(res.mu) == np.float32(ref["mu"]) and np.float32(res.lam) == np.float32(ref["lambda"])
             done += 1
+            if not ok and res.clamped > 0:
+                # a draw beyond the last cumulative frequency: Seq-Gen returns state 4 there, prints it as '\0' (the sampled row ends early) and reads
+                # the next branch's probabilities out of bounds (seqgen/evolve.c:173,304) -- undefined behaviour the oracle does not imitate
+                # (it clamps to state 3 and counts)
+                ub += 1
+                print(f"reference UB round {rounds}: {b.n} x {b.cols}, n={n_samples}, seed={seed}: {res.clamped} clamped draw(s), results differ as documented")
+                continue
+            if not ok and only:
+                mo, mr = np.float32(res.maxScores), np.float32(ref["maxScores"])
+                print("maxima differ at", np.flatnonzero(mo != mr)[:10], mo[mo != mr][:5], mr[mo != mr][:5], "evd", res.evd_rc, ref["evd_rc"], res.mu, ref.get("mu"))
+                print("hss oracle", [(g["strand"], g["frame"], g["start"], g["end"], g["score"]) for g in got][:6])
+                print("hss ref   ", [(w["strand"], w["frame"], w["start"], w["end"], w["score"]) for w in want][:6])
             if not ok:
                 bad += 1
                 print(f"MISMATCH round {rounds}: {b.n} x {b.cols}, n={n_samples}, seed={seed}, pars={pars}, blosum={blosum}")
-    print(f"oracle vs reference: {rounds} harness runs, {done} blocks compared in {time.time() - t0:.0f} s, {bad} mismatches")
+    print(f"oracle vs reference: {rounds} harness runs, {done} blocks compared in {time.time() - t0:.0f} s, {bad} mismatches, "
+          f"{ub} blocks where the reference ran into its out-of-bounds draw")
     return 1 if bad else 0
 
 
