@@ -143,7 +143,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
       }
     }
-    if (clamped && sidx < A.sampleN) atomicAdd(A.clampCount, static_cast<unsigned long long>(clamped));
+    if (clamped && sidx < A.sampleN && onlyCombo <= 0) atomicAdd(A.clampCount, static_cast<unsigned long long>(clamped));   // (the six parts of a split item redo the same simulation)
 
     // ---- both strands x 3 frames: DP over (start a, end j) + serial HSS scan (score.c:496-535, 830-845, 888-962)
     float best = -1.0f;

@@ -312,7 +312,8 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
           }
         }
       }
-      if (clamped && sidx < A.sampleN) atomicAdd(A.clampCount, static_cast<unsigned long long>(clamped));   // padding lanes do not count
+      // padding lanes do not count; with comboSplit the six parts of an item redo the same simulation: the first one reports
+      if (clamped && sidx < A.sampleN && onlyCombo <= 0) atomicAdd(A.clampCount, static_cast<unsigned long long>(clamped));
     }
 
     // ---- phase B: both strands x 3 frames: DP over (start a, end j) + serial HSS scan

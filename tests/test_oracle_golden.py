@@ -110,3 +110,20 @@ def test_sk_digest_and_backtrack():
                     assert list(st[k, idx]) == bt["k"][k - 1]["states"]
                     assert list(z[k, idx]) == bt["k"][k - 1]["z"]
                     assert list(tr[k, idx]) == bt["k"][k - 1]["transitions"]
+
+
+def test_reference_out_of_bounds_draw_is_the_only_divergence():
+    """tests/data/reference_ub_block.json.gz: a block on which the unmodified reference draws beyond the last cumulative frequency
+    (seqgen/evolve.c:173: SetState returns 4, printed as '\\0', the branches below read out of bounds).  The oracle clamps to state 3 and
+    counts: it reports exactly one such draw and agrees with the reference on every other sample."""
+    import gzip
+    import json
+    import os
+    from conftest import ROOT
+    with gzip.open(os.path.join(ROOT, "tests", "data", "reference_ub_block.json.gz"), "rb") as fh:
+        doc = json.loads(fh.read().decode())
+    res = ob.run_block(doc["rows"], doc["names"], doc["start"], doc["length"], doc["tree"], doc["kappa"], ob.default_params(doc["samples"]), doc["seed_base"])
+    assert res.clamped == 1
+    got, ref = np.float32(res.maxScores), np.float32(doc["ref_maxScores"])
+    assert list(np.flatnonzero(got != ref)) == [doc["ub_sample"]]
+    np.testing.assert_array_equal(got, np.float32(doc["oracle_maxScores"]))
