@@ -394,7 +394,8 @@ def main():
             "sample_alignments_per_s": sa * args.steps / elapsed,
             # draws beyond the last cumulative frequency (float frequencies need not sum to 1): the reference reads out of bounds there
             # (seqgen/evolve.c:173), this path clamps to state 3 and counts -- the one documented divergence
-            "reference_ub_draws_per_step": {"count": int(batch.clamped()), "of_draws": int(sum(int(b.cols) * (2 * int(b.n) - 2) for b in blocks)) * int(params.sampleN)},
+            "reference_ub_draws_per_step": {"count": int(batch.clamped()), "draws": int(sum(int(b.cols) * (2 * int(b.n) - 2) for b in blocks)) * int(params.sampleN),
+                                            "note": "sample s of every block reads the one MT19937 stream seeded seed_base + s, so blocks of equal shape compare the same draws with their own thresholds"},
         }
         out["value_resident"] = value
         if s_elapsed is not None:

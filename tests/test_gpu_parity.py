@@ -790,22 +790,20 @@ def test_bulk_hss_fetch_equals_per_block_fetch(ctx):
     batch.close()
 
 
-def test_draw_beyond_the_last_cumulative_frequency_is_clamped_and_counted(ctx):
-    """The block of tests/data/reference_ub_block.json.gz (the reference reads out of bounds on sample 8): the HIP path counts the
-    draw (rc_batch_clamped == 1) and gives the oracle's maxima -- equal to the reference's on the other 63 samples."""
-    import gzip
-    import json
-    import os
-    from conftest import ROOT
+@pytest.mark.parametrize("name", ["reference_ub_block_70x30", "reference_ub_block_6x120"])
+def test_draw_beyond_the_last_cumulative_frequency_is_clamped_and_counted(ctx, name):
+    """The blocks of tests/data/reference_ub_block_*.json.gz (the reference reads out of bounds on one sample; 70 rows: the generic kernel,
+    split into its six strand x frame parts; 6 rows: k_null): the HIP path counts the draw once (rc_batch_clamped == 1) and gives the oracle's
+    maxima -- equal to the reference's on all the other samples."""
+    from test_oracle_golden import load_ub_block
     from rnacode_amd import api
     from rnacode_amd.alnio import AlnBlock, AlnRow
-    with gzip.open(os.path.join(ROOT, "tests", "data", "reference_ub_block.json.gz"), "rb") as fh:
-        doc = json.loads(fh.read().decode())
+    doc = load_ub_block(name)
     rows = [AlnRow(n, s, doc["start"], doc["length"], "+", 10000000) for n, s in zip(doc["names"], doc["rows"])]
     b = AlnBlock(rows, "ub", doc["tree"], doc["kappa"])
     batch = api.Batch(ctx, [b], api.default_params(sampleN=doc["samples"], seed_base=doc["seed_base"])).run()
     assert batch.clamped() == 1
     got = batch.maxScores(0)
     np.testing.assert_array_equal(got, np.float32(doc["oracle_maxScores"]))
-    assert list(np.flatnonzero(got != np.float32(doc["ref_maxScores"]))) == [doc["ub_sample"]]
+    assert list(np.flatnonzero(got != np.float32(doc["ref_maxScores"]))) == doc["ub_samples"]
     batch.close()
