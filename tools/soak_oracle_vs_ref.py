@@ -29,7 +29,7 @@ def main():
     rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     only = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # replay: do the work of this round only (the generator is advanced through the others)
     t0 = time.time()
-    rounds = done = bad = ub = 0
+    rounds = done = bad = ub = nbt = 0
     while time.time() - t0 < budget:
         rounds += 1
         n_samples = int(rng.choice([1, 2, 5, 20, 64, 65, 100]))
@@ -68,6 +68,7 @@ def main():
             for x, row in zip(b.rows, rows):
                 x.seq = row.decode(); x.length = sum(ch != "-" for ch in x.seq)
             blocks.append(b)
+        want_bt = bool(rng.rand() < 0.3)   # also the backtrack of the best HSS (score.c:558-797), a third of the rounds
         if only and rounds != only:
             if rounds > only:
                 break
@@ -79,7 +80,7 @@ def main():
             print("replay: /tmp/replay.blk", "--samples", n_samples, "--seed", seed, extra)
         try:
             write_harness_blocks(blocks, path)
-            out = subprocess.run([HARNESS, path, "--samples", str(n_samples), "--seed", str(seed), "--no-backtrack", *extra], capture_output=True)
+            out = subprocess.run([HARNESS, path, "--samples", str(n_samples), "--seed", str(seed), "--no-digest", *([] if want_bt else ["--no-backtrack"]), *extra], capture_output=True)
         finally:
             os.unlink(path)
         if out.returncode != 0:
@@ -100,6 +101,22 @@ def main():
                 [(w["strand"], w["frame"], w["start"], w["end"], np.float32(w["score"])) for w in want]
             if ok and ref["evd_rc"] == 1:
                 ok = np.float32(res.mu) == np.float32(ref["mu"]) and np.float32(res.lam) == np.float32(ref["lambda"])
+            if ok and "backtrack" in ref:
+                bt = ref["backtrack"]
+                rows = [x.seq.upper() for x in b.rows]
+                names = [x.name for x in b.rows]
+                m = ob.get_models(b.tree, rows, names, b.kappa, blosum)
+                rrows = ob.rev_aln(rows)
+                mr = ob.get_models(b.tree, rrows, names, b.kappa, blosum)
+                _h, skf, skr = ob.score_aln(rows, b.rows[0].start, b.rows[0].length, m, mr, p, want_sk=True)
+                top = want[0]
+                sk, rr = (skf, rows) if top["strand"] == "+" else (skr, rrows)
+                st, z, tr = ob.backtrack(bt["b"], bt["i"], sk, rr, p)
+                idx = list(range(bt["i"], bt["b"] + 1, -3))
+                for k in range(1, b.n):
+                    ok = ok and list(st[k, idx]) == bt["k"][k - 1]["states"] and list(z[k, idx]) == bt["k"][k - 1]["z"] and \
+                        list(tr[k, idx]) == bt["k"][k - 1]["transitions"]
+                nbt += 1
             done += 1
             if not ok and res.clamped > 0:
                 # a draw beyond the last cumulative frequency: Seq-Gen returns state 4 there, prints it as '\0' (the sampled row ends early) and reads
@@ -117,7 +134,7 @@ def main():
                 bad += 1
                 print(f"MISMATCH round {rounds}: {b.n} x {b.cols}, n={n_samples}, seed={seed}, pars={pars}, blosum={blosum}")
     print(f"oracle vs reference: {rounds} harness runs, {done} blocks compared in {time.time() - t0:.0f} s, {bad} mismatches, "
-          f"{ub} blocks where the reference ran into its out-of-bounds draw")
+          f"{ub} blocks where the reference ran into its out-of-bounds draw; {nbt} backtrack paths compared")
     return 1 if bad else 0
 
 
