@@ -23,7 +23,7 @@ def main():
     rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     ctx = api.Context(0)
     t0 = time.time()
-    rounds = blocks_done = bad = 0
+    rounds = blocks_done = bad = paths = 0
     while time.time() - t0 < budget:
         rounds += 1
         n_samples = int(rng.choice([1, 2, 63, 64, 65, 100, 129, 200, 333]))
@@ -90,13 +90,28 @@ def main():
                 [(w["strand"], w["frame"], w["start"], w["end"], np.float32(w["score"])) for w in want]
             rc, mu, lam = batch.getExtremeValuePars(i)
             ok = ok and rc == res.evd_rc and (rc != 1 or (abs(mu - res.mu) <= 1e-6 * max(1, abs(res.mu)) and abs(lam - res.lam) <= 1e-6 * max(1, abs(res.lam))))
+            if ok and got and rng.rand() < 0.15:   # state path of the best HSS: rc_batch_backtrack against the oracle's backtrack
+                h = got[0]
+                strand = 0 if h["strand"] == "+" else 1
+                st, z, tr = batch.backtrack(i, strand, h["start"], h["end"])
+                rows, names = [x.seq for x in b.rows], [x.name for x in b.rows]
+                bl = pars.get("blosum", 62)
+                m = ob.get_models(b.tree, rows, names, b.kappa, bl)
+                rrows = ob.rev_aln(rows)
+                mr = ob.get_models(b.tree, rrows, names, b.kappa, bl)
+                _h, skf, skr = ob.score_aln(rows, b.rows[0].start, b.rows[0].length, m, mr, p, want_sk=True)
+                ws, wz, wt = ob.backtrack(h["start"], h["end"], skf if strand == 0 else skr, rows if strand == 0 else rrows, p)
+                idx = list(range(h["end"], h["start"] + 1, -3))
+                for k in range(1, b.n):
+                    ok = ok and list(st[k, idx]) == list(ws[k, idx]) and list(z[k, idx]) == list(wz[k, idx]) and list(tr[k, idx]) == list(wt[k, idx])
+                paths += 1
             blocks_done += 1
             if not ok:
                 bad += 1
                 print(f"MISMATCH round {rounds} block {i}: {b.n} x {b.cols}, n={n_samples}, seed={seed}, pars={pars}")
         for pb in parts:
             pb.close()
-    print(f"soak: {rounds} batches, {blocks_done} blocks compared in {time.time() - t0:.0f} s, {bad} mismatches")
+    print(f"soak: {rounds} batches, {blocks_done} blocks compared in {time.time() - t0:.0f} s, {bad} mismatches; {paths} backtrack paths compared")
     return 1 if bad else 0
 
 
