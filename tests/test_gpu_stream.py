@@ -317,3 +317,45 @@ def test_bench_under_torchrun_goes_through_rccl(tmp_path):
     assert line["config"]["exchange"] == "all-gather of maxima" and line["n_gpus"] == 1 and line["stream"]["value"] > 0
     one, m1 = _bench(tmp_path, 1, extra=("--blocks", "40", "--samples", "128"))
     np.testing.assert_array_equal(np.load(dump), m1)
+
+
+def test_two_contexts_on_two_host_threads_do_not_interfere():
+    """The library keeps no state outside rc_ctx / rc_batch (the last-error text is per thread): two host threads, each with its own context
+    on the same device, score different batches at the same time; every result equals the one a single context gives."""
+    import threading
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_blocks
+    sets = [[b.upper() for b in synth_blocks(60, 5 + t, 60 + 30 * t, seed=50 + t)] for t in range(2)]
+    pars = [api.default_params(sampleN=130 + 70 * t, seed_base=7 + t) for t in range(2)]
+    ctx = api.Context(0)
+    want = []
+    for blocks, p in zip(sets, pars):
+        batch = api.Batch(ctx, blocks, p).run()
+        want.append([(batch.maxScores(i).copy(), batch.getExtremeValuePars(i)) for i in range(batch.n)])
+        batch.close()
+    ctx.close()
+    got = [None, None]
+    errors = []
+
+    def worker(t):
+        try:
+            c = api.Context(0)
+            for _ in range(3):
+                batch = api.Batch(c, sets[t], pars[t]).run()
+                got[t] = [(batch.maxScores(i).copy(), batch.getExtremeValuePars(i)) for i in range(batch.n)]
+                batch.close()
+            c.close()
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t in range(2):
+        assert len(got[t]) == len(want[t])
+        for (gm, gf), (wm, wf) in zip(got[t], want[t]):
+            np.testing.assert_array_equal(gm, wm)
+            assert gf == wf
