@@ -7,6 +7,8 @@ from rnacode_amd.synth import synth_block
 rng = np.random.RandomState(77)
 ctx = api.Context(0)
 shapes = [(12, 300)] * 12 + [(20, 200)] * 6 + [(32, 150)] * 4 + [(6, 600)] * 4 + [(3, 1200)] * 3
+if len(sys.argv) > 1 and sys.argv[1] == "wide":   # the generic kernels: several tiles per DP row, many sequences, long rows
+    shapes = [(70, 300)] * 3 + [(100, 200)] * 2 + [(130, 150)] * 2 + [(250, 90)] + [(66, 600)] + [(48, 300)] * 2 + [(64, 200)]
 blocks = [synth_block(rng, n, c, index=i, gaps=True).upper() for i, (n, c) in enumerate(shapes)]
 n_s, seed = 130, 4242
 t = time.time()
