@@ -194,7 +194,8 @@ int rc_batch_clamped(const rc_batch *b, int64_t *count);
 
 /* Debug/parity access: multiple-score matrix S[a][j] of the native block for one strand and
  * frame (score.c:811-848 restricted to that frame): sites x sites floats, row a = start
- * codon, column j = end codon; entries with j < a are 0.  Returns sites. */
+ * codon, column j = end codon; entries with j < a are 0.  Returns sites.  (The scoring pass does
+ * not keep these matrices; the call recomputes the block's with the scoring kernel.) */
 int rc_batch_native_S(const rc_batch *b, int32_t blk, int32_t strand /*0:'+',1:'-'*/, int32_t frame, float *out, int32_t cap);
 
 /* backtrack (score.c:558-797) for the native block: states/z/transitions for rows 1..N-1 at

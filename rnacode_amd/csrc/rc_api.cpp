@@ -247,7 +247,7 @@ struct rc_batch {
   size_t S_floats = 0;
   std::vector<uint64_t> offS;
   // device
-  DevBuf dblob, dmaxima, dS, dhss, dhssCount, dhssPacked, dhssOffsets, dfit, dflags, dexact, dcounters, dscratch, dnativeScratch;
+  DevBuf dblob, dmaxima, dS, dhss, dhssCount, dhssPacked, dhssOffsets, dfit, dflags, dexact, dcounters, dscratch, dnativeScratch, dnativeTile;
   float *maxPtr = nullptr;
   bool maximaExternal = false;
   PinBuf hstage, hpacked;
@@ -471,8 +471,10 @@ static int batch_prepare(rc_batch *b, const rc_block *blocks, int32_t n_blocks, 
     b->maxL = std::max(b->maxL, m.L);
     b->maxDraws = std::max(b->maxDraws, b->db[i].nnodes * m.cols);
     const size_t smax = static_cast<size_t>(m.L) / 3;
-    b->offS[i] = sOff;
-    sOff += 6 * smax * smax;
+    if (m.N >= ctx->genericMinRows) {   // only the blocks of more than 64 rows keep their native S matrices (k_native_dp_generic -> k_native_scan)
+      b->offS[i] = sOff;
+      sOff += 6 * smax * smax;
+    }
     b->hssCap = std::max(b->hssCap, static_cast<int>(smax) / 3 + 2);
   }
   b->S_floats = sOff;
@@ -632,6 +634,17 @@ static int launch_native_block(const RunEnv &R) {
   na.hss = b->dhss.as<DevHss>(); na.hssCount = b->dhssCount.as<int>(); na.hssCap = b->hssCap; na.tieThr = c->tieThr;
   HIP_TRY(hipMemsetAsync(b->dhssCount.p, 0, static_cast<size_t>(R.n) * 6 * sizeof(int), st));
   launch_native_sigma(na, static_cast<int>(b->okBlocks.size()), st); b->nl[3]++;
+  {   // one 64-row buffer per persistent workgroup, shared by the class launches (same stream)
+    size_t need = 0;
+    for (auto &kv : b->classes) {
+      if (kv.first == kGenericClass) continue;
+      int smaxClass = 1;
+      for (int bi : kv.second) smaxClass = std::max(smaxClass, b->meta[bi].L / 3);
+      const size_t grid = std::max<size_t>(1, std::min<size_t>(kv.second.size() * 6, static_cast<size_t>(c->numCU) * 8));
+      need = std::max(need, grid * kWave * smaxClass);
+    }
+    HIP_TRY(b->dnativeTile.ensure(std::max<size_t>(need, 4) * sizeof(float)));
+  }
   for (auto &kv : b->classes) {
     NativeArgs nc = na;
     nc.blocks = R.classList + b->classOff[kv.first];
@@ -649,11 +662,22 @@ static int launch_native_block(const RunEnv &R) {
       }
       continue;
     }
-    if (!launch_native_dp(kv.first, nc, static_cast<int>(kv.second.size()), st))
+    // up to 64 rows: DP and getHSS fused, 64 rows of one matrix at a time through a per-workgroup buffer (persistent grid)
+    int smaxClass = 1;
+    for (int bi : kv.second) smaxClass = std::max(smaxClass, b->meta[bi].L / 3);
+    nc.nItems = static_cast<int>(kv.second.size()) * 6;
+    nc.tileStride = static_cast<size_t>(kWave) * smaxClass;
+    const int grid = std::max(1, std::min(nc.nItems, c->numCU * 8));
+    nc.tile = b->dnativeTile.as<float>();
+    if (!launch_native_dp(kv.first, nc, grid, st))
       return fail(RC_ERR_UNSUPPORTED, "no native DP kernel for this number of rows");
     b->nl[3]++;
   }
-  launch_native_scan(na, static_cast<int>(b->okBlocks.size()), st); b->nl[3]++;
+  if (b->classes.count(kGenericClass)) {
+    NativeArgs ng = na;
+    ng.blocks = R.classList + b->classOff[kGenericClass];
+    launch_native_scan(ng, static_cast<int>(b->classes[kGenericClass].size()), st); b->nl[3]++;
+  }
   HIP_TRY(hipMemsetAsync(b->dhssOffsets.as<int>() + R.slots, 0, sizeof(int), st));
   launch_hss_pack(b->dhss.as<DevHss>(), b->dhssCount.as<int>(), b->hssCap, R.slots, b->dhssPacked.as<DevHss>(), b->dhssOffsets.as<int>(),
                   b->dhssOffsets.as<int>() + R.slots, st);
@@ -1226,9 +1250,30 @@ int rc_batch_native_S(const rc_batch *b, int32_t blk, int32_t strand, int32_t fr
   const int sites = (h.L - frame) / 3, smax = h.L / 3;
   if (cap < sites * sites) return fail(RC_ERR_ARG, "output too small");
   HIP_TRY(hipSetDevice(b->device));
-  if (sites > 0)
-    HIP_TRY(hipMemcpy(out, b->dS.as<float>() + b->offS[blk] + static_cast<size_t>(strand * 3 + frame) * smax * smax,
-                      sizeof(float) * sites * sites, hipMemcpyDeviceToHost));
+  if (sites > 0) {
+    const size_t at = static_cast<size_t>(strand * 3 + frame) * smax * smax;
+    if (h.N >= b->ctx->genericMinRows) {   // more than 64 rows: the matrices are kept
+      HIP_TRY(hipMemcpy(out, b->dS.as<float>() + b->offS[blk] + at, sizeof(float) * sites * sites, hipMemcpyDeviceToHost));
+    } else {
+      // the scoring pass never materialises S: recompute this block's six matrices with the same kernel (fullS set: no records written)
+      rc_ctx *c = b->ctx;
+      DevBuf full, tile, idx;
+      HIP_TRY(full.ensure(static_cast<size_t>(6) * smax * smax * sizeof(float)));
+      HIP_TRY(tile.ensure(static_cast<size_t>(6) * kWave * smax * sizeof(float)));
+      HIP_TRY(idx.ensure(sizeof(int)));
+      const int bi = blk;
+      HIP_TRY(hipMemcpy(idx.p, &bi, sizeof(int), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemset(full.p, 0, static_cast<size_t>(6) * smax * smax * sizeof(float)));
+      NativeArgs na{};
+      const uint8_t *blob = b->dblob.as<uint8_t>();
+      na.blob = b->dblob.as<uint8_t>(); na.dblocks = reinterpret_cast<const DevBlock *>(blob + b->oDblocks); na.blocks = idx.as<int>();
+      na.hssCap = b->hssCap; na.tieThr = c->tieThr; na.tile = tile.as<float>(); na.tileStride = static_cast<size_t>(kWave) * smax; na.nItems = 6;
+      na.fullS = full.as<float>();
+      if (!launch_native_dp(h.NK, na, 6, nullptr)) return fail(RC_ERR_UNSUPPORTED, "no native DP kernel for this number of rows");
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipMemcpy(out, full.as<float>() + at, sizeof(float) * sites * sites, hipMemcpyDeviceToHost));
+    }
+  }
   for (int a = 0; a < sites; a++)
     for (int j = 0; j < a; j++) out[a * sites + j] = 0.0f;
   return sites;

@@ -239,45 +239,87 @@ __global__ __launch_bounds__(256) void k_native_sigma(NativeArgs A) {
   }
 }
 
-template <int NK>
-__global__ __launch_bounds__(64) void k_native_dp(NativeArgs A) {
-  const int lane = threadIdx.x;
-  const int bi = A.blocks[blockIdx.x / 6];
-  const int combo = blockIdx.x % 6, s = combo / 3, f = combo % 3;
-  const DevBlock *__restrict__ db = A.dblocks + bi;
-  const int L = db->L, L1 = L + 1;
-  const float Delta = db->Delta, Omega = db->Omega, omega = db->omega, nkf = db->nkf;
-  const unsigned long long *zw = reinterpret_cast<const unsigned long long *>(A.blob + db->off_zw);
-  const float *sigma = reinterpret_cast<const float *>(A.blob + db->off_sigma);
-  const int sites = (L - f) / 3, smax = L / 3;
-  float *S = A.S + A.offS[bi] + static_cast<size_t>(combo) * smax * smax;
-  for (int a0 = 0; a0 < sites; a0 += kWave) {
-    const int a = a0 + lane;
-    float s0[NK], s1[NK], s2[NK];
-#pragma unroll
-    for (int k = 0; k < NK; k++) s0[k] = s1[k] = s2[k] = 0.0f;
-    for (int j = a0; j < sites; j++) {
-      const int i = 3 * j + 3 + f;
-      constexpr int ZW = (NK + 31) / 32;
-      unsigned long long z[ZW];
-#pragma unroll
-      for (int x = 0; x < ZW; x++) z[x] = zw[static_cast<size_t>(s * L1 + i) * ZW + x];
-      if (a <= j && a < sites) {
-        float sum = 0.0f;
-#pragma unroll
-        for (int k = 0; k < NK; k++) {
-          const float sig = sigma[(s * NK + k) * L1 + i];
-          pair_step(static_cast<int>((z[k >> 5] >> (2 * (k & 31))) & 3ull), sig, Delta, Omega, omega, s0[k], s1[k], s2[k]);
-          sum = sum + fmaxf(fmaxf(s0[k], s1[k]), s2[k]);
-        }
-        S[static_cast<size_t>(a) * sites + j] = fmaxf(sum, Delta) / nkf;
+// getHSS (score.c:864-974) over the rows [aLo, aHi) of one strand x frame, the rows' entries at row[(a - aLo) * sites + j]:
+// the state machine only looks at positive entries and at the frame's final one (score.c:898); the wavefront finds them with a
+// ballot and walks the set bits in order (every lane the same walk, the entry's value comes from its lane by a shuffle; lane 0
+// writes the records).  No LDS: these kernels run beside k_null, whose workgroups hold all of a CU's LDS.
+__device__ __forceinline__ void native_scan_rows(const float *rows, int aLo, int aHi, int sites, int s, int f, float tieThr, ScanState &st, int &n,
+                                                 DevHss *out, int hssCap, int lane) {
+  for (int a = aLo; a < aHi; a++) {
+    for (int j0 = a; j0 < sites; j0 += kWave) {
+      const int j = j0 + lane;
+      const float v = (j < sites) ? rows[static_cast<size_t>(a - aLo) * sites + j] : 0.0f;
+      const bool last = (a == sites - 1) && (j == sites - 1);
+      unsigned long long m = __ballot((j < sites) && (v > 0.0f || last));
+      while (m) {
+        const int t = __builtin_ctzll(m);
+        m &= m - 1ull;
+        const int jj = j0 + t;
+        const float vt = __shfl(v, t, kWave);
+        scan_step(st, vt, a, jj, (a == sites - 1) && (jj == sites - 1), tieThr, [&](const ScanState &e) {
+          if (out && lane == 0 && n < hssCap) out[n] = DevHss{s, f, e.ss, e.se, e.cm};
+          n++;
+        });
       }
     }
   }
 }
 
+// Native block, up to 64 rows: pairwise + multiple score matrix (score.c:441-556, 811-848) and getHSS in one pass.  A persistent
+// grid of single-wavefront workgroups takes the (block, strand x frame) items in turn; lane = start codon, 64 rows of S at a time
+// go through a per-workgroup buffer (global memory, L2-resident) and are scanned in the reference's order before the next 64:
+// the matrices themselves are never materialised (they were 6 (L/3)^2 floats per block: 24 GB for 10^5 blocks of 300 columns).
+template <int NK>
+__global__ __launch_bounds__(64) void k_native_dp(NativeArgs A) {
+  const int lane = threadIdx.x;
+  float *__restrict__ tile = A.tile + static_cast<size_t>(blockIdx.x) * A.tileStride;
+  for (int item = blockIdx.x; item < A.nItems; item += gridDim.x) {
+    const int bi = A.blocks[item / 6];
+    const int combo = item % 6, s = combo / 3, f = combo % 3;
+    const DevBlock *__restrict__ db = A.dblocks + bi;
+    const int L = db->L, L1 = L + 1;
+    const float Delta = db->Delta, Omega = db->Omega, omega = db->omega, nkf = db->nkf;
+    const unsigned long long *zw = reinterpret_cast<const unsigned long long *>(A.blob + db->off_zw);
+    const float *sigma = reinterpret_cast<const float *>(A.blob + db->off_sigma);
+    const int sites = (L - f) / 3, smax = L / 3;
+    float *full = A.fullS ? A.fullS + static_cast<size_t>(combo) * smax * smax : nullptr;
+    DevHss *out = A.fullS ? nullptr : A.hss + (static_cast<size_t>(bi) * 6 + combo) * A.hssCap;
+    int n = 0;
+    ScanState st{0.0f, -1, -1};
+    for (int a0 = 0; a0 < sites; a0 += kWave) {
+      const int a = a0 + lane;
+      float s0[NK], s1[NK], s2[NK];
+#pragma unroll
+      for (int k = 0; k < NK; k++) s0[k] = s1[k] = s2[k] = 0.0f;
+      for (int j = a0; j < sites; j++) {
+        const int i = 3 * j + 3 + f;
+        constexpr int ZW = (NK + 31) / 32;
+        unsigned long long z[ZW];
+#pragma unroll
+        for (int x = 0; x < ZW; x++) z[x] = zw[static_cast<size_t>(s * L1 + i) * ZW + x];
+        if (a <= j && a < sites) {
+          float sum = 0.0f;
+#pragma unroll
+          for (int k = 0; k < NK; k++) {
+            const float sig = sigma[(s * NK + k) * L1 + i];
+            pair_step(static_cast<int>((z[k >> 5] >> (2 * (k & 31))) & 3ull), sig, Delta, Omega, omega, s0[k], s1[k], s2[k]);
+            sum = sum + fmaxf(fmaxf(s0[k], s1[k]), s2[k]);
+          }
+          const float v = fmaxf(sum, Delta) / nkf;
+          tile[static_cast<size_t>(lane) * sites + j] = v;
+          if (full) full[static_cast<size_t>(a) * sites + j] = v;
+        }
+      }
+      __syncthreads();   // the rows written by the other lanes (one wavefront: a fence, no waiting for anybody)
+      native_scan_rows(tile, a0, (a0 + kWave < sites) ? a0 + kWave : sites, sites, s, f, A.tieThr, st, n, out, A.hssCap, lane);
+      __syncthreads();   // all read before the next 64 rows (or the next item) overwrite the buffer
+    }
+    if (out && lane == 0) A.hssCount[static_cast<size_t>(bi) * 6 + combo] = n;
+  }
+}
+
+// getHSS on materialised matrices: the blocks of more than 64 rows (k_native_dp_generic writes S)
 __global__ __launch_bounds__(64) void k_native_scan(NativeArgs A) {
-  // no LDS: this kernel runs beside k_null, whose workgroups hold all of a CU's LDS
   const int lane = threadIdx.x;
   const int slot = blockIdx.x;            // position in the blocks list
   const int bi = A.blocks[slot / 6];
@@ -289,27 +331,7 @@ __global__ __launch_bounds__(64) void k_native_scan(NativeArgs A) {
   DevHss *out = A.hss + (static_cast<size_t>(bi) * 6 + combo) * A.hssCap;
   int n = 0;
   ScanState st{0.0f, -1, -1};
-  for (int a = 0; a < sites; a++) {
-    for (int j0 = a; j0 < sites; j0 += kWave) {
-      // the state machine only looks at positive entries and at the frame's final one (score.c:898):
-      // the wave finds them with a ballot and walks the set bits in order (every lane the same walk, the
-      // entry's value comes from its lane by a shuffle; lane 0 writes the records)
-      const int j = j0 + lane;
-      const float v = (j < sites) ? S[static_cast<size_t>(a) * sites + j] : 0.0f;
-      const bool last = (a == sites - 1) && (j == sites - 1);
-      unsigned long long m = __ballot((j < sites) && (v > 0.0f || last));
-      while (m) {
-        const int t = __builtin_ctzll(m);
-        m &= m - 1ull;
-        const int jj = j0 + t;
-        const float vt = __shfl(v, t, kWave);
-        scan_step(st, vt, a, jj, (a == sites - 1) && (jj == sites - 1), A.tieThr, [&](const ScanState &e) {
-          if (lane == 0 && n < A.hssCap) out[n] = DevHss{s, f, e.ss, e.se, e.cm};
-          n++;
-        });
-      }
-    }
-  }
+  native_scan_rows(S, 0, sites, sites, s, f, A.tieThr, st, n, out, A.hssCap, lane);
   if (lane == 0) A.hssCount[static_cast<size_t>(bi) * 6 + combo] = n;
 }
 
@@ -574,9 +596,9 @@ void launch_native_sigma(const NativeArgs &a, int nblocks, hipStream_t stream) {
   hipLaunchKernelGGL(k_native_sigma, dim3(nblocks), dim3(256), 0, stream, a);
 }
 
-bool launch_native_dp(int NK, const NativeArgs &a, int nblocks, hipStream_t stream) {
+bool launch_native_dp(int NK, const NativeArgs &a, int grid, hipStream_t stream) {
   switch (NK) {
-#define X(n) case n: hipLaunchKernelGGL(k_native_dp<n>, dim3(nblocks * 6), dim3(64), 0, stream, a); return true;
+#define X(n) case n: hipLaunchKernelGGL(k_native_dp<n>, dim3(grid), dim3(64), 0, stream, a); return true;
     RC_FOR_NK(X)
 #undef X
     default: return false;
