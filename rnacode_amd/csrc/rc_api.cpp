@@ -182,6 +182,7 @@ void trace(const char *what, const void *obj) {
 struct rc_ctx {
   int device = 0;
   int numCU = 0;
+  int nativeWavesPerCU = 8;   // persistent wavefronts of k_native_dp per CU (RC_NATIVE_WAVES_PER_CU): it runs beside k_null and should not crowd it out
   size_t genericScratchWords = static_cast<size_t>(1) << 30;   // uint32 of staging scratch one k_null_generic launch may take: a twelfth of the device memory (24 GB of 288)
   hipStream_t compute[2] = {nullptr, nullptr};   // null sampling + fit; consecutive batches alternate, so the tail of one overlaps the head of the next
   hipStream_t native = nullptr;    // table preparation and native-block kernels: small and latency-bound, they run beside the null sampling
@@ -341,6 +342,7 @@ int rc_ctx_create(int device, rc_ctx **out) {
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   c->numCU = prop.multiProcessorCount;
   c->genericScratchWords = std::max<size_t>(static_cast<size_t>(1) << 30, prop.totalGlobalMem / 12 / sizeof(uint32_t));
+  if (const char *e = std::getenv("RC_NATIVE_WAVES_PER_CU")) c->nativeWavesPerCU = std::max(1, std::min(32, std::atoi(e)));
   if (const char *e = std::getenv("RC_GENERIC_SCRATCH_MB")) c->genericScratchWords = std::max<size_t>(1, static_cast<size_t>(std::atoll(e))) * (1u << 20) / sizeof(uint32_t);
   // non-blocking streams: no implicit ordering against the legacy default stream that a host framework in
   // the same process (torch, RCCL) may be using; the native stream gets the higher priority so that the
@@ -640,7 +642,7 @@ static int launch_native_block(const RunEnv &R) {
       if (kv.first == kGenericClass) continue;
       int smaxClass = 1;
       for (int bi : kv.second) smaxClass = std::max(smaxClass, b->meta[bi].L / 3);
-      const size_t grid = std::max<size_t>(1, std::min<size_t>(kv.second.size() * 6, static_cast<size_t>(c->numCU) * 8));
+      const size_t grid = std::max<size_t>(1, std::min<size_t>(kv.second.size() * 6, static_cast<size_t>(c->nativeWavesPerCU) * c->numCU));
       need = std::max(need, grid * kWave * smaxClass);
     }
     HIP_TRY(b->dnativeTile.ensure(std::max<size_t>(need, 4) * sizeof(float)));
@@ -667,7 +669,7 @@ static int launch_native_block(const RunEnv &R) {
     for (int bi : kv.second) smaxClass = std::max(smaxClass, b->meta[bi].L / 3);
     nc.nItems = static_cast<int>(kv.second.size()) * 6;
     nc.tileStride = static_cast<size_t>(kWave) * smaxClass;
-    const int grid = std::max(1, std::min(nc.nItems, c->numCU * 8));
+    const int grid = std::max(1, std::min(nc.nItems, c->numCU * c->nativeWavesPerCU));
     nc.tile = b->dnativeTile.as<float>();
     if (!launch_native_dp(kv.first, nc, grid, st))
       return fail(RC_ERR_UNSUPPORTED, "no native DP kernel for this number of rows");
