@@ -243,12 +243,10 @@ struct rc_batch {
   // blob
   PinBuf hblob;
   size_t hostCap = 0, hostUsed = 0, devCap = 0;
-  size_t oDblocks = 0, oOk = 0, oClass = 0, oOffS = 0, oPrefix = 0;   // tail arrays inside the host part
+  size_t oDblocks = 0, oOk = 0, oClass = 0, oPrefix = 0;   // tail arrays inside the host part
   int nModels = 0;
-  size_t S_floats = 0;
-  std::vector<uint64_t> offS;
   // device
-  DevBuf dblob, dmaxima, dS, dhss, dhssCount, dhssPacked, dhssOffsets, dfit, dflags, dexact, dcounters, dscratch, dnativeScratch, dnativeTile;
+  DevBuf dblob, dmaxima, dhss, dhssCount, dhssPacked, dhssOffsets, dfit, dflags, dexact, dcounters, dscratch, dnativeScratch, dnativeTile;
   float *maxPtr = nullptr;
   bool maximaExternal = false;
   PinBuf hstage, hpacked;
@@ -460,8 +458,6 @@ static int batch_prepare(rc_batch *b, const rc_block *blocks, int32_t n_blocks, 
   }
 
   // lists and per-block result areas
-  b->offS.assign(n_blocks, 0);
-  size_t sOff = 0;
   bool sameL = true;
   for (int i = 0; i < n_blocks; i++) {
     const BlockMeta &m = b->meta[i];
@@ -473,13 +469,8 @@ static int batch_prepare(rc_batch *b, const rc_block *blocks, int32_t n_blocks, 
     b->maxL = std::max(b->maxL, m.L);
     b->maxDraws = std::max(b->maxDraws, b->db[i].nnodes * m.cols);
     const size_t smax = static_cast<size_t>(m.L) / 3;
-    if (m.N >= ctx->genericMinRows) {   // only the blocks of more than 64 rows keep their native S matrices (k_native_dp_generic -> k_native_scan)
-      b->offS[i] = sOff;
-      sOff += 6 * smax * smax;
-    }
     b->hssCap = std::max(b->hssCap, static_cast<int>(smax) / 3 + 2);
   }
-  b->S_floats = sOff;
   // longest blocks first: k_null's workgroups pull items from a shared counter, so the order of the
   // list is the order of dispatch (longest-processing-time-first keeps the tail short)
   if (!sameL)
@@ -492,7 +483,6 @@ static int batch_prepare(rc_batch *b, const rc_block *blocks, int32_t n_blocks, 
   b->oDblocks = take(nn * sizeof(DevBlock));
   b->oOk = take(nn * sizeof(int));
   b->oClass = take(nn * sizeof(int));
-  b->oOffS = take(nn * sizeof(uint64_t));
   b->oPrefix = take((nn + 1) * sizeof(int));
   if (o > b->hostCap) return fail(RC_ERR_ARG, "internal: blob tail does not fit");
   b->hostUsed = o;
@@ -507,7 +497,6 @@ static int batch_prepare(rc_batch *b, const rc_block *blocks, int32_t n_blocks, 
       std::memcpy(cl + at, kv.second.data(), sizeof(int) * kv.second.size());
       at += static_cast<int>(kv.second.size());
     }
-    if (n_blocks > 0) std::memcpy(base + b->oOffS, b->offS.data(), sizeof(uint64_t) * n_blocks);
     int *pf = reinterpret_cast<int *>(base + b->oPrefix);
     int run = 0;
     for (size_t k = 0; k < b->okBlocks.size(); k++) { pf[k] = run; run += 2 * b->meta[b->okBlocks[k]].N; }
@@ -526,7 +515,6 @@ static int batch_upload(rc_batch *b) {
   const size_t nn = static_cast<size_t>(std::max(n, 1));
   HIP_TRY(b->dblob.ensure(b->hostCap + b->devCap));
   if (!b->maximaExternal) { HIP_TRY(b->dmaxima.ensure(nn * b->par.sampleN * sizeof(float))); b->maxPtr = b->dmaxima.as<float>(); }
-  HIP_TRY(b->dS.ensure(std::max<size_t>(b->S_floats, 4) * sizeof(float)));
   HIP_TRY(b->dhss.ensure(nn * 6 * b->hssCap * sizeof(DevHss)));
   HIP_TRY(b->dhssCount.ensure(nn * 6 * sizeof(int)));
   HIP_TRY(b->dhssPacked.ensure(nn * 6 * b->hssCap * sizeof(DevHss)));
@@ -632,7 +620,6 @@ static int launch_native_block(const RunEnv &R) {
   HIP_TRY(b->evN0.record(st));
   NativeArgs na{};
   na.blob = b->dblob.as<uint8_t>(); na.dblocks = R.dblocks; na.blocks = R.okList; na.pair = R.tp.pair;
-  na.S = b->dS.as<float>(); na.offS = reinterpret_cast<const uint64_t *>(R.blob + b->oOffS);
   na.hss = b->dhss.as<DevHss>(); na.hssCount = b->dhssCount.as<int>(); na.hssCap = b->hssCap; na.tieThr = c->tieThr;
   HIP_TRY(hipMemsetAsync(b->dhssCount.p, 0, static_cast<size_t>(R.n) * 6 * sizeof(int), st));
   launch_native_sigma(na, static_cast<int>(b->okBlocks.size()), st); b->nl[3]++;
@@ -651,9 +638,9 @@ static int launch_native_block(const RunEnv &R) {
     NativeArgs nc = na;
     nc.blocks = R.classList + b->classOff[kv.first];
     if (kv.first == kGenericClass) {   // more than 64 rows: states in a scratch, at most 256 blocks per launch share it
-      int maxNK = 0;
-      for (int bi : kv.second) maxNK = std::max(maxNK, b->meta[bi].NK);
-      const size_t stride = static_cast<size_t>(3) * maxNK * kWave;
+      int maxNK = 0, smaxG = 1;
+      for (int bi : kv.second) { maxNK = std::max(maxNK, b->meta[bi].NK); smaxG = std::max(smaxG, b->meta[bi].L / 3); }
+      const size_t stride = static_cast<size_t>(3) * maxNK * kWave + static_cast<size_t>(kWave) * smaxG;   // states, then 64 rows of S
       const int chunk = 256;
       HIP_TRY(b->dnativeScratch.ensure(stride * 6 * std::min<size_t>(chunk, kv.second.size()) * sizeof(float)));
       for (size_t at = 0; at < kv.second.size(); at += chunk) {
@@ -674,11 +661,6 @@ static int launch_native_block(const RunEnv &R) {
     if (!launch_native_dp(kv.first, nc, grid, st))
       return fail(RC_ERR_UNSUPPORTED, "no native DP kernel for this number of rows");
     b->nl[3]++;
-  }
-  if (b->classes.count(kGenericClass)) {
-    NativeArgs ng = na;
-    ng.blocks = R.classList + b->classOff[kGenericClass];
-    launch_native_scan(ng, static_cast<int>(b->classes[kGenericClass].size()), st); b->nl[3]++;
   }
   HIP_TRY(hipMemsetAsync(b->dhssOffsets.as<int>() + R.slots, 0, sizeof(int), st));
   launch_hss_pack(b->dhss.as<DevHss>(), b->dhssCount.as<int>(), b->hssCap, R.slots, b->dhssPacked.as<DevHss>(), b->dhssOffsets.as<int>(),
@@ -1254,27 +1236,26 @@ int rc_batch_native_S(const rc_batch *b, int32_t blk, int32_t strand, int32_t fr
   HIP_TRY(hipSetDevice(b->device));
   if (sites > 0) {
     const size_t at = static_cast<size_t>(strand * 3 + frame) * smax * smax;
-    if (h.N >= b->ctx->genericMinRows) {   // more than 64 rows: the matrices are kept
-      HIP_TRY(hipMemcpy(out, b->dS.as<float>() + b->offS[blk] + at, sizeof(float) * sites * sites, hipMemcpyDeviceToHost));
-    } else {
-      // the scoring pass never materialises S: recompute this block's six matrices with the same kernel (fullS set: no records written)
-      rc_ctx *c = b->ctx;
-      DevBuf full, tile, idx;
-      HIP_TRY(full.ensure(static_cast<size_t>(6) * smax * smax * sizeof(float)));
-      HIP_TRY(tile.ensure(static_cast<size_t>(6) * kWave * smax * sizeof(float)));
-      HIP_TRY(idx.ensure(sizeof(int)));
-      const int bi = blk;
-      HIP_TRY(hipMemcpy(idx.p, &bi, sizeof(int), hipMemcpyHostToDevice));
-      HIP_TRY(hipMemset(full.p, 0, static_cast<size_t>(6) * smax * smax * sizeof(float)));
-      NativeArgs na{};
-      const uint8_t *blob = b->dblob.as<uint8_t>();
-      na.blob = b->dblob.as<uint8_t>(); na.dblocks = reinterpret_cast<const DevBlock *>(blob + b->oDblocks); na.blocks = idx.as<int>();
-      na.hssCap = b->hssCap; na.tieThr = c->tieThr; na.tile = tile.as<float>(); na.tileStride = static_cast<size_t>(kWave) * smax; na.nItems = 6;
-      na.fullS = full.as<float>();
-      if (!launch_native_dp(h.NK, na, 6, nullptr)) return fail(RC_ERR_UNSUPPORTED, "no native DP kernel for this number of rows");
-      HIP_TRY(hipDeviceSynchronize());
-      HIP_TRY(hipMemcpy(out, full.as<float>() + at, sizeof(float) * sites * sites, hipMemcpyDeviceToHost));
-    }
+    // the scoring pass never materialises S: recompute this block's six matrices with the same kernel (fullS set: no records written)
+    rc_ctx *c = b->ctx;
+    DevBuf full, tile, idx;
+    const bool generic = h.N >= c->genericMinRows;
+    const size_t tileStride = generic ? static_cast<size_t>(3) * h.NK * kWave + static_cast<size_t>(kWave) * smax : static_cast<size_t>(kWave) * smax;
+    HIP_TRY(full.ensure(static_cast<size_t>(6) * smax * smax * sizeof(float)));
+    HIP_TRY(tile.ensure(6 * tileStride * sizeof(float)));
+    HIP_TRY(idx.ensure(sizeof(int)));
+    const int bi = blk;
+    HIP_TRY(hipMemcpy(idx.p, &bi, sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(full.p, 0, static_cast<size_t>(6) * smax * smax * sizeof(float)));
+    NativeArgs na{};
+    const uint8_t *blob = b->dblob.as<uint8_t>();
+    na.blob = b->dblob.as<uint8_t>(); na.dblocks = reinterpret_cast<const DevBlock *>(blob + b->oDblocks); na.blocks = idx.as<int>();
+    na.hssCap = b->hssCap; na.tieThr = c->tieThr; na.tile = tile.as<float>(); na.tileStride = tileStride; na.nItems = 6;
+    na.fullS = full.as<float>();
+    if (generic) launch_native_dp_generic(na, 1, tile.as<float>(), tileStride, nullptr);
+    else if (!launch_native_dp(h.NK, na, 6, nullptr)) return fail(RC_ERR_UNSUPPORTED, "no native DP kernel for this number of rows");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, full.as<float>() + at, sizeof(float) * sites * sites, hipMemcpyDeviceToHost));
   }
   for (int a = 0; a < sites; a++)
     for (int j = 0; j < a; j++) out[a * sites + j] = 0.0f;

@@ -9,7 +9,7 @@
 //   k_native_sigma    calculateSigma for the native block                     (score.c:375-426)
 //   k_native_dp<NK>   pairwise + multiple score matrix of the native block, one lane per start codon
 //                                                                             (score.c:441-556, 811-848)
-//   k_native_scan     getHSS on the native S matrix                           (score.c:864-974)
+//                     (getHSS, score.c:864-974, runs inside k_native_dp: native_scan_rows in rc_null_kernel.h)
 //   k_sk_row          one row b of Sk for backtracking                        (score.c:496-535)
 //   k_evd_fit         Gumbel maximum-likelihood fit per block                 (extreme_fit.c:157-251)
 //
@@ -239,32 +239,6 @@ __global__ __launch_bounds__(256) void k_native_sigma(NativeArgs A) {
   }
 }
 
-// getHSS (score.c:864-974) over the rows [aLo, aHi) of one strand x frame, the rows' entries at row[(a - aLo) * sites + j]:
-// the state machine only looks at positive entries and at the frame's final one (score.c:898); the wavefront finds them with a
-// ballot and walks the set bits in order (every lane the same walk, the entry's value comes from its lane by a shuffle; lane 0
-// writes the records).  No LDS: these kernels run beside k_null, whose workgroups hold all of a CU's LDS.
-__device__ __forceinline__ void native_scan_rows(const float *rows, int aLo, int aHi, int sites, int s, int f, float tieThr, ScanState &st, int &n,
-                                                 DevHss *out, int hssCap, int lane) {
-  for (int a = aLo; a < aHi; a++) {
-    for (int j0 = a; j0 < sites; j0 += kWave) {
-      const int j = j0 + lane;
-      const float v = (j < sites) ? rows[static_cast<size_t>(a - aLo) * sites + j] : 0.0f;
-      const bool last = (a == sites - 1) && (j == sites - 1);
-      unsigned long long m = __ballot((j < sites) && (v > 0.0f || last));
-      while (m) {
-        const int t = __builtin_ctzll(m);
-        m &= m - 1ull;
-        const int jj = j0 + t;
-        const float vt = __shfl(v, t, kWave);
-        scan_step(st, vt, a, jj, (a == sites - 1) && (jj == sites - 1), tieThr, [&](const ScanState &e) {
-          if (out && lane == 0 && n < hssCap) out[n] = DevHss{s, f, e.ss, e.se, e.cm};
-          n++;
-        });
-      }
-    }
-  }
-}
-
 // Native block, up to 64 rows: pairwise + multiple score matrix (score.c:441-556, 811-848) and getHSS in one pass.  A persistent
 // grid of single-wavefront workgroups takes the (block, strand x frame) items in turn; lane = start codon, 64 rows of S at a time
 // go through a per-workgroup buffer (global memory, L2-resident) and are scanned in the reference's order before the next 64:
@@ -316,23 +290,6 @@ __global__ __launch_bounds__(64) void k_native_dp(NativeArgs A) {
     }
     if (out && lane == 0) A.hssCount[static_cast<size_t>(bi) * 6 + combo] = n;
   }
-}
-
-// getHSS on materialised matrices: the blocks of more than 64 rows (k_native_dp_generic writes S)
-__global__ __launch_bounds__(64) void k_native_scan(NativeArgs A) {
-  const int lane = threadIdx.x;
-  const int slot = blockIdx.x;            // position in the blocks list
-  const int bi = A.blocks[slot / 6];
-  const int combo = slot % 6, s = combo / 3, f = combo % 3;
-  const DevBlock *__restrict__ db = A.dblocks + bi;
-  const int L = db->L;
-  const int sites = (L - f) / 3, smax = L / 3;
-  const float *S = A.S + A.offS[bi] + static_cast<size_t>(combo) * smax * smax;
-  DevHss *out = A.hss + (static_cast<size_t>(bi) * 6 + combo) * A.hssCap;
-  int n = 0;
-  ScanState st{0.0f, -1, -1};
-  native_scan_rows(S, 0, sites, sites, s, f, A.tieThr, st, n, out, A.hssCap, lane);
-  if (lane == 0) A.hssCount[static_cast<size_t>(bi) * 6 + combo] = n;
 }
 
 // One row b of Sk for all k (lane = k-1): out[(k-1)*3 + x][t] for i = b+2+3t <= iMax.
@@ -623,9 +580,6 @@ void launch_hss_pack(const DevHss *hss, const int *count, int cap, int slots, De
   hipLaunchKernelGGL(k_hss_pack, dim3((slots + 255) / 256), dim3(256), 0, stream, hss, count, cap, slots, packed, offsets, total);
 }
 
-void launch_native_scan(const NativeArgs &a, int nblocks, hipStream_t stream) {
-  hipLaunchKernelGGL(k_native_scan, dim3(nblocks * 6), dim3(64), 0, stream, a);
-}
 
 void launch_sk_row(const uint8_t *blob, const DevBlock *dblocks, int bi, int s, int b, int iMax, float *out, int stride,
                    hipStream_t stream) {

@@ -46,8 +46,6 @@ struct NativeArgs {
   const DevBlock *dblocks;
   const int *blocks;          // batch indices handled by this launch
   const uint8_t *pair;
-  float *S;                   // native multiple-score matrices of the blocks of more than 64 rows (k_native_dp_generic -> k_native_scan)
-  const uint64_t *offS;       // per batch index: offset (floats) of its 6 * (L/3)^2 matrices
   float *tile;                // k_native_dp: per-workgroup buffer for 64 rows of one matrix, [gridDim][tileStride]
   size_t tileStride;          // floats: 64 * (largest L/3 of the launch)
   int nItems;                 // k_native_dp: (block, strand x frame) items of the launch = 6 * blocks
@@ -118,7 +116,6 @@ int null_occupancy(int NK, size_t ldsBytes);   // resident workgroups per CU (0 
 bool launch_null(int NK, const NullArgs &a, int grid, size_t ldsBytes, bool exact, hipStream_t stream);
 void launch_native_sigma(const NativeArgs &a, int nblocks, hipStream_t stream);
 bool launch_native_dp(int NK, const NativeArgs &a, int grid, hipStream_t stream);   // a.nItems items over `grid` persistent workgroups
-void launch_native_scan(const NativeArgs &a, int nblocks, hipStream_t stream);
 void launch_hss_pack(const DevHss *hss, const int *count, int cap, int slots, DevHss *packed, int *offsets, int *total,
                      hipStream_t stream);
 void launch_sk_row(const uint8_t *blob, const DevBlock *dblocks, int bi, int s, int b, int iMax, float *out, int stride,

@@ -227,7 +227,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 }
 
 // native block, any number of rows: one wavefront per (block, strand x frame), lane = start codon, the states of the lane's row
-// in a scratch [3][NK][64] per workgroup (score.c:441-556, 811-848)
+// in a scratch [3][NK][64] per workgroup (score.c:441-556, 811-848); like k_native_dp, 64 rows of S at a time go through a buffer
+// [64][sites] behind the states and are scanned (getHSS) before the next 64
 __global__ __launch_bounds__(64) void k_native_dp_generic(NativeArgs A, float *__restrict__ scratch, size_t scratchStride) {
   const int lane = threadIdx.x;
   const int bi = A.blocks[blockIdx.x / 6];
@@ -238,8 +239,12 @@ __global__ __launch_bounds__(64) void k_native_dp_generic(NativeArgs A, float *_
   const unsigned long long *zw = reinterpret_cast<const unsigned long long *>(A.blob + db->off_zw);
   const float *sigma = reinterpret_cast<const float *>(A.blob + db->off_sigma);
   const int sites = (L - f) / 3, smax = L / 3;
-  float *S = A.S + A.offS[bi] + static_cast<size_t>(combo) * smax * smax;
   float *dp = scratch + static_cast<size_t>(blockIdx.x) * scratchStride;
+  float *tile = dp + static_cast<size_t>(3) * NK * kWave;
+  float *full = A.fullS ? A.fullS + static_cast<size_t>(combo) * smax * smax : nullptr;
+  DevHss *out = A.fullS ? nullptr : A.hss + (static_cast<size_t>(bi) * 6 + combo) * A.hssCap;
+  int n = 0;
+  ScanState st{0.0f, -1, -1};
   for (int a0 = 0; a0 < sites; a0 += kWave) {
     const int a = a0 + lane;
     for (int k = 0; k < 3 * NK; k++) dp[static_cast<size_t>(k) * kWave + lane] = 0.0f;
@@ -257,10 +262,16 @@ __global__ __launch_bounds__(64) void k_native_dp_generic(NativeArgs A, float *_
           dp[(2 * static_cast<size_t>(NK) + k) * kWave + lane] = s2;
           sum = sum + fmaxf(fmaxf(s0, s1), s2);
         }
-        S[static_cast<size_t>(a) * sites + j] = fmaxf(sum, Delta) / nkf;
+        const float v = fmaxf(sum, Delta) / nkf;
+        tile[static_cast<size_t>(lane) * sites + j] = v;
+        if (full) full[static_cast<size_t>(a) * sites + j] = v;
       }
     }
+    __syncthreads();   // the rows written by the other lanes
+    native_scan_rows(tile, a0, (a0 + kWave < sites) ? a0 + kWave : sites, sites, s, f, A.tieThr, st, n, out, A.hssCap, lane);
+    __syncthreads();
   }
+  if (out && lane == 0) A.hssCount[static_cast<size_t>(bi) * 6 + combo] = n;
 }
 
 }  // namespace rc

@@ -56,6 +56,32 @@ __device__ __forceinline__ void scan_step(ScanState &st, float v, int a, int j, 
 }
 
 // reverse the three 2-bit fields of a codon index
+// getHSS (score.c:864-974) over the rows [aLo, aHi) of one strand x frame, the rows' entries at row[(a - aLo) * sites + j]:
+// the state machine only looks at positive entries and at the frame's final one (score.c:898); the wavefront finds them with a
+// ballot and walks the set bits in order (every lane the same walk, the entry's value comes from its lane by a shuffle; lane 0
+// writes the records).  No LDS: these kernels run beside k_null, whose workgroups hold all of a CU's LDS.
+__device__ __forceinline__ void native_scan_rows(const float *rows, int aLo, int aHi, int sites, int s, int f, float tieThr, ScanState &st, int &n,
+                                                 DevHss *out, int hssCap, int lane) {
+  for (int a = aLo; a < aHi; a++) {
+    for (int j0 = a; j0 < sites; j0 += kWave) {
+      const int j = j0 + lane;
+      const float v = (j < sites) ? rows[static_cast<size_t>(a - aLo) * sites + j] : 0.0f;
+      const bool last = (a == sites - 1) && (j == sites - 1);
+      unsigned long long m = __ballot((j < sites) && (v > 0.0f || last));
+      while (m) {
+        const int t = __builtin_ctzll(m);
+        m &= m - 1ull;
+        const int jj = j0 + t;
+        const float vt = __shfl(v, t, kWave);
+        scan_step(st, vt, a, jj, (a == sites - 1) && (jj == sites - 1), tieThr, [&](const ScanState &e) {
+          if (out && lane == 0 && n < hssCap) out[n] = DevHss{s, f, e.ss, e.se, e.cm};
+          n++;
+        });
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ uint32_t codon_flip(uint32_t c) { return ((c & 3u) << 4) | (c & 12u) | ((c >> 4) & 3u); }
 
 // ------------------------------------------------------------------------------------------
