@@ -34,6 +34,8 @@ import sys
 import tempfile
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before torch starts the HIP runtime: see rnacode_amd/api.py
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -24,6 +24,10 @@ import numpy as np
 
 from .alnio import AlnBlock
 
+# the library asks the HIP runtime for eight hardware queues (rc_api.cpp, want_hw_queues); in a Python process torch may start the runtime
+# first, so the request is made here as well (an explicit setting wins)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RC_LIB_PATH: load another build of the library (tools/ab.sh compares builds without touching the product .so)
 LIB_PATH = os.environ.get("RC_LIB_PATH") or os.path.join(_HERE, "librnacode_hip.so")

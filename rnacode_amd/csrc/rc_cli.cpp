@@ -198,7 +198,7 @@ int main(int argc, char **argv) {
   rc_default_params(&par);
   Listing list;
   std::string file, outfile, trees, limit;
-  int device = 0, subBlocks = 2048;
+  int device = 0, subBlocks = 0;   // 0: 2048, or 512 per distinct row count if that is more
   bool dumpBlocks = false;
   for (int a = 1; a < argc; a++) {
     const std::string o = argv[a];
@@ -305,6 +305,14 @@ int main(int argc, char **argv) {
     b.ref_start = blocks[i].rows[0].start; b.ref_length = blocks[i].rows[0].length;
   }
 
+  if (subBlocks <= 0) {
+    // every row count is a launch of its own (a kernel instantiation per number of sequences): a sub-batch should give each of them
+    // enough blocks to fill the chip
+    std::vector<char> seen(RC_MAX_ROWS + 2, 0);
+    int classes = 0;
+    for (const Block &b : blocks) { const size_t r = std::min<size_t>(b.rows.size(), RC_MAX_ROWS + 1); if (!seen[r]) { seen[r] = 1; classes++; } }
+    subBlocks = std::max(2048, 512 * classes);
+  }
   rc_stream *stream = nullptr;
   if (rc_stream_create(ctx, &par, 3, &stream) != RC_OK) die(rc_last_error());
   int cap = 1 << 14;   // per block: room for the widest block's Newick text
