@@ -182,6 +182,7 @@ void trace(const char *what, const void *obj) {
 struct rc_ctx {
   int device = 0;
   int numCU = 0;
+  size_t togetherWords = static_cast<size_t>(2) << 30;   // uint32 of staging scratch the side-by-side class launches of a batch may take (RC_TOGETHER_MAX_MB)
   int nativeWavesPerCU = 8;   // persistent wavefronts of k_native_dp per CU (RC_NATIVE_WAVES_PER_CU): it runs beside k_null and should not crowd it out
   size_t genericScratchWords = static_cast<size_t>(1) << 30;   // uint32 of staging scratch one k_null_generic launch may take: a twelfth of the device memory (24 GB of 288)
   hipStream_t compute[2] = {nullptr, nullptr};   // null sampling + fit; consecutive batches alternate, so the tail of one overlaps the head of the next
@@ -348,6 +349,8 @@ int rc_ctx_create(int device, rc_ctx **out) {
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   c->numCU = prop.multiProcessorCount;
   c->genericScratchWords = std::max<size_t>(static_cast<size_t>(1) << 30, prop.totalGlobalMem / 12 / sizeof(uint32_t));
+  c->togetherWords = std::max<size_t>(static_cast<size_t>(1) << 30, prop.totalGlobalMem / 16 / sizeof(uint32_t));   // 18 GB of 288
+  if (const char *e = std::getenv("RC_TOGETHER_MAX_MB")) c->togetherWords = static_cast<size_t>(std::max(0ll, std::atoll(e))) * (1u << 20) / sizeof(uint32_t);
   if (const char *e = std::getenv("RC_NATIVE_WAVES_PER_CU")) c->nativeWavesPerCU = std::max(1, std::min(32, std::atoi(e)));
   if (const char *e = std::getenv("RC_GENERIC_SCRATCH_MB")) c->genericScratchWords = std::max<size_t>(1, static_cast<size_t>(std::atoll(e))) * (1u << 20) / sizeof(uint32_t);
   // non-blocking streams: no implicit ordering against the legacy default stream that a host framework in
@@ -749,7 +752,7 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
   // of the previous one.  One class, a scratch that would exceed 4 GiB, or RC_SERIAL_NATIVE: this run's stream only.
   // the classes with the longest items first (longest-processing-time-first across the launches too)
   std::stable_sort(plans.begin(), plans.end(), [](const Plan &x, const Plan &y) { return x.itemCost > y.itemCost; });
-  if (together && needSum > (static_cast<size_t>(2) << 30)) { together = false; goto plan_again; }
+  if (together && needSum > c->togetherWords) { together = false; goto plan_again; }
   const bool concurrent = together;
   const size_t need = concurrent ? needSum : needMax;
   if (sizeOnly) { *sizeOnly = need; return RC_OK; }
