@@ -1,0 +1,10 @@
+import sys, time, os
+sys.path.insert(0, ".")
+t=time.time()
+from rnacode_amd import api
+api.lib()
+t1=time.time()
+c=api.Context(0)
+t2=time.time()
+print("GPU_MAX_HW_QUEUES", os.environ.get("GPU_MAX_HW_QUEUES"), "load %.3f s, context %.3f s" % (t1-t, t2-t1))
+c.close()

@@ -1,5 +1,5 @@
 """End-to-end timing of the stand-alone driver on a synthetic 10k-block MAF (file -> trees -> scores -> listing).
-usage: python tools/run_cli_10k.py [n_blocks]"""
+usage: python tools/run_cli_10k.py [n_blocks] [mixed]     mixed: 3..12 rows, 60..200 columns instead of 6 x 120"""
 import os
 import sys
 import tempfile
@@ -12,8 +12,15 @@ from rnacode_amd.synth import synth_blocks, to_maf  # noqa: E402
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 d = tempfile.mkdtemp()
 maf = os.path.join(d, "in.maf")
+if len(sys.argv) > 2 and sys.argv[2] == "mixed":
+    import numpy as np
+    from rnacode_amd.synth import synth_block
+    rng = np.random.RandomState(5)
+    blocks = [synth_block(rng, int(rng.randint(3, 13)), int(rng.randint(60, 201)), index=i, gaps=True) for i in range(nb)]
+else:
+    blocks = synth_blocks(nb, 6, 120, seed=1)
 with open(maf, "w") as fh:
-    fh.write(to_maf(synth_blocks(nb, 6, 120, seed=1)))
+    fh.write(to_maf(blocks))
 t = time.time()
 rc = cli.main([maf, "-n", "1000", "-t", "-o", os.path.join(d, "out.tsv")])
 dt = time.time() - t

@@ -1,8 +1,12 @@
 import sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, ".")
 import ctypes as C
 from rnacode_amd import api, synth
 blocks = synth.synth_blocks(10000, 6, 120, seed=1)
+if len(sys.argv) > 1 and sys.argv[1] == "mixed":   # 3..12 rows, 60..200 columns
+    import numpy as np
+    rng = np.random.RandomState(5)
+    blocks = [synth.synth_block(rng, int(rng.randint(3, 13)), int(rng.randint(60, 201)), index=i, gaps=True) for i in range(10000)]
 ctx = api.Context(0)
 n = len(blocks)
 arr = (api.RcBlock * n)(); keep = []
