@@ -807,3 +807,80 @@ def test_draw_beyond_the_last_cumulative_frequency_is_clamped_and_counted(ctx, n
     np.testing.assert_array_equal(got, np.float32(doc["oracle_maxScores"]))
     assert list(np.flatnonzero(got != np.float32(doc["ref_maxScores"]))) == doc["ub_samples"]
     batch.close()
+
+
+def test_malformed_blocks_among_good_ones_do_not_disturb_them(ctx):
+    """Fuzz of the block intake: among valid blocks, blocks with broken trees (unknown or duplicate tips, garbage text, negative or huge
+    or non-numeric branch lengths, no tree), absurd kappa, bytes outside the alphabet, all-gap rows, too few rows or columns.  No crash;
+    every block either scores or carries a status with a reason (RNAcode.c:142-156 skips such blocks and goes on); the valid blocks'
+    results are those of a batch without the bad ones."""
+    from rnacode_amd import api
+    from rnacode_amd.alnio import AlnBlock, AlnRow
+    from rnacode_amd.synth import synth_blocks
+    rng = np.random.RandomState(99)
+    good = [b.upper() for b in synth_blocks(12, 5, 60, seed=21)]
+
+    def mutate(b, kind):
+        rows = [AlnRow(r.name, r.seq, r.start, r.length, r.strand, r.full_length) for r in b.rows]
+        tree, kappa = b.tree, b.kappa
+        if kind == 0:
+            tree = tree.replace(rows[1].name, "nobody")
+        elif kind == 1:
+            tree = tree.replace(rows[1].name, rows[2].name)          # duplicate tip
+        elif kind == 2:
+            tree = "".join(chr(int(x)) for x in rng.randint(33, 127, 40))
+        elif kind == 3:
+            tree = tree.replace(":0.", ":-0.", 1)
+        elif kind == 4:
+            tree = tree.replace(":0.", ":1e30", 1)
+        elif kind == 5:
+            tree = tree.replace(":0.", ":abc", 1)
+        elif kind == 6:
+            tree = tree[: len(tree) // 2]
+        elif kind == 7:
+            kappa = float(rng.choice([0.0, -3.0, 1e30, float("nan"), float("inf")]))
+        elif kind == 8:
+            s = bytearray(rows[2].seq.encode())
+            for q in rng.randint(0, len(s), 6):
+                s[q] = int(rng.choice([0x01, 0x7f, ord("*"), ord("."), ord("?"), ord("x")]))
+            rows[2].seq = s.decode("latin1")
+        elif kind == 9:
+            rows[3].seq = "-" * len(rows[3].seq)
+        elif kind == 10:
+            rows = rows[:2]
+        elif kind == 11:
+            rows = [AlnRow(r.name, r.seq[:2], r.start, 2, r.strand, r.full_length) for r in rows]
+        elif kind == 12:
+            rows[0].seq = "-" * len(rows[0].seq)                      # reference row without residues
+        elif kind == 13:
+            tree = "(" * 5000 + tree
+        return AlnBlock(rows, "m%d" % kind, tree, kappa)
+
+    batch_blocks, is_good = [], []
+    for i, g in enumerate(good):
+        batch_blocks.append(g); is_good.append(True)
+        for kind in rng.choice(14, size=3, replace=False):
+            batch_blocks.append(mutate(good[(i + 1) % len(good)], int(kind))); is_good.append(False)
+    p = api.default_params(sampleN=64, seed_base=5)
+    batch = api.Batch(ctx, batch_blocks, p).run()
+    clean = api.Batch(ctx, good, p).run()
+    gi = 0
+    statuses = set()
+    for i, ok in enumerate(is_good):
+        st = batch.status(i)
+        if ok:
+            assert st == api.RC_OK
+            np.testing.assert_array_equal(batch.maxScores(i), clean.maxScores(gi))
+            assert batch.scoreAln(i) == clean.scoreAln(gi)
+            assert batch.getExtremeValuePars(i) == clean.getExtremeValuePars(gi)
+            gi += 1
+        else:
+            statuses.add(st)
+            if st != api.RC_OK:
+                assert st in (api.RC_ERR_ARG, api.RC_ERR_SKIP, api.RC_ERR_UNSUPPORTED)
+                assert (batch.maxScores(i) == -1.0).all()
+                assert st == api.RC_ERR_SKIP or batch.block_error(i)
+            else:   # scored all the same (e.g. stray bytes count as unknown residues): finite results
+                assert np.isfinite(batch.maxScores(i)).all()
+    assert api.RC_ERR_ARG in statuses and api.RC_ERR_SKIP in statuses
+    batch.close(); clean.close()
