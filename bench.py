@@ -143,8 +143,8 @@ def free_port():
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
     ap.add_argument("--blocks", type=int)
     ap.add_argument("--cols", type=int)
