@@ -1490,7 +1490,7 @@ int rc_fit_trees_device(rc_ctx *c, const rc_block *blocks, int32_t n_blocks, cha
       for (int q = chunkStart[ch]; q < chunkStart[ch + 1]; q++) jobs[q].off_work -= b0;
     }
   }
-  struct DevMem { void *p = nullptr; ~DevMem() { if (p) hipFree(p); } } d_jobs, d_in, d_work, d_out;
+  struct DevMem { void *p = nullptr; ~DevMem() { if (p) (void)hipFree(p); } } d_jobs, d_in, d_work, d_out;
   HIP_TRY(hipMalloc(&d_jobs.p, sizeof(TreeJob) * nj));
   HIP_TRY(hipMalloc(&d_in.p, in.size()));
   HIP_TRY(hipMalloc(&d_work.p, sizeof(double) * maxChunk));
@@ -1546,7 +1546,7 @@ int rc_evd_fit(rc_ctx *c, const double *x, int32_t n, double *mu, double *lambda
   FitOut o;
   hipError_t e = hipStreamSynchronize(c->aux);
   if (e == hipSuccess) e = hipMemcpy(&o, d_o, sizeof o, hipMemcpyDeviceToHost);
-  hipFree(d_x); hipFree(d_o);
+  (void)hipFree(d_x); (void)hipFree(d_o);
   if (e != hipSuccess) return fail(RC_ERR_DEVICE, hipGetErrorString(e));
   if (mu) *mu = o.mu;
   if (lambda) *lambda = o.lambda;
@@ -1561,7 +1561,7 @@ int rc_mt_stream(rc_ctx *c, uint32_t seed, uint32_t *out, int32_t n) {
   launch_mt_stream(seed, 1, n, d, c->aux);
   hipError_t e = hipStreamSynchronize(c->aux);
   if (e == hipSuccess) e = hipMemcpy(out, d, sizeof(uint32_t) * n, hipMemcpyDeviceToHost);
-  hipFree(d);
+  (void)hipFree(d);
   if (e != hipSuccess) return fail(RC_ERR_DEVICE, hipGetErrorString(e));
   return RC_OK;
 }
