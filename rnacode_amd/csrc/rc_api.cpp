@@ -183,6 +183,8 @@ struct rc_ctx {
   int device = 0;
   int numCU = 0;
   size_t togetherWords = static_cast<size_t>(2) << 30;   // uint32 of staging scratch the side-by-side class launches of a batch may take (RC_TOGETHER_MAX_MB)
+  DevBuf treeJobs, treeIn, treeWork, treeOut;   // rc_fit_trees_device
+  std::mutex treeMutex;
   int nativeWavesPerCU = 8;   // persistent wavefronts of k_native_dp per CU (RC_NATIVE_WAVES_PER_CU): it runs beside k_null and should not crowd it out
   size_t genericScratchWords = static_cast<size_t>(1) << 30;   // uint32 of staging scratch one k_null_generic launch may take: a twelfth of the device memory (24 GB of 288)
   hipStream_t compute[2] = {nullptr, nullptr};   // null sampling + fit; consecutive batches alternate, so the tail of one overlaps the head of the next
@@ -1451,7 +1453,14 @@ int rc_fit_trees_device(rc_ctx *c, const rc_block *blocks, int32_t n_blocks, cha
   std::vector<uint8_t> in;
   size_t work_doubles = 0;
   int hostDone = 0;
-  for (int i = 0; i < n_blocks; i++) {
+  // the longest fits first: the launch hands workgroups out in order, and a fit of 12 rows x 200 patterns takes a hundred times one of 3 x 60
+  std::vector<int> order(n_blocks);
+  for (int i = 0; i < n_blocks; i++) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+    const auto cost = [&](int i) { return ok[i] == 1 ? static_cast<double>(ps[i].N) * ps[i].N * ps[i].P : -1.0; };
+    return cost(x) > cost(y);
+  });
+  for (int i : order) {
     if (ok[i] == 2) { hostDone++; continue; }   // fitted on the host above
     newick_out[static_cast<size_t>(i) * cap] = 0; kappa_out[i] = 0.0f;
     if (lnl_out) lnl_out[i] = 0.0;
@@ -1490,11 +1499,13 @@ int rc_fit_trees_device(rc_ctx *c, const rc_block *blocks, int32_t n_blocks, cha
       for (int q = chunkStart[ch]; q < chunkStart[ch + 1]; q++) jobs[q].off_work -= b0;
     }
   }
-  struct DevMem { void *p = nullptr; ~DevMem() { if (p) (void)hipFree(p); } } d_jobs, d_in, d_work, d_out;
-  HIP_TRY(hipMalloc(&d_jobs.p, sizeof(TreeJob) * nj));
-  HIP_TRY(hipMalloc(&d_in.p, in.size()));
-  HIP_TRY(hipMalloc(&d_work.p, sizeof(double) * maxChunk));
-  HIP_TRY(hipMalloc(&d_out.p, sizeof(TreeOut) * nj));
+  // device buffers live in the context: a driver fits its blocks in several calls
+  std::lock_guard<std::mutex> treeLock(c->treeMutex);
+  DevBuf &d_jobs = c->treeJobs, &d_in = c->treeIn, &d_work = c->treeWork, &d_out = c->treeOut;
+  HIP_TRY(d_jobs.ensure(sizeof(TreeJob) * nj));
+  HIP_TRY(d_in.ensure(in.size()));
+  HIP_TRY(d_work.ensure(sizeof(double) * maxChunk));
+  HIP_TRY(d_out.ensure(sizeof(TreeOut) * nj));
   HIP_TRY(hipMemcpyAsync(d_jobs.p, jobs.data(), sizeof(TreeJob) * nj, hipMemcpyHostToDevice, c->aux));
   HIP_TRY(hipMemcpyAsync(d_in.p, in.data(), in.size(), hipMemcpyHostToDevice, c->aux));
   for (size_t ch = 0; ch + 1 < chunkStart.size(); ch++) {
@@ -1506,21 +1517,33 @@ int rc_fit_trees_device(rc_ctx *c, const rc_block *blocks, int32_t n_blocks, cha
   std::vector<TreeOut> out(nj);
   HIP_TRY(hipMemcpyAsync(out.data(), d_out.p, sizeof(TreeOut) * nj, hipMemcpyDeviceToHost, c->aux));
   HIP_TRY(hipStreamSynchronize(c->aux));
-  int done = 0;
-  for (int q = 0; q < nj; q++) {
-    const int i = owner[q];
-    const rc_block &b = blocks[i];
-    std::vector<std::string> names(b.n_rows);
-    for (int r = 0; r < b.n_rows; r++) names[r] = b.names[r];
-    const TreeOut &o = out[q];
-    const std::string nwk = newick_of(b.n_rows, o.root, o.nchild, o.child, o.len, names);
-    if (static_cast<int>(nwk.size()) + 1 > cap) continue;
-    std::memcpy(newick_out + static_cast<size_t>(i) * cap, nwk.c_str(), nwk.size() + 1);
-    kappa_out[i] = static_cast<float>(o.kappa);
-    if (lnl_out) lnl_out[i] = o.lnl;
-    done++;
+  std::atomic<int> done{0};
+  {
+    std::atomic<int> next{0};
+    const unsigned nt = std::min<unsigned>(static_cast<unsigned>(c->hostThreads), static_cast<unsigned>(std::max(1, nj / 64)));
+    auto write = [&]() {
+      for (;;) {
+        const int q = next.fetch_add(1);
+        if (q >= nj) break;
+        const int i = owner[q];
+        const rc_block &b = blocks[i];
+        std::vector<std::string> names(b.n_rows);
+        for (int r = 0; r < b.n_rows; r++) names[r] = b.names[r];
+        const TreeOut &o = out[q];
+        const std::string nwk = newick_of(b.n_rows, o.root, o.nchild, o.child, o.len, names);
+        if (static_cast<int>(nwk.size()) + 1 > cap) continue;
+        std::memcpy(newick_out + static_cast<size_t>(i) * cap, nwk.c_str(), nwk.size() + 1);
+        kappa_out[i] = static_cast<float>(o.kappa);
+        if (lnl_out) lnl_out[i] = o.lnl;
+        done.fetch_add(1);
+      }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < std::max(1u, nt); t++) th.emplace_back(write);
+    write();
+    for (auto &x : th) x.join();
   }
-  return done + hostDone;
+  return done.load() + hostDone;
 }
 
 int rc_tree_lnl(const rc_block *blk, double *lnl_out) {

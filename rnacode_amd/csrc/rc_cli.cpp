@@ -329,7 +329,9 @@ int main(int argc, char **argv) {
         // what treeML() hands over (RNAcode.c:153): tree + kappa, fitted on the GPU.  One wavefront per block, latency-bound:
         // a call costs about the same for 100 blocks as for 2048 (the wavefronts the chip holds at once), so the fits
         // run ahead of the scoring in chunks of 8192 blocks
-        const int mf = std::min(std::max(subBlocks, 8192), n - fitted);
+        // (a remainder of less than half a chunk goes with the chunk before it: a short call costs as much as a long one)
+        const int chunk = std::max(subBlocks, 8192);
+        const int mf = (n - fitted <= chunk + chunk / 2) ? n - fitted : chunk;
         nwk.assign(static_cast<size_t>(mf) * cap, 0);
         kap.assign(mf, 0.0f);
         const double t = now();
