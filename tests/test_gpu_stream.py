@@ -359,3 +359,35 @@ def test_two_contexts_on_two_host_threads_do_not_interfere():
         for (gm, gf), (wm, wf) in zip(got[t], want[t]):
             np.testing.assert_array_equal(gm, wm)
             assert gf == wf
+
+
+def test_many_row_count_classes_side_by_side_equal_one_class_at_a_time():
+    """A batch with six row-count classes and enough items that its class launches run side by side on separate streams without the
+    small-launch split: every block's maxima, fit and HSS equal those of single-class batches (one launch at a time,
+    split or not as their size asks), and three of them equal the oracle's."""
+    from oracle import binding as ob
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_block
+    rng = np.random.RandomState(31)
+    blocks = [synth_block(rng, int(rng.randint(3, 9)), int(rng.randint(45, 121)), index=i, gaps=True).upper() for i in range(420)]
+    n, seed = 1000, 77
+    p = api.default_params(sampleN=n, seed_base=seed)
+    ctx = api.Context(0)
+    mixed = api.Batch(ctx, blocks, p).run()
+    by_n = {}
+    for i, b in enumerate(blocks):
+        by_n.setdefault(b.n, []).append(i)
+    assert len(by_n) == 6
+    for rows, idx in by_n.items():
+        solo = api.Batch(ctx, [blocks[i] for i in idx], p).run()
+        for j, i in enumerate(idx):
+            np.testing.assert_array_equal(mixed.maxScores(i), solo.maxScores(j))
+            assert mixed.getExtremeValuePars(i) == solo.getExtremeValuePars(j)
+            assert mixed.scoreAln(i) == solo.scoreAln(j)
+        solo.close()
+    for i in (5, 211, 419):
+        b = blocks[i]
+        res = ob.run_block([r.seq for r in b.rows], [r.name for r in b.rows], b.rows[0].start, b.rows[0].length, b.tree, b.kappa, ob.default_params(n), seed)
+        np.testing.assert_array_equal(mixed.maxScores(i), np.float32(res.maxScores))
+    mixed.close()
+    ctx.close()
