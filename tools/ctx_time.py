@@ -1,3 +1,4 @@
+"""Time the library load and rc_ctx_create (HIP runtime start, streams, tables): tools/ctx_time.py"""
 import sys, time, os
 sys.path.insert(0, ".")
 t=time.time()

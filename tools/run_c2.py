@@ -1,3 +1,4 @@
+"""BASELINE configs[1] (genomic-preprocessed.maf at n = 1000, from the golden fixture) as one batch: latency and device-time breakdown."""
 import sys, time, json
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from conftest import load_golden

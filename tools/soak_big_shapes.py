@@ -1,3 +1,4 @@
+"""Large-shape parity against the oracle (12 x 300 .. 3 x 1200; `wide`: 48 .. 250 rows): tools/soak_big_shapes.py [wide]"""
 import sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np

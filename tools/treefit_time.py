@@ -1,3 +1,4 @@
+"""Time rc_fit_trees_device on 10 000 blocks (6 x 120, or `mixed`: 3..12 rows, 60..200 columns): tools/treefit_time.py [mixed]"""
 import sys, time
 sys.path.insert(0, ".")
 import ctypes as C
