@@ -624,6 +624,14 @@ struct RunEnv {
 };
 }  // namespace
 
+// persistent workgroups of k_native_dp for `items` (block, strand x frame) items whose longest block has smax codons: each keeps 64 rows
+// of S (64 * smax floats), all of them together at most 2 GiB (very long blocks run on fewer workgroups)
+static size_t native_grid(const rc_ctx *c, size_t items, int smax) {
+  const size_t perGroup = static_cast<size_t>(kWave) * std::max(1, smax) * sizeof(float);
+  const size_t byMemory = std::max<size_t>(1, (static_cast<size_t>(2) << 30) / perGroup);
+  return std::max<size_t>(1, std::min(std::min(items, static_cast<size_t>(c->nativeWavesPerCU) * c->numCU), byMemory));
+}
+
 static int launch_native_block(const RunEnv &R) {
   rc_batch *b = R.b; rc_ctx *c = R.c;
   // ---- native block: sigma -> DP per N-1 class -> scan, on the native stream: these kernels are small and
@@ -642,7 +650,7 @@ static int launch_native_block(const RunEnv &R) {
       if (kv.first == kGenericClass) continue;
       int smaxClass = 1;
       for (int bi : kv.second) smaxClass = std::max(smaxClass, b->meta[bi].L / 3);
-      const size_t grid = std::max<size_t>(1, std::min<size_t>(kv.second.size() * 6, static_cast<size_t>(c->nativeWavesPerCU) * c->numCU));
+      const size_t grid = native_grid(c, kv.second.size() * 6, smaxClass);
       need = std::max(need, grid * kWave * smaxClass);
     }
     HIP_TRY(b->dnativeTile.ensure(std::max<size_t>(need, 4) * sizeof(float)));
@@ -669,7 +677,7 @@ static int launch_native_block(const RunEnv &R) {
     for (int bi : kv.second) smaxClass = std::max(smaxClass, b->meta[bi].L / 3);
     nc.nItems = static_cast<int>(kv.second.size()) * 6;
     nc.tileStride = static_cast<size_t>(kWave) * smaxClass;
-    const int grid = std::max(1, std::min(nc.nItems, c->numCU * c->nativeWavesPerCU));
+    const int grid = static_cast<int>(native_grid(c, static_cast<size_t>(nc.nItems), smaxClass));
     nc.tile = b->dnativeTile.as<float>();
     if (!launch_native_dp(kv.first, nc, grid, st))
       return fail(RC_ERR_UNSUPPORTED, "no native DP kernel for this number of rows");
