@@ -20,13 +20,15 @@ extern "C" {
 #define RC_OK 0
 #define RC_ERR_ARG (-1)         /* malformed block / tree / parameter */
 #define RC_ERR_DEVICE (-2)      /* no HIP device, or a HIP call failed */
-#define RC_ERR_UNSUPPORTED (-3) /* shape outside the built kernels (N > RC_MAX_ROWS) */
+#define RC_ERR_UNSUPPORTED (-3) /* shape outside the built kernels (N > RC_MAX_ROWS, more than RC_MAX_COLS columns) */
 #define RC_ERR_SKIP (-4)        /* block the reference driver skips (RNAcode.c:142-150) */
 
 #define RC_MAX_ROWS 500         /* rows per block, the reference's own limit (MAX_NUM_NAMES, rnaz_utils.h:7).  N <= 32 runs the
                                    register-resident kernels, 33..64 a slower instantiation of the same code, 65..500 generic kernels
-                                   with their per-sequence states in global memory (slow, complete); the built-in tree estimator
+                                   (sequence-by-sequence over register-tiled rows, codes in a global scratch); the built-in tree estimator
                                    runs on the GPU for up to 64 rows and on host threads for wider blocks */
+#define RC_MAX_COLS 65535       /* alignment columns per block (16-bit column indices); longer blocks get the status RC_ERR_UNSUPPORTED --
+                                   the reference's breakMAF.pl (python -m rnacode_amd.breakmaf) splits them first, as its README asks */
 
 /* Scoring parameters: the members of `parameters pars` (src/RNAcode.h:29-54) that the
  * scoring path reads (score.c:415,419,508-533,842,992,1040), plus the seed base that

@@ -441,7 +441,7 @@ static int batch_prepare(rc_batch *b, const rc_block *blocks, int32_t n_blocks, 
   size_t hostSum = 0, devSum = 0;
   for (int i = 0; i < n_blocks; i++) {
     size_t h = 0, d = 0;
-    if (blocks[i].n_rows >= 3 && blocks[i].n_rows <= kMaxRows && blocks[i].n_cols >= 3 && blocks[i].n_cols <= 65535)
+    if (blocks[i].n_rows >= 3 && blocks[i].n_rows <= kMaxRows && blocks[i].n_cols >= 3 && blocks[i].n_cols <= RC_MAX_COLS)
       block_footprint(blocks[i].n_rows, blocks[i].n_cols, &h, &d);
     hostSum += h; devSum += d;
   }

@@ -429,7 +429,7 @@ int prepare_block(const rc_block &in, const rc_params &par, const PairTable &pt,
   meta.L = L;
   if (N <= 2 || L < 3) return done(RC_ERR_SKIP);                 // RNAcode.c:142-150
   if (N > kMaxRows) { err = "more than RC_MAX_ROWS rows"; return done(RC_ERR_UNSUPPORTED); }
-  if (cols > 65535) { err = "more than 65535 columns"; return done(RC_ERR_UNSUPPORTED); }
+  if (cols > RC_MAX_COLS) { err = "more than 65535 columns"; return done(RC_ERR_UNSUPPORTED); }
 
   Tree t;
   if (!parse_newick(in.newick, t, err)) return done(RC_ERR_ARG);
