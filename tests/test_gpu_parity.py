@@ -178,6 +178,11 @@ def test_errors_and_empty(ctx):
     solo.close(); batch.close()
     with pytest.raises(api.RnacodeError):
         api.Batch(ctx, [good], api.default_params(blosum=45))
+    # more columns than RC_MAX_COLS: a status, not a crash (the reference's breakMAF.pl splits such blocks first)
+    long_rows = [AlnRow(n, ("ACGTTGCA" * 8750)[:70000]) for n in "abc"]
+    batch = api.Batch(ctx, [AlnBlock(long_rows, "long", "(a:0.1,b:0.1,c:0.1);", 2.0), good], api.default_params(sampleN=64)).run()
+    assert batch.status(0) == api.RC_ERR_UNSUPPORTED and "columns" in batch.block_error(0) and batch.status(1) == api.RC_OK
+    batch.close()
 
 
 def test_oracle_parity_on_fresh_seeds(ctx):
