@@ -335,9 +335,24 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
 // slowest block's fit (up to 300 evaluations of the four sums when Newton's method needs the bisection fallback) is the run time.
 // Either way the sums end as identical bits on every thread (xor butterfly, then a fixed-order sum of the wavefronts' values), so
 // the Newton / bisection control flow below is uniform.
+// Sum over the wavefront, the same bits on every lane, without LDS round trips: inside a row of 16 lanes the partner values come by DPP
+// (xor 1, xor 2, then the mirrored half row and the mirrored row -- after the first two steps a quad holds one value, so any lane of the
+// other quad / half will do); the four row sums come back through v_readlane and are added in one fixed order.  (The fit evaluates four
+// such sums up to 300 times per block: with ds_bpermute shuffles that was most of a small batch's fit time.)
+template <int CTRL> __device__ __forceinline__ double dpp_add(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+  return x + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_value(double x, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane), __builtin_amdgcn_readlane(__double2loint(x), lane));
+}
 __device__ __forceinline__ double wave_sum(double v) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);   // row_half_mirror
+  v = dpp_add<0x140>(v);   // row_mirror
+  return (row_value(v, 0) + row_value(v, 16)) + (row_value(v, 32) + row_value(v, 48));
 }
 
 template <int THREADS>
@@ -610,6 +625,7 @@ void launch_stop_mark(const FitArgs &a, int nblocks, hipStream_t stream) {
 void launch_evd_fit(const FitArgs &a, int nblocks, bool latency, hipStream_t stream) {
   // a small batch with the chip to itself: four wavefronts per block (latency); otherwise one LDS-free wavefront per block
   // (see fit_sum4: beside another batch's k_null the LDS variant waits milliseconds for its 128 bytes)
+  // (128 threads: 1.64 ms for the 33 blocks of genomic-preprocessed.maf at n = 1000, 256: 1.27 ms, 1024: 3.1 ms)
   if (latency && nblocks <= 2048) hipLaunchKernelGGL(k_evd_fit<256>, dim3(nblocks), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(k_evd_fit<64>, dim3(nblocks), dim3(64), 0, stream, a);
 }
