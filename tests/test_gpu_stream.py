@@ -391,3 +391,31 @@ def test_many_row_count_classes_side_by_side_equal_one_class_at_a_time():
         np.testing.assert_array_equal(mixed.maxScores(i), np.float32(res.maxScores))
     mixed.close()
     ctx.close()
+
+
+def test_stream_of_mixed_sub_batches_equals_one_batch():
+    """Sub-batches with six row-count classes each, three of them in flight: their side-by-side class launches share the context's class
+    streams and hardware queues.  Every block's maxima and fit equal those of the whole input scored as one batch."""
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_block
+    rng = np.random.RandomState(32)
+    blocks = [synth_block(rng, int(rng.randint(3, 9)), int(rng.randint(45, 100)), index=i, gaps=True).upper() for i in range(2400)]
+    p = api.default_params(sampleN=300, seed_base=9)
+    ctx = api.Context(0)
+    whole = api.Batch(ctx, blocks, p).run()
+    want_max = whole.maxScores_all().copy()
+    want_fit = whole.fits().copy()
+    whole.close()
+    m = api.Marshalled(blocks)
+    m.set_trees()
+    st = api.Stream(ctx, p, 3)
+    for _ in range(2):   # the second pass runs on recycled batches
+        at = 0
+        for part in api.score_stream(ctx, m, p, 600, depth=3, stream=st, ramp=False):
+            np.testing.assert_array_equal(part.maxScores_all(), want_max[at:at + part.n])
+            np.testing.assert_array_equal(part.fits(), want_fit[at:at + part.n])
+            at += part.n
+            part.close()
+        assert at == len(blocks)
+    st.close()
+    ctx.close()
