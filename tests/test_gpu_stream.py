@@ -413,7 +413,8 @@ def test_stream_of_mixed_sub_batches_equals_one_batch():
         at = 0
         for part in api.score_stream(ctx, m, p, 600, depth=3, stream=st, ramp=False):
             np.testing.assert_array_equal(part.maxScores_all(), want_max[at:at + part.n])
-            np.testing.assert_array_equal(part.fits(), want_fit[at:at + part.n])
+            # (the fit of a sub-batch that finds the chip idle runs four wavefronts per block, the others one: another summation order)
+            np.testing.assert_allclose(part.fits(), want_fit[at:at + part.n], rtol=1e-6, atol=1e-6)
             at += part.n
             part.close()
         assert at == len(blocks)
