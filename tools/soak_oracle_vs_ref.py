@@ -87,7 +87,13 @@ def main():
             print(f"harness failed (rc {out.returncode}) in round {rounds}: {out.stderr.decode()[:200]}")
             bad += 1
             continue
-        refs = [json.loads(re.sub(r"-?nan", "NaN", l)) for l in out.stdout.decode().splitlines() if l.strip()]
+        try:   # printf writes nan / inf where JSON wants NaN / Infinity
+            refs = [json.loads(re.sub(r"(?<![A-Za-z])(-?)inf(?![A-Za-z])", r"\1Infinity", re.sub(r"-?nan", "NaN", l)))
+                    for l in out.stdout.decode().splitlines() if l.strip()]
+        except json.JSONDecodeError as e:
+            print(f"unparsable harness output in round {rounds}: {e}; {out.stdout.decode()[max(0, e.pos - 80):e.pos + 80]!r}")
+            bad += 1
+            continue
         for b, ref in zip(blocks, refs):
             if "skipped" in ref:
                 continue
