@@ -1,6 +1,6 @@
 """Randomised parity soak: random block shapes, sample counts, seeds and parameters through the HIP path and the
 oracle until the time budget is used up; any difference in per-sample maxima, HSS tables or fit results is printed.
-usage: python tools/soak_parity.py [seconds] [rng_seed]"""
+usage: python tools/soak_parity.py [seconds] [rng_seed] [wide]     wide: 65..300 rows only (the kernels for more than 64 rows)"""
 import re
 import sys
 import time
@@ -21,6 +21,7 @@ def key(h):
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
     ctx = api.Context(0)
     t0 = time.time()
     rounds = blocks_done = bad = paths = 0
@@ -37,12 +38,16 @@ def main():
         elif r < 0.3:
             pars = dict(blosum=90)
         blocks = []
-        for i in range(int(rng.randint(1, 25))):
+        for i in range(int(rng.randint(1, 6 if wide else 25))):
             n = int(rng.choice([3, 3, 4, 5, 6, 6, 7, 8, 10, 12, 17, 32, 33, 40, 64, 65, 90, 130]))
             cols = int(rng.choice([9, 12, 30, 45, 60, 90, 120, 150, 200, 301]))
-            if n * cols > 4000:
+            if wide:
+                n = int(rng.choice([65, 66, 70, 90, 128, 129, 200, 300]))
+                cols = int(rng.choice([9, 30, 60, 99, 120, 150, 200]))
+                cols = max(9, min(cols, 9000 // n))
+            elif n * cols > 4000:
                 cols = max(9, 4000 // n)
-            if n > 32:
+            if n > 32 and not wide:
                 cols = min(cols, 45)
             b = synth_block(rng, n, cols, index=i, gaps=bool(rng.rand() < 0.8), mean_branch=float(rng.choice([0.01, 0.1, 0.4]))).upper()
             if rng.rand() < 0.3:   # common gap stretch (ties) / zero-length branch (degenerate rows)
