@@ -509,8 +509,10 @@ class Stream:
 
     def next(self) -> Batch:
         h = C.c_void_p()
-        _check(lib().rc_stream_next(self._h, C.byref(h)))
-        return Batch._from_stream(self, h, self._blocks.pop(0))
+        r = lib().rc_stream_next(self._h, C.byref(h))
+        blocks = self._blocks.pop(0) if self._blocks else []   # the C side has taken the oldest batch off its queue, whatever the outcome
+        _check(r)
+        return Batch._from_stream(self, h, blocks)
 
     def close(self):
         if self._h:

@@ -182,6 +182,7 @@ void trace(const char *what, const void *obj) {
 struct rc_ctx {
   int device = 0;
   int numCU = 0;
+  size_t totalMem = 0;             // device memory (bytes)
   size_t togetherWords = static_cast<size_t>(2) << 30;   // uint32 of staging scratch the side-by-side class launches of a batch may take (RC_TOGETHER_MAX_MB)
   DevBuf treeJobs, treeIn, treeWork, treeOut;   // rc_fit_trees_device
   std::mutex treeMutex;
@@ -350,6 +351,7 @@ int rc_ctx_create(int device, rc_ctx **out) {
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   c->numCU = prop.multiProcessorCount;
+  c->totalMem = prop.totalGlobalMem;
   c->genericScratchWords = std::max<size_t>(static_cast<size_t>(1) << 30, prop.totalGlobalMem / 12 / sizeof(uint32_t));
   c->togetherWords = std::max<size_t>(static_cast<size_t>(1) << 30, prop.totalGlobalMem / 36 / sizeof(uint32_t));   // 8 GB of 288: allocating more costs a short run more than it gains (tools/cli_mixed_sweep.sh)
   if (const char *e = std::getenv("RC_TOGETHER_MAX_MB")) c->togetherWords = static_cast<size_t>(std::max(0ll, std::atoll(e))) * (1u << 20) / sizeof(uint32_t);
@@ -472,9 +474,18 @@ static int batch_prepare(rc_batch *b, const rc_block *blocks, int32_t n_blocks, 
 
   // lists and per-block result areas
   bool sameL = true;
+  const size_t SpadBytes = (static_cast<size_t>(par->sampleN) + kWave - 1) / kWave * kWave * sizeof(uint32_t);
   for (int i = 0; i < n_blocks; i++) {
-    const BlockMeta &m = b->meta[i];
+    BlockMeta &m = b->meta[i];
     if (m.status != RC_OK) continue;
+    // The MT19937 streams of a batch are U[nodes x cols][samples padded to 64] (4 bytes each), one array for the batch's largest
+    // block: a block whose array would not fit a quarter of the device memory (288 GB: nodes x cols x samples > 1.8e10, e.g.
+    // 500 rows x 18 000 columns at n = 1000) gets a status of its own instead of failing the whole batch's allocation.
+    if (static_cast<double>(b->db[i].nnodes) * m.cols * static_cast<double>(SpadBytes) > static_cast<double>(ctx->totalMem) / 4.0) {
+      m.status = RC_ERR_UNSUPPORTED; b->db[i].status = RC_ERR_UNSUPPORTED;
+      b->errs[i] = "rows x columns x samples too large for the device: the block's random-number streams (4 bytes x tree nodes x columns x samples) exceed a quarter of its memory; split the block (breakmaf) or lower --num-samples";
+      continue;
+    }
     b->okBlocks.push_back(i);
     auto &cls = b->classes[m.N < ctx->genericMinRows ? m.NK : kGenericClass];
     if (!cls.empty() && b->meta[cls.front()].L != m.L) sameL = false;
@@ -1041,7 +1052,13 @@ int rc_stream_submit_bound(rc_stream *s, const rc_block *blocks, int32_t n_block
   trace("uploaded", b);
   if (r == RC_OK) r = batch_run_async(b);
   trace("queued", b);
-  if (r != RC_OK) { s->spare.push_back(b); return r; }
+  if (r != RC_OK) {
+    // the batch may hold a queued upload of its pinned blob (upload succeeded, run failed): let it finish before the batch is re-used
+    if (b->state == rc_batch::READY && b->evPrep.e) (void)hipEventSynchronize(b->evPrep);
+    b->state = rc_batch::EMPTY;
+    s->spare.push_back(b);
+    return r;
+  }
   s->inflight.push_back(b);
   return RC_OK;
 }
@@ -1311,7 +1328,12 @@ int rc_batch_backtrack(const rc_batch *b, int32_t blk, int32_t strand, int32_t o
   const int steps = (opt_i - (opt_b + 2)) / 3 + 1, NK = h.NK;
   const DevBlock &d = b->db[blk];
   const int L1 = h.L + 1, zww = d.zw_words;
-  const uint64_t *zw = reinterpret_cast<const uint64_t *>(b->hblob.as<uint8_t>() + d.off_zw) + static_cast<size_t>(strand) * L1 * zww;   // the batch keeps its pinned blob
+  // the z table of this strand is made on the device (k_prep_gaps): fetch it
+  std::vector<uint64_t> zwv(static_cast<size_t>(L1) * zww);
+  HIP_TRY(hipEventSynchronize(b->evPrep));
+  HIP_TRY(hipMemcpy(zwv.data(), b->dblob.as<uint8_t>() + d.off_zw + static_cast<size_t>(strand) * L1 * zww * sizeof(uint64_t),
+                    zwv.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  const uint64_t *zw = zwv.data();
   DevBuf d_out;
   HIP_TRY(d_out.ensure(sizeof(float) * NK * 3 * steps));
   hipStream_t st = c->aux;

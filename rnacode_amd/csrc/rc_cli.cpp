@@ -35,6 +35,7 @@ struct Block {
   std::vector<Row> rows;
   std::string tree;     // empty: none
   float kappa = 0.0f;
+  int index = 0;        // position in the input file (the --trees sidecar has one entry per block READ, before --limit drops any)
 };
 
 [[noreturn]] void die(const std::string &msg) {
@@ -241,6 +242,7 @@ int main(int argc, char **argv) {
     blocks = read_alignment(in);
   }
   const int nRead = static_cast<int>(blocks.size());
+  for (int i = 0; i < nRead; i++) blocks[i].index = i;
   if (!limit.empty()) {   // pruneAln (rnaz_utils.c:724-752, RNAcode.c:130-132): rows whose name starts with a listed string stay
     std::vector<std::string> keep;
     std::stringstream ss(limit);
@@ -249,7 +251,7 @@ int main(int argc, char **argv) {
     std::vector<Block> kept;
     for (Block &b : blocks) {
       Block nb;
-      nb.tree = b.tree; nb.kappa = b.kappa;
+      nb.tree = b.tree; nb.kappa = b.kappa; nb.index = b.index;
       for (const Row &r : b.rows)
         if (std::any_of(keep.begin(), keep.end(), [&](const std::string &x) { return r.name.compare(0, x.size(), x) == 0; })) nb.rows.push_back(r);
       if (nb.rows.empty()) {   // (the reference dereferences the missing first row here)
@@ -269,19 +271,22 @@ int main(int argc, char **argv) {
     }
     return 0;
   }
-  if (!trees.empty()) {   // one '<newick> TAB <kappa>' line per block, '-' for blocks without a tree
+  if (!trees.empty()) {   // one '<newick> TAB <kappa>' line per block of the input file, '-' for blocks without a tree
     std::ifstream in(trees);
     if (!in) die("Could not open " + trees);
+    std::vector<int> at(nRead, -1);   // input index -> kept block (--limit may have dropped some)
+    for (int i = 0; i < n; i++) at[blocks[i].index] = i;
     std::string line;
     int i = 0;
     while (std::getline(in, line)) {
       if (line.find_first_not_of(" \t\r\n") == std::string::npos) continue;
-      if (i >= n) { i++; continue; }
-      const size_t tab = line.find('\t');
-      if (tab != std::string::npos) { blocks[i].tree = line.substr(0, tab); blocks[i].kappa = static_cast<float>(std::atof(line.c_str() + tab + 1)); }
+      if (i < nRead && at[i] >= 0) {
+        const size_t tab = line.find('\t');
+        if (tab != std::string::npos) { blocks[at[i]].tree = line.substr(0, tab); blocks[at[i]].kappa = static_cast<float>(std::atof(line.c_str() + tab + 1)); }
+      }
       i++;
     }
-    if (i != n) die(std::to_string(n) + " alignment blocks but " + std::to_string(i) + " sidecar entries");
+    if (i != nRead) die(std::to_string(nRead) + " alignment blocks but " + std::to_string(i) + " sidecar entries");
   }
 
   if (!outfile.empty()) { list.out = std::fopen(outfile.c_str(), "w"); if (!list.out) die("Could not open " + outfile); }
@@ -315,8 +320,14 @@ int main(int argc, char **argv) {
   }
   rc_stream *stream = nullptr;
   if (rc_stream_create(ctx, &par, 3, &stream) != RC_OK) die(rc_last_error());
-  int cap = 1 << 14;   // per block: room for the widest block's Newick text
-  for (const Block &b : blocks) cap = std::max(cap, 96 * static_cast<int>(b.rows.size()));
+  // per block: room for the longest Newick text -- per tip its name, ':' and a "%f" length, per internal node two brackets, a comma
+  // and a length (a "%f" of a length <= 100 has at most 10 characters)
+  int cap = 64;
+  for (const Block &b : blocks) {
+    size_t need = 16;
+    for (const Row &r : b.rows) need += r.name.size() + 32;
+    cap = std::max(cap, static_cast<int>(need));
+  }
   std::vector<char> nwk;
   std::vector<float> kap;
   int next = 0, base = 0, fitted = 0;

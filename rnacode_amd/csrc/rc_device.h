@@ -4,7 +4,8 @@
 // background-model inputs) is packed by the host into one byte blob per batch; a DevBlock header
 // per block holds offsets into that blob.  The blob has two parts: the host-written part, which is
 // the only thing that crosses PCIe (one copy per batch), and a device-only arena behind it for the
-// tables the GPU derives itself (expected-score look-up tables, native sigma).
+// tables the GPU derives itself (gap-pattern tables, reverse-complement rows, expected-score look-up
+// tables, native sigma).
 // See DESIGN.md "Data layout in HBM".
 #pragma once
 #include <cstdint>
@@ -64,13 +65,14 @@ struct DevBlock {
   uint64_t off_nodes;    // NodeRec[nnodes]
   uint64_t off_qtip;     // u8[N padded to 16] node index of row r's tip (k_null reads words); meaningful for N <= 64 (fewer than 256 nodes)
   uint64_t off_qtip16;   // u16[N] the same for any N (k_null_generic)
-  uint64_t off_refcol;   // u16[2][L+1]  strand s: 0-based column of reference residue i (1..L) in that strand's alignment
-  uint64_t off_zw;       // u64[2][L+1][zw_words]  2 bits per k (bit 2((k-1)%32) of word (k-1)/32): 0 -> z=0, 1 -> z=+1, 2 -> z=-1
-  uint64_t off_mask;     // u32[2][L+1][ceil(NK/5)] 6-bit AND masks (field k%5 of word k/5) zeroing the codon fields where row k has '-'
-  uint64_t off_chars;    // u8[2][N][cols] native characters (strand 1 = reverse complement, rnaz_utils.c:316)
-  uint64_t off_zmask;    // u64[2][3][zm_words] bit j of (strand, frame): some sequence has z != 0 at codon site j
+  uint64_t off_chars;    // u8[N][cols] native characters, upper-cased (RNAcode.c:121-128)
   uint64_t off_models;   // ModelRec[2][N]
   // device-only arena
+  uint64_t off_chars_rev; // u8[N][cols] the reverse complement (rnaz_utils.c:316-348), k_prep_gaps
+  uint64_t off_refcol;   // u16[2][L+1]  strand s: 0-based column of reference residue i (1..L) in that strand's alignment (k_prep_gaps)
+  uint64_t off_zw;       // u64[2][L+1][zw_words]  2 bits per k (bit 2((k-1)%32) of word (k-1)/32): 0 -> z=0, 1 -> z=+1, 2 -> z=-1 (k_prep_gaps)
+  uint64_t off_mask;     // u32[2][L+1][ceil(NK/5)] 6-bit AND masks (field k%5 of word k/5) zeroing the codon fields where row k has '-' (k_prep_gaps)
+  uint64_t off_zmask;    // u64[2][3][zm_words] bit j of (strand, frame): some sequence has z != 0 at codon site j (k_prep_gaps)
   uint64_t off_lut;      // f32[2][NK][64] sigma value per code (k_prep_lut)
   uint64_t off_sigma;    // f32[2][NK][L+1] native sigma (k_native_sigma)
 };

@@ -7,8 +7,8 @@
 //   tip distances          treeSimulate.c:118-251
 //   Newick reader          seqgen/treefile.c:301-530
 //   HKY85 branch matrices  seqgen/nucmodels.c:87-131,187-196,302-362, model.c:116-119
-//   codon windows, z       misc.c:186-289 (getBlock, pos2col, getSeqLength)
-//   reverse complement     rnaz_utils.c:316-348
+// (the codon windows / z tables of misc.c:186-289 and the reverse-complement rows of rnaz_utils.c:316-348 are made on
+// the device from the uploaded characters: k_prep_gaps)
 // Float/double promotions follow the reference's C expressions exactly;
 // f32()/f64() below make every rounding step explicit.
 #include "rc_host.h"
@@ -27,11 +27,33 @@ static inline double f64(float x) { return static_cast<double>(x); }
 // ---------------------------------------------------------------------------------- Newick
 
 namespace {
+// "%lf" of a plain decimal (what PhyML's "%f" prints): digits [. digits], at most 15 significant digits and no exponent.  The value is
+// then m / 10^k with m < 2^53 and 10^k <= 10^22 both exact doubles, so the one IEEE division is the correctly rounded result, which is
+// what strtod returns.  Anything else (exponents, long mantissas, inf/nan, hex) goes to strtod.
+bool fast_decimal(const char *p, const char **end, double *out) {
+  static const double pow10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+  const char *q = p;
+  bool neg = false;
+  if (*q == '-' || *q == '+') { neg = (*q == '-'); q++; }
+  unsigned long long m = 0;
+  int digits = 0, frac = 0, any = 0;
+  for (; *q >= '0' && *q <= '9'; q++) { any = 1; if (m || *q != '0') { m = m * 10 + static_cast<unsigned>(*q - '0'); digits++; } if (digits > 15) return false; }
+  if (*q == '.') {
+    q++;
+    for (; *q >= '0' && *q <= '9'; q++) { any = 1; m = m * 10 + static_cast<unsigned>(*q - '0'); if (m) digits++; frac++; if (digits > 15 || frac > 22) return false; }
+  }
+  if (!any || *q == 'e' || *q == 'E' || *q == 'x' || *q == 'X' || *q == 'p' || *q == 'P') return false;
+  const double v = static_cast<double>(m) / pow10[frac];
+  *out = neg ? -v : v;
+  *end = q;
+  return true;
+}
+
 struct NwParser {
   const char *s;
   size_t pos = 0;
   Tree *t;
-  std::string err;
+  const char *err = nullptr;
   void ws() { while (s[pos] == ' ' || s[pos] == '\t' || s[pos] == '\n' || s[pos] == '\r') pos++; }
   int new_node(int parent) {
     int q = t->nnodes++;
@@ -64,23 +86,29 @@ struct NwParser {
       while (s[pos] && s[pos] != ':' && s[pos] != ',' && s[pos] != ')' && s[pos] != ';') pos++;  // label
     } else {
       q = new_node(parent);
-      std::string name;
-      while (s[pos] && s[pos] != ':' && s[pos] != ',' && s[pos] != ')' && name.size() < 256) {
+      const size_t at = t->namepool.size();
+      while (s[pos] && s[pos] != ':' && s[pos] != ',' && s[pos] != ')' && t->namepool.size() - at < 256) {
         char ch = s[pos++];
-        if (!(ch == ' ' || ch == '\t' || ch == '\n' || ch == '\r')) name.push_back(ch);
+        if (!(ch == ' ' || ch == '\t' || ch == '\n' || ch == '\r')) t->namepool.push_back(ch);
       }
-      if (name.empty()) { err = "empty tip label"; return false; }
-      t->tip[q] = static_cast<int>(t->tipname.size());
-      t->tipname.push_back(name);
+      if (t->namepool.size() == at) { err = "empty tip label"; return false; }
+      t->tip[q] = static_cast<int>(t->tipnode.size());
+      t->nameOff.push_back(static_cast<int>(at));
+      t->nameLen.push_back(static_cast<int>(t->namepool.size() - at));
       t->tipnode.push_back(q);
     }
     ws();
     if (s[pos] == ':') {
       pos++;
-      char *end = nullptr;
-      double len = std::strtod(s + pos, &end);
-      if (end == s + pos) { err = "unable to read branch length"; return false; }
-      pos = static_cast<size_t>(end - s);
+      double len = 0.0;
+      const char *endc = nullptr;
+      if (fast_decimal(s + pos, &endc, &len)) pos = static_cast<size_t>(endc - s);
+      else {
+        char *end = nullptr;
+        len = std::strtod(s + pos, &end);
+        if (end == s + pos) { err = "unable to read branch length"; return false; }
+        pos = static_cast<size_t>(end - s);
+      }
       t->length[q] = len;
       ws();
       if (s[pos] == '[') { while (s[pos] && s[pos] != ']') pos++; if (s[pos]) pos++; }
@@ -91,10 +119,20 @@ struct NwParser {
 };
 }  // namespace
 
+void Tree::clear() {
+  nnodes = 0; rooted = false;
+  parent.clear(); length.clear(); tip.clear(); namepool.clear(); nameOff.clear(); nameLen.clear(); tipnode.clear();
+}
+
+bool Tree::tip_is(int k, const char *name) const {
+  const size_t n = std::strlen(name);
+  return static_cast<size_t>(nameLen[k]) == n && std::memcmp(namepool.data() + nameOff[k], name, n) == 0;
+}
+
 bool parse_newick(const char *s, Tree &t, std::string &err) {
-  t = Tree();
+  t.clear();   // keeps the capacity: a thread that prepares many blocks allocates nothing after the first ones
   if (!s) { err = "no tree"; return false; }
-  NwParser p{s, 0, &t, {}};
+  NwParser p{s, 0, &t, nullptr};
   while (s[p.pos] && s[p.pos] != '(') p.pos++;
   if (!s[p.pos]) { err = "no tree found"; return false; }
   int root;
@@ -108,6 +146,9 @@ bool parse_newick(const char *s, Tree &t, std::string &err) {
 // countFreqsMono (score.c:255-280): all rows, '-' skipped, unknown characters count as A.  One pass over the
 // forward rows gives both strands: the reverse complement (rnaz_utils.c:316-348) maps T,U->A, A->T, C<->G and
 // leaves everything else -- which the count files under A -- unchanged.
+// The reference's counters are floats incremented by one: such a counter stops at 2^24 (16777216 + 1 rounds back to
+// 16777216), and so does its float total.  Integer counts clamped to 2^24 are the same numbers (a block reaches that only
+// beyond 16.7 million residues; RC_MAX_ROWS x RC_MAX_COLS allows 32.7 million).
 static void mono_freqs_both(const uint8_t *chars, size_t nchars, float fwd[4], float rev[4]) {
   unsigned long cnt[256];
   std::memset(cnt, 0, sizeof cnt);
@@ -116,22 +157,22 @@ static void mono_freqs_both(const uint8_t *chars, size_t nchars, float fwd[4], f
   const unsigned long c = cnt['C'], g = cnt['G'], t = cnt['T'] + cnt['U'], a = cnt['A'];
   const unsigned long other = total - a - c - g - t;       // N and the rest: index 0 on both strands
   const unsigned long f[4] = {a + other, c, g, t}, r[4] = {t + other, g, c, a};
-  // the reference increments float counters; counts stay far below 2^24 so they are exact
+  const unsigned long sat = 1ul << 24;
+  const float totalf = static_cast<float>(std::min(total, sat));
   for (int i = 0; i < 4; i++) {
-    fwd[i] = static_cast<float>(f[i]) / static_cast<float>(total);
-    rev[i] = static_cast<float>(r[i]) / static_cast<float>(total);
+    fwd[i] = static_cast<float>(std::min(f[i], sat)) / totalf;
+    rev[i] = static_cast<float>(std::min(r[i], sat)) / totalf;
   }
 }
 
 // patristic distance row 0 <-> every row, float accumulator += double length (treeSimulate.c:164-182)
-static bool tip_distances(const Tree &t, const std::vector<int> &rowtip, std::vector<float> &dist) {
-  const int N = static_cast<int>(rowtip.size());
+static void tip_distances(const Tree &t, const int *rowtip, int N, std::vector<float> &dist, std::vector<char> &mark) {
   dist.assign(N, 0.0f);
-  std::vector<char> mark(t.nnodes);
+  mark.assign(t.nnodes, 0);
+  const int a = t.tipnode[rowtip[0]];
+  for (int x = a;; x = t.parent[x]) { mark[x] = 1; if (x == 0) break; }   // the path from row 0's tip to the root, once
   for (int k = 1; k < N; k++) {
-    std::fill(mark.begin(), mark.end(), 0);
-    int a = t.tipnode[rowtip[0]], b = t.tipnode[rowtip[k]];
-    for (int x = a;; x = t.parent[x]) { mark[x] = 1; if (x == 0) break; }
+    const int b = t.tipnode[rowtip[k]];
     int lca = b;
     while (!mark[lca]) lca = t.parent[lca];
     float sum = 0.0f;
@@ -139,7 +180,6 @@ static bool tip_distances(const Tree &t, const std::vector<int> &rowtip, std::ve
     for (int x = b; x != lca; x = t.parent[x]) sum = f32(f64(sum) + t.length[x]);
     dist[k] = sum;
   }
-  return true;
 }
 
 // probHKY (score.c:204-244) for all 16 entries at once
@@ -312,52 +352,6 @@ void PairTable::build(const CodeTables &ct) {
   }
 }
 
-// ---------------------------------------------------------------------------------- gap pattern
-
-// getBlock (misc.c:186-246) reduced to what depends on the gap pattern only: z for every
-// reference position i >= 3 and sequence k, and which of the three codon columns are '-' in k.
-// rows: [N][cols] characters of one strand.  gp is scratch: [N][cols+1] prefix counts of '-'.
-static void gap_tables(const uint8_t *rows, int N, int cols, int L, int zwWords, int ncw, uint16_t *refcol, uint64_t *zw,
-                       uint32_t *maskw, std::vector<uint16_t> &gp) {
-  const int NK = N - 1, L1 = L + 1;
-  const uint8_t *r0 = rows;
-  refcol[0] = 0;
-  for (int c = 0, p = 0; c < cols; c++)
-    if (r0[c] != '-') { p++; if (p <= L) refcol[p] = static_cast<uint16_t>(c); }
-  // scratch: [0, cols]: prefix counts of '-' of the current row; then per reference position the window's
-  // bounds [lo, hi) as prefix indices, the reference's own gap count in it, and the row's "not a gap" flag there
-  gp.resize(static_cast<size_t>(cols + 1) + 4 * static_cast<size_t>(L1));
-  uint16_t *g = gp.data(), *lo = g + cols + 1, *hi = lo + L1, *g0 = hi + L1, *ng = g0 + L1;
-  auto prefix = [&](const uint8_t *row) {
-    uint16_t acc = 0;
-    g[0] = 0;
-    for (int c = 0; c < cols; c++) { acc = static_cast<uint16_t>(acc + (row[c] == '-')); g[c + 1] = acc; }
-  };
-  prefix(r0);
-  for (int i = 3; i <= L; i++) {
-    lo[i] = static_cast<uint16_t>((i > 3) ? refcol[i - 3] + 1 : 0);
-    hi[i] = static_cast<uint16_t>(refcol[i] + 1);
-    g0[i] = static_cast<uint16_t>(g[hi[i]] - g[lo[i]]);
-  }
-  std::memset(zw, 0, sizeof(uint64_t) * L1 * zwWords);
-  std::memset(maskw, 0, sizeof(uint32_t) * L1 * ncw);
-  for (int k = 0; k < NK; k++) {
-    const uint8_t *rk = rows + static_cast<size_t>(k + 1) * cols;
-    prefix(rk);
-    for (int i = 1; i <= L; i++) ng[i] = rk[refcol[i]] != '-';
-    uint64_t *zk = zw + (k >> 5);
-    uint32_t *mk = maskw + k / 5;
-    const int zs = 2 * (k & 31), ms = 6 * (k % 5);
-    for (int i = 3; i <= L; i++) {
-      const int gk = g[hi[i]] - g[lo[i]];
-      const int diff = std::abs(gk - static_cast<int>(g0[i])) % 3;        // misc.c:230-244: 0 -> z=0, 1 -> z=+1, 2 -> z=-1
-      zk[static_cast<size_t>(i) * zwWords] |= static_cast<uint64_t>(diff) << zs;
-      const uint32_t m = ng[i - 2] * 0x30u | ng[i - 1] * 0x0Cu | ng[i] * 0x03u;
-      mk[static_cast<size_t>(i) * ncw] |= m << ms;
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------- block
 
 // Every DP value is a float sum of table entries and gap parameters.  If each of them is 0 or
@@ -383,24 +377,25 @@ static inline size_t al16(size_t x) { return (x + 15) & ~static_cast<size_t>(15)
 namespace {
 // section sizes of one block in the two blob parts
 struct Sections {
-  size_t nodes, qtip, qtip16, refcol, zw, mask, chars, zmask, models, hostTotal;
-  size_t lut, sigma, devTotal;
+  size_t nodes, qtip, qtip16, chars, models, hostTotal;
+  size_t charsRev, refcol, zw, mask, zmask, lut, sigma, devTotal;
   Sections(int N, int cols, int L, int nnodes) {
     const size_t NK = static_cast<size_t>(N) - 1, L1 = static_cast<size_t>(L) + 1, ncw = (NK + 4) / 5, zww = (NK + 31) / 32;
     const size_t zmw = (static_cast<size_t>(L) / 3 + 63) / 64;
     nodes = al16(static_cast<size_t>(nnodes) * sizeof(NodeRec));
     qtip = al16(static_cast<size_t>(N));
     qtip16 = al16(2 * static_cast<size_t>(N));
+    chars = al16(static_cast<size_t>(N) * cols);
+    models = al16(2 * static_cast<size_t>(N) * sizeof(ModelRec));
+    hostTotal = nodes + qtip + qtip16 + chars + models;
+    charsRev = al16(static_cast<size_t>(N) * cols);
     refcol = al16(2 * L1 * 2);
     zw = al16(2 * L1 * zww * 8);
     mask = al16(2 * L1 * ncw * 4);
-    chars = al16(2 * static_cast<size_t>(N) * cols);
     zmask = al16(6 * zmw * 8);
-    models = al16(2 * static_cast<size_t>(N) * sizeof(ModelRec));
-    hostTotal = nodes + qtip + qtip16 + refcol + zw + mask + chars + zmask + models;
     lut = al16(2 * NK * kLutSize * 4);
     sigma = al16(2 * NK * L1 * 4);
-    devTotal = lut + sigma;
+    devTotal = charsRev + refcol + zw + mask + zmask + lut + sigma;
   }
 };
 }  // namespace
@@ -431,26 +426,28 @@ int prepare_block(const rc_block &in, const rc_params &par, const PairTable &pt,
   if (N > kMaxRows) { err = "more than RC_MAX_ROWS rows"; return done(RC_ERR_UNSUPPORTED); }
   if (cols > RC_MAX_COLS) { err = "more than 65535 columns"; return done(RC_ERR_UNSUPPORTED); }
 
-  Tree t;
+  // per-thread scratch: a thread that prepares many blocks allocates nothing after the first ones
+  static thread_local Tree t;
+  static thread_local std::vector<int> rowtipv;
+  static thread_local std::vector<char> used, mark;
+  static thread_local std::vector<float> dist;
   if (!parse_newick(in.newick, t, err)) return done(RC_ERR_ARG);
-  if (static_cast<int>(t.tipname.size()) != N) { err = "tree and alignment differ in the number of sequences"; return done(RC_ERR_ARG); }
+  if (t.ntips() != N) { err = "tree and alignment differ in the number of sequences"; return done(RC_ERR_ARG); }
   if (t.nnodes > kMaxNodes) { err = "tree too large"; return done(RC_ERR_UNSUPPORTED); }
-  std::vector<int> rowtipv(N, -1);
+  rowtipv.assign(N, -1);
   int *rowtip = rowtipv.data();
-  {
-    std::vector<char> used(N, 0);
-    for (int r = 0; r < N; r++) {
-      rowtip[r] = -1;
-      if (!in.names[r]) { err = "row without a name"; return done(RC_ERR_ARG); }
-      for (int k = 0; k < N; k++) if (t.tipname[k] == in.names[r]) { rowtip[r] = k; break; }
-      if (rowtip[r] < 0) { err = std::string("row name not found in tree: ") + in.names[r]; return done(RC_ERR_ARG); }
-      if (used[rowtip[r]]) { err = "duplicate row names"; return done(RC_ERR_ARG); }
-      used[rowtip[r]] = true;
-    }
+  used.assign(N, 0);
+  for (int r = 0; r < N; r++) {
+    if (!in.names[r]) { err = "row without a name"; return done(RC_ERR_ARG); }
+    // tips usually come in an order related to the rows: start looking at r
+    for (int x = 0; x < N; x++) { const int k = (r + x) % N; if (t.tip_is(k, in.names[r])) { rowtip[r] = k; break; } }
+    if (rowtip[r] < 0) { err = std::string("row name not found in tree: ") + in.names[r]; return done(RC_ERR_ARG); }
+    if (used[rowtip[r]]) { err = "duplicate row names"; return done(RC_ERR_ARG); }
+    used[rowtip[r]] = 1;
   }
 
   // this block's share of the blob
-  const int NK = N - 1, L1 = L + 1, ncw = (NK + 4) / 5, zww = (NK + 31) / 32, zmw = (L / 3 + 63) / 64;
+  const int NK = N - 1, zww = (NK + 31) / 32, zmw = (L / 3 + 63) / 64;
   const Sections sec(N, cols, L, t.nnodes);
   const size_t hoff = arena.hostUsed.fetch_add(sec.hostTotal), doff = arena.devUsed.fetch_add(sec.devTotal);
   if (hoff + sec.hostTotal > arena.hostCap || doff + sec.devTotal > arena.devCap) { err = "internal: blob arena too small"; return done(RC_ERR_ARG); }
@@ -459,14 +456,16 @@ int prepare_block(const rc_block &in, const rc_params &par, const PairTable &pt,
   d.off_nodes = o; o += sec.nodes;
   d.off_qtip = o; o += sec.qtip;
   d.off_qtip16 = o; o += sec.qtip16;
+  d.off_chars = o; o += sec.chars;
+  d.off_models = o; o += sec.models;
+  o = arena.hostCap + doff;
+  d.off_chars_rev = o; o += sec.charsRev;
   d.off_refcol = o; o += sec.refcol;
   d.off_zw = o; o += sec.zw;
   d.off_mask = o; o += sec.mask;
-  d.off_chars = o; o += sec.chars;
   d.off_zmask = o; o += sec.zmask;
-  d.off_models = o; o += sec.models;
-  d.off_lut = arena.hostCap + doff;
-  d.off_sigma = d.off_lut + sec.lut;
+  d.off_lut = o; o += sec.lut;
+  d.off_sigma = o;
 
   d.N = N; d.NK = NK; d.cols = cols; d.L = L;
   d.nnodes = t.nnodes;
@@ -477,26 +476,21 @@ int prepare_block(const rc_block &in, const rc_params &par, const PairTable &pt,
   d.code_zero = pt.code_zero; d.code_stop0 = pt.code_stop0; d.code_stopk = pt.code_stopk;
   d.zw_words = zww; d.zm_words = zmw;
 
-  // characters: upper-cased forward rows (RNAcode.c:121-128), then the reverse complement
-  // (rnaz_utils.c:316-348): T,U->A  A->T  C<->G, everything else unchanged
+  // characters: the upper-cased rows (RNAcode.c:121-128), counted on the way for countFreqsMono.  The reverse complement
+  // (rnaz_utils.c:316-348) and the gap-pattern tables of both strands (misc.c:186-289) are made from these on the device (k_prep_gaps).
   uint8_t *chars = base + d.off_chars;
   static const struct Luts {
-    uint8_t up[256], rc[256];
-    Luts() {
-      for (int c = 0; c < 256; c++) { up[c] = static_cast<uint8_t>((c >= 'a' && c <= 'z') ? c - 32 : c); rc[c] = static_cast<uint8_t>(c); }
-      rc['T'] = rc['U'] = 'A'; rc['A'] = 'T'; rc['C'] = 'G'; rc['G'] = 'C';
-    }
+    uint8_t up[256];
+    Luts() { for (int c = 0; c < 256; c++) up[c] = static_cast<uint8_t>((c >= 'a' && c <= 'z') ? c - 32 : c); }
   } luts;
   for (int r = 0; r < N; r++) {
     uint8_t *dst = chars + static_cast<size_t>(r) * cols;
     const uint8_t *src = reinterpret_cast<const uint8_t *>(in.rows[r]);
-    uint8_t *rv = chars + (static_cast<size_t>(N) + r) * cols;
-    for (int c = 0; c < cols; c++) { const uint8_t u = luts.up[src[c]]; dst[c] = u; rv[cols - 1 - c] = luts.rc[u]; }
+    for (int c = 0; c < cols; c++) dst[c] = luts.up[src[c]];
   }
 
   // getModels' inputs for both strands (RNAcode.c:164-165); scores and probs follow on the device
-  std::vector<float> dist;
-  tip_distances(t, rowtipv, dist);
+  tip_distances(t, rowtip, N, dist, mark);
   float freqs[2][4];
   mono_freqs_both(chars, static_cast<size_t>(N) * cols, freqs[0], freqs[1]);
   ModelRec *models = reinterpret_cast<ModelRec *>(base + d.off_models);
@@ -509,28 +503,6 @@ int prepare_block(const rc_block &in, const rc_params &par, const PairTable &pt,
       std::memcpy(m.freqs, freqs[s], sizeof m.freqs);
       hky_probs(m.dist, m.freqs, m.kappa, m.P);
     }
-
-  // gap pattern of both strands
-  {
-    static thread_local std::vector<uint16_t> gp;
-    uint16_t *refcol = reinterpret_cast<uint16_t *>(base + d.off_refcol);
-    uint64_t *zw = reinterpret_cast<uint64_t *>(base + d.off_zw);
-    uint32_t *maskw = reinterpret_cast<uint32_t *>(base + d.off_mask);
-    uint64_t *zm = reinterpret_cast<uint64_t *>(base + d.off_zmask);
-    std::memset(zm, 0, sizeof(uint64_t) * 6 * zmw);
-    for (int s = 0; s < 2; s++) {
-      uint64_t *zws = zw + static_cast<size_t>(s) * L1 * zww;
-      gap_tables(chars + static_cast<size_t>(s) * N * cols, N, cols, L, zww, ncw, refcol + static_cast<size_t>(s) * L1, zws,
-                 maskw + static_cast<size_t>(s) * L1 * ncw, gp);
-      for (int f = 0; f < 3; f++)
-        for (int j = 0; j < (L - f) / 3; j++) {
-          const uint64_t *z = zws + static_cast<size_t>(3 * j + 3 + f) * zww;
-          uint64_t any = 0;
-          for (int w = 0; w < zww; w++) any |= z[w];
-          if (any) zm[static_cast<size_t>(s * 3 + f) * zmw + (j >> 6)] |= 1ull << (j & 63);
-        }
-    }
-  }
 
   // simulation tables: null alignments use the forward frequencies and kappa (score.c:996-998)
   SeqGenHky hky(freqs[0], in.kappa);

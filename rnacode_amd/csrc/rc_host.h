@@ -18,8 +18,12 @@ struct Tree {
   std::vector<int> parent;          // parent[q] < q, parent[0] = 0
   std::vector<double> length;       // branch to parent as read by "%lf" (treefile.c:431)
   std::vector<int> tip;             // tip number in order of appearance, -1 for internal
-  std::vector<std::string> tipname; // by tip number
+  std::vector<char> namepool;       // tip labels back to back (white space removed, as the reference's reader does)
+  std::vector<int> nameOff, nameLen;   // by tip number: where its label sits in namepool
   std::vector<int> tipnode;         // node index by tip number
+  int ntips() const { return static_cast<int>(tipnode.size()); }
+  bool tip_is(int k, const char *name) const;
+  void clear();                     // empty, capacity kept
 };
 bool parse_newick(const char *s, Tree &t, std::string &err);
 

@@ -3,6 +3,7 @@
 //   k_mt_stream       MT19937 output streams, one wavefront per seed          (seqgen/twister.c:73-152)
 //   k_prep_models     calculateBG's two 4096-term accumulations per (block, strand, row)  (score.c:107-193)
 //   k_prep_lut        sigma value of every codon-pair code per (block, strand, k)         (score.c:406-425)
+//   k_prep_gaps       reverse-complement rows, codon windows and z of every reference position    (rnaz_utils.c:316-348, misc.c:186-289)
 //   k_null<NK>        simulate -> codon-pair codes -> 3-state DP -> HSS scan -> per-sample maximum,
 //                     one LANE per null sample, 64 samples of one block per wavefront
 //                                                                             (score.c:976-1064 loop body)
@@ -195,8 +196,87 @@ __global__ __launch_bounds__(64) void k_prep_lut(PrepArgs A) {   // one wavefron
   }
 }
 
+
+// The gap pattern of a block, both strands, from its uploaded characters: what getBlock / pos2col (misc.c:186-269) derive per
+// reference position i >= 3 and sequence k, reduced to what the DP needs -- z (misc.c:230-244) and which of the codon's three
+// columns hold '-' in row k -- plus the reverse-complement rows themselves (rnaz_utils.c:316-348) for k_native_sigma.
+// One wavefront per (block, strand), no LDS (it runs beside k_null).  Strand 1 is read through the mirrored column index: a
+// reverse complement keeps '-' where it was.  The window of position i is the columns (col(i-3), col(i)] (from column 0 for
+// i == 3): exactly three reference residues, so the reference row's own gap count there is the window's length minus 3.
+__global__ __launch_bounds__(64) void k_prep_gaps(PrepArgs A) {
+  const int bi = A.blocks[blockIdx.x >> 1];
+  const int s = blockIdx.x & 1;
+  const int lane = threadIdx.x;
+  const DevBlock *__restrict__ db = A.dblocks + bi;
+  const int N = db->N, NK = db->NK, cols = db->cols, L = db->L, L1 = L + 1;
+  const int zww = db->zw_words, ncw = (NK + 4) / 5, zmw = db->zm_words;
+  const uint8_t *__restrict__ fwd = A.blob + db->off_chars;
+  if (s == 1) {   // T,U -> A  A -> T  C <-> G, everything else unchanged; columns reversed
+    uint8_t *rev = A.blob + db->off_chars_rev;
+    for (int r = 0; r < N; r++)
+      for (int c = lane; c < cols; c += kWave) {
+        const uint8_t ch = fwd[static_cast<size_t>(r) * cols + c];
+        const uint8_t o = (ch == 'T' || ch == 'U') ? 'A' : ch == 'A' ? 'T' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch;
+        rev[static_cast<size_t>(r) * cols + (cols - 1 - c)] = o;
+      }
+  }
+  auto is_gap = [&](int r, int c) { return fwd[static_cast<size_t>(r) * cols + (s ? cols - 1 - c : c)] == '-'; };
+  uint16_t *refcol = reinterpret_cast<uint16_t *>(A.blob + db->off_refcol) + static_cast<size_t>(s) * L1;
+  unsigned long long *zw = reinterpret_cast<unsigned long long *>(A.blob + db->off_zw) + static_cast<size_t>(s) * L1 * zww;
+  uint32_t *maskw = reinterpret_cast<uint32_t *>(A.blob + db->off_mask) + static_cast<size_t>(s) * L1 * ncw;
+  unsigned long long *zm = reinterpret_cast<unsigned long long *>(A.blob + db->off_zmask) + static_cast<size_t>(s) * 3 * zmw;
+  // refcol[p] = column of the p-th reference residue (1-based): an ordered compaction of row 0's non-gap columns
+  if (lane == 0) refcol[0] = 0;
+  int seen = 0;
+  for (int c0 = 0; c0 < cols; c0 += kWave) {
+    const int c = c0 + lane;
+    const bool res = c < cols && !is_gap(0, c);
+    const unsigned long long m = __ballot(res);
+    const int p = seen + __builtin_popcountll(m & ((1ull << lane) - 1ull)) + 1;
+    if (res && p <= L) refcol[p] = static_cast<uint16_t>(c);
+    seen += __builtin_popcountll(m);
+  }
+  // positions 0..2 have no codon ending there: all-zero entries
+  if (lane < 3 && lane <= L) {
+    for (int w = 0; w < zww; w++) zw[static_cast<size_t>(lane) * zww + w] = 0ull;
+    for (int w = 0; w < ncw; w++) maskw[static_cast<size_t>(lane) * ncw + w] = 0u;
+  }
+  __syncthreads();   // one wavefront: makes refcol, written by other lanes, visible
+  for (int f = 0; f < 3; f++) {
+    const int sites = (L - f) / 3;
+    for (int j0 = 0; j0 < zmw * kWave; j0 += kWave) {
+      const int j = j0 + lane;
+      const bool active = j < sites;
+      bool any = false;
+      if (active) {
+        const int i = 3 * j + 3 + f;
+        const int c1 = refcol[i - 2], c2 = refcol[i - 1], c3 = refcol[i];
+        const int lo = (i > 3) ? refcol[i - 3] + 1 : 0, hi = c3 + 1;
+        const int g0 = (hi - lo) - 3;
+        unsigned long long zword = 0ull;
+        uint32_t mword = 0u;
+        for (int k = 0; k < NK; k++) {
+          int gk = 0;
+          for (int c = lo; c < hi; c++) gk += is_gap(k + 1, c) ? 1 : 0;
+          int diff = gk - g0;
+          diff = (diff < 0 ? -diff : diff) % 3;                 // misc.c:230-244: 0 -> z = 0, 1 -> z = +1, 2 -> z = -1
+          any |= diff != 0;
+          zword |= static_cast<unsigned long long>(diff) << (2 * (k & 31));
+          const uint32_t m = (is_gap(k + 1, c1) ? 0u : 0x30u) | (is_gap(k + 1, c2) ? 0u : 0x0Cu) | (is_gap(k + 1, c3) ? 0u : 0x03u);
+          mword |= m << (6 * (k % 5));
+          if ((k & 31) == 31 || k == NK - 1) { zw[static_cast<size_t>(i) * zww + (k >> 5)] = zword; zword = 0ull; }
+          if (k % 5 == 4 || k == NK - 1) { maskw[static_cast<size_t>(i) * ncw + k / 5] = mword; mword = 0u; }
+        }
+      }
+      const unsigned long long bits = __ballot(active && any);
+      if (lane == 0) zm[static_cast<size_t>(f) * zmw + (j0 >> 6)] = bits;
+    }
+  }
+}
+
 void launch_prep(const PrepArgs &a, hipStream_t stream) {
   if (a.nBlocks <= 0) return;
+  hipLaunchKernelGGL(k_prep_gaps, dim3(2 * a.nBlocks), dim3(kWave), 0, stream, a);
   hipLaunchKernelGGL(k_prep_models, dim3((a.nModels + kWave - 1) / kWave), dim3(kWave), 0, stream, a);
   hipLaunchKernelGGL(k_prep_lut, dim3(a.nBlocks), dim3(kWave), 0, stream, a);
 }
@@ -207,10 +287,10 @@ void launch_prep(const PrepArgs &a, hipStream_t stream) {
 __global__ __launch_bounds__(256) void k_native_sigma(NativeArgs A) {
   const int bi = A.blocks[blockIdx.x];
   const DevBlock *__restrict__ db = A.dblocks + bi;
-  const int N = db->N, NK = db->NK, cols = db->cols, L = db->L, L1 = L + 1;
+  const int NK = db->NK, cols = db->cols, L = db->L, L1 = L + 1;
   uint8_t *blob = A.blob;
   const uint16_t *refcol = reinterpret_cast<const uint16_t *>(blob + db->off_refcol);
-  const uint8_t *chars = blob + db->off_chars;
+  const uint8_t *chars = blob + db->off_chars, *charsRev = blob + db->off_chars_rev;
   const float *lut = reinterpret_cast<const float *>(blob + db->off_lut);
   float *sigma = reinterpret_cast<float *>(blob + db->off_sigma);
   const int total = 2 * NK * L1;
@@ -218,8 +298,8 @@ __global__ __launch_bounds__(256) void k_native_sigma(NativeArgs A) {
     const int i = idx % L1, k = (idx / L1) % NK, s = idx / (L1 * NK);
     float sg = 0.0f;
     if (i >= 3) {
-      const uint8_t *r0 = chars + static_cast<size_t>(s * N + 0) * cols;
-      const uint8_t *rk = chars + static_cast<size_t>(s * N + k + 1) * cols;
+      const uint8_t *r0 = (s ? charsRev : chars);
+      const uint8_t *rk = (s ? charsRev : chars) + static_cast<size_t>(k + 1) * cols;
       const uint16_t *rc = refcol + s * L1;
       uint32_t a = 0, b = 0;
       bool anyN = false;

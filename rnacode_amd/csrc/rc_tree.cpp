@@ -107,8 +107,10 @@ bool fit_tree(const std::vector<std::string> &rows, const std::vector<std::strin
   f.allocate(2 * ps.N - 2);
   SerialExec ex;
   const double l = treefit::fit(f.k, ex);
-  if (std::getenv("RC_TREE_DEBUG")) {
-    std::fprintf(stderr, "freqs %.10f %.10f %.10f %.10f\n", f.k.pi[0], f.k.pi[1], f.k.pi[2], f.k.pi[3]);
+  if (std::getenv("RC_TREE_DEBUG")) {   // every bit of the result (A/B runs of the estimator: tools/tree_bits.py)
+    std::fprintf(stderr, "freqs %.17g %.17g %.17g %.17g lnl %.17g kappa %.17g len", f.k.pi[0], f.k.pi[1], f.k.pi[2], f.k.pi[3], l, f.k.mod.kappa);
+    for (int v = 0; v < f.k.nn; v++) std::fprintf(stderr, " %.17g", f.k.len[v]);
+    std::fprintf(stderr, "\n");
   }
   newick = newick_of(ps.N, f.k.root, f.k.nchild, f.k.child, f.k.len, names);
   kappa = static_cast<float>(f.k.mod.kappa);
@@ -123,7 +125,7 @@ bool tree_lnl(const std::vector<std::string> &rows, const std::vector<std::strin
   Tree t;
   if (!parse_newick(newick, t, err)) return false;
   const int N = static_cast<int>(rows.size());
-  if (static_cast<int>(t.tipname.size()) != N) { err = "tree and alignment differ in the number of sequences"; return false; }
+  if (t.ntips() != N) { err = "tree and alignment differ in the number of sequences"; return false; }
   PatternSet ps;
   if (!compress_patterns(rows, ps, err)) return false;
   if (t.nnodes > treefit::kMaxNodes) { err = "tree too large"; return false; }
@@ -139,7 +141,7 @@ bool tree_lnl(const std::vector<std::string> &rows, const std::vector<std::strin
   for (int q = 0; q < t.nnodes; q++) {
     if (t.tip[q] >= 0) {
       int r = -1;
-      for (int i = 0; i < N; i++) if (names[i] == t.tipname[t.tip[q]]) r = i;
+      for (int i = 0; i < N; i++) if (t.tip_is(t.tip[q], names[i].c_str())) r = i;
       if (r < 0) { err = "tip not found among the row names"; return false; }
       id[q] = r;
     } else id[q] = next++;
@@ -155,6 +157,7 @@ bool tree_lnl(const std::vector<std::string> &rows, const std::vector<std::strin
   }
   for (int q = 0, n = 0; q < t.nnodes; q++) f.preorder[n++] = id[q];   // parse order is a pre-order
   treefit::tip_partials(f.k, ex);
+  treefit::invalidate_all(f.k);
   *lnl_out = treefit::total_lnl(f.k, ex);
   return true;
 }

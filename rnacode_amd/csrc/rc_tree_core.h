@@ -56,8 +56,10 @@ struct Hky {
   }
   RC_HD void probs(double t, double P[4][4]) const {
     const double e1 = exp(-beta * t);
+    // purines (A, G) share one exponential, pyrimidines (C, T) the other: grp[0] == grp[2], grp[1] == grp[3]
+    const double eR = exp(-beta * t * (1.0 + grp[0] * (kappa - 1.0))), eY = exp(-beta * t * (1.0 + grp[1] * (kappa - 1.0)));
     for (int i = 0; i < 4; i++) {
-      const double e2 = exp(-beta * t * (1.0 + grp[i] * (kappa - 1.0)));
+      const double e2 = (i & 1) ? eY : eR;
       for (int j = 0; j < 4; j++) {
         if (i == j) P[i][j] = pi[j] + pi[j] * (1.0 / grp[j] - 1.0) * e1 + (grp[j] - pi[j]) / grp[j] * e2;
         else if (((i ^ j) & 1) == 0) P[i][j] = pi[j] + pi[j] * (1.0 / grp[j] - 1.0) * e1 - pi[j] / grp[j] * e2;
@@ -121,6 +123,12 @@ struct Work {
   double *len;           // [nn]
   double *D, *V;         // [N][N]
   double *down, *msg, *up;   // [nn][4][P]
+  // which of those columns are current (bit v of word v / 64), see refresh_down / refresh_up: a branch-length change makes only
+  // part of them stale, and recomputing exactly the stale ones gives the same numbers as recomputing everything
+  uint64_t okDn[(kMaxNodes + 63) / 64], okMs[(kMaxNodes + 63) / 64], okUp[(kMaxNodes + 63) / 64];
+  RC_HD static bool bit(const uint64_t *m, int v) { return (m[v >> 6] >> (v & 63)) & 1ull; }
+  RC_HD static void set_bit(uint64_t *m, int v) { m[v >> 6] |= 1ull << (v & 63); }
+  RC_HD static void clear_bit(uint64_t *m, int v) { m[v >> 6] &= ~(1ull << (v & 63)); }
   RC_HD double &dn(int v, int s, int p) const { return down[(static_cast<size_t>(v) * 4 + s) * P + p]; }
   RC_HD double &ms(int v, int s, int p) const { return msg[(static_cast<size_t>(v) * 4 + s) * P + p]; }
   RC_HD double &upp(int v, int s, int p) const { return up[(static_cast<size_t>(v) * 4 + s) * P + p]; }
@@ -242,31 +250,65 @@ RC_HD void tip_partials(Work &k, Exec &ex) {
       for (int s = 0; s < 4; s++) k.dn(t, s, p) = (k.mask[static_cast<size_t>(t) * k.P + p] >> s & 1) ? 1.0 : 0.0;
 }
 
-// conditional likelihoods of the subtree below each node (down), their images across the node's
-// branch (msg), and the rest of the tree as seen from the top of each node's branch (up, excluding pi)
+// Conditional likelihoods of the subtree below each node (down), their images across the node's branch (msg), and the rest of
+// the tree as seen from the top of each node's branch (up, excluding pi).  What depends on what:
+//   down(v), msg(v): the branches strictly below v (msg(v) also v's own)
+//   up(v):           every branch outside v's subtree except v's own
+// so after branch v changed, msg(v), down/msg of v's ancestors and up of every node that is neither v nor an ancestor of v are
+// stale; after the model changed everything is.
+RC_HD inline void invalidate_all(Work &k) {
+  for (int x = 0; x < (kMaxNodes + 63) / 64; x++) k.okDn[x] = k.okMs[x] = k.okUp[x] = 0;
+  for (int t = 0; t < k.N; t++) Work::set_bit(k.okDn, t);   // tip columns are data (tip_partials)
+}
+RC_HD inline void branch_changed(Work &k, int v) {
+  uint64_t keep[(kMaxNodes + 63) / 64];
+  for (int x = 0; x < (kMaxNodes + 63) / 64; x++) keep[x] = 0;
+  Work::set_bit(keep, v);
+  Work::clear_bit(k.okMs, v);
+  for (int a = k.parent[v];; a = k.parent[a]) {
+    Work::set_bit(keep, a);
+    Work::clear_bit(k.okDn, a);
+    Work::clear_bit(k.okMs, a);
+    if (a == k.root) break;
+  }
+  for (int x = 0; x < (kMaxNodes + 63) / 64; x++) k.okUp[x] &= keep[x];
+}
+
+// every stale down / msg column, children before parents
 template <typename Exec>
-RC_HD void partials(Work &k, Exec &ex) {
+RC_HD void refresh_down(Work &k, Exec &ex) {
   for (int o = k.nn - 1; o >= 0; o--) {
     const int v = k.preorder[o];
-    if (v >= k.N)
+    if (v >= k.N && !Work::bit(k.okDn, v)) {
       for (int p = ex.lane(); p < k.P; p += ex.nlanes())
         for (int s = 0; s < 4; s++) {
           double d = 1.0;
           for (int c = 0; c < k.nchild[v]; c++) d *= k.ms(k.child[v * 3 + c], s, p);
           k.dn(v, s, p) = d;
         }
-    if (v != k.root) {
+      Work::set_bit(k.okDn, v);
+    }
+    if (v != k.root && !Work::bit(k.okMs, v)) {
       double Pm[4][4];
       k.mod.probs(k.len[v], Pm);
       for (int p = ex.lane(); p < k.P; p += ex.nlanes()) {
         const double d0 = k.dn(v, 0, p), d1 = k.dn(v, 1, p), d2 = k.dn(v, 2, p), d3 = k.dn(v, 3, p);
         for (int i = 0; i < 4; i++) k.ms(v, i, p) = Pm[i][0] * d0 + Pm[i][1] * d1 + Pm[i][2] * d2 + Pm[i][3] * d3;
       }
+      Work::set_bit(k.okMs, v);
     }
   }
+}
+
+// the stale up columns on the path from the root to `target` (parents before children); needs refresh_down first
+template <typename Exec>
+RC_HD void refresh_up(Work &k, Exec &ex, int target) {
+  uint64_t path[(kMaxNodes + 63) / 64];
+  for (int x = 0; x < (kMaxNodes + 63) / 64; x++) path[x] = 0;
+  for (int a = target; a != k.root; a = k.parent[a]) Work::set_bit(path, a);
   for (int o = 0; o < k.nn; o++) {
     const int v = k.preorder[o];
-    if (v == k.root) continue;
+    if (v == k.root || !Work::bit(path, v) || Work::bit(k.okUp, v)) continue;
     const int par = k.parent[v];
     double W[4][4];
     if (par != k.root) {   // what comes from above the parent, through the parent's own branch
@@ -286,6 +328,7 @@ RC_HD void partials(Work &k, Exec &ex) {
       }
       for (int s = 0; s < 4; s++) k.upp(v, s, p) = u[s];
     }
+    Work::set_bit(k.okUp, v);
   }
 }
 
@@ -303,10 +346,12 @@ RC_HD double edge_lnl(const Work &k, Exec &ex, int v, double t) {
   return ex.sum(lnl);
 }
 
+// log-likelihood of the current tree and model, read at the root's first branch (its up column needs no other up column)
 template <typename Exec>
 RC_HD double total_lnl(Work &k, Exec &ex) {
-  partials(k, ex);
   const int v = k.child[k.root * 3];
+  refresh_down(k, ex);
+  refresh_up(k, ex, v);
   return edge_lnl(k, ex, v, k.len[v]);
 }
 
@@ -315,23 +360,28 @@ RC_HD double total_lnl(Work &k, Exec &ex) {
 template <typename Exec>
 RC_HD double optimise(Work &k, Exec &ex) {
   tip_partials(k, ex);
+  invalidate_all(k);
   double prev = total_lnl(k, ex);
   for (int round = 0; round < 60; round++) {
     for (int v = 0; v < k.nn; v++) {
       if (v == k.root) continue;
-      partials(k, ex);
+      refresh_down(k, ex);
+      refresh_up(k, ex, v);
       k.len[v] = minimise([&](double t) { return -edge_lnl(k, ex, v, t); }, kBlMin, kBlMax, k.len[v], 1e-5, 60);
+      branch_changed(k, v);
     }
     const double kap = minimise(
         [&](double kk) {
           const Hky save = k.mod;
           k.mod.set(k.pi, kk);
+          invalidate_all(k);
           const double r = -total_lnl(k, ex);
           k.mod = save;
           return r;
         },
         0.1, 100.0, k.mod.kappa, 1e-5, 60);
     k.mod.set(k.pi, kap);
+    invalidate_all(k);
     const double cur = total_lnl(k, ex);
     if (fabs(cur - prev) < 1e-4) { prev = cur; break; }
     prev = cur;

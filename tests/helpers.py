@@ -20,3 +20,12 @@ def param_kwargs(doc):
 
 def f32(x):
     return np.float32(x)
+
+
+P_REL = 1e-6
+
+
+def close_p(a, b, rel=P_REL):
+    """p-values are compared by RELATIVE error on p itself (north_star: scores and p-values within 1e-6): an absolute
+    tolerance would accept 0 for a p of 2e-9 (RNAcode.c:182; the 99.0 sentinel of a failed fit compares equal)."""
+    return abs(a - b) <= rel * abs(b)

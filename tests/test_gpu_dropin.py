@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from conftest import ROOT, hss_key, load_golden
-from helpers import block_from_golden
+from helpers import block_from_golden, close_p
 from rnacode_amd.alnio import write_harness_blocks
 
 pytestmark = pytest.mark.gpu
@@ -55,7 +55,7 @@ def test_harness_on_hip_backend_matches_reference(name):
             for k in ("strand", "frame", "startSite", "endSite", "start", "end", "startGenomic", "endGenomic", "name"):
                 assert a[k] == b[k]
             assert np.float32(a["score"]) == np.float32(b["score"])
-            assert abs(a["pvalue"] - b["pvalue"]) <= 1e-6 * max(1.0, abs(b["pvalue"]))
+            assert close_p(a["pvalue"], b["pvalue"])
         assert g["evd_rc"] == w["evd_rc"]
         np.testing.assert_array_equal(np.float32(g["maxScores"]), np.float32(w["maxScores"]))
         for mg, mw in zip(g["models"] + g["modelsRev"], w["models"] + w["modelsRev"]):

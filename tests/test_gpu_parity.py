@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import golden_names, hss_key, load_golden
-from helpers import block_from_golden, param_kwargs
+from helpers import block_from_golden, close_p, param_kwargs
 
 pytestmark = pytest.mark.gpu
 
@@ -68,7 +68,7 @@ def check_entry(batch, i, entry):
             assert g[k] == w[k], (k, g, w)
         assert np.float32(g["score"]) == np.float32(w["score"])
         if rc == 1:
-            assert close(g["pvalue"], w["pvalue"]), (g, w)
+            assert close_p(g["pvalue"], w["pvalue"]), (g, w)
         else:
             assert g["pvalue"] == 99.0
     if ref["maxScores"]:
@@ -207,7 +207,7 @@ def test_oracle_parity_on_fresh_seeds(ctx):
             for k in ("strand", "frame", "startSite", "endSite", "start", "end", "startGenomic", "endGenomic"):
                 assert g[k] == w[k]
             assert np.float32(g["score"]) == np.float32(w["score"])
-            assert close(g["pvalue"], w["pvalue"])
+            assert close_p(g["pvalue"], w["pvalue"])
         rc, mu, lam = batch.getExtremeValuePars(i)
         assert rc == res.evd_rc
         if rc == 1:

@@ -205,7 +205,7 @@ def test_sample_range_sharding_on_the_hip_path(ctx):
     (SURVEY 8e).  Three 'ranks' run one after the other on the one GPU of the test box, each through
     hip_sample_sharded with a gather that concatenates their slices; the result must equal the reference's goldens."""
     from conftest import load_golden
-    from helpers import block_from_golden
+    from helpers import block_from_golden, close_p
     from rnacode_amd import api
     from rnacode_amd import distributed as rd
     doc = load_golden("genomic_preprocessed_n1000")
@@ -238,7 +238,7 @@ def test_sample_range_sharding_on_the_hip_path(ctx):
         gh, wh = sorted(hss, key=hss_key), sorted(ref["hss"], key=hss_key)
         assert [(np.float32(h["score"]),) + hss_key(h)[1:5] for h in gh] == [(np.float32(h["score"]),) + hss_key(h)[1:5] for h in wh]
         for a, b in zip(gh, wh):
-            assert abs(a["pvalue"] - b["pvalue"]) <= 1e-6 * max(1.0, abs(b["pvalue"]))
+            assert close_p(a["pvalue"], b["pvalue"])
     rows = [i for i, e in enumerate(entries) if "skipped" not in e["ref"] and e["ref"]["maxScores"]]
     for i in rows:
         np.testing.assert_array_equal(full[i], np.float32(entries[i]["ref"]["maxScores"]))

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from conftest import golden_names, hss_key, load_golden
-from helpers import block_from_golden, param_kwargs
+from helpers import block_from_golden, close_p, param_kwargs
 from oracle import binding as ob
 
 FAST = [n for n in golden_names() if n != "genomic_preprocessed_n1000"]
@@ -47,7 +47,7 @@ def check_block(entry, doc):
             assert g[k] == w[k], (k, g, w)
         assert np.float32(g["score"]) == np.float32(w["score"])
         if ref["evd_rc"] == 1:
-            assert abs(g["pvalue"] - w["pvalue"]) <= 1e-6 * max(1.0, abs(w["pvalue"]))
+            assert close_p(g["pvalue"], w["pvalue"])
         else:
             assert g["pvalue"] == 99.0
     assert res.evd_rc == ref["evd_rc"]
