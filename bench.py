@@ -14,6 +14,13 @@ driver's torchrun it just runs as one rank.  The 10 000 blocks are split across 
 configs[3]; `--scaling weak` gives every rank its own 10 000), no data-path collective, and every step ends
 with the path's one exchange: an RCCL all-gather of the per-sample maxima.
 
+With one GPU and no flags the same JSON line also carries four further legs, each with a timed region of about three seconds
+(`--no-extra` leaves them out): `end_to_end` -- the native driver rnacode_amd/rnacode_hip as a fresh process on a 10 000-block
+MAF file, wall time from exec to exit, trees fitted on the GPU (no sidecar): SURVEY.md section 8d's metric with I/O included
+(RNAcode.c:115-228); `shard` -- the 1250 blocks ONE of eight ranks holds under configs[3], resident and streamed with an eighth
+of the host's CPUs; `c5` -- the long-block slice of configs[4] with a roofline object of its own; `mixed` -- a stream of
+10 000 blocks of 3..12 rows and 60..200 columns (ten row-count classes).
+
 A step is one pass of the hot path over this rank's blocks.  Two measurements per run, K steps each:
   * resident (`value`, the contract's definition: inputs in HBM when the timed region starts): MT19937
     streams -> native scoring -> null sampling -> EVD fit on a resident batch, then the all-gather;
@@ -42,7 +49,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 VALU_PEAK_GOPS = 78643.2       # 256 CU x 4 SIMD x 64 lanes / 2 cycles x 2.4 GHz (v_add/v_max wave64 = 2 cyc/SIMD)
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 CONFIGS = {
     # name: (blocks, cols, seqs, samples, description)
@@ -66,22 +73,129 @@ def algorithmic_work(blocks, sampleN):
     return by, fl
 
 
-def measured_traffic(config):
+def measured_traffic(config, kernel):
     """HBM-side bytes per k_null launch from the committed rocprofv3 PMC passes of this same command
     (profiles/collect.sh -> profiles/<round>/k_null_<config>_pmc.json): FETCH_SIZE and WRITE_SIZE are in KiB,
     collected in separate passes; on gfx950 FETCH_SIZE under-reports streaming reads by 2x
-    (MI355X_MICROARCH.md, HBM), so the read side is doubled.  None if no profile is committed."""
-    for rnd in (PROFILE_ROUND, "r01"):
+    (MI355X_MICROARCH.md, HBM), so the read side is doubled.  `kernel` is the instantiation this run just timed
+    (rc_batch_null_kernel): a profile of another kernel is refused.  (None, reason) if no usable profile is committed."""
+    why = "no committed profile"
+    for rnd in (PROFILE_ROUND, "r02", "r01"):
         for name in (f"k_null_{config}_pmc.json", "k_null_pmc.json" if config == "c3" else None):
             if not name:
                 continue
             try:
                 with open(os.path.join(ROOT, "profiles", rnd, name)) as fh:
                     d = json.load(fh)
+                prof_kernel = (d.get("kernel") or "").split("(")[0].replace("void ", "").strip()
+                if prof_kernel != kernel:
+                    why = f"profiles/{rnd}/{name} is a profile of {prof_kernel!r}, this run timed {kernel!r}: refused"
+                    continue
                 return (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0, f"profiles/{rnd}/{name}"
             except Exception:
                 continue
-    return None, None
+    return None, why
+
+
+def roofline_object(blocks, sampleN, null_ms, kernel, config, with_traffic):
+    """The contract's roofline object for one k_null launch of `null_ms` ms over `blocks` (algorithmic work: SURVEY.md section 8d)."""
+    by, fl = algorithmic_work(blocks, sampleN)
+    ach = by / (null_ms * 1e-3) / 1e9
+    traffic, src = measured_traffic(config, kernel) if with_traffic else (None, "not the profiled configuration")
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": src, "kernel": kernel, "kernel_ms": null_ms, "algorithmic_bytes_per_launch": by,
+            "valu": {"achieved_gops": fl / (null_ms * 1e-3) / 1e9, "peak_gops": VALU_PEAK_GOPS,
+                     "frac": fl / (null_ms * 1e-3) / 1e9 / VALU_PEAK_GOPS, "algorithmic_flops_per_launch": fl}}
+
+
+def end_to_end_leg(blocks, sampleN, seed, runs=3):
+    """SURVEY.md section 8d's metric as the reference's driver would be timed (RNAcode.c:115-228: read -> tree -> models -> score ->
+    sample -> print): the native stand-alone driver as a fresh process on a MAF file, wall time from exec to exit, trees and kappa
+    fitted on the GPU (no sidecar), listing written to a file.  Runs before this process touches a GPU."""
+    from rnacode_amd.synth import to_maf
+    exe = os.path.join(ROOT, "rnacode_amd", "rnacode_hip")
+    if not os.path.exists(exe):
+        return {"error": "rnacode_amd/rnacode_hip is not built"}
+    d = tempfile.mkdtemp(prefix="rc_e2e_")
+    maf, out = os.path.join(d, "in.maf"), os.path.join(d, "out.tsv")
+    try:
+        with open(maf, "w") as fh:
+            fh.write(to_maf(blocks))
+        units = sum(b.cols for b in blocks) * sampleN
+        walls, stages = [], []
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, maf, "-n", str(sampleN), "-t", "-o", out, "--seed-base", str(seed)], capture_output=True, text=True,
+                               env=dict(os.environ, RC_CLI_TIMES="1"))
+            walls.append(time.perf_counter() - t0)
+            if r.returncode != 0:
+                return {"error": f"rnacode_hip exited with {r.returncode}: {r.stderr.strip()[-300:]}"}
+            line = [ln for ln in r.stderr.splitlines() if ln.startswith("[rnacode_hip]")]
+            stages.append(line[-1][len("[rnacode_hip] "):] if line else "")
+        with open(out) as fh:
+            hss_lines = sum(1 for _ in fh)
+        best = min(range(runs), key=lambda i: walls[i])
+        walls_sorted = sorted(walls)
+        return {"value": units / walls_sorted[len(walls) // 2], "unit": "alignment-columns*samples/s", "wall_s_median": walls_sorted[len(walls) // 2],
+                "wall_s_best": walls[best], "wall_s_all": walls, "stages_of_best_run": stages[best], "hss_lines": hss_lines,
+                "maf_bytes": os.path.getsize(maf), "blocks": len(blocks), "samples": sampleN,
+                "includes": "process start, library load, HIP context, MAF parsing, tree + kappa fits on the GPU (k_tree_fit, no sidecar), block "
+                            "preparation, scoring, sampling, fits, p-values, the tabular listing written to a file",
+                "note": "fresh process per run; value = units / median wall time of the runs"}
+    finally:
+        for f in (maf, out):
+            if os.path.exists(f):
+                os.unlink(f)
+        os.rmdir(d)
+
+
+def timed_region(step, min_s, min_steps=3):
+    """Run `step` until at least min_s seconds and min_steps steps have passed; (seconds, steps)."""
+    n = 0
+    t0 = time.perf_counter()
+    while True:
+        step()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= min_s and n >= min_steps:
+            return dt, n
+
+
+def resident_leg(api, ctx, blocks, params, min_s, warmup=2):
+    """Resident steps of `blocks` for about min_s seconds: (ms per step, average k_null launch ms, kernel name, units per step, batch timing)."""
+    m = api.Marshalled(blocks)
+    m.set_trees()
+    batch = api.Batch(ctx, m, params)
+    for _ in range(warmup):
+        batch.run()
+    acc = {"null": 0.0, "n": 0, "launches": 1}
+
+    def step():
+        batch.run()
+        t, nl = batch.timing()
+        acc["null"] += t["null"]; acc["n"] += 1; acc["launches"] = max(1, nl.get("null", 1))
+
+    dt, n = timed_region(step, min_s)
+    kernel = batch.null_kernel()
+    _, cs = batch.work()
+    batch.close()
+    return dt / n * 1e3, acc["null"] / acc["n"] / acc["launches"], kernel, cs, n, m
+
+
+def stream_leg(api, ctx, m, params, sub_blocks, min_s, depth=3, warmup=2):
+    """Streamed passes over the Marshalled blocks `m` for about min_s seconds: (ms per pass, passes)."""
+    st = api.Stream(ctx, params, depth)
+
+    def step():
+        for sb in api.score_stream(ctx, m, params, sub_blocks, stream=st):
+            sb.fits()
+            sb.close()
+
+    for _ in range(warmup):
+        step()
+    dt, n = timed_region(step, min_s)
+    st.close()
+    return dt / n * 1e3, n
 
 
 def cpu_baseline(blocks, sampleN, seed, target_s=12.0):
@@ -166,6 +280,8 @@ def parse_args():
                     help="strong (default): --blocks in total, split across the ranks (BASELINE configs[3]); weak: --blocks per GPU")
     ap.add_argument("--no-weak", action="store_true", help="N > 1, strong scaling: skip the extra weak-scaling measurement")
     ap.add_argument("--dump-gathered", help="rank 0 writes the gathered per-sample maxima of the last resident step here (.npy; tests)")
+    ap.add_argument("--no-extra", action="store_true", help="one GPU: skip the end_to_end / shard / c5 / mixed legs")
+    ap.add_argument("--extra-seconds", type=float, default=3.0, help="length of the timed region of each extra leg")
     a = ap.parse_args()
     blocks, cols, seqs, samples, _ = CONFIGS[a.config]
     a.blocks = a.blocks or blocks
@@ -227,6 +343,17 @@ def main():
         blocks = [b.upper() for b in synth_blocks(args.blocks, args.seqs, args.cols, seed=1)[lo:hi]]
         counts = [rd.shard_range(args.blocks, r, world)[1] - rd.shard_range(args.blocks, r, world)[0] for r in range(world)]
     t_gen = time.perf_counter() - t0
+
+    # one GPU, the default workload: the legs that start child processes run first, before this process touches a GPU
+    single = world == 1 and not multi
+    default_workload = (args.blocks, args.cols, args.seqs, args.samples) == CONFIGS[args.config][:4]
+    extras = single and not args.no_extra and default_workload and args.config == "c3"
+    cpu = None
+    if single and not args.no_cpu_baseline:
+        cpu = cpu_baseline(blocks, args.samples, args.seed_base)
+    legs = {}
+    if extras:
+        legs["end_to_end"] = end_to_end_leg(blocks, args.samples, args.seed_base)
 
     ctx = api.Context(local_rank)
     cpus = api.lib().rc_host_cpus()
@@ -367,13 +494,57 @@ def main():
         cs, sa = int(tot[0].item()), int(tot[1].item())
     total_units = cs * args.steps
     value = total_units / elapsed
+    kernel_name = batch.null_kernel()
+    if extras:
+        main_ms = elapsed / args.steps * 1e3
+        # ---- shard: what ONE of eight ranks holds under configs[3] (strong scaling), with an eighth of the host's CPUs
+        lo, hi = rd.shard_range(len(blocks), 0, 8)
+        t8 = max(1, cpus // 8)
+        ctx.set_host_threads(t8)
+        sh_ms, sh_null, sh_kernel, sh_units, sh_steps, sh_m = resident_leg(api, ctx, blocks[lo:hi], params, args.extra_seconds)
+        sh_sub = max(1, -(-(hi - lo) // 4))
+        sh_stream_ms, sh_passes = stream_leg(api, ctx, sh_m, params, sh_sub, args.extra_seconds)
+        legs["shard"] = {
+            "blocks": hi - lo, "of": len(blocks), "ranks": 8, "host_threads": t8, "usable_cpus": cpus,
+            "ms_per_step": sh_ms, "steps": sh_steps, "kernel_ms": sh_null, "ideal_ms": main_ms / 8,
+            "efficiency": (main_ms / 8) / sh_ms, "value": sh_units / (sh_ms * 1e-3),
+            "stream": {"ms_per_step": sh_stream_ms, "passes": sh_passes, "frac_of_resident": sh_ms / sh_stream_ms, "sub_batches": -(-(hi - lo) // sh_sub),
+                       "efficiency": (main_ms / 8) / sh_stream_ms},
+            "note": "efficiency = (ms per step of the whole 10 000-block workload on this GPU / 8) / ms per step of the shard: what strong "
+                    "scaling to eight GPUs can reach before the all-gather; the stream prepares its blocks on usable_cpus // 8 host threads"}
+        ctx.set_host_threads(threads)
+        del sh_m
+        # ---- c5: the long-block slice of configs[4]
+        nb5, cols5, seqs5, n5, desc5 = CONFIGS["c5"]
+        t0 = time.perf_counter()
+        blocks5 = [b.upper() for b in synth_blocks(nb5, seqs5, cols5, seed=1)]
+        gen5 = time.perf_counter() - t0
+        params5 = api.default_params(sampleN=n5, seed_base=args.seed_base)
+        c5_ms, c5_null, c5_kernel, c5_units, c5_steps, c5_m = resident_leg(api, ctx, blocks5, params5, args.extra_seconds, warmup=1)
+        legs["c5"] = {"workload": f"synthetic MAF {nb5} blocks x {cols5} cols x {seqs5} seqs, --num-samples {n5} ({desc5})",
+                      "value": c5_units / (c5_ms * 1e-3), "unit": "alignment-columns*samples/s", "ms_per_step": c5_ms, "steps": c5_steps,
+                      "generate_s": gen5, "roofline": roofline_object(blocks5, n5, c5_null, c5_kernel, "c5", True)}
+        del c5_m, blocks5
+        # ---- mixed: ten row-count classes, ragged lengths, as a stream from host blocks
+        import numpy as _np
+        from rnacode_amd.synth import synth_block
+        rng = _np.random.RandomState(5)
+        t0 = time.perf_counter()
+        mixed = [synth_block(rng, int(rng.randint(3, 13)), int(rng.randint(60, 201)), index=i, gaps=True).upper() for i in range(10000)]
+        genm = time.perf_counter() - t0
+        mx_ms, mx_null, mx_kernel, mx_units, mx_steps, mx_m = resident_leg(api, ctx, mixed, params, args.extra_seconds, warmup=1)
+        classes = len({b.n for b in mixed})
+        mx_sub = max(2048, 512 * classes)
+        mx_stream_ms, mx_passes = stream_leg(api, ctx, mx_m, params, mx_sub, args.extra_seconds, warmup=1)
+        legs["mixed"] = {"workload": "synthetic MAF 10000 blocks of 3..12 rows x 60..200 cols, --num-samples %d" % args.samples,
+                         "row_count_classes": classes, "value": mx_units / (mx_stream_ms * 1e-3), "unit": "alignment-columns*samples/s",
+                         "ms_per_step": mx_stream_ms, "passes": mx_passes, "blocks_per_sub_batch": mx_sub, "host_threads": threads,
+                         "resident": {"ms_per_step": mx_ms, "steps": mx_steps, "value": mx_units / (mx_ms * 1e-3)},
+                         "generate_s": genm, "note": "value = the streamed rate (host rc_block arrays -> fitted results on the host)"}
+        del mx_m, mixed
+
     if rank == 0:
-        by, fl = algorithmic_work(blocks, args.samples)
         null_ms = tk["null"] / args.steps / max(1, nlaunch.get("null", 1))   # average duration of one k_null launch
-        ach = by / (null_ms * 1e-3) / 1e9
-        traffic, traffic_src = (None, None)
-        if (args.blocks, args.cols, args.seqs, args.samples) == CONFIGS[args.config][:4] and world == 1:
-            traffic, traffic_src = measured_traffic(args.config)
         desc = CONFIGS[args.config][4]
         out = {
             "metric": "alignment-columns x samples scored /sec",
@@ -395,12 +566,7 @@ def main():
                        "seed_base": args.seed_base, "sharding": f"blocks x{world}",
                        "exchange": ("all-gather of " + args.exchange) if multi else "none"},
             "value_definition": "resident: inputs in HBM when the timed region starts (bench contract); the host-inclusive pipeline is stream.value",
-            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_null<%d>" % (args.seqs - 1), "kernel_ms": null_ms,
-                         "algorithmic_bytes_per_launch": by,
-                         "valu": {"achieved_gops": fl / (null_ms * 1e-3) / 1e9, "peak_gops": VALU_PEAK_GOPS,
-                                  "frac": fl / (null_ms * 1e-3) / 1e9 / VALU_PEAK_GOPS,
-                                  "algorithmic_flops_per_launch": fl}},
+            "roofline": roofline_object(blocks, args.samples, null_ms, kernel_name, args.config, default_workload and world == 1),
             "device_ms_per_step": {k: v / args.steps for k, v in tk.items()},
             "device_ms_note": "HIP-event intervals; the native-block kernels run on a second stream beside k_null, so "
                               "'native' is the interval until they are done (they fill k_null's tail), not their busy time",
@@ -429,9 +595,11 @@ def main():
                 "excludes": "file parsing and tree fitting (sidecar trees, as for the cpu_baseline)"}
         if weak is not None:
             out["weak_scaling"] = weak
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(blocks, args.samples, args.seed_base)
-            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+            out["speedup_vs_cpu_baseline"] = value / cpu["value"]
+        for k, v in legs.items():
+            out[k] = v
         print(json.dumps(out))
     if stream is not None:
         stream.close()

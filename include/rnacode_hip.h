@@ -172,6 +172,9 @@ int rc_batch_work(const rc_batch *b, int64_t *sample_alignments, int64_t *column
  * t[0] total, t[1] MT19937 stream kernel, t[2] null-sampling kernels (simulate+score),
  * t[3] native scoring kernels, t[4] EVD fit kernel.  n_launch[i] = launches behind t[i]. */
 int rc_batch_timing(const rc_batch *b, float t[5], int32_t n_launch[5]);
+/* The null-sampling kernel instantiation that did most of the last run's work, spelled as a profiler prints it
+ * ("rc::k_null<5, true, false>"): lets a benchmark check that counter data it quotes belongs to the kernel it timed. */
+const char *rc_batch_null_kernel(const rc_batch *b);
 /* Preparation of the batch: wall time of the host part (ms), duration of the device kernels that make the
  * expected-score tables (ms, known after a run), bytes copied to the device. */
 int rc_batch_prep_timing(const rc_batch *b, double *host_ms, float *table_kernels_ms, int64_t *uploaded_bytes);

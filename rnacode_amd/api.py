@@ -123,6 +123,8 @@ def lib():
         l.rc_batch_work.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         l.rc_batch_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
         l.rc_batch_status.argtypes = [C.c_void_p, C.c_int32]
+        l.rc_batch_null_kernel.argtypes = [C.c_void_p]
+        l.rc_batch_null_kernel.restype = C.c_char_p
         l.rc_batch_models.argtypes = [C.c_void_p, C.c_int32, C.POINTER(RcModel), C.POINTER(RcModel)]
         l.rc_batch_maxima.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float)]
         l.rc_batch_maxima_all.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -154,7 +156,7 @@ EXPORTED_SYMBOLS = [
     "rc_default_params", "rc_last_error", "rc_device_count", "rc_ctx_create", "rc_ctx_destroy", "rc_batch_create",
     "rc_batch_destroy", "rc_batch_bind_maxima", "rc_batch_run", "rc_batch_run_async", "rc_batch_wait", "rc_batch_size", "rc_batch_block_error",
     "rc_batch_prep_timing", "rc_host_cpus", "rc_ctx_set_host_threads", "rc_ctx_host_threads", "rc_stream_create", "rc_stream_submit", "rc_stream_submit_bound",
-    "rc_stream_next", "rc_stream_recycle", "rc_stream_pending", "rc_stream_destroy", "rc_set_stream_cache", "rc_batch_work", "rc_batch_timing", "rc_batch_status",
+    "rc_stream_next", "rc_stream_recycle", "rc_stream_pending", "rc_stream_destroy", "rc_set_stream_cache", "rc_batch_work", "rc_batch_timing", "rc_batch_null_kernel", "rc_batch_status",
     "rc_batch_models", "rc_batch_maxima", "rc_batch_maxima_all", "rc_batch_fit", "rc_batch_fit_all", "rc_batch_hss", "rc_batch_hss_all", "rc_batch_clamped",
     "rc_batch_native_S", "rc_batch_backtrack", "rc_fit_tree", "rc_fit_trees", "rc_fit_trees_device", "rc_tree_lnl", "rc_evd_fit", "rc_pvalue", "rc_mt_stream", "rc_code_tables",
 ]
@@ -402,6 +404,10 @@ class Batch:
         _check(lib().rc_batch_timing(self._h, t, nl))
         keys = ("total", "mt_stream", "null", "native", "evd_fit")
         return {k: float(t[i]) for i, k in enumerate(keys)}, {k: int(nl[i]) for i, k in enumerate(keys)}
+
+    def null_kernel(self) -> str:
+        """The k_null instantiation behind most of the last run's sampling, as rocprofv3 names it."""
+        return lib().rc_batch_null_kernel(self._h).decode()
 
     def status(self, blk: int) -> int:
         return lib().rc_batch_status(self._h, blk)

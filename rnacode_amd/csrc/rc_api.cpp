@@ -184,7 +184,8 @@ struct rc_ctx {
   int numCU = 0;
   size_t totalMem = 0;             // device memory (bytes)
   size_t togetherWords = static_cast<size_t>(2) << 30;   // uint32 of staging scratch the side-by-side class launches of a batch may take (RC_TOGETHER_MAX_MB)
-  DevBuf treeJobs, treeIn, treeWork, treeOut;   // rc_fit_trees_device
+  DevBuf treeJobs, treeIn, treeWork, treeOut, treeRes;   // rc_fit_trees_device
+  PinBuf treeInPin, treeResPin;
   std::mutex treeMutex;
   int nativeWavesPerCU = 8;   // persistent wavefronts of k_native_dp per CU (RC_NATIVE_WAVES_PER_CU): it runs beside k_null and should not crowd it out
   size_t genericScratchWords = static_cast<size_t>(1) << 30;   // uint32 of staging scratch one k_null_generic launch may take: a twelfth of the device memory (24 GB of 288)
@@ -268,6 +269,8 @@ struct rc_batch {
   float t[6] = {0, 0, 0, 0, 0, 0};
   int nl[6] = {0, 0, 0, 0, 0, 0};
   double prepHostMs = 0.0;
+  std::string nullKernel;   // the k_null instantiation that did most of the last run's sampling, as rocprofv3 prints it
+  double nullKernelCost = 0.0;
   rc_stream *owner = nullptr;
 };
 
@@ -805,6 +808,17 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
     a.tieThr = c->tieThr; a.debugSkip = c->debugSkip; a.comboSplit = p.comboSplit;
     a.cellStats = c->d_cellStats.as<unsigned long long>();
     unsigned int *work = b->dcounters.as<unsigned int>() + kCntWork + static_cast<size_t>(phase) * 2 * kClassSlots * 8;
+    {
+      const double cost = p.itemCost * static_cast<double>(members.size()) * groupsHere;
+      if (cost > b->nullKernelCost) {
+        b->nullKernelCost = cost;
+        if (p.NK == kGenericClass) b->nullKernel = "rc::k_null_generic";
+        else {
+          const bool ex = b->allExact || p.NK >= kFastRows;
+          b->nullKernel = "rc::k_null<" + std::to_string(p.NK) + (!ex && p.ldsBytes ? ", true" : ", false") + (ex ? ", true>" : ", false>");
+        }
+      }
+    }
     if (p.NK == kGenericClass) {
       a.skipMask = extraSkip;
       a.scratchStride = p.stride * sizeof(uint32_t);   // bytes for this kernel
@@ -847,6 +861,7 @@ static int batch_run_async(rc_batch *b) {
   std::fill(b->t, b->t + 6, 0.0f);
   std::fill(b->nl, b->nl + 6, 0);
   b->maximaFetched = false;
+  b->nullKernel.clear(); b->nullKernelCost = 0.0;
   const int n = b->n, sampleN = b->par.sampleN;
   const int groups = (sampleN + kWave - 1) / kWave, Spad = groups * kWave;
   b->clamped = 0;
@@ -1101,6 +1116,8 @@ int rc_batch_timing(const rc_batch *b, float t[5], int32_t nl[5]) {
   for (int i = 0; i < 5; i++) { if (t) t[i] = b->t[i]; if (nl) nl[i] = b->nl[i]; }
   return RC_OK;
 }
+
+const char *rc_batch_null_kernel(const rc_batch *b) { return b ? b->nullKernel.c_str() : ""; }
 
 int rc_batch_prep_timing(const rc_batch *b, double *host_ms, float *table_kernels_ms, int64_t *uploaded_bytes) {
   if (!b || b->state == rc_batch::EMPTY) return fail(RC_ERR_ARG, "batch has not been prepared");
@@ -1467,10 +1484,11 @@ int rc_fit_trees_device(rc_ctx *c, const rc_block *blocks, int32_t n_blocks, cha
           }
           continue;
         }
-        std::vector<std::string> rows(b.n_rows);
-        for (int r = 0; r < b.n_rows; r++) rows[r] = b.rows[r];
+        bool lengths = b.n_cols > 0;
+        for (int r = 0; r < b.n_rows && lengths; r++)
+          lengths = b.rows[r] && static_cast<int>(strnlen(b.rows[r], static_cast<size_t>(b.n_cols) + 1)) == b.n_cols;
         std::string err;
-        ok[i] = compress_patterns(rows, ps[i], err) ? 1 : 0;
+        ok[i] = (lengths && compress_patterns(b.rows, b.n_rows, b.n_cols, ps[i], err)) ? 1 : 0;
       }
     };
     std::vector<std::thread> th;
@@ -1480,8 +1498,7 @@ int rc_fit_trees_device(rc_ctx *c, const rc_block *blocks, int32_t n_blocks, cha
   }
   std::vector<TreeJob> jobs;
   std::vector<int> owner;
-  std::vector<uint8_t> in;
-  size_t work_doubles = 0;
+  size_t work_doubles = 0, in_bytes = 0, res_doubles = 0;
   int hostDone = 0;
   // the longest fits first: the launch hands workgroups out in order, and a fit of 12 rows x 200 patterns takes a hundred times one of 3 x 60
   std::vector<int> order(n_blocks);
@@ -1497,14 +1514,14 @@ int rc_fit_trees_device(rc_ctx *c, const rc_block *blocks, int32_t n_blocks, cha
     if (!ok[i]) continue;
     TreeJob j{};
     j.N = ps[i].N; j.P = ps[i].P;
-    j.off_mask = in.size();
-    in.insert(in.end(), ps[i].mask.begin(), ps[i].mask.end());
-    in.resize((in.size() + 7) & ~static_cast<size_t>(7));
-    j.off_w = in.size();
-    const uint8_t *wp = reinterpret_cast<const uint8_t *>(ps[i].w.data());
-    in.insert(in.end(), wp, wp + sizeof(double) * ps[i].P);
+    j.off_mask = in_bytes;
+    in_bytes = (in_bytes + ps[i].mask.size() + 7) & ~static_cast<size_t>(7);
+    j.off_w = in_bytes;
+    in_bytes += sizeof(double) * ps[i].P;
     j.off_work = work_doubles;
     work_doubles += 2 * static_cast<size_t>(j.N) * j.N + 3 * static_cast<size_t>(2 * j.N - 2) * 4 * j.P;
+    j.off_out = res_doubles;
+    res_doubles += tree_result_doubles(j.N);
     jobs.push_back(j);
     owner.push_back(i);
   }
@@ -1516,6 +1533,7 @@ int rc_fit_trees_device(rc_ctx *c, const rc_block *blocks, int32_t n_blocks, cha
   if (const char *e = std::getenv("RC_TREE_SCRATCH_BYTES")) capDoubles = std::max<size_t>(1, static_cast<size_t>(std::atoll(e)) / sizeof(double));
   std::vector<int> chunkStart{0};
   size_t maxChunk = 0;
+  int maxJobs = 0;
   {
     size_t base = 0;
     for (int q = 0; q < nj; q++) {
@@ -1527,44 +1545,69 @@ int rc_fit_trees_device(rc_ctx *c, const rc_block *blocks, int32_t n_blocks, cha
     for (size_t ch = 0; ch + 1 < chunkStart.size(); ch++) {
       const size_t b0 = static_cast<size_t>(jobs[chunkStart[ch]].off_work);
       for (int q = chunkStart[ch]; q < chunkStart[ch + 1]; q++) jobs[q].off_work -= b0;
+      maxJobs = std::max(maxJobs, chunkStart[ch + 1] - chunkStart[ch]);
     }
   }
-  // device buffers live in the context: a driver fits its blocks in several calls
+  // device and pinned buffers live in the context: a driver fits its blocks in several calls
   std::lock_guard<std::mutex> treeLock(c->treeMutex);
-  DevBuf &d_jobs = c->treeJobs, &d_in = c->treeIn, &d_work = c->treeWork, &d_out = c->treeOut;
+  DevBuf &d_jobs = c->treeJobs, &d_in = c->treeIn, &d_work = c->treeWork, &d_out = c->treeOut, &d_res = c->treeRes;
   HIP_TRY(d_jobs.ensure(sizeof(TreeJob) * nj));
-  HIP_TRY(d_in.ensure(in.size()));
+  HIP_TRY(d_in.ensure(in_bytes));
   HIP_TRY(d_work.ensure(sizeof(double) * maxChunk));
-  HIP_TRY(d_out.ensure(sizeof(TreeOut) * nj));
+  HIP_TRY(d_out.ensure(sizeof(TreeOut) * maxJobs));   // the kernel's working copies: one launch at a time uses them
+  HIP_TRY(d_res.ensure(sizeof(double) * res_doubles));
+  HIP_TRY(c->treeInPin.ensure(in_bytes));
+  HIP_TRY(c->treeResPin.ensure(sizeof(double) * res_doubles));
+  {   // masks and weights straight into pinned memory (threads), one copy
+    uint8_t *in = c->treeInPin.as<uint8_t>();
+    std::atomic<int> next{0};
+    const unsigned nt = std::min<unsigned>(static_cast<unsigned>(c->hostThreads), static_cast<unsigned>(std::max(1, nj / 256)));
+    auto fill = [&]() {
+      for (;;) {
+        const int q = next.fetch_add(1);
+        if (q >= nj) break;
+        const PatternSet &p = ps[owner[q]];
+        std::memcpy(in + jobs[q].off_mask, p.mask.data(), p.mask.size());
+        std::memcpy(in + jobs[q].off_w, p.w.data(), sizeof(double) * p.P);
+      }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < std::max(1u, nt); t++) th.emplace_back(fill);
+    fill();
+    for (auto &x : th) x.join();
+  }
   HIP_TRY(hipMemcpyAsync(d_jobs.p, jobs.data(), sizeof(TreeJob) * nj, hipMemcpyHostToDevice, c->aux));
-  HIP_TRY(hipMemcpyAsync(d_in.p, in.data(), in.size(), hipMemcpyHostToDevice, c->aux));
+  HIP_TRY(hipMemcpyAsync(d_in.p, c->treeInPin.p, in_bytes, hipMemcpyHostToDevice, c->aux));
   for (size_t ch = 0; ch + 1 < chunkStart.size(); ch++) {
     const int q0 = chunkStart[ch], q1 = chunkStart[ch + 1];
     launch_tree_fit(static_cast<const TreeJob *>(d_jobs.p) + q0, q1 - q0, static_cast<const uint8_t *>(d_in.p), static_cast<double *>(d_work.p),
-                    static_cast<TreeOut *>(d_out.p) + q0, c->aux);
+                    static_cast<TreeOut *>(d_out.p), static_cast<double *>(d_res.p), c->aux);
   }
   HIP_TRY(hipGetLastError());
-  std::vector<TreeOut> out(nj);
-  HIP_TRY(hipMemcpyAsync(out.data(), d_out.p, sizeof(TreeOut) * nj, hipMemcpyDeviceToHost, c->aux));
+  HIP_TRY(hipMemcpyAsync(c->treeResPin.p, d_res.p, sizeof(double) * res_doubles, hipMemcpyDeviceToHost, c->aux));
   HIP_TRY(hipStreamSynchronize(c->aux));
+  const double *res = c->treeResPin.as<double>();
   std::atomic<int> done{0};
   {
     std::atomic<int> next{0};
     const unsigned nt = std::min<unsigned>(static_cast<unsigned>(c->hostThreads), static_cast<unsigned>(std::max(1, nj / 64)));
     auto write = [&]() {
+      std::vector<std::string> names;
       for (;;) {
         const int q = next.fetch_add(1);
         if (q >= nj) break;
         const int i = owner[q];
         const rc_block &b = blocks[i];
-        std::vector<std::string> names(b.n_rows);
+        names.resize(b.n_rows);
         for (int r = 0; r < b.n_rows; r++) names[r] = b.names[r];
-        const TreeOut &o = out[q];
-        const std::string nwk = newick_of(b.n_rows, o.root, o.nchild, o.child, o.len, names);
+        const int nn = 2 * jobs[q].N - 2;
+        const double *rd = res + jobs[q].off_out;
+        const int *ri = reinterpret_cast<const int *>(rd + 2 + nn);
+        const std::string nwk = newick_of(b.n_rows, ri[0], ri + 1, ri + 1 + nn, rd + 2, names);
         if (static_cast<int>(nwk.size()) + 1 > cap) continue;
         std::memcpy(newick_out + static_cast<size_t>(i) * cap, nwk.c_str(), nwk.size() + 1);
-        kappa_out[i] = static_cast<float>(o.kappa);
-        if (lnl_out) lnl_out[i] = o.lnl;
+        kappa_out[i] = static_cast<float>(rd[0]);
+        if (lnl_out) lnl_out[i] = rd[1];
         done.fetch_add(1);
       }
     };

@@ -437,6 +437,12 @@ int prepare_block(const rc_block &in, const rc_params &par, const PairTable &pt,
   rowtipv.assign(N, -1);
   int *rowtip = rowtipv.data();
   used.assign(N, 0);
+  for (int x = 1; x < N; x++)   // two tips with one label: the rows could not be told apart (treeSimulate.c:266-276 matches by name)
+    for (int y = 0; y < x; y++)
+      if (t.nameLen[x] == t.nameLen[y] && std::memcmp(t.namepool.data() + t.nameOff[x], t.namepool.data() + t.nameOff[y], static_cast<size_t>(t.nameLen[x])) == 0) {
+        err = "duplicate row names";
+        return done(RC_ERR_ARG);
+      }
   for (int r = 0; r < N; r++) {
     if (!in.names[r]) { err = "row without a name"; return done(RC_ERR_ARG); }
     // tips usually come in an order related to the rows: start looking at r

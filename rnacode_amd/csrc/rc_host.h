@@ -78,6 +78,7 @@ struct PatternSet {
   std::vector<double> w;       // [P] how many columns show the pattern
 };
 bool compress_patterns(const std::vector<std::string> &rows, PatternSet &ps, std::string &err);
+bool compress_patterns(const char *const *rows, int N, int cols, PatternSet &ps, std::string &err);   // rows of `cols` characters each
 std::string newick_of(int N, int root, const int *nchild, const int *child, const double *len, const std::vector<std::string> &names);
 bool fit_tree(const std::vector<std::string> &rows, const std::vector<std::string> &names, std::string &newick,
               float &kappa, double *lnl_out, std::string &err);

@@ -101,14 +101,19 @@ struct TreeJob {
   uint64_t off_mask;          // bytes into the input blob: [N][P] state masks
   uint64_t off_w;             // bytes into the input blob (8-aligned): [P] pattern weights
   uint64_t off_work;          // doubles into the scratch: 2 N^2 + 3 (2N-2) 4 P
+  uint64_t off_out;           // doubles into the result buffer: the job's TreeResult record (tree_result_doubles(N) doubles)
 };
+// the kernel's working copy of the tree (global memory, one per job of a launch)
 struct TreeOut {
   int root;
-  int parent[127], nchild[127], child[127 * 3], preorder[127];   // 2 kMaxRows - 1 nodes
+  int parent[127], nchild[127], child[127 * 3], preorder[127];   // 2 kMaxTipsDevice - 1 nodes
   double len[127];
   double kappa, lnl;
 };
-void launch_tree_fit(const TreeJob *jobs, int njobs, const uint8_t *in, double *scratch, TreeOut *out, hipStream_t stream);
+// What travels back to the host per job, nn = 2N - 2 nodes: doubles {kappa, lnl, len[nn]} then ints {root, nchild[nn], child[3 nn]}
+// (260 bytes for six rows; the working copy above is 4 KB)
+inline size_t tree_result_doubles(int N) { const size_t nn = 2 * static_cast<size_t>(N) - 2; return 2 + nn + (1 + 4 * nn + 1) / 2; }
+void launch_tree_fit(const TreeJob *jobs, int njobs, const uint8_t *in, double *scratch, TreeOut *work, double *results, hipStream_t stream);
 
 void launch_mt_stream(uint32_t seedBase, int Spad, int D, uint32_t *U, hipStream_t stream);
 void launch_prep(const PrepArgs &a, hipStream_t stream);   // k_prep_models, then k_prep_lut

@@ -11,7 +11,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <map>
 #include <string>
 #include <vector>
 
@@ -58,25 +57,57 @@ struct Fitter {
 
 }  // namespace
 
+// distinct alignment columns (as allowed-state masks) in the order of their first appearance, with their multiplicities
+bool compress_patterns(const char *const *rows, int N, int cols, PatternSet &ps, std::string &err) {
+  if (N < 3) { err = "at least three sequences are needed"; return false; }
+  if (N > treefit::kMaxTips) { err = "too many sequences for the tree estimator"; return false; }
+  // per-thread scratch: column keys (N mask bytes each), an open-addressing table of first appearances
+  static thread_local std::vector<uint8_t> keys;
+  static thread_local std::vector<int> table, first;
+  static const struct MaskLut {
+    uint8_t m[256];
+    MaskLut() { for (int c = 0; c < 256; c++) m[c] = static_cast<uint8_t>(treefit::state_mask(static_cast<char>(std::toupper(c)))); }
+  } lut;
+  keys.resize(static_cast<size_t>(cols) * N);
+  for (int r = 0; r < N; r++) {
+    const uint8_t *row = reinterpret_cast<const uint8_t *>(rows[r]);
+    for (int c = 0; c < cols; c++) keys[static_cast<size_t>(c) * N + r] = lut.m[row[c]];
+  }
+  size_t tsize = 16;
+  while (tsize < 2 * static_cast<size_t>(cols)) tsize <<= 1;
+  table.assign(tsize, -1);
+  first.clear();
+  ps.N = N; ps.P = 0; ps.w.clear();
+  for (int c = 0; c < cols; c++) {
+    const uint8_t *key = keys.data() + static_cast<size_t>(c) * N;
+    uint64_t h = 1469598103934665603ull;
+    for (int r = 0; r < N; r++) { h ^= key[r]; h *= 1099511628211ull; }
+    size_t at = static_cast<size_t>(h ^ (h >> 29)) & (tsize - 1);
+    for (;;) {
+      const int p = table[at];
+      if (p < 0) { table[at] = ps.P++; first.push_back(c); ps.w.push_back(1.0); break; }
+      if (std::memcmp(keys.data() + static_cast<size_t>(first[p]) * N, key, static_cast<size_t>(N)) == 0) { ps.w[p] += 1.0; break; }
+      at = (at + 1) & (tsize - 1);
+    }
+  }
+  ps.mask.resize(static_cast<size_t>(N) * ps.P);
+  for (int p = 0; p < ps.P; p++) {
+    const uint8_t *key = keys.data() + static_cast<size_t>(first[p]) * N;
+    for (int r = 0; r < N; r++) ps.mask[static_cast<size_t>(r) * ps.P + p] = key[r];
+  }
+  return true;
+}
+
 bool compress_patterns(const std::vector<std::string> &rows, PatternSet &ps, std::string &err) {
   const int N = static_cast<int>(rows.size());
   if (N < 3) { err = "at least three sequences are needed"; return false; }
-  if (N > treefit::kMaxTips) { err = "too many sequences for the tree estimator"; return false; }
   const int cols = static_cast<int>(rows[0].size());
-  for (auto &r : rows) if (static_cast<int>(r.size()) != cols) { err = "Sequences are of unequal length."; return false; }
-  std::map<std::string, int> seen;
-  std::vector<std::string> keys;
-  ps.N = N; ps.P = 0; ps.w.clear();
-  for (int c = 0; c < cols; c++) {
-    std::string key(N, ' ');
-    for (int r = 0; r < N; r++) key[r] = static_cast<char>(treefit::state_mask(static_cast<char>(std::toupper(static_cast<unsigned char>(rows[r][c])))));
-    auto it = seen.find(key);
-    if (it == seen.end()) { seen.emplace(key, ps.P++); keys.push_back(key); ps.w.push_back(1.0); }
-    else ps.w[it->second] += 1.0;
+  std::vector<const char *> ptr(N);
+  for (int r = 0; r < N; r++) {
+    if (static_cast<int>(rows[r].size()) != cols) { err = "Sequences are of unequal length."; return false; }
+    ptr[r] = rows[r].c_str();
   }
-  ps.mask.assign(static_cast<size_t>(N) * ps.P, 0);
-  for (int p = 0; p < ps.P; p++) for (int r = 0; r < N; r++) ps.mask[static_cast<size_t>(r) * ps.P + p] = static_cast<uint8_t>(keys[p][r]);
-  return true;
+  return compress_patterns(ptr.data(), N, cols, ps, err);
 }
 
 static void write_node(int v, int N, int root, const int *nchild, const int *child, const double *len,

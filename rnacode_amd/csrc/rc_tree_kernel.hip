@@ -28,7 +28,7 @@ struct WaveExec {
   __device__ int broadcast_root(int r) const { return __shfl(r, 0, kWave); }
 };
 
-__global__ __launch_bounds__(kWave) void k_tree_fit(const TreeJob *jobs, const uint8_t *in, double *scratch, TreeOut *out) {
+__global__ __launch_bounds__(kWave) void k_tree_fit(const TreeJob *jobs, const uint8_t *in, double *scratch, TreeOut *out, double *results) {
   const TreeJob j = jobs[blockIdx.x];
   TreeOut &o = out[blockIdx.x];
   treefit::Work k;
@@ -42,14 +42,22 @@ __global__ __launch_bounds__(kWave) void k_tree_fit(const TreeJob *jobs, const u
   k.down = s + 2 * nn2; k.msg = k.down + part; k.up = k.msg + part;
   WaveExec ex;
   const double lnl = treefit::fit(k, ex);
-  if (threadIdx.x == 0) { o.root = k.root; o.kappa = k.mod.kappa; o.lnl = lnl; }
+  // the compact result record (rc_launch.h, tree_result_doubles)
+  double *rd = results + j.off_out;
+  int *ri = reinterpret_cast<int *>(rd + 2 + k.nn);
+  if (threadIdx.x == 0) { rd[0] = k.mod.kappa; rd[1] = lnl; ri[0] = k.root; }
+  for (int v = threadIdx.x; v < k.nn; v += kWave) {
+    rd[2 + v] = k.len[v];
+    ri[1 + v] = k.nchild[v];
+    for (int c = 0; c < 3; c++) ri[1 + k.nn + 3 * v + c] = k.child[3 * v + c];
+  }
 }
 
 }  // namespace
 
-void launch_tree_fit(const TreeJob *jobs, int njobs, const uint8_t *in, double *scratch, TreeOut *out, hipStream_t stream) {
+void launch_tree_fit(const TreeJob *jobs, int njobs, const uint8_t *in, double *scratch, TreeOut *work, double *results, hipStream_t stream) {
   if (njobs <= 0) return;
-  hipLaunchKernelGGL(k_tree_fit, dim3(njobs), dim3(kWave), 0, stream, jobs, in, scratch, out);
+  hipLaunchKernelGGL(k_tree_fit, dim3(njobs), dim3(kWave), 0, stream, jobs, in, scratch, work, results);
 }
 
 }  // namespace rc

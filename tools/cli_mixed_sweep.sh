@@ -1,5 +1,5 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT
+cd ${GRAFT_REPO_ROOT:-.}
 python - <<'PY'
 import sys, os
 sys.path.insert(0, ".")
