@@ -1,6 +1,6 @@
 """Time the library load and rc_ctx_create (HIP runtime start, streams, tables): tools/ctx_time.py"""
 import sys, time, os
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 t=time.time()
 from rnacode_amd import api
 api.lib()

@@ -1,6 +1,6 @@
 """Very long blocks (4 x 6000 against the oracle, 3 x 15000 for completion): the native tile buffer and the staging scratch are bounded by memory, not by the block."""
 import sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np
 from oracle import binding as ob
 from rnacode_amd import api

@@ -4,7 +4,7 @@ import re
 import sys
 import time
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from rnacode_amd import api, synth  # noqa: E402
 
 

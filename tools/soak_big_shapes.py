@@ -1,6 +1,6 @@
 """Large-shape parity against the oracle (12 x 300 .. 3 x 1200; `wide`: 48 .. 250 rows): tools/soak_big_shapes.py [wide]"""
 import sys, time
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))); sys.path.insert(0, "tests")
 import numpy as np
 from oracle import binding as ob
 from rnacode_amd import api

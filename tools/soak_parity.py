@@ -7,7 +7,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 sys.path.insert(0, "tests")
 from oracle import binding as ob  # noqa: E402
 from rnacode_amd import api  # noqa: E402

@@ -5,7 +5,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from rnacode_amd import api  # noqa: E402
 from rnacode_amd.synth import synth_block  # noqa: E402
 

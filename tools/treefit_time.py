@@ -1,6 +1,6 @@
 """Time rc_fit_trees_device on 10 000 blocks (6 x 120, or `mixed`: 3..12 rows, 60..200 columns): tools/treefit_time.py [mixed]"""
 import sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import ctypes as C
 from rnacode_amd import api, synth
 blocks = synth.synth_blocks(10000, 6, 120, seed=1)
