@@ -10,7 +10,7 @@ out = sys.argv[1]
 
 
 def short(name):
-    name = name.replace("rc::", "")
+    name = name.replace("(anonymous namespace)::", "").replace("rc::", "").replace("void ", "")
     return name.split("(")[0][:60]
 
 

@@ -187,6 +187,7 @@ struct rc_ctx {
   DevBuf treeJobs, treeIn, treeWork, treeOut, treeRes;   // rc_fit_trees_device
   PinBuf treeInPin, treeResPin;
   std::mutex treeMutex;
+  double splitFactor = 0.5;   // a k_null launch with fewer (block, sample group) items than this fraction of the chip's wavefront slots splits every item into its six strand x frame parts (RC_SPLIT_FACTOR)
   int nativeWavesPerCU = 8;   // persistent wavefronts of k_native_dp per CU (RC_NATIVE_WAVES_PER_CU): it runs beside k_null and should not crowd it out
   size_t genericScratchWords = static_cast<size_t>(1) << 30;   // uint32 of staging scratch one k_null_generic launch may take: a twelfth of the device memory (24 GB of 288)
   hipStream_t compute[2] = {nullptr, nullptr};   // null sampling + fit; consecutive batches alternate, so the tail of one overlaps the head of the next
@@ -358,6 +359,7 @@ int rc_ctx_create(int device, rc_ctx **out) {
   c->genericScratchWords = std::max<size_t>(static_cast<size_t>(1) << 30, prop.totalGlobalMem / 12 / sizeof(uint32_t));
   c->togetherWords = std::max<size_t>(static_cast<size_t>(1) << 30, prop.totalGlobalMem / 36 / sizeof(uint32_t));   // 8 GB of 288: allocating more costs a short run more than it gains (tools/cli_mixed_sweep.sh)
   if (const char *e = std::getenv("RC_TOGETHER_MAX_MB")) c->togetherWords = static_cast<size_t>(std::max(0ll, std::atoll(e))) * (1u << 20) / sizeof(uint32_t);
+  if (const char *e = std::getenv("RC_SPLIT_FACTOR")) c->splitFactor = std::max(0.0, std::atof(e));
   if (const char *e = std::getenv("RC_NATIVE_WAVES_PER_CU")) c->nativeWavesPerCU = std::max(1, std::min(32, std::atoi(e)));
   if (const char *e = std::getenv("RC_GENERIC_SCRATCH_MB")) c->genericScratchWords = std::max<size_t>(1, static_cast<size_t>(std::atoll(e))) * (1u << 20) / sizeof(uint32_t);
   // non-blocking streams: no implicit ordering against the legacy default stream that a host framework in
@@ -716,7 +718,7 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
   // if their staging areas do not fit side by side, planned again as one launch after the other, each filling the chip by itself.
   bool together = b->classes.size() > 1 && !c->serialNative;
   // ... unless all of them together are too few to fill the chip: then every item is split into its six parts, as for a single small class
-  const bool splitAll = static_cast<long long>(b->okBlocks.size()) * groupsHere * 2 <= static_cast<long long>(c->numCU) * 16;
+  const bool splitAll = static_cast<double>(b->okBlocks.size()) * groupsHere <= c->splitFactor * c->numCU * 16;
  plan_again:
   plans.clear(); needSum = 0; needMax = 0;
   for (auto &kv : b->classes) {
@@ -734,7 +736,7 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
       if (!c->occ.count(key)) c->occ[key] = null_generic_occupancy(p.ldsBytes);
       const int occ = std::max(1, c->occ[key]);
       long long items = static_cast<long long>(kv.second.size()) * groupsHere;
-      p.comboSplit = (together ? splitAll : items * 2 <= static_cast<long long>(c->numCU) * occ) ? 1 : 0;
+      p.comboSplit = (together ? splitAll : static_cast<double>(items) <= c->splitFactor * c->numCU * occ) ? 1 : 0;
       if (p.comboSplit) items *= 6;
       p.grid = static_cast<int>(std::min<long long>(items, static_cast<long long>(c->numCU) * occ));
       // every wavefront keeps the sigma codes of its 64 samples (N x L x 2 bytes per sample): the scratch, not the registers, bounds the occupancy
@@ -759,7 +761,7 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
     const int occ = std::max(1, c->occ[std::pair<int, size_t>(p.NK, p.ldsBytes)]);
     int items = static_cast<int>(kv.second.size()) * groupsHere;
     // small batches: split every item into its six strand x frame parts to fill the chip
-    p.comboSplit = (together ? splitAll : items * 2 <= c->numCU * occ) ? 1 : 0;
+    p.comboSplit = (together ? splitAll : static_cast<double>(items) <= c->splitFactor * c->numCU * occ) ? 1 : 0;
     if (p.comboSplit) items *= 6;
     p.grid = std::min(items, c->numCU * occ);
     // very long blocks: bound the sigma-code staging area (4 GiB of uint32) by running fewer workgroups
@@ -1519,7 +1521,7 @@ int rc_fit_trees_device(rc_ctx *c, const rc_block *blocks, int32_t n_blocks, cha
     j.off_w = in_bytes;
     in_bytes += sizeof(double) * ps[i].P;
     j.off_work = work_doubles;
-    work_doubles += 2 * static_cast<size_t>(j.N) * j.N + 3 * static_cast<size_t>(2 * j.N - 2) * 4 * j.P;
+    work_doubles += tree_work_doubles(j.N, j.P);
     j.off_out = res_doubles;
     res_doubles += tree_result_doubles(j.N);
     jobs.push_back(j);

@@ -100,7 +100,7 @@ struct TreeJob {
   int N, P;
   uint64_t off_mask;          // bytes into the input blob: [N][P] state masks
   uint64_t off_w;             // bytes into the input blob (8-aligned): [P] pattern weights
-  uint64_t off_work;          // doubles into the scratch: 2 N^2 + 3 (2N-2) 4 P
+  uint64_t off_work;          // doubles into the scratch: tree_work_doubles(N, P)
   uint64_t off_out;           // doubles into the result buffer: the job's TreeResult record (tree_result_doubles(N) doubles)
 };
 // the kernel's working copy of the tree (global memory, one per job of a launch)
@@ -112,6 +112,11 @@ struct TreeOut {
 };
 // What travels back to the host per job, nn = 2N - 2 nodes: doubles {kappa, lnl, len[nn]} then ints {root, nchild[nn], child[3 nn]}
 // (260 bytes for six rows; the working copy above is 4 KB)
+// a job's work area: D, V [N][N]; down, msg, up [nn][4][P]; bionj's temporaries (N doubles, 2 N + nn ints)
+inline size_t tree_work_doubles(int N, int P) {
+  const size_t n = static_cast<size_t>(N), nn = 2 * n - 2;
+  return 2 * n * n + 3 * nn * 4 * static_cast<size_t>(P) + n + (2 * n + nn + 1) / 2;
+}
 inline size_t tree_result_doubles(int N) { const size_t nn = 2 * static_cast<size_t>(N) - 2; return 2 + nn + (1 + 4 * nn + 1) / 2; }
 void launch_tree_fit(const TreeJob *jobs, int njobs, const uint8_t *in, double *scratch, TreeOut *work, double *results, hipStream_t stream);
 

@@ -35,8 +35,8 @@ struct SerialExec {
 struct Fitter {
   treefit::Work k{};
   std::vector<uint8_t> mask;
-  std::vector<double> w, D, V, len, down, msg, up;
-  std::vector<int> parent, nchild, child, preorder;
+  std::vector<double> w, D, V, len, down, msg, up, tmpD;
+  std::vector<int> parent, nchild, child, preorder, tmpI;
 
   void load(const PatternSet &ps) {
     mask = ps.mask; w = ps.w;
@@ -52,6 +52,8 @@ struct Fitter {
     k.mask = mask.data(); k.w = w.data(); k.D = D.data(); k.V = V.data(); k.len = len.data();
     k.parent = parent.data(); k.nchild = nchild.data(); k.child = child.data(); k.preorder = preorder.data();
     k.down = down.data(); k.msg = msg.data(); k.up = up.data();
+    tmpD.assign(N, 0.0); tmpI.assign(static_cast<size_t>(2) * N + nn, 0);
+    k.tmpD = tmpD.data(); k.tmpI = tmpI.data();
   }
 };
 

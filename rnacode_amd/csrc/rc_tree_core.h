@@ -69,15 +69,35 @@ struct Hky {
   }
 };
 
-// 1-D minimiser on [lo, hi]: golden section with parabolic steps
-template <typename F>
-RC_HD double minimise(F f, double lo, double hi, double x0, double xtol, int itmax) {
-  const double cg = 0.3819660112501051;
-  double a = lo, b = hi, x = x0 < lo ? lo : (x0 > hi ? hi : x0), w = x, v = x;
-  double fx = f(x), fw = fx, fv = fx, d = 0, e = 0;
-  for (int it = 0; it < itmax; it++) {
+// 1-D minimiser on [lo, hi]: golden section with parabolic steps, as a resumable object -- start(), then feed() the value at `u`
+// until it returns false; the minimiser is `x`.  (Written this way so that the code that evaluates the objective exists once: the
+// kernel's instruction stream has to fit the instruction cache.)
+struct Brent {
+  double a, b, x, w, v, fx, fw, fv, d, e, xtol, u;
+  int it, itmax;
+  bool first;
+  RC_HD void start(double lo, double hi, double x0, double xtol_, int itmax_) {
+    a = lo; b = hi; x = x0 < lo ? lo : (x0 > hi ? hi : x0); w = x; v = x;
+    fx = fw = fv = 0; d = 0; e = 0; xtol = xtol_; itmax = itmax_; it = 0; first = true; u = x;
+  }
+  // takes f(u); true: evaluate at the new u, false: done
+  RC_HD bool feed(double fu) {
+    if (first) { fx = fw = fv = fu; first = false; }
+    else {
+      if (fu <= fx) {
+        if (u >= x) a = x; else b = x;
+        v = w; fv = fw; w = x; fw = fx; x = u; fx = fu;
+      } else {
+        if (u < x) a = u; else b = u;
+        if (fu <= fw || w == x) { v = w; fv = fw; w = u; fw = fu; }
+        else if (fu <= fv || v == x || v == w) { v = u; fv = fu; }
+      }
+      it++;
+    }
+    if (it >= itmax) return false;
+    const double cg = 0.3819660112501051;
     const double xm = 0.5 * (a + b), tol1 = xtol * fabs(x) + 1e-10, tol2 = 2 * tol1;
-    if (fabs(x - xm) <= tol2 - 0.5 * (b - a)) break;
+    if (fabs(x - xm) <= tol2 - 0.5 * (b - a)) return false;
     bool golden = true;
     if (fabs(e) > tol1) {
       double r = (x - w) * (fx - fv), q = (x - v) * (fx - fw), p = (x - v) * q - (x - w) * r;
@@ -88,24 +108,24 @@ RC_HD double minimise(F f, double lo, double hi, double x0, double xtol, int itm
       e = d;
       if (!(fabs(p) >= fabs(0.5 * q * etemp) || p <= q * (a - x) || p >= q * (b - x))) {
         d = p / q;
-        const double u = x + d;
-        if (u - a < tol2 || b - u < tol2) d = (xm >= x) ? tol1 : -tol1;
+        const double un = x + d;
+        if (un - a < tol2 || b - un < tol2) d = (xm >= x) ? tol1 : -tol1;
         golden = false;
       }
     }
     if (golden) { e = (x >= xm) ? a - x : b - x; d = cg * e; }
-    const double u = (fabs(d) >= tol1) ? x + d : x + ((d > 0) ? tol1 : -tol1);
-    const double fu = f(u);
-    if (fu <= fx) {
-      if (u >= x) a = x; else b = x;
-      v = w; fv = fw; w = x; fw = fx; x = u; fx = fu;
-    } else {
-      if (u < x) a = u; else b = u;
-      if (fu <= fw || w == x) { v = w; fv = fw; w = u; fw = fu; }
-      else if (fu <= fv || v == x || v == w) { v = u; fv = fu; }
-    }
+    u = (fabs(d) >= tol1) ? x + d : x + ((d > 0) ? tol1 : -tol1);
+    return true;
   }
-  return x;
+};
+
+template <typename F>
+RC_HD double minimise(F f, double lo, double hi, double x0, double xtol, int itmax) {
+  Brent br;
+  br.start(lo, hi, x0, xtol, itmax);
+  double val;
+  do { val = f(br.u); } while (br.feed(val));
+  return br.x;
 }
 
 // everything one fit works on; the arrays are provided by the caller (host vectors / GPU scratch)
@@ -122,13 +142,28 @@ struct Work {
   int *preorder;         // [nn]
   double *len;           // [nn]
   double *D, *V;         // [N][N]
+  double *tmpD;          // [N]           bionj's row sums
+  int *tmpI;             // [2 N + nn]    bionj's slot tables and the stack of its pre-order walk (kept out of the kernel's private memory:
+                         //               a kernel with 1.8 KB of scratch per lane gets fewer wavefronts from the runtime than its registers allow)
   double *down, *msg, *up;   // [nn][4][P]
   // which of those columns are current (bit v of word v / 64), see refresh_down / refresh_up: a branch-length change makes only
   // part of them stale, and recomputing exactly the stale ones gives the same numbers as recomputing everything
-  uint64_t okDn[(kMaxNodes + 63) / 64], okMs[(kMaxNodes + 63) / 64], okUp[(kMaxNodes + 63) / 64];
-  RC_HD static bool bit(const uint64_t *m, int v) { return (m[v >> 6] >> (v & 63)) & 1ull; }
-  RC_HD static void set_bit(uint64_t *m, int v) { m[v >> 6] |= 1ull << (v & 63); }
-  RC_HD static void clear_bit(uint64_t *m, int v) { m[v >> 6] &= ~(1ull << (v & 63)); }
+  static constexpr int kSetWords = (kMaxNodes + 63) / 64;
+  uint64_t okDn[kSetWords], okMs[kSetWords], okUp[kSetWords];
+  // On the device a set is two words: the word is picked by comparison, not by a run-time index, so that the sets stay in registers
+  // (a run-time index would put them, and with them a scratch allocation per lane, into private memory).
+  RC_HD static bool bit(const uint64_t *m, int v) {
+    if constexpr (kSetWords <= 2) { uint64_t w = m[0]; for (int x = 1; x < kSetWords; x++) if ((v >> 6) == x) w = m[x]; return (w >> (v & 63)) & 1ull; }
+    else return (m[v >> 6] >> (v & 63)) & 1ull;
+  }
+  RC_HD static void set_bit(uint64_t *m, int v) {
+    if constexpr (kSetWords <= 2) { for (int x = 0; x < kSetWords; x++) m[x] |= ((v >> 6) == x) ? (1ull << (v & 63)) : 0ull; }
+    else m[v >> 6] |= 1ull << (v & 63);
+  }
+  RC_HD static void clear_bit(uint64_t *m, int v) {
+    if constexpr (kSetWords <= 2) { for (int x = 0; x < kSetWords; x++) m[x] &= ((v >> 6) == x) ? ~(1ull << (v & 63)) : ~0ull; }
+    else m[v >> 6] &= ~(1ull << (v & 63));
+  }
   RC_HD double &dn(int v, int s, int p) const { return down[(static_cast<size_t>(v) * 4 + s) * P + p]; }
   RC_HD double &ms(int v, int s, int p) const { return msg[(static_cast<size_t>(v) * 4 + s) * P + p]; }
   RC_HD double &upp(int v, int s, int p) const { return up[(static_cast<size_t>(v) * 4 + s) * P + p]; }
@@ -162,7 +197,8 @@ RC_HD inline double pair_distance(const Work &k, int x, int y) {
     const int a = k.mask[static_cast<size_t>(x) * k.P + p], b = k.mask[static_cast<size_t>(y) * k.P + p];
     if ((a & (a - 1)) || (b & (b - 1))) continue;   // ambiguous in either row: hidden
     const int ia = (a == 1) ? 0 : (a == 2) ? 1 : (a == 4) ? 2 : 3, ib = (b == 1) ? 0 : (b == 2) ? 1 : (b == 4) ? 2 : 3;
-    F[ia][ib] += k.w[p];
+    // F[ia][ib] += w with compile-time subscripts (x + 0.0 == x for these sums): a run-time subscript would move F into private memory
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) F[i][j] += (i == ia && j == ib) ? k.w[p] : 0.0;
     tot += k.w[p];
   }
   if (tot <= 0) return -1.0;
@@ -190,8 +226,8 @@ RC_HD inline void bionj(Work &k) {
   const int N = k.N;
   double *D = k.D, *V = k.V;
   for (int i = 0; i < N * N; i++) V[i] = D[i];
-  int node[kMaxTips], on[kMaxTips];
-  double S[kMaxTips];
+  int *node = k.tmpI, *on = k.tmpI + N;
+  double *S = k.tmpD;
   for (int i = 0; i < N; i++) { node[i] = i; on[i] = 1; }
   for (int v = 0; v < k.nn; v++) { k.parent[v] = -1; k.nchild[v] = 0; k.len[v] = kBlMin; }
   int r = N, next = N;
@@ -234,7 +270,7 @@ RC_HD inline void bionj(Work &k) {
   for (int i = 0; i < 3; i++) { k.parent[node[s3[i]]] = k.root; k.child[k.root * 3 + i] = node[s3[i]]; }
   k.nchild[k.root] = 3;
   // pre-order
-  int stack[kMaxNodes], sp = 0, n = 0;
+  int *stack = k.tmpI + 2 * N, sp = 0, n = 0;
   stack[sp++] = k.root;
   while (sp) {
     const int v = stack[--sp];
@@ -257,12 +293,12 @@ RC_HD void tip_partials(Work &k, Exec &ex) {
 // so after branch v changed, msg(v), down/msg of v's ancestors and up of every node that is neither v nor an ancestor of v are
 // stale; after the model changed everything is.
 RC_HD inline void invalidate_all(Work &k) {
-  for (int x = 0; x < (kMaxNodes + 63) / 64; x++) k.okDn[x] = k.okMs[x] = k.okUp[x] = 0;
+  for (int x = 0; x < Work::kSetWords; x++) k.okDn[x] = k.okMs[x] = k.okUp[x] = 0;
   for (int t = 0; t < k.N; t++) Work::set_bit(k.okDn, t);   // tip columns are data (tip_partials)
 }
 RC_HD inline void branch_changed(Work &k, int v) {
-  uint64_t keep[(kMaxNodes + 63) / 64];
-  for (int x = 0; x < (kMaxNodes + 63) / 64; x++) keep[x] = 0;
+  uint64_t keep[Work::kSetWords];
+  for (int x = 0; x < Work::kSetWords; x++) keep[x] = 0;
   Work::set_bit(keep, v);
   Work::clear_bit(k.okMs, v);
   for (int a = k.parent[v];; a = k.parent[a]) {
@@ -271,7 +307,7 @@ RC_HD inline void branch_changed(Work &k, int v) {
     Work::clear_bit(k.okMs, a);
     if (a == k.root) break;
   }
-  for (int x = 0; x < (kMaxNodes + 63) / 64; x++) k.okUp[x] &= keep[x];
+  for (int x = 0; x < Work::kSetWords; x++) k.okUp[x] &= keep[x];
 }
 
 // every stale down / msg column, children before parents
@@ -303,8 +339,8 @@ RC_HD void refresh_down(Work &k, Exec &ex) {
 // the stale up columns on the path from the root to `target` (parents before children); needs refresh_down first
 template <typename Exec>
 RC_HD void refresh_up(Work &k, Exec &ex, int target) {
-  uint64_t path[(kMaxNodes + 63) / 64];
-  for (int x = 0; x < (kMaxNodes + 63) / 64; x++) path[x] = 0;
+  uint64_t path[Work::kSetWords];
+  for (int x = 0; x < Work::kSetWords; x++) path[x] = 0;
   for (int a = target; a != k.root; a = k.parent[a]) Work::set_bit(path, a);
   for (int o = 0; o < k.nn; o++) {
     const int v = k.preorder[o];
@@ -356,35 +392,146 @@ RC_HD double total_lnl(Work &k, Exec &ex) {
 }
 
 // coordinate-wise ML: every branch, then kappa, until the log-likelihood moves by less than 1e-4
-// (PhyML's Round_Optimize stops at 1e-3, phyml/utilities.c:5207)
+// (PhyML's Round_Optimize stops at 1e-3, phyml/utilities.c:5207).
+//
+// Written as ONE loop that performs one micro-operation per pass -- bring one stale down/msg column up to date, or one stale
+// up column on the way to the branch under evaluation, or evaluate the log-likelihood at that branch -- so that every heavy piece
+// of code (the HKY85 matrix with its three exponentials, the column updates, the per-pattern likelihood with its logarithm, the
+// minimiser's step) exists exactly once.  The numbers are those of the plain formulation (every branch: refresh_down, refresh_up,
+// minimise(edge_lnl); then minimise over kappa of total_lnl; then total_lnl): the same operations on the same operands in the same order.
 template <typename Exec>
 RC_HD double optimise(Work &k, Exec &ex) {
   tip_partials(k, ex);
   invalidate_all(k);
-  double prev = total_lnl(k, ex);
-  for (int round = 0; round < 60; round++) {
-    for (int v = 0; v < k.nn; v++) {
-      if (v == k.root) continue;
-      refresh_down(k, ex);
-      refresh_up(k, ex, v);
-      k.len[v] = minimise([&](double t) { return -edge_lnl(k, ex, v, t); }, kBlMin, kBlMax, k.len[v], 1e-5, 60);
-      branch_changed(k, v);
+  enum { PH_TOTAL_INIT, PH_BRANCH, PH_KAPPA, PH_TOTAL_ROUND };
+  enum { OP_EVAL, OP_DOWN, OP_UP };
+  const int v0 = k.child[k.root * 3];   // the likelihood of the whole tree is read at the root's first branch (its up column needs no other)
+  int phase = PH_TOTAL_INIT, round = 0, bv = 0;
+  int ev = v0;                    // branch under evaluation ...
+  double et = k.len[v0];          // ... at this length
+  double prev = 0.0;
+  Brent br;
+  br.start(0, 1, 0, 0, 0);
+  // refresh state: scanning positions in the pre-order, the path root -> ev
+  int curDn = k.nn - 1, curUp = 0;
+  bool refreshing = true;
+  uint64_t path[Work::kSetWords];
+  auto request = [&](int v, double t) {   // evaluate branch v at length t after bringing the columns it needs up to date
+    ev = v; et = t;
+    curDn = k.nn - 1; curUp = 0; refreshing = true;
+    for (int x = 0; x < Work::kSetWords; x++) path[x] = 0;
+    for (int a = v; a != k.root; a = k.parent[a]) Work::set_bit(path, a);
+  };
+  auto first_branch = [&](int from) { int v = from; while (v < k.nn && v == k.root) v++; return v; };
+  request(v0, k.len[v0]);
+  for (;;) {
+    // ---- 1. the next micro-operation
+    int op = OP_EVAL, v = ev;
+    double t = et;
+    if (refreshing) {
+      while (curDn >= 0) {
+        const int c = k.preorder[curDn];
+        if ((c >= k.N && !Work::bit(k.okDn, c)) || (c != k.root && !Work::bit(k.okMs, c))) break;
+        curDn--;
+      }
+      if (curDn >= 0) { op = OP_DOWN; v = k.preorder[curDn]; t = k.len[v]; }
+      else {
+        while (curUp < k.nn) {
+          const int c = k.preorder[curUp];
+          if (c != k.root && Work::bit(path, c) && !Work::bit(k.okUp, c)) break;
+          curUp++;
+        }
+        if (curUp < k.nn) { op = OP_UP; v = k.preorder[curUp]; t = k.len[k.parent[v]]; }
+        else refreshing = false;
+      }
     }
-    const double kap = minimise(
-        [&](double kk) {
-          const Hky save = k.mod;
-          k.mod.set(k.pi, kk);
-          invalidate_all(k);
-          const double r = -total_lnl(k, ex);
-          k.mod = save;
-          return r;
-        },
-        0.1, 100.0, k.mod.kappa, 1e-5, 60);
-    k.mod.set(k.pi, kap);
-    invalidate_all(k);
-    const double cur = total_lnl(k, ex);
-    if (fabs(cur - prev) < 1e-4) { prev = cur; break; }
-    prev = cur;
+    // ---- 2. the branch matrix (the root's product and an up column directly below the root need none)
+    double Pm[4][4];
+    const bool needP = !(op == OP_DOWN && v == k.root) && !(op == OP_UP && k.parent[v] == k.root);
+    if (needP) k.mod.probs(t, Pm);
+    if (op == OP_DOWN) {
+      if (v >= k.N && !Work::bit(k.okDn, v)) {
+        for (int p = ex.lane(); p < k.P; p += ex.nlanes())
+          for (int s = 0; s < 4; s++) {
+            double d = 1.0;
+            for (int c = 0; c < k.nchild[v]; c++) d *= k.ms(k.child[v * 3 + c], s, p);
+            k.dn(v, s, p) = d;
+          }
+        Work::set_bit(k.okDn, v);
+      }
+      if (v != k.root && !Work::bit(k.okMs, v)) {
+        for (int p = ex.lane(); p < k.P; p += ex.nlanes()) {
+          const double d0 = k.dn(v, 0, p), d1 = k.dn(v, 1, p), d2 = k.dn(v, 2, p), d3 = k.dn(v, 3, p);
+          for (int i = 0; i < 4; i++) k.ms(v, i, p) = Pm[i][0] * d0 + Pm[i][1] * d1 + Pm[i][2] * d2 + Pm[i][3] * d3;
+        }
+        Work::set_bit(k.okMs, v);
+      }
+      continue;
+    }
+    if (op == OP_UP) {
+      const int par = k.parent[v];
+      double W[4][4];
+      if (par != k.root)   // what comes from above the parent, through the parent's own branch
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) W[i][j] = Pm[j][i] * k.mod.pi[j] / k.mod.pi[i];
+      for (int p = ex.lane(); p < k.P; p += ex.nlanes()) {
+        double u[4] = {1.0, 1.0, 1.0, 1.0};
+        for (int c = 0; c < k.nchild[par]; c++) {
+          const int sib = k.child[par * 3 + c];
+          if (sib != v) for (int s = 0; s < 4; s++) u[s] *= k.ms(sib, s, p);
+        }
+        if (par != k.root) {
+          const double a0 = k.upp(par, 0, p), a1 = k.upp(par, 1, p), a2 = k.upp(par, 2, p), a3 = k.upp(par, 3, p);
+          for (int i = 0; i < 4; i++) u[i] *= W[i][0] * a0 + W[i][1] * a1 + W[i][2] * a2 + W[i][3] * a3;
+        }
+        for (int s = 0; s < 4; s++) k.upp(v, s, p) = u[s];
+      }
+      Work::set_bit(k.okUp, v);
+      continue;
+    }
+    // ---- 3. the log-likelihood read at branch ev with length et (edge_lnl)
+    double lnl = 0;
+    for (int p = ex.lane(); p < k.P; p += ex.nlanes()) {
+      const double d0 = k.dn(v, 0, p), d1 = k.dn(v, 1, p), d2 = k.dn(v, 2, p), d3 = k.dn(v, 3, p);
+      double sm = 0;
+      for (int i = 0; i < 4; i++)
+        sm += k.mod.pi[i] * k.upp(v, i, p) * (Pm[i][0] * d0 + Pm[i][1] * d1 + Pm[i][2] * d2 + Pm[i][3] * d3);
+      lnl += k.w[p] * log(sm > 1e-300 ? sm : 1e-300);
+    }
+    lnl = ex.sum(lnl);
+    // ---- 4. who asked
+    if (phase == PH_BRANCH) {
+      if (br.feed(-lnl)) { et = br.u; continue; }       // another length of the same branch: nothing is stale
+      k.len[bv] = br.x;
+      branch_changed(k, bv);
+      bv = first_branch(bv + 1);
+      if (bv < k.nn) { br.start(kBlMin, kBlMax, k.len[bv], 1e-5, 60); request(bv, br.u); continue; }
+      phase = PH_KAPPA;
+      br.start(0.1, 100.0, k.mod.kappa, 1e-5, 60);
+      k.mod.set(k.pi, br.u);                            // try a kappa: every column depends on the model
+      invalidate_all(k);
+      request(v0, k.len[v0]);
+      continue;
+    }
+    if (phase == PH_KAPPA) {
+      const bool more = br.feed(-lnl);
+      k.mod.set(k.pi, more ? br.u : br.x);              // the next candidate, or the minimiser
+      invalidate_all(k);
+      if (!more) phase = PH_TOTAL_ROUND;
+      request(v0, k.len[v0]);
+      continue;
+    }
+    if (phase == PH_TOTAL_ROUND) {
+      const double cur = lnl;
+      if (fabs(cur - prev) < 1e-4) { prev = cur; break; }
+      prev = cur;
+      if (++round == 60) break;
+    } else {
+      prev = lnl;                                       // PH_TOTAL_INIT
+    }
+    phase = PH_BRANCH;
+    bv = first_branch(0);
+    br.start(kBlMin, kBlMax, k.len[bv], 1e-5, 60);
+    request(bv, br.u);
   }
   return prev;
 }

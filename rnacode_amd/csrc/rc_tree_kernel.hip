@@ -10,6 +10,8 @@
 // matters is that 10^4 blocks are fitted concurrently instead of ~10^3 per second per host core.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "rc_launch.h"
 #include "rc_tree_core.h"
 
@@ -28,7 +30,7 @@ struct WaveExec {
   __device__ int broadcast_root(int r) const { return __shfl(r, 0, kWave); }
 };
 
-__global__ __launch_bounds__(kWave) void k_tree_fit(const TreeJob *jobs, const uint8_t *in, double *scratch, TreeOut *out, double *results) {
+__device__ __forceinline__ void tree_fit_body(const TreeJob *jobs, const uint8_t *in, double *scratch, TreeOut *out, double *results) {
   const TreeJob j = jobs[blockIdx.x];
   TreeOut &o = out[blockIdx.x];
   treefit::Work k;
@@ -40,6 +42,8 @@ __global__ __launch_bounds__(kWave) void k_tree_fit(const TreeJob *jobs, const u
   const size_t nn2 = static_cast<size_t>(j.N) * j.N, part = static_cast<size_t>(k.nn) * 4 * j.P;
   k.D = s; k.V = s + nn2;
   k.down = s + 2 * nn2; k.msg = k.down + part; k.up = k.msg + part;
+  k.tmpD = k.up + part;
+  k.tmpI = reinterpret_cast<int *>(k.tmpD + j.N);
   WaveExec ex;
   const double lnl = treefit::fit(k, ex);
   // the compact result record (rc_launch.h, tree_result_doubles)
@@ -53,11 +57,28 @@ __global__ __launch_bounds__(kWave) void k_tree_fit(const TreeJob *jobs, const u
   }
 }
 
+
+// The same body under three register budgets (wavefronts per SIMD the compiler must leave room for): the fit is latency-bound,
+// so more resident wavefronts hide more of it, until the spills a smaller budget forces cost more than they hide
+// (RC_TREE_WAVES picks one at run time; the default is the measured best).
+#define RC_TREE_KERNEL(W)                                                                                                        \
+  __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(W, W))) void k_tree_fit_w##W(                            \
+      const TreeJob *jobs, const uint8_t *in, double *scratch, TreeOut *out, double *results) {                                    \
+    tree_fit_body(jobs, in, scratch, out, results);                                                                                \
+  }
+RC_TREE_KERNEL(2)
+RC_TREE_KERNEL(3)
+RC_TREE_KERNEL(4)
+#undef RC_TREE_KERNEL
+
 }  // namespace
 
 void launch_tree_fit(const TreeJob *jobs, int njobs, const uint8_t *in, double *scratch, TreeOut *work, double *results, hipStream_t stream) {
   if (njobs <= 0) return;
-  hipLaunchKernelGGL(k_tree_fit, dim3(njobs), dim3(kWave), 0, stream, jobs, in, scratch, work, results);
+  static const int waves = [] { const char *e = std::getenv("RC_TREE_WAVES"); const int w = e ? std::atoi(e) : 2; return (w >= 2 && w <= 4) ? w : 2; }();
+  if (waves == 4) hipLaunchKernelGGL(k_tree_fit_w4, dim3(njobs), dim3(kWave), 0, stream, jobs, in, scratch, work, results);
+  else if (waves == 3) hipLaunchKernelGGL(k_tree_fit_w3, dim3(njobs), dim3(kWave), 0, stream, jobs, in, scratch, work, results);
+  else hipLaunchKernelGGL(k_tree_fit_w2, dim3(njobs), dim3(kWave), 0, stream, jobs, in, scratch, work, results);
 }
 
 }  // namespace rc

@@ -160,6 +160,73 @@ def test_config3_full_size_stream_and_resident_against_oracle(ctx):
     big.close()
 
 
+def test_config5_one_gpus_share_streamed_against_oracle(ctx):
+    """BASELINE configs[4] at ONE GPU's share of eight: 12 500 blocks x 300 cols x 12 seqs at n = 10 000 (1.25e8 sample-alignments,
+    about 8 s of GPU) through rc_stream_* in sub-batches of 1000.  Checked: every block fitted; a 1000-block slice scored as one
+    resident batch gives the stream's maxima and fits; sample-range sharding by seed (score.c:1004-1048 with seed_base + s) reproduces
+    the full rows; eight random blocks x their first 64 samples and their HSS tables equal the CPU oracle.  (The two reference-scored
+    blocks of this shape are the golden synth_12x300_n40, test_gpu_parity.)"""
+    from oracle import binding as ob
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_blocks
+    nb, n, seed = 12500, 10000, 42
+    blocks = [b.upper() for b in synth_blocks(nb, 12, 300, seed=1)]
+    p = api.default_params(sampleN=n, seed_base=seed)
+    m = api.Marshalled(blocks)
+    m.set_trees()
+    rng = np.random.RandomState(321)
+    picks = sorted(rng.choice(nb, 8, replace=False).tolist())
+    lo_s, hi_s = 3000, 4000                      # the slice that is also scored as one resident batch
+    in_slice = [3100, 3555, 3999]
+    keep_max, keep_hss = {}, {}
+    fits = np.zeros((nb, 4), dtype=np.float32)
+    slice_max = np.zeros((hi_s - lo_s, n), dtype=np.float32)
+    clamped = 0
+    at = 0
+    for batch in api.score_stream(ctx, m, p, 1000, depth=3):
+        fits[at:at + batch.n] = batch.fits()
+        clamped += batch.clamped()
+        for i in picks + in_slice:
+            if at <= i < at + batch.n:
+                keep_max[i] = batch.maxScores(i - at)
+                keep_hss[i] = batch.scoreAln(i - at)
+        a, b = max(at, lo_s), min(at + batch.n, hi_s)
+        if a < b:
+            slice_max[a - lo_s:b - lo_s] = batch.maxScores_all()[a - at:b - at]
+        at += batch.n
+        batch.close()
+    assert at == nb
+    assert clamped <= 2000                       # about 1e-7 per root draw (DESIGN.md section 4): 1.25e8 x 300 root draws
+    assert (fits[:, 0] == 1).all()               # every block scored and fitted (no stop-early here)
+    assert np.isfinite(fits[:, 1:3]).all() and (fits[:, 2] > 0).all()
+    # ---- the 1000-block slice as one resident batch
+    part = api.Batch(ctx, blocks[lo_s:hi_s], p).run()
+    np.testing.assert_array_equal(part.maxScores_all(), slice_max)
+    np.testing.assert_array_equal(part.fits()[:, 0], fits[lo_s:hi_s, 0])
+    np.testing.assert_allclose(part.fits()[:, 1:3], fits[lo_s:hi_s, 1:3], rtol=1e-6)
+    for i in in_slice:
+        assert part.scoreAln(i - lo_s) == keep_hss[i]
+    part.close()
+    # ---- sample-range sharding: samples [0, 4992) and [4992, 10000) as two runs, seeds seed and seed + 4992
+    some = [blocks[i] for i in picks[:4]]
+    cut = 4992
+    first = api.Batch(ctx, some, api.default_params(sampleN=cut, seed_base=seed)).run()
+    second = api.Batch(ctx, some, api.default_params(sampleN=n - cut, seed_base=seed + cut)).run()
+    for t, i in enumerate(picks[:4]):
+        np.testing.assert_array_equal(np.concatenate([first.maxScores(t), second.maxScores(t)]), keep_max[i])
+    first.close(); second.close()
+    # ---- the CPU oracle on eight random blocks: the first 64 samples and the native HSS table
+    for i in picks:
+        b = blocks[i]
+        res = ob.run_block([r.seq for r in b.rows], [r.name for r in b.rows], b.rows[0].start, b.rows[0].length, b.tree, b.kappa,
+                           ob.default_params(64), seed)
+        np.testing.assert_array_equal(keep_max[i][:64], np.float32(res.maxScores))
+        got = sorted(keep_hss[i], key=hss_key)
+        want = sorted(res.hss, key=hss_key)
+        assert [(h["strand"], h["frame"], h["start"], h["end"], np.float32(h["score"])) for h in got] == \
+               [(h["strand"], h["frame"], h["start"], h["end"], np.float32(h["score"])) for h in want]
+
+
 def test_stop_early_runs_fewer_samples_and_agrees_with_the_oracle(monkeypatch):
     """--stop-early (score.c:992,1036-1042): blocks whose first samples already beat the native score more often
     than the cutoff allows are decided (rc = -1) and get no further samples; all others are sampled in full.
