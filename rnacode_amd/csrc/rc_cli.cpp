@@ -23,6 +23,8 @@
 #include <thread>
 #include <vector>
 
+#include <unistd.h>
+
 #include "../../include/rnacode_hip.h"
 
 namespace {
@@ -237,6 +239,7 @@ int main(int argc, char **argv) {
   list.cutoff = par.cutoff;
 
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double tMain = now();
   double tRead = now(), tCtx = 0, tTrees = 0, tSubmit = 0, tWait = 0, tList = 0;
   // the HIP runtime and the context come up (0.1-0.3 s) on a thread of their own while this one reads and parses the input
   rc_ctx *ctx = nullptr;
@@ -401,14 +404,21 @@ int main(int argc, char **argv) {
   }
   rc_stream_destroy(stream);
   if (std::getenv("RC_CLI_TIMES"))
-    std::fprintf(stderr, "[rnacode_hip] read %.3f s, context (beside the reading) %.3f s, trees %.3f s, submit %.3f s, wait %.3f s, listing %.3f s\n", tRead, tCtx, tTrees, tSubmit, tWait, tList);
+    std::fprintf(stderr, "[rnacode_hip] read %.3f s, context (beside the reading) %.3f s, trees %.3f s, submit %.3f s, wait %.3f s, listing %.3f s, main() so far %.3f s\n",
+                 tRead, tCtx, tTrees, tSubmit, tWait, tList, now() - tMain);
   if (list.fmt == 0) {   // RNAcode.c:223-228
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::fprintf(list.out, "\n%i alignment(s) scored in %.2f seconds. Parameters used:\nN=%i, Delta=%.2f, Omega=%.2f, omega=%.2f, stop penalty=%.2f\n\n",
                  nRead, secs, par.sampleN, static_cast<double>(par.Delta), static_cast<double>(par.Omega), static_cast<double>(par.omega),
                  static_cast<double>(par.stopPenalty_k));
   }
-  rc_ctx_destroy(ctx);
+  // Everything has been written; every batch has been waited for.  Tearing the HIP runtime down (streams, code objects, the device
+  // context) takes longer than the operating system needs to reclaim the process, so a driver that is done leaves at once
+  // (RC_CLI_TEARDOWN=1: the orderly way, for leak checkers).
   if (list.out != stdout) std::fclose(list.out);
+  std::fflush(stdout);
+  std::fflush(stderr);
+  if (!std::getenv("RC_CLI_TEARDOWN")) _exit(0);
+  rc_ctx_destroy(ctx);
   return 0;
 }

@@ -67,6 +67,27 @@ struct Hky {
       }
     }
   }
+  // P(t) with dP/dt and d2P/dt2 (the same three exponentials: d/dt exp(-beta c t) = -beta c exp(-beta c t))
+  RC_HD void probs_d(double t, double P[4][4], double P1[4][4], double P2[4][4]) const {
+    const double cR = 1.0 + grp[0] * (kappa - 1.0), cY = 1.0 + grp[1] * (kappa - 1.0);
+    const double e1 = exp(-beta * t), eR = exp(-beta * t * cR), eY = exp(-beta * t * cY);
+    const double d1 = -beta * e1, dd1 = beta * beta * e1;
+    for (int i = 0; i < 4; i++) {
+      const double c = (i & 1) ? cY : cR, e2 = (i & 1) ? eY : eR;
+      const double d2 = -beta * c * e2, dd2 = beta * beta * c * c * e2;
+      for (int j = 0; j < 4; j++) {
+        if (i == j) {
+          const double x = pi[j] * (1.0 / grp[j] - 1.0), y = (grp[j] - pi[j]) / grp[j];
+          P[i][j] = pi[j] + x * e1 + y * e2; P1[i][j] = x * d1 + y * d2; P2[i][j] = x * dd1 + y * dd2;
+        } else if (((i ^ j) & 1) == 0) {
+          const double x = pi[j] * (1.0 / grp[j] - 1.0), y = pi[j] / grp[j];
+          P[i][j] = pi[j] + x * e1 - y * e2; P1[i][j] = x * d1 - y * d2; P2[i][j] = x * dd1 - y * dd2;
+        } else {
+          P[i][j] = pi[j] * (1.0 - e1); P1[i][j] = -pi[j] * d1; P2[i][j] = -pi[j] * dd1;
+        }
+      }
+    }
+  }
 };
 
 // 1-D minimiser on [lo, hi]: golden section with parabolic steps, as a resumable object -- start(), then feed() the value at `u`
@@ -126,6 +147,30 @@ RC_HD double minimise(F f, double lo, double hi, double x0, double xtol, int itm
   double val;
   do { val = f(br.u); } while (br.feed(val));
   return br.x;
+}
+
+// The same minimiser on a bracket around the starting point, [x0 / factor, x0 * factor] inside [lo, hi]: a branch length or kappa
+// that is being re-optimised sits close to its optimum, and golden-section steps across all of [1e-6, 100] cost three times the
+// evaluations.  If the minimum comes out at an end of the bracket that is not an end of [lo, hi], the search goes on from there
+// with a wider bracket.
+template <typename F>
+RC_HD double minimise_local(F f, double lo, double hi, double x0, double factor, double xtol, int itmax) {
+  double x = x0 < lo ? lo : (x0 > hi ? hi : x0);
+  for (int attempt = 0; attempt < 8; attempt++) {
+    double a = x / factor, b = x * factor;
+    if (a < lo) a = lo;
+    if (b > hi) b = hi;
+    Brent br;
+    br.start(a, b, x, xtol, itmax);
+    double val;
+    do { val = f(br.u); } while (br.feed(val));
+    x = br.x;
+    const double tol = 4 * (xtol * fabs(x) + 1e-10);
+    const bool atLow = (x - a) <= tol && a > lo, atHigh = (b - x) <= tol && b < hi;
+    if (!atLow && !atHigh) break;
+    factor *= 4.0;
+  }
+  return x;
 }
 
 // everything one fit works on; the arrays are provided by the caller (host vectors / GPU scratch)
@@ -382,6 +427,46 @@ RC_HD double edge_lnl(const Work &k, Exec &ex, int v, double t) {
   return ex.sum(lnl);
 }
 
+// Maximum-likelihood length of branch v by Newton's method on d lnL / dt (what the columns below and above the branch make it a
+// function of t alone): t <- t - f'/f'' while f'' < 0, a step along the gradient by a factor 4 where the curve is not concave,
+// every step kept within a factor 8 of the current length and inside [kBlMin, kBlMax]; stops when the length moves by less than
+// 1e-5 of itself.  Three or four evaluations where a bracketing search needs ten: near its optimum lnL(t) is very nearly a parabola.
+template <typename Exec>
+RC_HD double edge_newton(const Work &k, Exec &ex, int v, double t) {
+  for (int it = 0; it < 40; it++) {
+    double Pm[4][4], P1[4][4], P2[4][4], g = 0, h = 0;
+    k.mod.probs_d(t, Pm, P1, P2);
+    for (int p = ex.lane(); p < k.P; p += ex.nlanes()) {
+      const double d0 = k.dn(v, 0, p), d1 = k.dn(v, 1, p), d2 = k.dn(v, 2, p), d3 = k.dn(v, 3, p);
+      double s0 = 0, s1 = 0, s2 = 0;
+      for (int i = 0; i < 4; i++) {
+        const double u = k.mod.pi[i] * k.upp(v, i, p);
+        s0 += u * (Pm[i][0] * d0 + Pm[i][1] * d1 + Pm[i][2] * d2 + Pm[i][3] * d3);
+        s1 += u * (P1[i][0] * d0 + P1[i][1] * d1 + P1[i][2] * d2 + P1[i][3] * d3);
+        s2 += u * (P2[i][0] * d0 + P2[i][1] * d1 + P2[i][2] * d2 + P2[i][3] * d3);
+      }
+      if (s0 > 1e-300) {
+        const double r1 = s1 / s0;
+        g += k.w[p] * r1;
+        h += k.w[p] * (s2 / s0 - r1 * r1);
+      }
+    }
+    g = ex.sum(g);
+    h = ex.sum(h);
+    double tn;
+    if (h < 0) tn = t - g / h;
+    else tn = g > 0 ? t * 4.0 : t * 0.25;
+    if (tn > t * 8.0) tn = t * 8.0;
+    if (tn < t * 0.125) tn = t * 0.125;
+    if (tn < kBlMin) tn = kBlMin;
+    if (tn > kBlMax) tn = kBlMax;
+    const bool done = fabs(tn - t) <= 1e-5 * t + 1e-10;
+    t = tn;
+    if (done) break;
+  }
+  return t;
+}
+
 // log-likelihood of the current tree and model, read at the root's first branch (its up column needs no other up column)
 template <typename Exec>
 RC_HD double total_lnl(Work &k, Exec &ex) {
@@ -392,146 +477,46 @@ RC_HD double total_lnl(Work &k, Exec &ex) {
 }
 
 // coordinate-wise ML: every branch, then kappa, until the log-likelihood moves by less than 1e-4
-// (PhyML's Round_Optimize stops at 1e-3, phyml/utilities.c:5207).
-//
-// Written as ONE loop that performs one micro-operation per pass -- bring one stale down/msg column up to date, or one stale
-// up column on the way to the branch under evaluation, or evaluate the log-likelihood at that branch -- so that every heavy piece
-// of code (the HKY85 matrix with its three exponentials, the column updates, the per-pattern likelihood with its logarithm, the
-// minimiser's step) exists exactly once.  The numbers are those of the plain formulation (every branch: refresh_down, refresh_up,
-// minimise(edge_lnl); then minimise over kappa of total_lnl; then total_lnl): the same operations on the same operands in the same order.
+// (PhyML's Round_Optimize stops at 1e-3, phyml/utilities.c:5207).  Branch lengths by Newton's method (edge_newton); kappa, whose
+// every evaluation is a pass over the whole tree, by the bracketing minimiser on a bracket around the current value
+// (minimise_local: a factor 4 either way in the first round, 2 later).
 template <typename Exec>
 RC_HD double optimise(Work &k, Exec &ex) {
   tip_partials(k, ex);
   invalidate_all(k);
-  enum { PH_TOTAL_INIT, PH_BRANCH, PH_KAPPA, PH_TOTAL_ROUND };
-  enum { OP_EVAL, OP_DOWN, OP_UP };
-  const int v0 = k.child[k.root * 3];   // the likelihood of the whole tree is read at the root's first branch (its up column needs no other)
-  int phase = PH_TOTAL_INIT, round = 0, bv = 0;
-  int ev = v0;                    // branch under evaluation ...
-  double et = k.len[v0];          // ... at this length
-  double prev = 0.0;
-  Brent br;
-  br.start(0, 1, 0, 0, 0);
-  // refresh state: scanning positions in the pre-order, the path root -> ev
-  int curDn = k.nn - 1, curUp = 0;
-  bool refreshing = true;
-  uint64_t path[Work::kSetWords];
-  auto request = [&](int v, double t) {   // evaluate branch v at length t after bringing the columns it needs up to date
-    ev = v; et = t;
-    curDn = k.nn - 1; curUp = 0; refreshing = true;
-    for (int x = 0; x < Work::kSetWords; x++) path[x] = 0;
-    for (int a = v; a != k.root; a = k.parent[a]) Work::set_bit(path, a);
-  };
-  auto first_branch = [&](int from) { int v = from; while (v < k.nn && v == k.root) v++; return v; };
-  request(v0, k.len[v0]);
-  for (;;) {
-    // ---- 1. the next micro-operation
-    int op = OP_EVAL, v = ev;
-    double t = et;
-    if (refreshing) {
-      while (curDn >= 0) {
-        const int c = k.preorder[curDn];
-        if ((c >= k.N && !Work::bit(k.okDn, c)) || (c != k.root && !Work::bit(k.okMs, c))) break;
-        curDn--;
-      }
-      if (curDn >= 0) { op = OP_DOWN; v = k.preorder[curDn]; t = k.len[v]; }
-      else {
-        while (curUp < k.nn) {
-          const int c = k.preorder[curUp];
-          if (c != k.root && Work::bit(path, c) && !Work::bit(k.okUp, c)) break;
-          curUp++;
-        }
-        if (curUp < k.nn) { op = OP_UP; v = k.preorder[curUp]; t = k.len[k.parent[v]]; }
-        else refreshing = false;
-      }
+  double prev = total_lnl(k, ex);
+  for (int round = 0; round < 60; round++) {
+    const double factor = round == 0 ? 4.0 : 2.0;
+    for (int v = 0; v < k.nn; v++) {
+      if (v == k.root) continue;
+      refresh_down(k, ex);
+      refresh_up(k, ex, v);
+      k.len[v] = edge_newton(k, ex, v, k.len[v]);
+      branch_changed(k, v);
     }
-    // ---- 2. the branch matrix (the root's product and an up column directly below the root need none)
-    double Pm[4][4];
-    const bool needP = !(op == OP_DOWN && v == k.root) && !(op == OP_UP && k.parent[v] == k.root);
-    if (needP) k.mod.probs(t, Pm);
-    if (op == OP_DOWN) {
-      if (v >= k.N && !Work::bit(k.okDn, v)) {
-        for (int p = ex.lane(); p < k.P; p += ex.nlanes())
-          for (int s = 0; s < 4; s++) {
-            double d = 1.0;
-            for (int c = 0; c < k.nchild[v]; c++) d *= k.ms(k.child[v * 3 + c], s, p);
-            k.dn(v, s, p) = d;
-          }
-        Work::set_bit(k.okDn, v);
-      }
-      if (v != k.root && !Work::bit(k.okMs, v)) {
-        for (int p = ex.lane(); p < k.P; p += ex.nlanes()) {
-          const double d0 = k.dn(v, 0, p), d1 = k.dn(v, 1, p), d2 = k.dn(v, 2, p), d3 = k.dn(v, 3, p);
-          for (int i = 0; i < 4; i++) k.ms(v, i, p) = Pm[i][0] * d0 + Pm[i][1] * d1 + Pm[i][2] * d2 + Pm[i][3] * d3;
-        }
-        Work::set_bit(k.okMs, v);
-      }
-      continue;
-    }
-    if (op == OP_UP) {
-      const int par = k.parent[v];
-      double W[4][4];
-      if (par != k.root)   // what comes from above the parent, through the parent's own branch
-        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) W[i][j] = Pm[j][i] * k.mod.pi[j] / k.mod.pi[i];
-      for (int p = ex.lane(); p < k.P; p += ex.nlanes()) {
-        double u[4] = {1.0, 1.0, 1.0, 1.0};
-        for (int c = 0; c < k.nchild[par]; c++) {
-          const int sib = k.child[par * 3 + c];
-          if (sib != v) for (int s = 0; s < 4; s++) u[s] *= k.ms(sib, s, p);
-        }
-        if (par != k.root) {
-          const double a0 = k.upp(par, 0, p), a1 = k.upp(par, 1, p), a2 = k.upp(par, 2, p), a3 = k.upp(par, 3, p);
-          for (int i = 0; i < 4; i++) u[i] *= W[i][0] * a0 + W[i][1] * a1 + W[i][2] * a2 + W[i][3] * a3;
-        }
-        for (int s = 0; s < 4; s++) k.upp(v, s, p) = u[s];
-      }
-      Work::set_bit(k.okUp, v);
-      continue;
-    }
-    // ---- 3. the log-likelihood read at branch ev with length et (edge_lnl)
-    double lnl = 0;
-    for (int p = ex.lane(); p < k.P; p += ex.nlanes()) {
-      const double d0 = k.dn(v, 0, p), d1 = k.dn(v, 1, p), d2 = k.dn(v, 2, p), d3 = k.dn(v, 3, p);
-      double sm = 0;
-      for (int i = 0; i < 4; i++)
-        sm += k.mod.pi[i] * k.upp(v, i, p) * (Pm[i][0] * d0 + Pm[i][1] * d1 + Pm[i][2] * d2 + Pm[i][3] * d3);
-      lnl += k.w[p] * log(sm > 1e-300 ? sm : 1e-300);
-    }
-    lnl = ex.sum(lnl);
-    // ---- 4. who asked
-    if (phase == PH_BRANCH) {
-      if (br.feed(-lnl)) { et = br.u; continue; }       // another length of the same branch: nothing is stale
-      k.len[bv] = br.x;
-      branch_changed(k, bv);
-      bv = first_branch(bv + 1);
-      if (bv < k.nn) { br.start(kBlMin, kBlMax, k.len[bv], 1e-5, 60); request(bv, br.u); continue; }
-      phase = PH_KAPPA;
-      br.start(0.1, 100.0, k.mod.kappa, 1e-5, 60);
-      k.mod.set(k.pi, br.u);                            // try a kappa: every column depends on the model
+    // kappa: every evaluation is a pass over the whole tree.  A Newton step from three values one per cent apart (the round's closing
+    // total_lnl shows what it achieved, the next round refines it); where the curve is not convex there, or the step would more than
+    // double or halve kappa, the bracketing minimiser instead.
+    auto at_kappa = [&](double kk) {
+      k.mod.set(k.pi, kk);
       invalidate_all(k);
-      request(v0, k.len[v0]);
-      continue;
+      return -total_lnl(k, ex);
+    };
+    double kap = k.mod.kappa;
+    {
+      const double h = 0.01 * kap;
+      double fs[3];
+      for (int q = 0; q < 3; q++) fs[q] = at_kappa(kap + (q - 1) * h);   // one call site: the objective's code exists once here
+      const double c = fs[0] - 2 * fs[1] + fs[2];
+      const double kn = c > 0 ? kap + 0.5 * h * (fs[0] - fs[2]) / c : 0.0;
+      if (c > 0 && kn > 0.5 * kap && kn < 2.0 * kap && kn > 0.1 && kn < 100.0) kap = kn;
+      else kap = minimise_local(at_kappa, 0.1, 100.0, kap, factor, 1e-5, 60);
     }
-    if (phase == PH_KAPPA) {
-      const bool more = br.feed(-lnl);
-      k.mod.set(k.pi, more ? br.u : br.x);              // the next candidate, or the minimiser
-      invalidate_all(k);
-      if (!more) phase = PH_TOTAL_ROUND;
-      request(v0, k.len[v0]);
-      continue;
-    }
-    if (phase == PH_TOTAL_ROUND) {
-      const double cur = lnl;
-      if (fabs(cur - prev) < 1e-4) { prev = cur; break; }
-      prev = cur;
-      if (++round == 60) break;
-    } else {
-      prev = lnl;                                       // PH_TOTAL_INIT
-    }
-    phase = PH_BRANCH;
-    bv = first_branch(0);
-    br.start(kBlMin, kBlMax, k.len[bv], 1e-5, 60);
-    request(bv, br.u);
+    k.mod.set(k.pi, kap);
+    invalidate_all(k);
+    const double cur = total_lnl(k, ex);
+    if (fabs(cur - prev) < 1e-4) { prev = cur; break; }
+    prev = cur;
   }
   return prev;
 }

@@ -58,7 +58,7 @@ __device__ __forceinline__ void tree_fit_body(const TreeJob *jobs, const uint8_t
 }
 
 
-// The same body under three register budgets (wavefronts per SIMD the compiler must leave room for): the fit is latency-bound,
+// The same body under three register budgets (wavefronts per SIMD the compiler must leave room for: 1, 2 or 3): the fit is latency-bound,
 // so more resident wavefronts hide more of it, until the spills a smaller budget forces cost more than they hide
 // (RC_TREE_WAVES picks one at run time; the default is the measured best).
 #define RC_TREE_KERNEL(W)                                                                                                        \
@@ -66,17 +66,17 @@ __device__ __forceinline__ void tree_fit_body(const TreeJob *jobs, const uint8_t
       const TreeJob *jobs, const uint8_t *in, double *scratch, TreeOut *out, double *results) {                                    \
     tree_fit_body(jobs, in, scratch, out, results);                                                                                \
   }
+RC_TREE_KERNEL(1)
 RC_TREE_KERNEL(2)
 RC_TREE_KERNEL(3)
-RC_TREE_KERNEL(4)
 #undef RC_TREE_KERNEL
 
 }  // namespace
 
 void launch_tree_fit(const TreeJob *jobs, int njobs, const uint8_t *in, double *scratch, TreeOut *work, double *results, hipStream_t stream) {
   if (njobs <= 0) return;
-  static const int waves = [] { const char *e = std::getenv("RC_TREE_WAVES"); const int w = e ? std::atoi(e) : 2; return (w >= 2 && w <= 4) ? w : 2; }();
-  if (waves == 4) hipLaunchKernelGGL(k_tree_fit_w4, dim3(njobs), dim3(kWave), 0, stream, jobs, in, scratch, work, results);
+  static const int waves = [] { const char *e = std::getenv("RC_TREE_WAVES"); const int w = e ? std::atoi(e) : 2; return (w >= 1 && w <= 3) ? w : 2; }();
+  if (waves == 1) hipLaunchKernelGGL(k_tree_fit_w1, dim3(njobs), dim3(kWave), 0, stream, jobs, in, scratch, work, results);
   else if (waves == 3) hipLaunchKernelGGL(k_tree_fit_w3, dim3(njobs), dim3(kWave), 0, stream, jobs, in, scratch, work, results);
   else hipLaunchKernelGGL(k_tree_fit_w2, dim3(njobs), dim3(kWave), 0, stream, jobs, in, scratch, work, results);
 }
