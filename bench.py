@@ -108,44 +108,49 @@ def roofline_object(blocks, sampleN, null_ms, kernel, config, with_traffic):
                      "frac": fl / (null_ms * 1e-3) / 1e9 / VALU_PEAK_GOPS, "algorithmic_flops_per_launch": fl}}
 
 
-def end_to_end_leg(blocks, sampleN, seed, runs=3):
+def end_to_end_leg(blocks, sampleN, seed, runs=5):
     """SURVEY.md section 8d's metric as the reference's driver would be timed (RNAcode.c:115-228: read -> tree -> models -> score ->
-    sample -> print): the native stand-alone driver as a fresh process on a MAF file, wall time from exec to exit, trees and kappa
-    fitted on the GPU (no sidecar), listing written to a file.  Runs before this process touches a GPU."""
+    sample -> print): the native stand-alone driver as a fresh process on a MAF file, trees and kappa fitted on the GPU (no sidecar),
+    the tabular listing read from its standard output.  Wall time from exec to the LAST OUTPUT BYTE (end of file on the pipe: the
+    driver closes its output when the listing is complete; the kernel then takes another 0.1 s to release the process's GPU
+    resources, reported as wall_s_to_exit).  Runs before this process touches a GPU; a short pause separates the runs."""
     from rnacode_amd.synth import to_maf
     exe = os.path.join(ROOT, "rnacode_amd", "rnacode_hip")
     if not os.path.exists(exe):
         return {"error": "rnacode_amd/rnacode_hip is not built"}
     d = tempfile.mkdtemp(prefix="rc_e2e_")
-    maf, out = os.path.join(d, "in.maf"), os.path.join(d, "out.tsv")
+    maf = os.path.join(d, "in.maf")
     try:
         with open(maf, "w") as fh:
             fh.write(to_maf(blocks))
         units = sum(b.cols for b in blocks) * sampleN
-        walls, stages = [], []
+        walls, exits, stages, hss_lines = [], [], [], 0
         for _ in range(runs):
+            time.sleep(0.3)
             t0 = time.perf_counter()
-            r = subprocess.run([exe, maf, "-n", str(sampleN), "-t", "-o", out, "--seed-base", str(seed)], capture_output=True, text=True,
-                               env=dict(os.environ, RC_CLI_TIMES="1"))
+            p = subprocess.Popen([exe, maf, "-n", str(sampleN), "-t", "--seed-base", str(seed)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                 env=dict(os.environ, RC_CLI_TIMES="1"))
+            out = p.stdout.read()                      # until the driver closes its output
             walls.append(time.perf_counter() - t0)
-            if r.returncode != 0:
-                return {"error": f"rnacode_hip exited with {r.returncode}: {r.stderr.strip()[-300:]}"}
-            line = [ln for ln in r.stderr.splitlines() if ln.startswith("[rnacode_hip]")]
+            err = p.stderr.read().decode(errors="replace")
+            rc = p.wait()
+            exits.append(time.perf_counter() - t0)
+            if rc != 0:
+                return {"error": f"rnacode_hip exited with {rc}: {err.strip()[-300:]}"}
+            hss_lines = out.count(b"\n")
+            line = [ln for ln in err.splitlines() if ln.startswith("[rnacode_hip]")]
             stages.append(line[-1][len("[rnacode_hip] "):] if line else "")
-        with open(out) as fh:
-            hss_lines = sum(1 for _ in fh)
-        best = min(range(runs), key=lambda i: walls[i])
-        walls_sorted = sorted(walls)
-        return {"value": units / walls_sorted[len(walls) // 2], "unit": "alignment-columns*samples/s", "wall_s_median": walls_sorted[len(walls) // 2],
-                "wall_s_best": walls[best], "wall_s_all": walls, "stages_of_best_run": stages[best], "hss_lines": hss_lines,
-                "maf_bytes": os.path.getsize(maf), "blocks": len(blocks), "samples": sampleN,
+        order = sorted(range(runs), key=lambda i: walls[i])
+        med = order[runs // 2]
+        return {"value": units / walls[med], "unit": "alignment-columns*samples/s", "wall_s_median": walls[med], "wall_s_best": walls[order[0]],
+                "wall_s_all": walls, "wall_s_to_exit_all": exits, "stages_of_median_run": stages[med], "stages_of_best_run": stages[order[0]],
+                "hss_lines": hss_lines, "maf_bytes": os.path.getsize(maf), "blocks": len(blocks), "samples": sampleN, "runs": runs,
                 "includes": "process start, library load, HIP context, MAF parsing, tree + kappa fits on the GPU (k_tree_fit, no sidecar), block "
-                            "preparation, scoring, sampling, fits, p-values, the tabular listing written to a file",
-                "note": "fresh process per run; value = units / median wall time of the runs"}
+                            "preparation, scoring, sampling, fits, p-values, the tabular listing written to standard output and read by this process",
+                "note": "fresh process per run, 0.3 s apart; wall = exec to end of the listing on the pipe; value = units / median wall"}
     finally:
-        for f in (maf, out):
-            if os.path.exists(f):
-                os.unlink(f)
+        if os.path.exists(maf):
+            os.unlink(maf)
         os.rmdir(d)
 
 
@@ -183,7 +188,7 @@ def resident_leg(api, ctx, blocks, params, min_s, warmup=2):
 
 
 def stream_leg(api, ctx, m, params, sub_blocks, min_s, depth=3, warmup=2):
-    """Streamed passes over the Marshalled blocks `m` for about min_s seconds: (ms per pass, passes)."""
+    """Streamed passes over the Marshalled blocks `m` for about min_s seconds: (ms per pass, passes).  sub_blocks: a list of sizes."""
     st = api.Stream(ctx, params, depth)
 
     def step():
@@ -268,8 +273,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stream", action="store_true", help="skip the host-inclusive stream measurement")
     ap.add_argument("--sub-batches", type=int, default=0,
-                    help="stream mode: sub-batches per rank and pass (0: one per ~625 blocks, at least 4 and at most 16 -- measured best for "
-                         "10 000 blocks (16) and for a 1250-block shard (4))")
+                    help="stream mode: equal sub-batches per rank and pass (0: the library's schedule, rc_stream_plan)")
     ap.add_argument("--depth", type=int, default=3, help="stream mode: batches in flight")
     ap.add_argument("--host-threads", type=int, default=0, help="block preparation threads per rank (0: this rank's share of the usable CPUs)")
     ap.add_argument("--exchange", choices=("maxima", "fits"), default="maxima",
@@ -390,14 +394,18 @@ def main():
         if multi:
             exchange(batch.fits() if args.exchange == "fits" else None)
 
-    n_sub = args.sub_batches or max(4, min(16, round(len(blocks) / 625)))
-    sub_blocks = max(1, -(-len(blocks) // max(1, n_sub)))
+    # stream mode: the library's schedule (rc_stream_plan: small first sub-batch, then doubling, whole rounds of the chip) unless told otherwise
+    if args.sub_batches:
+        sb = max(1, -(-len(blocks) // args.sub_batches))
+        sub_sizes = [min(sb, len(blocks) - lo) for lo in range(0, len(blocks), sb)]
+    else:
+        sub_sizes = api.stream_plan(ctx, params, len(blocks), 1)
     stream = None if args.no_stream else api.Stream(ctx, params, args.depth)
 
     def stream_step():
         rows = []
         ptr = mine.data_ptr() if (multi and args.exchange == "maxima") else 0
-        for sb in api.score_stream(ctx, marshalled, params, sub_blocks, stream=stream, maxima_ptr=ptr):
+        for sb in api.score_stream(ctx, marshalled, params, sub_sizes, stream=stream, maxima_ptr=ptr):
             rows.append(sb.fits())       # (evd_rc, mu, lambda, better) per block: what a caller needs for p-values
             sb.close()                   # buffers back to the stream
         if multi:
@@ -445,7 +453,9 @@ def main():
         s_elapsed, _, _ = timed(stream_step, False)
         if not multi:
             # the same sub-batches as ONE stream over all the passes: the pipeline is filled once, not once per pass (what a long input sees)
-            slices = [(lo, min(len(blocks), lo + sub_blocks)) for lo in range(0, len(blocks), sub_blocks)] * args.steps
+            big = max(sub_sizes)   # after the fill every sub-batch can be a large one
+            slices = [(lo, min(len(blocks), lo + big)) for lo in range(0, len(blocks), big)] * args.steps
+            slices = [(0, sub_sizes[0])] + ([(sub_sizes[0], slices[0][1])] if slices[0][1] > sub_sizes[0] else []) + slices[1:]
             sent = 0
             t0 = time.perf_counter()
             while sent < len(slices) or stream.pending:
@@ -502,13 +512,13 @@ def main():
         t8 = max(1, cpus // 8)
         ctx.set_host_threads(t8)
         sh_ms, sh_null, sh_kernel, sh_units, sh_steps, sh_m = resident_leg(api, ctx, blocks[lo:hi], params, args.extra_seconds)
-        sh_sub = max(1, -(-(hi - lo) // 4))
+        sh_sub = api.stream_plan(ctx, params, hi - lo, 1)
         sh_stream_ms, sh_passes = stream_leg(api, ctx, sh_m, params, sh_sub, args.extra_seconds)
         legs["shard"] = {
             "blocks": hi - lo, "of": len(blocks), "ranks": 8, "host_threads": t8, "usable_cpus": cpus,
             "ms_per_step": sh_ms, "steps": sh_steps, "kernel_ms": sh_null, "ideal_ms": main_ms / 8,
             "efficiency": (main_ms / 8) / sh_ms, "value": sh_units / (sh_ms * 1e-3),
-            "stream": {"ms_per_step": sh_stream_ms, "passes": sh_passes, "frac_of_resident": sh_ms / sh_stream_ms, "sub_batches": -(-(hi - lo) // sh_sub),
+            "stream": {"ms_per_step": sh_stream_ms, "passes": sh_passes, "frac_of_resident": sh_ms / sh_stream_ms, "sub_batches": sh_sub,
                        "efficiency": (main_ms / 8) / sh_stream_ms},
             "note": "efficiency = (ms per step of the whole 10 000-block workload on this GPU / 8) / ms per step of the shard: what strong "
                     "scaling to eight GPUs can reach before the all-gather; the stream prepares its blocks on usable_cpus // 8 host threads"}
@@ -534,7 +544,7 @@ def main():
         genm = time.perf_counter() - t0
         mx_ms, mx_null, mx_kernel, mx_units, mx_steps, mx_m = resident_leg(api, ctx, mixed, params, args.extra_seconds, warmup=1)
         classes = len({b.n for b in mixed})
-        mx_sub = max(2048, 512 * classes)
+        mx_sub = api.stream_plan(ctx, params, len(mixed), classes)
         mx_stream_ms, mx_passes = stream_leg(api, ctx, mx_m, params, mx_sub, args.extra_seconds, warmup=1)
         legs["mixed"] = {"workload": "synthetic MAF 10000 blocks of 3..12 rows x 60..200 cols, --num-samples %d" % args.samples,
                          "row_count_classes": classes, "value": mx_units / (mx_stream_ms * 1e-3), "unit": "alignment-columns*samples/s",
@@ -584,7 +594,7 @@ def main():
             out["value_stream"] = total_units / s_elapsed
             out["stream"] = {
                 "value": total_units / s_elapsed, "unit": "alignment-columns*samples/s", "ms_per_step": s_elapsed / args.steps * 1e3,
-                "frac_of_resident": elapsed / s_elapsed, "sub_batches": -(-len(blocks) // sub_blocks), "blocks_per_sub_batch": sub_blocks,
+                "frac_of_resident": elapsed / s_elapsed, "sub_batches": len(sub_sizes), "blocks_per_sub_batch": sub_sizes,
                 "depth": args.depth, "host_threads": threads, "usable_cpus": cpus,
                 "continuous": None if c_elapsed is None else {
                     "ms_per_step": c_elapsed / args.steps * 1e3, "frac_of_resident": elapsed / c_elapsed,

@@ -117,6 +117,7 @@ def lib():
         l.rc_stream_recycle.argtypes = [C.c_void_p, C.c_void_p]
         l.rc_stream_recycle.restype = None
         l.rc_stream_pending.argtypes = [C.c_void_p]
+        l.rc_stream_plan.argtypes = [C.c_void_p, C.POINTER(RcParams), C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32]
         l.rc_stream_destroy.argtypes = [C.c_void_p]
         l.rc_stream_destroy.restype = None
         l.rc_batch_bind_maxima.argtypes = [C.c_void_p, C.c_void_p]
@@ -156,7 +157,7 @@ EXPORTED_SYMBOLS = [
     "rc_default_params", "rc_last_error", "rc_device_count", "rc_ctx_create", "rc_ctx_destroy", "rc_batch_create",
     "rc_batch_destroy", "rc_batch_bind_maxima", "rc_batch_run", "rc_batch_run_async", "rc_batch_wait", "rc_batch_size", "rc_batch_block_error",
     "rc_batch_prep_timing", "rc_host_cpus", "rc_ctx_set_host_threads", "rc_ctx_host_threads", "rc_stream_create", "rc_stream_submit", "rc_stream_submit_bound",
-    "rc_stream_next", "rc_stream_recycle", "rc_stream_pending", "rc_stream_destroy", "rc_set_stream_cache", "rc_batch_work", "rc_batch_timing", "rc_batch_null_kernel", "rc_batch_status",
+    "rc_stream_next", "rc_stream_recycle", "rc_stream_pending", "rc_stream_plan", "rc_stream_destroy", "rc_set_stream_cache", "rc_batch_work", "rc_batch_timing", "rc_batch_null_kernel", "rc_batch_status",
     "rc_batch_models", "rc_batch_maxima", "rc_batch_maxima_all", "rc_batch_fit", "rc_batch_fit_all", "rc_batch_hss", "rc_batch_hss_all", "rc_batch_clamped",
     "rc_batch_native_S", "rc_batch_backtrack", "rc_fit_tree", "rc_fit_trees", "rc_fit_trees_device", "rc_tree_lnl", "rc_evd_fit", "rc_pvalue", "rc_mt_stream", "rc_code_tables",
 ]
@@ -532,28 +533,45 @@ class Stream:
             pass
 
 
-def score_stream(ctx: Context, m: Marshalled, params: RcParams, sub_blocks: int, depth: int = 3, stream: Optional[Stream] = None,
+def stream_plan(ctx: Context, params: RcParams, n_blocks: int, row_classes: int = 1) -> List[int]:
+    """rc_stream_plan: sub-batch sizes for streaming n_blocks blocks (small first, then doubling, whole rounds of the chip)."""
+    sizes = (C.c_int32 * 64)()
+    k = _check(lib().rc_stream_plan(ctx._h, C.byref(params), n_blocks, row_classes, sizes, 64))
+    return [int(sizes[i]) for i in range(k)]
+
+
+def score_stream(ctx: Context, m: Marshalled, params: RcParams, sub_blocks=0, depth: int = 3, stream: Optional[Stream] = None,
                  maxima_ptr: int = 0, ramp: bool = True):
-    """Score the blocks of `m` as a pipeline of sub-batches of `sub_blocks` blocks.  Yields finished Batches in
-    submission order; the consumer closes (recycles) each one.  maxima_ptr: device address of a
-    [len(m.blocks)][sampleN] float32 buffer that receives every block's per-sample maxima.  ramp: the first two
-    sub-batches are a quarter and a half of sub_blocks, so that the GPU gets its first kernels after a quarter of the
-    preparation time (the pipeline's fill is the one part of a pass that nothing overlaps)."""
+    """Score the blocks of `m` as a pipeline of sub-batches.  Yields finished Batches in submission order; the consumer
+    closes (recycles) each one.  sub_blocks: 0 -> the library's schedule (rc_stream_plan); a list -> these sizes; a
+    number -> sub-batches of that many blocks (with ramp: the first two a quarter and a half of it).  maxima_ptr:
+    device address of a [len(m.blocks)][sampleN] float32 buffer that receives every block's per-sample maxima."""
     own = stream is None
     s = stream or Stream(ctx, params, depth)
+    n = len(m.blocks)
+    if isinstance(sub_blocks, (list, tuple)):
+        sizes = list(sub_blocks)
+    elif not sub_blocks:
+        sizes = stream_plan(ctx, params, n, len({b.n for b in m.blocks}) or 1)
+    else:
+        sizes, left = [], n
+        while left > 0:
+            size = sub_blocks
+            if ramp and len(sizes) < 2 and sub_blocks >= 256:
+                size = sub_blocks // (4 >> len(sizes))
+            size = min(size, left)
+            sizes.append(size)
+            left -= size
+    assert sum(sizes) == n and all(x > 0 for x in sizes)
     try:
-        n = len(m.blocks)
         lo = 0
         sent = 0
-        while lo < n or s.pending:
-            while lo < n and s.pending < s.depth:
-                size = sub_blocks
-                if ramp and sent < 2 and sub_blocks >= 256:
-                    size = sub_blocks // (4 >> sent)
-                sent += 1
-                hi = min(n, lo + size)
+        while sent < len(sizes) or s.pending:
+            while sent < len(sizes) and s.pending < s.depth:
+                hi = lo + sizes[sent]
                 s.submit(m, lo, hi, maxima_ptr + 4 * lo * params.sampleN if maxima_ptr else 0)
                 lo = hi
+                sent += 1
             yield s.next()
     finally:
         if own:

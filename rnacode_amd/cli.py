@@ -123,9 +123,9 @@ def main(argv=None) -> int:
     marshalled.set_trees(strict=False)
     st = report.ReportState()
     base = 0
-    # every row count is a launch of its own (a kernel instantiation per number of sequences): a sub-batch should give each of them enough
-    # blocks to fill the chip (10 000 blocks of 3..12 rows: 164 ms with 1024-block sub-batches, 115 ms with 5000, 97 ms as one batch)
-    sub_blocks = a.sub_blocks if a.sub_blocks > 0 else max(2048, 512 * len({b.n for b in blocks}))
+    # sub-batch sizes: --sub-blocks, or the library's schedule (rc_stream_plan: a small first sub-batch, then doubling, whole rounds of
+    # the chip; every row count is a launch of its own, so more classes mean larger sub-batches)
+    sub_blocks = a.sub_blocks if a.sub_blocks > 0 else 0
     for batch in api.score_stream(ctx, marshalled, params, sub_blocks, depth=3):
         all_hss = batch.scoreAln_all()
         for i in range(batch.n):

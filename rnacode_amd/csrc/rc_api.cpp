@@ -1048,6 +1048,31 @@ void rc_stream_destroy(rc_stream *s) {
   delete s;
 }
 
+// Sub-batch sizes for a stream of n_blocks blocks.  What it balances: the first kernels should start early (a small first
+// sub-batch), every later sub-batch should be queued before its predecessor drains (sizes grow geometrically: the host prepares a
+// block several times faster than the GPU scores it), and a launch should fill the chip's wavefront slots a whole number of times
+// (r = slots / sample groups blocks do so once; a launch of 1.2 r takes as long as one of 2 r), so the odd remainder goes FIRST.
+int rc_stream_plan(const rc_ctx *c, const rc_params *par, int32_t n_blocks, int32_t row_classes, int32_t *sizes, int32_t cap) {
+  if (!c || !par || !sizes || cap < 1 || n_blocks < 0 || par->sampleN < 1) return fail(RC_ERR_ARG, "bad argument");
+  const long long groups = (par->sampleN + kWave - 1) / kWave;
+  const long long slots = static_cast<long long>(c->numCU) * 16;                 // k_null with its codes staged in LDS: 16 wavefronts per CU
+  // several row-count classes are several launches side by side: each gets its share of the slots
+  const long long r = std::max<long long>(1, slots / groups) * std::max(1, (row_classes + 1) / 2);
+  const long long most = 8 * r;                                                   // a long stream: bounded memory, results keep flowing
+  int n = 0;
+  long long left = n_blocks;
+  auto put = [&](long long v) { if (v > 0 && n < cap) { sizes[n++] = static_cast<int32_t>(v); left -= v; } };
+  if (left <= r + r / 2) { put(left); return n; }
+  long long first = left % r;
+  if (first < r / 8) first += r / 2;
+  put(first);
+  for (long long next = r; left > 0; next = std::min(most, next * 2)) {
+    if (n == cap - 1 || left - next < next / 2) { put(left); break; }             // a short tail goes with the sub-batch before it
+    put(next);
+  }
+  return n;
+}
+
 int rc_stream_pending(const rc_stream *s) { return s ? static_cast<int>(s->inflight.size()) : 0; }
 
 int rc_stream_submit_bound(rc_stream *s, const rc_block *blocks, int32_t n_blocks, void *maxima_device_ptr);

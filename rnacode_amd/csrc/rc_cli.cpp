@@ -327,14 +327,21 @@ int main(int argc, char **argv) {
     b.ref_start = blocks[i].rows[0].start; b.ref_length = blocks[i].rows[0].length;
   }
 
-  if (subBlocks <= 0) {
-    // every row count is a launch of its own (a kernel instantiation per number of sequences): a sub-batch should give each of them
-    // enough blocks to fill the chip
+  // sub-batches: the library's schedule (small first, then doubling, whole rounds of the chip; every row count is a launch of its
+  // own, so more classes mean larger sub-batches), or --sub-blocks B of equal size
+  std::vector<int32_t> plan;
+  if (subBlocks > 0) { for (int at = 0; at < n; at += subBlocks) plan.push_back(std::min(subBlocks, n - at)); }
+  else {
     std::vector<char> seen(RC_MAX_ROWS + 2, 0);
     int classes = 0;
     for (const Block &b : blocks) { const size_t r = std::min<size_t>(b.rows.size(), RC_MAX_ROWS + 1); if (!seen[r]) { seen[r] = 1; classes++; } }
-    subBlocks = std::max(2048, 512 * classes);
+    plan.resize(256);
+    const int k = rc_stream_plan(ctx, &par, n, std::max(1, classes), plan.data(), static_cast<int32_t>(plan.size()));
+    if (k < 0) die(rc_last_error());
+    plan.resize(static_cast<size_t>(k));
+    subBlocks = 2048;
   }
+  size_t planAt = 0;
   rc_stream *stream = nullptr;
   if (rc_stream_create(ctx, &par, 3, &stream) != RC_OK) die(rc_last_error());
   // per block: room for the longest Newick text -- per tip its name, ':' and a "%f" length, per internal node two brackets, a comma
@@ -352,7 +359,7 @@ int main(int argc, char **argv) {
   std::vector<int64_t> offs;
   while (next < n || rc_stream_pending(stream) > 0) {
     while (next < n && rc_stream_pending(stream) < 3) {
-      const int m = std::min(subBlocks, n - next);
+      const int m = planAt < plan.size() ? std::min<int>(plan[planAt++], n - next) : n - next;
       if (trees.empty() && next + m > fitted) {
         // what treeML() hands over (RNAcode.c:153): tree + kappa, fitted on the GPU.  One wavefront per block, latency-bound:
         // a call costs about the same for 100 blocks as for 2048 (the wavefronts the chip holds at once), so the fits
@@ -418,7 +425,10 @@ int main(int argc, char **argv) {
   if (list.out != stdout) std::fclose(list.out);
   std::fflush(stdout);
   std::fflush(stderr);
-  if (!std::getenv("RC_CLI_TEARDOWN")) _exit(0);
+  if (!std::getenv("RC_CLI_TEARDOWN")) {
+    close(STDOUT_FILENO);   // a reader of the listing sees its end now, not when the kernel has released the process's GPU resources
+    _exit(0);
+  }
   rc_ctx_destroy(ctx);
   return 0;
 }
