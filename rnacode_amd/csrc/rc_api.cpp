@@ -59,7 +59,23 @@ struct Event {
   operator hipEvent_t() const { return e; }
 };
 
-// device / pinned buffers that only grow (batches of a stream are recycled: steady state allocates nothing)
+// Buffers that only grow (batches of a stream are recycled: the steady state allocates nothing).  Growing never frees on the
+// spot: hipFree and hipHostFree wait for the whole device, and a stream whose sub-batches grow (a small first one, then doubling)
+// would stop at every submit until the kernels of the batches in flight had finished (10 ms per submit in the stand-alone driver).
+// The old allocation is retired instead and released when nothing of this library is in flight.
+struct Retired {
+  std::mutex m;
+  std::vector<std::pair<void *, bool>> list;   // pointer, pinned host memory?
+  void add(void *p, bool host) { std::lock_guard<std::mutex> lk(m); list.emplace_back(p, host); }
+  void drain() {
+    std::vector<std::pair<void *, bool>> take;
+    { std::lock_guard<std::mutex> lk(m); take.swap(list); }
+    for (auto &e : take) { if (e.second) (void)hipHostFree(e.first); else (void)hipFree(e.first); }
+  }
+  bool empty() { std::lock_guard<std::mutex> lk(m); return list.empty(); }
+};
+Retired g_retired;
+
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
@@ -67,7 +83,8 @@ struct DevBuf {
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
   hipError_t ensure(size_t bytes) {
     if (bytes <= cap && p) return hipSuccess;
-    release();
+    if (p) g_retired.add(p, false);
+    p = nullptr; cap = 0;
     const size_t want = std::max<size_t>(bytes + bytes / 8, 256);
     hipError_t r = hipMalloc(&p, want);
     if (r == hipSuccess) cap = want; else p = nullptr;
@@ -82,7 +99,8 @@ struct PinBuf {
   void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
   hipError_t ensure(size_t bytes) {
     if (bytes <= cap && p) return hipSuccess;
-    release();
+    if (p) g_retired.add(p, true);
+    p = nullptr; cap = 0;
     const size_t want = std::max<size_t>(bytes + bytes / 8, 4096);
     hipError_t r = hipHostMalloc(&p, want, hipHostMallocDefault);
     if (r == hipSuccess) cap = want; else p = nullptr;
@@ -187,6 +205,7 @@ struct rc_ctx {
   DevBuf treeJobs, treeIn, treeWork, treeOut, treeRes;   // rc_fit_trees_device
   PinBuf treeInPin, treeResPin;
   std::mutex treeMutex;
+  int gridCapPerCU = 0;       // RC_GRID_CAP_PER_CU: at most this many k_null workgroups per CU (experiments on cache residency of the code scratch); 0 = what fits
   double splitFactor = 0.5;   // a k_null launch with fewer (block, sample group) items than this fraction of the chip's wavefront slots splits every item into its six strand x frame parts (RC_SPLIT_FACTOR)
   int nativeWavesPerCU = 8;   // persistent wavefronts of k_native_dp per CU (RC_NATIVE_WAVES_PER_CU): it runs beside k_null and should not crowd it out
   size_t genericScratchWords = static_cast<size_t>(1) << 30;   // uint32 of staging scratch one k_null_generic launch may take: a twelfth of the device memory (24 GB of 288)
@@ -322,6 +341,7 @@ void rc_ctx_destroy(rc_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
+  g_retired.drain();
   c->pool.reset();
   if (kProfiling && c->d_cellStats.p) {
     unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
@@ -345,8 +365,10 @@ int rc_ctx_create(int device, rc_ctx **out) {
   *out = nullptr;
   want_hw_queues();
   int n = 0;
+  trace("ctx: start", nullptr);
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
     return fail(RC_ERR_DEVICE, "no HIP device available: the scoring path has no CPU fallback");
+  trace("ctx: runtime up", nullptr);
   if (device < 0 || device >= n) return fail(RC_ERR_ARG, "device index out of range");
   HIP_TRY(hipSetDevice(device));
   std::unique_ptr<rc_ctx, void (*)(rc_ctx *)> guard(new rc_ctx(), rc_ctx_destroy);
@@ -359,6 +381,7 @@ int rc_ctx_create(int device, rc_ctx **out) {
   c->genericScratchWords = std::max<size_t>(static_cast<size_t>(1) << 30, prop.totalGlobalMem / 12 / sizeof(uint32_t));
   c->togetherWords = std::max<size_t>(static_cast<size_t>(1) << 30, prop.totalGlobalMem / 36 / sizeof(uint32_t));   // 8 GB of 288: allocating more costs a short run more than it gains (tools/cli_mixed_sweep.sh)
   if (const char *e = std::getenv("RC_TOGETHER_MAX_MB")) c->togetherWords = static_cast<size_t>(std::max(0ll, std::atoll(e))) * (1u << 20) / sizeof(uint32_t);
+  if (const char *e = std::getenv("RC_GRID_CAP_PER_CU")) c->gridCapPerCU = std::max(0, std::atoi(e));
   if (const char *e = std::getenv("RC_SPLIT_FACTOR")) c->splitFactor = std::max(0.0, std::atof(e));
   if (const char *e = std::getenv("RC_NATIVE_WAVES_PER_CU")) c->nativeWavesPerCU = std::max(1, std::min(32, std::atoi(e)));
   if (const char *e = std::getenv("RC_GENERIC_SCRATCH_MB")) c->genericScratchWords = std::max<size_t>(1, static_cast<size_t>(std::atoll(e))) * (1u << 20) / sizeof(uint32_t);
@@ -373,6 +396,7 @@ int rc_ctx_create(int device, rc_ctx **out) {
   HIP_TRY(hipStreamCreateWithPriority(&c->native, hipStreamNonBlocking, prioHigh));
   HIP_TRY(hipStreamCreateWithPriority(&c->copy, hipStreamNonBlocking, prioHigh));
   HIP_TRY(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prioHigh));
+  trace("ctx: streams", nullptr);
   c->serialNative = std::getenv("RC_SERIAL_NATIVE") ? 1 : 0;   // profiling: one kernel at a time, clean per-kernel intervals
   c->stopTwoRoundsMinItems = 4LL * c->numCU * 16;   // the chip filled four times over
   if (const char *e = std::getenv("RC_STOP_MIN_ITEMS")) c->stopTwoRoundsMinItems = std::atoll(e);
@@ -397,6 +421,7 @@ int rc_ctx_create(int device, rc_ctx **out) {
     HIP_TRY(c->d_tables.ensure(h.size()));
     HIP_TRY(hipMemcpy(c->d_tables.p, h.data(), h.size(), hipMemcpyHostToDevice));
   }
+  trace("ctx: tables", nullptr);
   c->tieThr = float_threshold_lt(0.0001);
   if (const char *e = std::getenv("RC_LDS_MAX_BYTES")) c->ldsMaxBytes = static_cast<size_t>(std::atol(e));
   if (kProfiling) if (const char *e = std::getenv("RC_DEBUG_SKIP")) c->debugSkip = std::atoi(e);   // RC_PROFILING builds only: results are wrong
@@ -758,7 +783,8 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
     const std::pair<int, size_t> key(p.NK, p.ldsBytes);
     if (!c->occ.count(key)) c->occ[key] = null_occupancy(p.NK, p.ldsBytes);
     if (c->occ[key] <= 0 && p.ldsBytes) { p.ldsBytes = 0; const std::pair<int, size_t> k2(p.NK, 0); if (!c->occ.count(k2)) c->occ[k2] = null_occupancy(p.NK, 0); }
-    const int occ = std::max(1, c->occ[std::pair<int, size_t>(p.NK, p.ldsBytes)]);
+    int occ = std::max(1, c->occ[std::pair<int, size_t>(p.NK, p.ldsBytes)]);
+    if (c->gridCapPerCU > 0) occ = std::min(occ, c->gridCapPerCU);
     int items = static_cast<int>(kv.second.size()) * groupsHere;
     // small batches: split every item into its six strand x frame parts to fill the chip
     p.comboSplit = (together ? splitAll : static_cast<double>(items) <= c->splitFactor * c->numCU * occ) ? 1 : 0;
@@ -876,7 +902,7 @@ static int batch_run_async(rc_batch *b) {
   HIP_TRY(b->evStart.record(cs));
   if (!b->okBlocks.empty()) {
     RC_TRY(ensure_mt_stream(c, b, cs, b->par.seed_base, Spad, b->maxDraws));
-    // ---- null sampling per N-1 class (queued first: it is the long pole; the native block's dozen launches follow on their own stream)
+    // ---- null sampling per N-1 class
     uint32_t *cnt = b->dcounters.as<uint32_t>();
     HIP_TRY(hipMemsetAsync(cnt + kCntWork, 0, (kCntTotal - kCntWork) * sizeof(uint32_t), cs));   // work queues and the clamp counter
     // -1.0f everywhere first: skipped blocks report "no HSS" rows
@@ -905,8 +931,10 @@ static int batch_run_async(rc_batch *b) {
       }
       HIP_TRY(b->dscratch.ensure(most * sizeof(uint32_t)));
     }
-    bool nativeQueued = false;
-    if (c->serialNative) { RC_TRY(launch_native_block(R)); nativeQueued = true; }   // profiling: one kernel at a time on one stream, clean intervals
+    // the native block's kernels go first: queued behind k_null's persistent grid they would find no free wavefront slot until its
+    // tail, and the fit waits for them (long blocks: 1000 blocks of 12 x 300 took 628 ms per step that way instead of 600)
+    bool nativeQueued = true;
+    RC_TRY(launch_native_block(R));
     int round = 0;
     for (int lo = 0, hi = g1; lo < groups; round++) {
       if (round == c->stopRounds - 1) hi = groups;
@@ -960,7 +988,7 @@ static int batch_wait(rc_batch *b) {
   rc_ctx *c = b->ctx;
   HIP_TRY(hipSetDevice(c->device));
   hipError_t e = hipEventSynchronize(b->evDone);
-  c->inflight.fetch_sub(1);
+  if (c->inflight.fetch_sub(1) == 1 && !g_retired.empty()) g_retired.drain();   // nothing in flight: releasing outgrown buffers stalls nobody
   b->state = rc_batch::READY;   // a failed run may be repeated
   if (e != hipSuccess) return fail(RC_ERR_DEVICE, std::string("hipEventSynchronize: ") + hipGetErrorString(e));
   HIP_TRY(hipGetLastError());

@@ -11,5 +11,5 @@ for i in 1 2 3; do RC_CLI_TIMES=1 rnacode_amd/rnacode_hip /tmp/c3.maf -n 1000 -t
 echo "--- with RC_TRACE"
 RC_TRACE=1 RC_CLI_TIMES=1 rnacode_amd/rnacode_hip /tmp/c3.maf -n 1000 -t -o /tmp/o.tsv 2>&1 | tail -60
 echo "--- orderly teardown, wall by /usr/bin/env time"
-for i in 1 2 3; do s=$(date +%s.%N); RC_CLI_TEARDOWN=1 rnacode_amd/rnacode_hip /tmp/c3.maf -n 1000 -t -o /tmp/o.tsv; e=$(date +%s.%N); echo "teardown run: $(echo "$e - $s" | bc) s"; sleep 0.3; done
-for i in 1 2 3; do s=$(date +%s.%N); rnacode_amd/rnacode_hip /tmp/c3.maf -n 1000 -t -o /tmp/o.tsv; e=$(date +%s.%N); echo "immediate exit run: $(echo "$e - $s" | bc) s"; sleep 0.3; done
+for i in 1 2 3; do python3 -c "import subprocess,time,os; t=time.time(); subprocess.run([\"rnacode_amd/rnacode_hip\",\"/tmp/c3.maf\",\"-n\",\"1000\",\"-t\",\"-o\",\"/tmp/o.tsv\"], env=dict(os.environ, RC_CLI_TEARDOWN=\"1\")); print(\"teardown run:\", round(time.time()-t,3))"; sleep 0.3; done
+for i in 1 2 3; do python3 -c "import subprocess,time; t=time.time(); subprocess.run([\"rnacode_amd/rnacode_hip\",\"/tmp/c3.maf\",\"-n\",\"1000\",\"-t\",\"-o\",\"/tmp/o.tsv\"]); print(\"immediate exit run:\", round(time.time()-t,3))"; sleep 0.3; done

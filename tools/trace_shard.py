@@ -11,7 +11,7 @@ from rnacode_amd.synth import synth_blocks  # noqa: E402
 
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 1250
 threads = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-sub = int(sys.argv[3]) if len(sys.argv) > 3 else -(-nb // 4)
+sub = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else 0   # sub-batch sizes (default: rc_stream_plan)
 blocks = [b.upper() for b in synth_blocks(nb, 6, 120, seed=1)]
 ctx = api.Context(0)
 ctx.set_host_threads(threads)
@@ -31,11 +31,17 @@ times = []
 for rep in range(8):
     print(f"---- pass {rep}", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
+    rows = []
     for sb in api.score_stream(ctx, m, params, sub, stream=st):
         sb.fits()
+        t, _ = sb.timing()
+        rows.append((sb.n, (time.perf_counter() - t0) * 1e3, t))
         sb.close()
     times.append((time.perf_counter() - t0) * 1e3)
-print(f"{nb} blocks, {threads} host threads, sub-batches of {sub}: resident {res_ms:.3f} ms, stream passes " + " ".join(f"{t:.3f}" for t in times))
+    if rep == 7:
+        for n, done, t in rows:
+            print(f"  sub-batch of {n:5d}: results on the host at {done:7.3f} ms; device intervals: start->fit {t['total']:.3f}, k_null {t['null']:.3f}, native {t['native']:.3f}, fit {t['evd_fit']:.3f}")
+print(f"{nb} blocks, {threads} host threads, sub-batches {sub or api.stream_plan(ctx, params, nb, 1)}: resident {res_ms:.3f} ms, stream passes " + " ".join(f"{t:.3f}" for t in times))
 st.close()
 batch.close()
 ctx.close()
