@@ -882,7 +882,7 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
   return RC_OK;
 }
 
-static int batch_run_async(rc_batch *b) {
+static int batch_run_async(rc_batch *b, bool streaming = false) {
   rc_ctx *c = b->ctx;
   if (b->state != rc_batch::READY && b->state != rc_batch::DONE) return fail(RC_ERR_ARG, "batch is not ready to run");
   HIP_TRY(hipSetDevice(c->device));
@@ -953,7 +953,9 @@ static int batch_run_async(rc_batch *b) {
     if (!nativeQueued) RC_TRY(launch_native_block(R));
     // ---- EVD fit
     if (!c->serialNative) HIP_TRY(hipStreamWaitEvent(cs, b->evN1, 0));   // native HSS of the native stream
-    launch_evd_fit(fa, static_cast<int>(b->okBlocks.size()), c->inflight.load() == 0, cs); b->nl[4]++;
+    // (a batch of a stream: the next sub-batch's k_null will be holding the LDS by the time this fit runs)
+    // (a small input -- a few dozen blocks -- is one sub-batch by itself and keeps the four-wavefront fit, whose latency is its run time)
+    launch_evd_fit(fa, static_cast<int>(b->okBlocks.size()), c->inflight.load() == 0 && (!streaming || b->okBlocks.size() <= 64), cs); b->nl[4]++;
   }
   HIP_TRY(b->evFit.record(cs));
   // small results back to the host: four copies into one pinned staging area behind the fit
@@ -1123,7 +1125,7 @@ int rc_stream_submit_bound(rc_stream *s, const rc_block *blocks, int32_t n_block
   trace("prepared", b);
   if (r == RC_OK) r = batch_upload(b);
   trace("uploaded", b);
-  if (r == RC_OK) r = batch_run_async(b);
+  if (r == RC_OK) r = batch_run_async(b, true);
   trace("queued", b);
   if (r != RC_OK) {
     // the batch may hold a queued upload of its pinned blob (upload succeeded, run failed): let it finish before the batch is re-used

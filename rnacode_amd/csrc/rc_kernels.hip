@@ -90,6 +90,7 @@ template <int B, typename F> __device__ __forceinline__ void for_codon_b(F &&f) 
 }
 
 __global__ __launch_bounds__(64) void k_prep_models(PrepArgs A) {
+  __builtin_amdgcn_s_setprio(3);   // a short latency-bound kernel beside k_null: the SIMD issues its instructions first
   const int lane = threadIdx.x;
   int t = blockIdx.x * kWave + lane;
   const bool active = t < A.nModels;
@@ -170,6 +171,7 @@ __device__ __forceinline__ bool in_div_range_dev(float v) {
 // with a value outside the range proven for the constant-divisor division is flagged and appended to its
 // class's list for the EXACT launch.
 __global__ __launch_bounds__(64) void k_prep_lut(PrepArgs A) {   // one wavefront per block, no LDS (it runs beside k_null)
+  __builtin_amdgcn_s_setprio(3);   // a short latency-bound kernel beside k_null: the SIMD issues its instructions first
   const int bi = A.blocks[blockIdx.x];
   const DevBlock *db = A.dblocks + bi;
   const int N = db->N, NK = db->NK;
@@ -204,6 +206,7 @@ __global__ __launch_bounds__(64) void k_prep_lut(PrepArgs A) {   // one wavefron
 // reverse complement keeps '-' where it was.  The window of position i is the columns (col(i-3), col(i)] (from column 0 for
 // i == 3): exactly three reference residues, so the reference row's own gap count there is the window's length minus 3.
 __global__ __launch_bounds__(64) void k_prep_gaps(PrepArgs A) {
+  __builtin_amdgcn_s_setprio(3);   // a short latency-bound kernel beside k_null: the SIMD issues its instructions first
   const int bi = A.blocks[blockIdx.x >> 1];
   const int s = blockIdx.x & 1;
   const int lane = threadIdx.x;
@@ -285,6 +288,7 @@ void launch_prep(const PrepArgs &a, hipStream_t stream) {
 // native block
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_native_sigma(NativeArgs A) {
+  __builtin_amdgcn_s_setprio(3);   // a short latency-bound kernel beside k_null: the SIMD issues its instructions first
   const int bi = A.blocks[blockIdx.x];
   const DevBlock *__restrict__ db = A.dblocks + bi;
   const int NK = db->NK, cols = db->cols, L = db->L, L1 = L + 1;
@@ -325,6 +329,7 @@ __global__ __launch_bounds__(256) void k_native_sigma(NativeArgs A) {
 // the matrices themselves are never materialised (they were 6 (L/3)^2 floats per block: 24 GB for 10^5 blocks of 300 columns).
 template <int NK>
 __global__ __launch_bounds__(64) void k_native_dp(NativeArgs A) {
+  __builtin_amdgcn_s_setprio(3);   // a short latency-bound kernel beside k_null: the SIMD issues its instructions first
   const int lane = threadIdx.x;
   float *__restrict__ tile = A.tile + static_cast<size_t>(blockIdx.x) * A.tileStride;
   for (int item = blockIdx.x; item < A.nItems; item += gridDim.x) {
@@ -523,6 +528,7 @@ __device__ __forceinline__ float best_native(const FitArgs &A, int bi) {
 // (int)(cutoff * sampleN) samples beat the best native score.  That count only grows, so a block is decided
 // once the samples simulated so far exceed it; the remaining sample groups are then not run for it.
 __global__ __launch_bounds__(64) void k_stop_mark(FitArgs A) {
+  __builtin_amdgcn_s_setprio(3);   // a short latency-bound kernel beside k_null: the SIMD issues its instructions first
   const int bi = A.blocks[blockIdx.x];
   const DevBlock *db = A.dblocks + bi;
   const float *x = A.maxima + static_cast<size_t>(db->out_index) * A.sampleN;
@@ -537,6 +543,7 @@ __global__ __launch_bounds__(64) void k_stop_mark(FitArgs A) {
 
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_evd_fit(FitArgs A) {
+  __builtin_amdgcn_s_setprio(3);   // a short latency-bound kernel beside k_null: the SIMD issues its instructions first
   __shared__ double sh[THREADS > kWave ? (THREADS / kWave) * 4 : 1];   // not referenced (and not allocated) for THREADS = 64
   const int bi = A.blocks[blockIdx.x];
   const DevBlock *db = A.dblocks + bi;
