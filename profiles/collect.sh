@@ -9,7 +9,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-stream $*"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-stream --no-extra $*"
 # one kernel at a time while profiling: by default the native-block kernels run on a second stream beside k_null and
 # their trace intervals then span its whole duration
 export RC_SERIAL_NATIVE=1

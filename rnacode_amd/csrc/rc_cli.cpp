@@ -19,6 +19,10 @@
 #include <fstream>
 #include <iostream>
 #include <sstream>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -240,7 +244,7 @@ int main(int argc, char **argv) {
 
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double tMain = now();
-  double tRead = now(), tCtx = 0, tTrees = 0, tSubmit = 0, tWait = 0, tList = 0;
+  double tRead = now(), tCtx = 0, tTrees = 0, tSubmit = 0, tWait = 0, tList = 0, tFetch = 0;
   // the HIP runtime and the context come up (0.1-0.3 s) on a thread of their own while this one reads and parses the input
   rc_ctx *ctx = nullptr;
   int ctxRc = RC_OK;
@@ -355,8 +359,46 @@ int main(int argc, char **argv) {
   std::vector<char> nwk;
   std::vector<float> kap;
   int next = 0, base = 0, fitted = 0;
-  std::vector<rc_hss> hss;
-  std::vector<int64_t> offs;
+  // The listing is written by a thread of its own, batch by batch in input order: formatting 10^5 lines takes as long as the GPU
+  // needs for the blocks behind them, and this thread has the next sub-batch to prepare.
+  struct Job {
+    int base = 0, m = 0;
+    std::vector<rc_hss> hss;
+    std::vector<int64_t> offs;
+    std::vector<int> status;
+    std::vector<std::string> why;
+  };
+  std::mutex jm;
+  std::condition_variable jcv;
+  std::deque<std::unique_ptr<Job>> jobs;
+  bool jobsDone = false;
+  std::thread printer([&] {
+    for (;;) {
+      std::unique_ptr<Job> j;
+      {
+        std::unique_lock<std::mutex> lk(jm);
+        jcv.wait(lk, [&] { return jobsDone || !jobs.empty(); });
+        if (jobs.empty()) return;
+        j = std::move(jobs.front());
+        jobs.pop_front();
+      }
+      const double t = now();
+      for (int i = 0; i < j->m; i++) {
+        const int st = j->status[i];
+        const Block &blk = blocks[j->base + i];
+        if (st == RC_ERR_SKIP) {   // RNAcode.c:142-150
+          std::fprintf(stderr, "Skipping alignment. %s\n", blk.rows.size() <= 2 ? "There must be at least three sequences in the alignment." : "Too short.");
+          continue;
+        }
+        if (st != RC_OK) {         // RNAcode.c:153-156
+          std::fprintf(stderr, "Skipping alignment. Failed to build ML tree. (%s)\n", j->why[i].empty() ? "not scored" : j->why[i].c_str());
+          continue;
+        }
+        list.block(std::vector<rc_hss>(j->hss.begin() + j->offs[i], j->hss.begin() + j->offs[i + 1]), blk.rows[0].name);
+      }
+      tList += now() - t;
+    }
+  });
   while (next < n || rc_stream_pending(stream) > 0) {
     while (next < n && rc_stream_pending(stream) < 3) {
       const int m = planAt < plan.size() ? std::min<int>(plan[planAt++], n - next) : n - next;
@@ -386,33 +428,32 @@ int main(int argc, char **argv) {
     if (rc_stream_next(stream, &b) != RC_OK) die(rc_last_error());
     tWait += now() - t;
     t = now();
-    const int m = rc_batch_size(b);
-    offs.assign(static_cast<size_t>(m) + 1, 0);
-    if (rc_batch_hss_all(b, nullptr, 0, offs.data()) != RC_OK) die(rc_last_error());
-    hss.resize(static_cast<size_t>(std::max<int64_t>(offs[m], 1)));
-    if (rc_batch_hss_all(b, hss.data(), offs[m], offs.data()) != RC_OK) die(rc_last_error());
-    for (int i = 0; i < m; i++) {
-      const int st = rc_batch_status(b, i);
-      const Block &blk = blocks[base + i];
-      if (st == RC_ERR_SKIP) {   // RNAcode.c:142-150
-        std::fprintf(stderr, "Skipping alignment. %s\n", blk.rows.size() <= 2 ? "There must be at least three sequences in the alignment." : "Too short.");
-        continue;
-      }
-      if (st != RC_OK) {         // RNAcode.c:153-156
-        const char *why = rc_batch_block_error(b, i);
-        std::fprintf(stderr, "Skipping alignment. Failed to build ML tree. (%s)\n", (why && *why) ? why : "not scored");
-        continue;
-      }
-      list.block(std::vector<rc_hss>(hss.begin() + offs[i], hss.begin() + offs[i + 1]), blk.rows[0].name);
+    std::unique_ptr<Job> j(new Job());
+    j->base = base;
+    j->m = rc_batch_size(b);
+    j->offs.assign(static_cast<size_t>(j->m) + 1, 0);
+    if (rc_batch_hss_all(b, nullptr, 0, j->offs.data()) != RC_OK) die(rc_last_error());
+    j->hss.resize(static_cast<size_t>(std::max<int64_t>(j->offs[j->m], 1)));
+    if (rc_batch_hss_all(b, j->hss.data(), j->offs[j->m], j->offs.data()) != RC_OK) die(rc_last_error());
+    j->status.resize(j->m);
+    j->why.resize(j->m);
+    for (int i = 0; i < j->m; i++) {
+      j->status[i] = rc_batch_status(b, i);
+      if (j->status[i] != RC_OK && j->status[i] != RC_ERR_SKIP) { const char *why = rc_batch_block_error(b, i); j->why[i] = why ? why : ""; }
     }
-    base += m;
-    tList += now() - t;
+    base += j->m;
+    tFetch += now() - t;
     rc_stream_recycle(stream, b);
+    { std::lock_guard<std::mutex> lk(jm); jobs.push_back(std::move(j)); }
+    jcv.notify_one();
   }
+  { std::lock_guard<std::mutex> lk(jm); jobsDone = true; }
+  jcv.notify_one();
+  printer.join();
   rc_stream_destroy(stream);
   if (std::getenv("RC_CLI_TIMES"))
-    std::fprintf(stderr, "[rnacode_hip] read %.3f s, context (beside the reading) %.3f s, trees %.3f s, submit %.3f s, wait %.3f s, listing %.3f s, main() so far %.3f s\n",
-                 tRead, tCtx, tTrees, tSubmit, tWait, tList, now() - tMain);
+    std::fprintf(stderr, "[rnacode_hip] read %.3f s, context (beside the reading) %.3f s, trees %.3f s, submit %.3f s, wait %.3f s, results %.3f s, listing (its own thread) %.3f s, main() so far %.3f s\n",
+                 tRead, tCtx, tTrees, tSubmit, tWait, tFetch, tList, now() - tMain);
   if (list.fmt == 0) {   // RNAcode.c:223-228
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::fprintf(list.out, "\n%i alignment(s) scored in %.2f seconds. Parameters used:\nN=%i, Delta=%.2f, Omega=%.2f, omega=%.2f, stop penalty=%.2f\n\n",

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64) void k_mt_stream(uint32_t seedBase, int Spad, i
 // block-constant tables derived on the device
 // ------------------------------------------------------------------------------------------
 
-// calculateBG (score.c:107-193) for one model per lane: two 4096-term float accumulations in the loop
+// calculateBG (score.c:107-193) for one model per lane and Hamming class per wavefront: two 4096-term float accumulations in the loop
 // order a1,a2,a3,b1,b2,b3, every product and sum a single binary32 operation in the reference's order
 // (SURVEY appendix A.4).  The codon a is a run-time loop (its three HKY85 rows, 12 floats, are re-read per a);
 // the 64 codons b are unrolled, so row entries, stop tests and Hamming classes of b are compile-time and the
@@ -91,8 +91,13 @@ template <int B, typename F> __device__ __forceinline__ void for_codon_b(F &&f) 
 
 __global__ __launch_bounds__(64) void k_prep_models(PrepArgs A) {
   __builtin_amdgcn_s_setprio(3);   // a short latency-bound kernel beside k_null: the SIMD issues its instructions first
+  // Four wavefronts per 64 models, one per Hamming class: a wavefront is a serial instruction stream (one VALU instruction per ~9 cycles
+  // when it has a SIMD to itself, fewer beside k_null), and this kernel's latency is what the first k_null of a stream waits for.  The
+  // class of a term is wave-uniform (a is the loop counter, b is unrolled), so a wavefront skips the terms of the other classes with a
+  // scalar branch, division included; its two accumulators see exactly the terms they saw when all four classes shared one lane.
   const int lane = threadIdx.x;
-  int t = blockIdx.x * kWave + lane;
+  const int hq = blockIdx.x & 3;
+  int t = (blockIdx.x >> 2) * kWave + lane;
   const bool active = t < A.nModels;
   if (!active) t = A.nModels - 1;
   int lo = 0, hi = A.nBlocks;                       // block whose [prefix, next prefix) holds t
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(64) void k_prep_models(PrepArgs A) {
       }
     });
   }
-  float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f, s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  float cq = 0.0f, sq = 0.0f;
   const float keep = 1.0f - probStop;   // (1 - probStop): int 1 converted to float
   for (int a = 0; a < 64; a++) {
     const int pa = A.pep[a];
@@ -140,24 +145,20 @@ __global__ __launch_bounds__(64) void k_prep_models(PrepArgs A) {
       if constexpr (pb != -1) {
         const int x = a ^ b;
         const int h = ((x & 48) != 0) + ((x & 12) != 0) + ((x & 3) != 0);
-        float pAB = r1[b >> 4] * r2[(b >> 2) & 3] * r3[b & 3];
-        pAB = pAB * fa;
-        pAB = pAB / keep;
-        const float sc = static_cast<float>(blosum[pa * 20 + pb]);
-        // exactly one Hamming class receives the term; the other three add +0, which changes nothing (x + 0 == x
-        // bit for bit for every x these sums can hold: they start at +0).  h is wave-uniform, the selects are cheap;
-        // written as a branch per class the compiler turns the eight accumulators into an array in scratch memory.
-        const float p0 = h == 0 ? pAB : 0.0f, p1 = h == 1 ? pAB : 0.0f, p2 = h == 2 ? pAB : 0.0f, p3 = h == 3 ? pAB : 0.0f;
-        c0 = c0 + p0; s0 = s0 + sc * p0;
-        c1 = c1 + p1; s1 = s1 + sc * p1;
-        c2 = c2 + p2; s2 = s2 + sc * p2;
-        c3 = c3 + p3; s3 = s3 + sc * p3;
+        if (h == hq) {   // wave-uniform: a scalar branch
+          float pAB = r1[b >> 4] * r2[(b >> 2) & 3] * r3[b & 3];
+          pAB = pAB * fa;
+          pAB = pAB / keep;
+          const float sc = static_cast<float>(blosum[pa * 20 + pb]);
+          cq = cq + pAB;
+          sq = sq + sc * pAB;
+        }
       }
     });
   }
   if (active) {
-    m->scores[0] = s0 / c0; m->scores[1] = s1 / c1; m->scores[2] = s2 / c2; m->scores[3] = s3 / c3;
-    m->probs[0] = c0; m->probs[1] = c1; m->probs[2] = c2; m->probs[3] = c3;
+    m->scores[hq] = sq / cq;
+    m->probs[hq] = cq;
   }
 }
 
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(64) void k_prep_gaps(PrepArgs A) {
 void launch_prep(const PrepArgs &a, hipStream_t stream) {
   if (a.nBlocks <= 0) return;
   hipLaunchKernelGGL(k_prep_gaps, dim3(2 * a.nBlocks), dim3(kWave), 0, stream, a);
-  hipLaunchKernelGGL(k_prep_models, dim3((a.nModels + kWave - 1) / kWave), dim3(kWave), 0, stream, a);
+  hipLaunchKernelGGL(k_prep_models, dim3(4 * ((a.nModels + kWave - 1) / kWave)), dim3(kWave), 0, stream, a);
   hipLaunchKernelGGL(k_prep_lut, dim3(a.nBlocks), dim3(kWave), 0, stream, a);
 }
 

@@ -141,7 +141,7 @@ int run(const char *name, int sites, float drift) {
 int main() {
   printf("lane = start codon, one wavefront per sample; 12 sequences x 300 columns (100 codon sites per frame)\n");
   printf("reference point: k_null<11,false,false> (lane = sample) scores 1000 blocks x 10 000 samples x 6 strand x frame units in ~600 ms = 1.0e8 units/s\n");
-  for (float drift : {-0.6f, -0.9f, -1.2f}) {
+  for (float drift : {0.3f, 0.1f, -0.1f, -0.3f, -0.6f}) {
     printf("sigma drift %.1f:\n", drift);
     run<false>("DP only (no getHSS fold)", 100, drift);
     run<true>("DP + serial fold over positives", 100, drift);
