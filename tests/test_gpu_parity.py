@@ -608,6 +608,23 @@ def test_duplicate_row_names_are_rejected(ctx):
     batch.close()
 
 
+def test_block_too_large_for_the_device_gets_its_own_status(ctx):
+    """A block whose MT19937 streams (4 bytes x tree nodes x columns x samples) would not fit a quarter of the device memory is left
+    out with RC_ERR_UNSUPPORTED and a reason; the other blocks of the batch are scored (include/rnacode_hip.h, bounds on a block)."""
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_blocks
+    big = synth_blocks(1, 500, 20000, seed=11)[0].upper()        # 998 nodes x 20 000 columns x 1024 samples x 4 B = 82 GB
+    small = synth_blocks(2, 5, 60, seed=12)
+    blocks = [small[0].upper(), big, small[1].upper()]
+    batch = api.Batch(ctx, blocks, api.default_params(sampleN=1000)).run()
+    assert batch.status(1) == api.RC_ERR_UNSUPPORTED and "too large for the device" in batch.block_error(1)
+    assert batch.status(0) == api.RC_OK and batch.status(2) == api.RC_OK
+    alone = api.Batch(ctx, [blocks[0], blocks[2]], api.default_params(sampleN=1000)).run()
+    np.testing.assert_array_equal(batch.maxScores(0), alone.maxScores(0))
+    np.testing.assert_array_equal(batch.maxScores(2), alone.maxScores(1))
+    batch.close(); alone.close()
+
+
 def _newick_parts(nwk):
     import re
     return re.sub(r":[0-9.]+", "", nwk), [float(x) for x in re.findall(r":([0-9.]+)", nwk)]

@@ -227,6 +227,37 @@ def test_config5_one_gpus_share_streamed_against_oracle(ctx):
                [(h["strand"], h["frame"], h["start"], h["end"], np.float32(h["score"])) for h in want]
 
 
+def test_stream_plan_sizes(ctx):
+    """rc_stream_plan: the sizes sum to the number of blocks; after the first, every sub-batch fills the chip's wavefront slots a
+    whole number of times (r = slots / sample groups blocks do so once) and none exceeds eight rounds; short inputs are one batch;
+    and streaming by the plan gives the results of one resident batch."""
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_blocks
+    p = api.default_params(sampleN=1000)
+    for n in (1, 33, 300, 1250, 10000, 123457):
+        sizes = api.stream_plan(ctx, p, n, 1)
+        assert sum(sizes) == n and all(x > 0 for x in sizes)
+        if len(sizes) > 1:
+            r = sizes[1]
+            assert all(x % r == 0 for x in sizes[1:-1]) and max(sizes) <= 8 * r + r
+    assert api.stream_plan(ctx, p, 300, 1) == [300]
+    assert len(api.stream_plan(ctx, p, 10000, 10)) < len(api.stream_plan(ctx, p, 10000, 1))   # more row-count classes: larger sub-batches
+    blocks = [b.upper() for b in synth_blocks(700, 5, 60, seed=21)]
+    p = api.default_params(sampleN=1000, seed_base=7)
+    m = api.Marshalled(blocks)
+    m.set_trees()
+    whole = api.Batch(ctx, m, p).run()
+    want = whole.maxScores_all()
+    got = []
+    plan = api.stream_plan(ctx, p, len(blocks), 1)
+    assert len(plan) >= 2
+    for sb in api.score_stream(ctx, m, p):
+        got.append(sb.maxScores_all())
+        sb.close()
+    np.testing.assert_array_equal(np.concatenate(got), want)
+    whole.close()
+
+
 def test_stop_early_runs_fewer_samples_and_agrees_with_the_oracle(monkeypatch):
     """--stop-early (score.c:992,1036-1042): blocks whose first samples already beat the native score more often
     than the cutoff allows are decided (rc = -1) and get no further samples; all others are sampled in full.
