@@ -186,13 +186,13 @@ class Pool {
 
 size_t al256(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
 
-// RC_TRACE=1: host-side time stamps of the pipeline stages on stderr (microseconds since the first stamp)
+// RC_TRACE=1: host-side time stamps of the pipeline stages on stderr
+bool trace_on() { static const bool on = std::getenv("RC_TRACE") != nullptr; return on; }
+// CLOCK_MONOTONIC in microseconds (what Python's time.monotonic() reads as well: a driver script can put its own stamps on the same axis)
+double trace_now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 void trace(const char *what, const void *obj) {
-  static const bool on = std::getenv("RC_TRACE") != nullptr;
-  if (!on) return;
-  static const auto t0 = std::chrono::steady_clock::now();
-  const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-  std::fprintf(stderr, "[rc %10.1f us] %-14s %p\n", us, what, obj);
+  if (!trace_on()) return;
+  std::fprintf(stderr, "[rc %14.1f us] %-14s %p\n", trace_now_us(), what, obj);
 }
 
 }  // namespace
@@ -207,6 +207,8 @@ struct rc_ctx {
   std::mutex treeMutex;
   int gridCapPerCU = 0;       // RC_GRID_CAP_PER_CU: at most this many k_null workgroups per CU (experiments on cache residency of the code scratch); 0 = what fits
   double splitFactor = 0.5;   // a k_null launch with fewer (block, sample group) items than this fraction of the chip's wavefront slots splits every item into its six strand x frame parts (RC_SPLIT_FACTOR)
+  int copyResults = 0;        // RC_COPY_RESULTS=1: the small results go back with hipMemcpyAsync instead of k_results_out (A/B)
+  int tailSharing = 1;        // k_null: items taken near the end of the queues are shared part by part with workgroups that have run out of work (RC_TAIL_SHARING=0: off)
   int nativeWavesPerCU = 8;   // persistent wavefronts of k_native_dp per CU (RC_NATIVE_WAVES_PER_CU): it runs beside k_null and should not crowd it out
   size_t genericScratchWords = static_cast<size_t>(1) << 30;   // uint32 of staging scratch one k_null_generic launch may take: a twelfth of the device memory (24 GB of 288)
   hipStream_t compute[2] = {nullptr, nullptr};   // null sampling + fit; consecutive batches alternate, so the tail of one overlaps the head of the next
@@ -271,7 +273,7 @@ struct rc_batch {
   size_t oDblocks = 0, oOk = 0, oClass = 0, oPrefix = 0;   // tail arrays inside the host part
   int nModels = 0;
   // device
-  DevBuf dblob, dmaxima, dhss, dhssCount, dhssPacked, dhssOffsets, dfit, dflags, dexact, dcounters, dscratch, dnativeScratch, dnativeTile;
+  DevBuf dblob, dmaxima, dhss, dhssCount, dhssPacked, dhssOffsets, dfit, dflags, dexact, dcounters, dscratch, dnativeScratch, dnativeTile, dsteal;
   float *maxPtr = nullptr;
   bool maximaExternal = false;
   PinBuf hstage, hpacked;
@@ -384,6 +386,8 @@ int rc_ctx_create(int device, rc_ctx **out) {
   if (const char *e = std::getenv("RC_GRID_CAP_PER_CU")) c->gridCapPerCU = std::max(0, std::atoi(e));
   if (const char *e = std::getenv("RC_SPLIT_FACTOR")) c->splitFactor = std::max(0.0, std::atof(e));
   if (const char *e = std::getenv("RC_NATIVE_WAVES_PER_CU")) c->nativeWavesPerCU = std::max(1, std::min(32, std::atoi(e)));
+  if (const char *e = std::getenv("RC_TAIL_SHARING")) c->tailSharing = std::atoi(e) != 0;
+  if (const char *e = std::getenv("RC_COPY_RESULTS")) c->copyResults = std::atoi(e) != 0;
   if (const char *e = std::getenv("RC_GENERIC_SCRATCH_MB")) c->genericScratchWords = std::max<size_t>(1, static_cast<size_t>(std::atoll(e))) * (1u << 20) / sizeof(uint32_t);
   // non-blocking streams: no implicit ordering against the legacy default stream that a host framework in
   // the same process (torch, RCCL) may be using; the native stream gets the higher priority so that the
@@ -662,6 +666,7 @@ struct RunEnv {
   const uint8_t *blob;
   const DevBlock *dblocks;
   const int *okList, *classList;
+  bool streaming;     // a sub-batch of a stream: others are queued behind it
 };
 }  // namespace
 
@@ -733,6 +738,10 @@ static int launch_native_block(const RunEnv &R) {
 
 // null sampling of the sample groups [gLo, gHi) for every class; phase 0 or 1 selects the work counters
 // sizeOnly: no launch, *sizeOnly = uint32 of staging scratch this round needs (the rounds of a run share one allocation made up front)
+// tail sharing of k_null (rc_null_kernel.h): per launch one claim word and a (block, group) pair per workgroup
+static size_t steal_slots(const rc_ctx *c) { return static_cast<size_t>(c->numCU) * 32; }
+static size_t steal_words(const rc_ctx *c) { return 16 + 4 * steal_slots(c); }   // header, claim words, (block, group) pairs, list of published slots
+
 static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t extraSkip, size_t *sizeOnly = nullptr) {
   rc_batch *b = R.b; rc_ctx *c = R.c;
   const int groupsHere = gHi - gLo;
@@ -861,6 +870,12 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
     } else {
       a.skipMask = kFlagExact | extraSkip;
       a.workCounter = work + p.NK * 8;
+      // tail sharing: one slot per workgroup of this launch in the zeroed dsteal area (see batch_run_async)
+      if (c->tailSharing && !p.comboSplit && static_cast<size_t>(p.grid) <= steal_slots(c) && b->dsteal.p) {
+        const size_t idx = static_cast<size_t>(phase) * b->classes.size() + pi;
+        if ((idx + 1) * steal_words(c) * sizeof(uint32_t) <= b->dsteal.cap) a.steal = b->dsteal.as<unsigned int>() + idx * steal_words(c);
+        a.stealWait = R.streaming ? 0 : 1;
+      }
       if (!launch_null(p.NK, a, p.grid, p.ldsBytes, false, st)) return fail(RC_ERR_UNSUPPORTED, "no null kernel for this number of rows");
       b->nl[2]++;
       NullArgs e = a;
@@ -869,6 +884,7 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
       e.nClassBlocks = 0;
       e.skipMask = extraSkip;
       e.comboSplit = 0;
+      e.steal = nullptr;
       e.workCounter = work + kClassSlots * 8 + p.NK * 8;
       if (!launch_null(p.NK, e, p.gridExact, 0, true, st)) return fail(RC_ERR_UNSUPPORTED, "no null kernel for this number of rows");
     }
@@ -897,7 +913,7 @@ static int batch_run_async(rc_batch *b, bool streaming = false) {
   const uint8_t *blob = b->dblob.as<uint8_t>();
   const RunEnv R{b, c, cs, n, sampleN, groups, Spad, n * 6, table_ptrs(c, b->par.blosum), blob,
                  reinterpret_cast<const DevBlock *>(blob + b->oDblocks), reinterpret_cast<const int *>(blob + b->oOk),
-                 reinterpret_cast<const int *>(blob + b->oClass)};
+                 reinterpret_cast<const int *>(blob + b->oClass), streaming};
   HIP_TRY(hipStreamWaitEvent(cs, b->evPrep, 0));   // upload + expected-score tables
   HIP_TRY(b->evStart.record(cs));
   if (!b->okBlocks.empty()) {
@@ -907,7 +923,6 @@ static int batch_run_async(rc_batch *b, bool streaming = false) {
     HIP_TRY(hipMemsetAsync(cnt + kCntWork, 0, (kCntTotal - kCntWork) * sizeof(uint32_t), cs));   // work queues and the clamp counter
     // -1.0f everywhere first: skipped blocks report "no HSS" rows
     HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->maxPtr), 0xBF800000u, static_cast<size_t>(n) * sampleN, cs));
-    HIP_TRY(b->evS0.record(cs));
     FitArgs fa{};
     fa.dblocks = R.dblocks; fa.blocks = R.okList; fa.maxima = b->maxPtr; fa.hss = b->dhss.as<DevHss>();
     fa.hssCount = b->dhssCount.as<int>(); fa.hssCap = b->hssCap; fa.out = b->dfit.as<FitOut>(); fa.flags = b->dflags.as<uint32_t>();
@@ -930,7 +945,13 @@ static int batch_run_async(rc_batch *b, bool streaming = false) {
         lo = hi; hi = std::min(groups, hi * 2);
       }
       HIP_TRY(b->dscratch.ensure(most * sizeof(uint32_t)));
+      if (c->tailSharing) {   // claim words of every (round, class) launch, zeroed: "nothing to take"
+        const size_t bytes = static_cast<size_t>(r) * b->classes.size() * steal_words(c) * sizeof(uint32_t);
+        HIP_TRY(b->dsteal.ensure(bytes));
+        HIP_TRY(hipMemsetAsync(b->dsteal.p, 0, bytes, cs));
+      }
     }
+    HIP_TRY(b->evS0.record(cs));   // the class launches of the first round fork from here: every memset above is behind it
     // the native block's kernels go first: queued behind k_null's persistent grid they would find no free wavefront slot until its
     // tail, and the fit waits for them (long blocks: 1000 blocks of 12 x 300 took 628 ms per step that way instead of 600)
     bool nativeQueued = true;
@@ -966,15 +987,33 @@ static int batch_run_async(rc_batch *b, bool streaming = false) {
     HIP_TRY(b->hstage.ensure(total));
     if (!b->okBlocks.empty()) {
       uint8_t *hs = b->hstage.as<uint8_t>();
-      HIP_TRY(hipMemcpyAsync(hs + oFit, b->dfit.p, szFit, hipMemcpyDeviceToHost, cs));
-      HIP_TRY(hipMemcpyAsync(hs + oCnt, b->dhssCount.p, szCnt, hipMemcpyDeviceToHost, cs));
-      HIP_TRY(hipMemcpyAsync(hs + oOff, b->dhssOffsets.p, szOff, hipMemcpyDeviceToHost, cs));
-      HIP_TRY(hipMemcpyAsync(hs + oClamp, b->dcounters.as<uint32_t>() + kCntClamp, sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
       // the packed HSS records: their number is only known on the device, so a generous prefix travels with the
       // counts (16 per block; 9 on average for random blocks) and rc_batch_wait fetches the rest only if there are more
       b->packedAhead = std::min(static_cast<size_t>(slots) * b->hssCap, static_cast<size_t>(n) * 16);
       HIP_TRY(b->hpacked.ensure(sizeof(DevHss) * std::max<size_t>(b->packedAhead, 1)));
-      HIP_TRY(hipMemcpyAsync(b->hpacked.p, b->dhssPacked.p, sizeof(DevHss) * b->packedAhead, hipMemcpyDeviceToHost, cs));
+      // written by a kernel of ours into the mapped pinned buffers (k_results_out explains why not hipMemcpyAsync)
+      void *dStage = nullptr, *dPacked = nullptr;
+      static_assert(sizeof(FitOut) % 4 == 0 && sizeof(DevHss) % 4 == 0, "results travel as 32-bit words");
+      if (!c->copyResults && hipHostGetDevicePointer(&dStage, b->hstage.p, 0) == hipSuccess &&
+          hipHostGetDevicePointer(&dPacked, b->hpacked.p, 0) == hipSuccess) {
+        uint8_t *ds = static_cast<uint8_t *>(dStage);
+        ResultsOutArgs ro{};
+        auto part = [&](int x, void *dst, const void *src, size_t bytes) {
+          ro.dst[x] = static_cast<uint32_t *>(dst); ro.src[x] = static_cast<const uint32_t *>(src); ro.words[x] = bytes / 4;
+        };
+        part(0, ds + oFit, b->dfit.p, szFit);
+        part(1, ds + oCnt, b->dhssCount.p, szCnt);
+        part(2, ds + oOff, b->dhssOffsets.p, szOff);
+        part(3, ds + oClamp, b->dcounters.as<uint32_t>() + kCntClamp, sizeof(unsigned long long));
+        part(4, dPacked, b->dhssPacked.p, sizeof(DevHss) * b->packedAhead);
+        launch_results_out(ro, cs);
+      } else {
+        HIP_TRY(hipMemcpyAsync(hs + oFit, b->dfit.p, szFit, hipMemcpyDeviceToHost, cs));
+        HIP_TRY(hipMemcpyAsync(hs + oCnt, b->dhssCount.p, szCnt, hipMemcpyDeviceToHost, cs));
+        HIP_TRY(hipMemcpyAsync(hs + oOff, b->dhssOffsets.p, szOff, hipMemcpyDeviceToHost, cs));
+        HIP_TRY(hipMemcpyAsync(hs + oClamp, b->dcounters.as<uint32_t>() + kCntClamp, sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
+        HIP_TRY(hipMemcpyAsync(b->hpacked.p, b->dhssPacked.p, sizeof(DevHss) * b->packedAhead, hipMemcpyDeviceToHost, cs));
+      }
     }
   }
   HIP_TRY(b->evDone.record(cs));
@@ -1057,6 +1096,23 @@ int rc_batch_bind_maxima(rc_batch *b, void *device_ptr) {
   b->maximaExternal = true;
   if (b->state == rc_batch::DONE) b->state = rc_batch::READY;
   return RC_OK;
+}
+
+// RC_TRACE=1: where a finished batch's device events lie on the host's clock (a reference event is recorded and synchronised
+// once; later events are placed by their elapsed time from it) -- one line per batch on stderr
+static void trace_device(rc_batch *b) {
+  if (!trace_on() || b->okBlocks.empty()) return;
+  static Event ref;
+  static double refHostUs = 0.0;
+  if (!ref.e) {
+    if (ref.record(b->ctx->aux) != hipSuccess || hipEventSynchronize(ref) != hipSuccess) return;
+    refHostUs = trace_now_us();
+    std::fprintf(stderr, "[rc device clock: reference recorded now; a batch finished before it shows negative offsets]\n");
+  }
+  auto at = [&](const Event &e) { float ms = 0; return (e.e && hipEventElapsedTime(&ms, ref, e) == hipSuccess) ? refHostUs + ms * 1e3 : -1.0; };
+  std::fprintf(stderr, "[rc device %p n=%d] now %.1f | prep0 %.1f prep %.1f start %.1f null0 %.1f null1 %.1f native0 %.1f native1 %.1f fit %.1f done %.1f (us on the device-reference clock)\n",
+               static_cast<void *>(b), b->n, trace_now_us(), at(b->evPrep0), at(b->evPrep), at(b->evStart), at(b->evS0), at(b->evS1), at(b->evN0), at(b->evN1),
+               at(b->evFit), at(b->evDone));
 }
 
 // ------------------------------------------------------------------------------------------ streams of batches
@@ -1147,6 +1203,7 @@ int rc_stream_next(rc_stream *s, rc_batch **out) {
   trace("wait", b);
   const int r = batch_wait(b);
   trace("done", b);
+  if (r == RC_OK) trace_device(b);
   if (r != RC_OK) { s->spare.push_back(b); return r; }
   *out = b;
   return RC_OK;

@@ -684,6 +684,26 @@ void launch_hss_pack(const DevHss *hss, const int *count, int cap, int slots, De
 }
 
 
+// A batch's small results, written by the GPU straight into the batch's pinned host buffers (mapped into the device's address
+// space).  One LDS-free kernel instead of five hipMemcpyAsync: the runtime turns such small device-to-host copies into blit
+// kernels, and those found no place on the chip beside another batch's k_null until its tail -- in a stream the results of a
+// sub-batch, and with them the next sub-batch on the same compute stream, were held back by a millisecond or more.
+__global__ __launch_bounds__(64) void k_results_out(ResultsOutArgs a) {
+  __builtin_amdgcn_s_setprio(3);   // a short latency-bound kernel beside k_null: the SIMD issues its instructions first
+  const size_t t = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x, step = static_cast<size_t>(gridDim.x) * blockDim.x;
+#pragma unroll
+  for (int x = 0; x < ResultsOutArgs::kParts; x++)
+    for (size_t i = t; i < a.words[x]; i += step) a.dst[x][i] = a.src[x][i];
+}
+
+void launch_results_out(const ResultsOutArgs &a, hipStream_t stream) {
+  size_t most = 0;
+  for (int x = 0; x < ResultsOutArgs::kParts; x++) most = std::max(most, a.words[x]);
+  if (!most) return;
+  const int grid = static_cast<int>(std::min<size_t>(256, (most + 255) / 256));
+  hipLaunchKernelGGL(k_results_out, dim3(grid), dim3(64), 0, stream, a);
+}
+
 void launch_sk_row(const uint8_t *blob, const DevBlock *dblocks, int bi, int s, int b, int iMax, float *out, int stride,
                    hipStream_t stream) {
   hipLaunchKernelGGL(k_sk_row, dim3(1), dim3(64), 0, stream, blob, dblocks, bi, s, b, iMax, out, stride);

@@ -37,6 +37,8 @@ struct NullArgs {
   float tieThr;               // float form of the 0.0001 tie tolerance (score.c:954)
   int comboSplit;             // 1: items are (block, group, strand x frame); maxima combined by atomic max
   unsigned int *workCounter;  // [8], zeroed before the launch: next unclaimed work item of each XCD queue
+  unsigned int *steal;        // tail sharing (see k_null): 16 + 4 x grid words, zeroed before the launch; null = off
+  int stealWait;              // 1: a workgroup without work waits for owners that are still simulating a late item; 0: it leaves at once (a stream: the next sub-batch's workgroups want its place)
   int debugSkip;              // RC_PROFILING builds only: bit0 skip the DP/scan phase, bit1 skip simulation
   unsigned long long *cellStats;   // RC_PROFILING builds only: [0] wavefront-cells, [1] of those with no lane's sum > 0, [2] lanes with sum > 0, [3..5] cells before the row's first event / at events / after its last
 };
@@ -128,6 +130,14 @@ void launch_native_sigma(const NativeArgs &a, int nblocks, hipStream_t stream);
 bool launch_native_dp(int NK, const NativeArgs &a, int grid, hipStream_t stream);   // a.nItems items over `grid` persistent workgroups
 void launch_hss_pack(const DevHss *hss, const int *count, int cap, int slots, DevHss *packed, int *offsets, int *total,
                      hipStream_t stream);
+// k_results_out: up to five word arrays copied from device memory into (mapped) pinned host memory
+struct ResultsOutArgs {
+  static constexpr int kParts = 5;
+  uint32_t *dst[kParts];
+  const uint32_t *src[kParts];
+  size_t words[kParts];
+};
+void launch_results_out(const ResultsOutArgs &a, hipStream_t stream);
 void launch_sk_row(const uint8_t *blob, const DevBlock *dblocks, int bi, int s, int b, int iMax, float *out, int stride,
                    hipStream_t stream);
 // wider blocks (N > 64): generic kernels with their states in a global scratch (rc_null_generic.h)

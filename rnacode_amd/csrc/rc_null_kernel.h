@@ -187,7 +187,6 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
   extern __shared__ uint32_t lds_codes[];
 
   const int lane = threadIdx.x;
-  uint32_t *__restrict__ cod = scratch + static_cast<size_t>(blockIdx.x) * A.scratchStride;
   // Work items -- (block, 64-sample group), or with comboSplit (small batches) one strand x frame part
   // of such an item, so that 6x more wavefronts exist; each part recomputes phase A and the six partial
   // maxima meet in an atomic max -- are pulled from shared counters, not strided: blocks of one launch
@@ -200,25 +199,102 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
   const int home = static_cast<int>(xcc & 7u);
   const int parts = A.comboSplit ? 6 : 1;
   const int nBlocks = A.nBlocksPtr ? *A.nBlocksPtr : A.nClassBlocks;
-  for (int qi = 0; qi < 8;) {
-    const int q = (home + qi) & 7;
-    const int g0 = A.gLo + ((q - A.gLo) & 7);      // sample groups g0, g0 + 8, ... < gHi: those congruent to q
-    const int gq = g0 < A.gHi ? ((A.gHi - 1 - g0) >> 3) + 1 : 0;
-    const int perBlock = gq * parts;
-    const int nq = nBlocks * perBlock;
-    int t = nq;
-    if (nq > 0) {
-      if (lane == 0) t = static_cast<int>(atomicAdd(A.workCounter + q, 1u));
-      t = __builtin_amdgcn_readfirstlane(t);
+  // The tail of the launch: when the queues have run dry, the workgroups that are still busy hold one item each and the others would
+  // idle until the slowest has done its six strand x frame parts.  Instead an item taken near the end of a queue ("late") is
+  // published once its sigma codes are in the staging scratch, and its parts are claimed one by one through a claim word, by its
+  // owner and by any workgroup that found all queues empty and reads the codes from the owner's scratch.  The partial maxima
+  // meet in an atomic max (the maxima are preset to -1).  A.steal (zeroed before the launch), G = gridDim.x:
+  //   [0] published items, [1] late items still being simulated, [16 + slot] claim word of workgroup `slot` (0 nothing, 1..6 next
+  //   unclaimed part + 1, > 6 all taken), [16 + G + 2 slot] its (block, group), [16 + 3 G + i] the i-th published item: slot + 1, XCD in the top byte.
+  // Queue counters only grow, so once a workgroup has seen all of them exhausted no workgroup starts another item and a
+  // published scratch is not rewritten while helpers read it.  Helpers poll two words and sleep in between: thousands of them
+  // sweeping all claim words slowed the owners' simulation more than the sharing gained.
+  // (the pointers are re-derived from the kernel arguments where they are needed: nothing of this lives in scalar registers across the DP)
+  const bool stealing = A.steal != nullptr && !A.comboSplit;
+  constexpr int kStealHdr = 16;
+  auto claim_part = [&](int slot) -> int {   // the next unclaimed part of the item published in `slot`, 6 = none left
+    unsigned int v = 0;
+    if (lane == 0) v = atomicAdd(A.steal + kStealHdr + slot, 1u);
+    v = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(v)));
+    return (v >= 1u && v <= 6u) ? static_cast<int>(v) - 1 : 6;
+  };
+  auto steal_word = [&](size_t at) -> unsigned int { return __hip_atomic_load(A.steal + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  int helpCursor = 0;   // published items before this one have no part left
+  bool helping = false;
+  for (int qi = 0;;) {
+    int bi, grp, onlyCombo = -1, firstCombo = 0;
+    bool shared = false;
+    int slot = static_cast<int>(blockIdx.x);   // whose staging scratch holds the item's codes
+    if (!helping) {
+      if (qi >= 8) {
+        if (!stealing) break;
+        helping = true;
+        continue;
+      }
+      const int q = (home + qi) & 7;
+      const int g0 = A.gLo + ((q - A.gLo) & 7);      // sample groups g0, g0 + 8, ... < gHi: those congruent to q
+      const int gq = g0 < A.gHi ? ((A.gHi - 1 - g0) >> 3) + 1 : 0;
+      const int perBlock = gq * parts;
+      const int nq = nBlocks * perBlock;
+      int t = nq;
+      if (nq > 0) {
+        if (lane == 0) t = static_cast<int>(atomicAdd(A.workCounter + q, 1u));
+        t = __builtin_amdgcn_readfirstlane(t);
+      }
+      if (t >= nq) { qi++; continue; }
+      bi = classBlocks[t / perBlock];
+      // blocks another launch takes care of (score tables outside the fast division's range -> the EXACT launch)
+      // or that need no more samples (--stop-early decided)
+      if (A.skipMask && (flags[bi] & A.skipMask)) continue;
+      const int sub = t % perBlock;
+      grp = g0 + 8 * (sub / parts);
+      onlyCombo = A.comboSplit ? sub % parts : -1;
+      // items per queue that may still be running when the queues run dry (generous: a wrong guess costs six atomics)
+      if (stealing && nq - t <= static_cast<int>(gridDim.x >> 3) + 16) {
+        shared = true;
+        if (lane == 0) atomicAdd(A.steal + 1, 1u);
+      }
+    } else {
+      // a published item with unclaimed parts: 64 list entries per step, one per lane
+      const size_t G = gridDim.x;
+      const int np = __builtin_amdgcn_readfirstlane(static_cast<int>(steal_word(0)));
+      int victim = -1;
+      while (helpCursor < np) {
+        const int i = helpCursor + lane;
+        const unsigned int ent = i < np ? steal_word(kStealHdr + 3 * G + i) : 0u;        // 0: the entry is not written yet
+        // only items of this XCD: owner and helper then share an L2, and the owner's codes need no write-back to memory
+        const bool foreign = ent != 0u && (ent >> 24) != static_cast<unsigned int>(home);
+        const unsigned int e = ent & 0xFFFFFFu;
+        const unsigned int v = (e && !foreign) ? steal_word(kStealHdr + e - 1) : 0u;
+        const unsigned long long open = __ballot(v >= 1u && v <= 6u);
+        if (open) {   // spread the helpers over the open items of this step
+          int pick = static_cast<int>(blockIdx.x % static_cast<unsigned int>(__builtin_popcountll(open)));
+          unsigned long long m = open;
+          while (pick--) m &= m - 1ull;
+          victim = __builtin_amdgcn_readlane(static_cast<int>(e), __builtin_ctzll(m)) - 1;   // wave-uniform (a scalar): everything below branches on it
+          break;
+        }
+        const unsigned long long notDone = ~__ballot(e != 0u && (v > 6u || foreign));
+        const int adv = notDone ? __builtin_ctzll(notDone) : kWave;   // leading entries whose parts are all taken: never looked at again
+        helpCursor += adv;
+        if (adv < kWave) break;
+      }
+      if (victim < 0) {
+        // nothing to take right now: done if nothing can come any more
+        if (!A.stealWait) break;
+        if (helpCursor >= np && steal_word(1) == 0u && static_cast<int>(steal_word(0)) == np) break;
+        __builtin_amdgcn_s_sleep(127);
+        continue;
+      }
+      firstCombo = claim_part(victim);
+      if (firstCombo >= 6) continue;
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);   // the owner's codes and its (block, group)
+      shared = true;
+      slot = victim;
+      bi = __builtin_amdgcn_readfirstlane(static_cast<int>(steal_word(kStealHdr + G + 2 * victim)));
+      grp = __builtin_amdgcn_readfirstlane(static_cast<int>(steal_word(kStealHdr + G + 2 * victim + 1)));
     }
-    if (t >= nq) { qi++; continue; }
-    const int bi = classBlocks[t / perBlock];
-    // blocks another launch takes care of (score tables outside the fast division's range -> the EXACT launch)
-    // or that need no more samples (--stop-early decided)
-    if (A.skipMask && (flags[bi] & A.skipMask)) continue;
-    const int sub = t % perBlock;
-    const int grp = g0 + 8 * (sub / parts);
-    const int onlyCombo = A.comboSplit ? sub % parts : -1;
+    uint32_t *__restrict__ cod = scratch + static_cast<size_t>(slot) * A.scratchStride;
     const DevBlock *__restrict__ db = dblocks + bi;
     const int cols = db->cols, L = db->L, nnodes = db->nnodes;
     const float Delta = db->Delta, Omega = db->Omega, omega = db->omega, nkf = db->nkf;
@@ -237,7 +313,7 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
     // so that the stream loads and threshold look-ups of independent sites overlap; emit sigma
     // codes for both strands.  Node states of a site are packed 2 bits per node into NODEW
     // registers; the per-branch threshold table sits in LDS (the region phase B reuses for codes).
-    if (!kProfiling || !(A.debugSkip & 2)) {
+    if (!helping && (!kProfiling || !(A.debugSkip & 2))) {
       constexpr int SPI = 4;
       constexpr int NODEW = (2 * N - 1 + 15) / 16;   // 16 nodes per 32-bit word
       // The EXACT instantiation uses no LDS at all and reads both tables from global memory (L1/L2): its launches are
@@ -341,6 +417,24 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
       // padding lanes do not count; with comboSplit the six parts of an item redo the same simulation: the first one reports
       if (clamped && sidx < A.sampleN && onlyCombo <= 0) atomicAdd(A.clampCount, static_cast<unsigned long long>(clamped));
     }
+    if (!helping && shared) {   // a late item: its codes are in the scratch, open it to the workgroups that have run out of work
+      const size_t G = gridDim.x;
+      if (lane == 0) {
+        __hip_atomic_store(A.steal + kStealHdr + G + 2 * blockIdx.x, static_cast<unsigned int>(bi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(A.steal + kStealHdr + G + 2 * blockIdx.x + 1, static_cast<unsigned int>(grp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // The codes only have to reach this XCD's L2 (the L1 writes through): helpers are taken from the same XCD.  A device-scope
+      // release would write back the whole L2 -- for every late item, and in a stream of small sub-batches most items are late.
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_s_waitcnt(0);
+      if (lane == 0) {
+        atomicExch(A.steal + kStealHdr + blockIdx.x, 1u);
+        const unsigned int idx = atomicAdd(A.steal, 1u);
+        __hip_atomic_store(A.steal + kStealHdr + 3 * G + idx, (blockIdx.x + 1u) | (static_cast<unsigned int>(home) << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicSub(A.steal + 1, 1u);
+      }
+      firstCombo = claim_part(slot);
+    }
 
     // ---- phase B: both strands x 3 frames: DP over (start a, end j) + serial HSS scan
     float best = -1.0f;
@@ -349,19 +443,28 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
     // with an SGPR operand at ~60 % of it (tools/microbench.hip)
     float omega_v, Delta_v = 0.0f;
     asm volatile("v_mov_b32 %0, %1" : "=v"(omega_v) : "s"(omega));
+    float rcpNk_v = 0.0f, negNk_v = 0.0f;
+    if constexpr (!EXACT && (NK & (NK - 1)) != 0) {
+      asm volatile("v_mov_b32 %0, %1" : "=v"(rcpNk_v) : "s"(1.0f / static_cast<float>(NK)));
+      asm volatile("v_mov_b32 %0, %1" : "=v"(negNk_v) : "s"(-static_cast<float>(NK)));
+    }
     if constexpr (EXACT) asm volatile("v_mov_b32 %0, %1" : "=v"(Delta_v) : "s"(Delta));
-    if (!kProfiling || !(A.debugSkip & 1))
-    for (int s = 0; s < 2; s++) {
-      if (onlyCombo >= 0 && onlyCombo / 3 != s) continue;
+    // the strand x frame parts c = 3 s + f: all six in turn, the one part of a split item, or -- a shared item -- those this
+    // workgroup gets from the item's claim word
+    if (!kProfiling || !(A.debugSkip & 1)) {
       Regs R;
-      static_for<NK>([&](auto kc) {  // 64-entry sigma table of sequence k spread over the 64 lanes
-        constexpr int k = decltype(kc)::value;
-        R.template at<k>().lut = __float_as_int(lut[(s * NK + k) * kLutSize + lane]);
-      });
-      for (int f = 0; f < 3; f++) {
+      int curS = -1;
+      for (int c = onlyCombo >= 0 ? onlyCombo : firstCombo; c < 6; c = onlyCombo >= 0 ? 6 : (shared ? claim_part(slot) : c + 1)) {
+        const int s = c >= 3 ? 1 : 0, f = c - 3 * s;
+        if (s != curS) {
+          static_for<NK>([&](auto kc) {  // 64-entry sigma table of sequence k spread over the 64 lanes
+            constexpr int k = decltype(kc)::value;
+            R.template at<k>().lut = __float_as_int(lut[(s * NK + k) * kLutSize + lane]);
+          });
+          curS = s;
+        }
         const int sites = (L - f) / 3;
         if (sites <= 0) continue;
-        if (onlyCombo >= 0 && onlyCombo % 3 != f) continue;
         const uint32_t *__restrict__ cbase = cod + (static_cast<size_t>(s * L1 + 3 + f) * NCW) * kWave + lane;  // site j: + j*3*NCW*64
         const unsigned long long *__restrict__ zbase = zw + static_cast<size_t>(s * L1 + 3 + f) * ZW;               // site j: [3j * ZW + word]
         const unsigned long long *__restrict__ zany = zmask + static_cast<size_t>(s * 3 + f) * zmWords;            // bit j: some z != 0 at site j
@@ -436,6 +539,8 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
         // Only positive S values ever reach a sample's result (getHSS ignores the rest and the frame's
         // final entry is never reported), and for Delta < 0 a positive S equals sum/(N-1): the fast
         // instantiation skips the MAX3 with Delta; blocks with Delta >= 0 are routed to EXACT.
+        // the constants of the constant-divisor division as per-lane registers: a literal operand goes over the constant bus like an
+        // SGPR, and such VALU instructions issue at the single rate (tools/microbench.hip)
         auto finish = [&](float sum) -> float {
           if constexpr (kProfiling) {   // how often a wave-uniform "no lane has sum > 0" test could skip the division and the scan step
             const unsigned long long pos = __ballot(sum > 0.0f);
@@ -445,7 +550,12 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
             const float top = (sum > Delta_v) ? sum : Delta_v;
             return div_by_nk<NK, EXACT>(top, nkf);
           } else {
-            return div_by_nk<NK, EXACT>(sum, nkf);
+            if constexpr ((NK & (NK - 1)) == 0) return div_by_nk<NK, EXACT>(sum, nkf);
+            else {   // div_by_nk's sequence on register operands
+              const float q0 = sum * rcpNk_v;
+              const float r = __builtin_fmaf(negNk_v, q0, sum);
+              return __builtin_fmaf(r, rcpNk_v, q0);
+            }
           }
         };
         // codon without a frame shift in any sequence (z == 0 for all k, score.c:506-510): straight-line
@@ -631,7 +741,8 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
     if (sidx < A.sampleN) {
       float *dst = maxima + static_cast<size_t>(db->out_index) * A.sampleN + sidx;
       // scores are positive floats or the -1 sentinel: integer order == float order on that set
-      if (A.comboSplit) atomicMax(reinterpret_cast<int *>(dst), __float_as_int(best));
+      // (parts of one item scored by several workgroups: the maxima are preset to -1, which no partial maximum needs to replace)
+      if (A.comboSplit || shared) { if (best > -1.0f) atomicMax(reinterpret_cast<int *>(dst), __float_as_int(best)); }
       else *dst = best;
     }
   }

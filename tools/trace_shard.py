@@ -29,7 +29,7 @@ res_ms = (time.perf_counter() - t0) / 10 * 1e3
 st = api.Stream(ctx, params, 3)
 times = []
 for rep in range(8):
-    print(f"---- pass {rep}", file=sys.stderr, flush=True)
+    print(f"---- pass {rep} starts at {time.monotonic() * 1e6:.1f} us", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     rows = []
     for sb in api.score_stream(ctx, m, params, sub, stream=st):
@@ -38,6 +38,7 @@ for rep in range(8):
         rows.append((sb.n, (time.perf_counter() - t0) * 1e3, t))
         sb.close()
     times.append((time.perf_counter() - t0) * 1e3)
+    print(f"---- pass {rep} ends at {time.monotonic() * 1e6:.1f} us", file=sys.stderr, flush=True)
     if rep == 7:
         for n, done, t in rows:
             print(f"  sub-batch of {n:5d}: results on the host at {done:7.3f} ms; device intervals: start->fit {t['total']:.3f}, k_null {t['null']:.3f}, native {t['native']:.3f}, fit {t['evd_fit']:.3f}")
