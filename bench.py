@@ -280,6 +280,9 @@ def parse_args():
                     help="what the ranks all-gather per step: the per-sample maxima (north_star's exchange; 4 B x samples per "
                          "block, written by the kernel straight into the gathered tensor) or only the per-block fit results "
                          "(16 B per block: enough for p-values, since every rank fits its own blocks on the device)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1: wait for every step's all-gather before the next step starts (default: step i's gather runs over "
+                         "xGMI while step i + 1 is scored; all of them are complete when the timed region ends)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
                     help="strong (default): --blocks in total, split across the ranks (BASELINE configs[3]); weak: --blocks per GPU")
     ap.add_argument("--no-weak", action="store_true", help="N > 1, strong scaling: skip the extra weak-scaling measurement")
@@ -373,8 +376,16 @@ def main():
 
     gathered = None
     mine = None
+    # The exchange overlapped with the next step (equal shards, maxima, RCCL): two source tensors alternate, step i's all-gather is
+    # started without waiting for it, and the tensor is written again (step i + 2) only after that gather has read it.
+    overlap = None
+    step_no = 0
     if multi and args.exchange == "maxima":
-        mine = torch.empty((len(blocks), args.samples), dtype=torch.float32, device=f"cuda:{local_rank}")
+        if not args.no_overlap and coll_dev != "cpu" and len(set(counts)) == 1:
+            overlap = rd.OverlappedGather(len(blocks), args.samples, f"cuda:{local_rank}")
+            mine = overlap.src[0]
+        else:
+            mine = torch.empty((len(blocks), args.samples), dtype=torch.float32, device=f"cuda:{local_rank}")
         batch.bind_maxima(mine.data_ptr())
 
     def exchange(fit_rows):
@@ -390,6 +401,13 @@ def main():
             torch.cuda.current_stream().synchronize()
 
     def resident_step():
+        nonlocal step_no
+        if overlap is not None:
+            batch.bind_maxima(overlap.source(step_no).data_ptr())   # (waits for the gather of two steps ago, long done)
+            batch.run()                  # synchronous: this step's maxima are complete in the tensor
+            overlap.launch(step_no)      # their all-gather runs while the next step is scored
+            step_no += 1
+            return
         batch.run()                      # synchronous: kernels done, small results on the host
         if multi:
             exchange(batch.fits() if args.exchange == "fits" else None)
@@ -403,17 +421,27 @@ def main():
     stream = None if args.no_stream else api.Stream(ctx, params, args.depth)
 
     def stream_step():
+        nonlocal step_no
         rows = []
-        ptr = mine.data_ptr() if (multi and args.exchange == "maxima") else 0
+        src = overlap.source(step_no) if overlap is not None else mine
+        ptr = src.data_ptr() if (multi and args.exchange == "maxima") else 0
         for sb in api.score_stream(ctx, marshalled, params, sub_sizes, stream=stream, maxima_ptr=ptr):
             rows.append(sb.fits())       # (evd_rc, mu, lambda, better) per block: what a caller needs for p-values
             sb.close()                   # buffers back to the stream
-        if multi:
+        if overlap is not None:
+            overlap.launch(step_no)
+            step_no += 1
+        elif multi:
             exchange(np.concatenate(rows) if args.exchange == "fits" else None)
         return rows
 
     def sync():
+        nonlocal gathered
         if multi:
+            if overlap is not None:          # every all-gather started so far is complete before the clock is read
+                g = overlap.finish()
+                if g is not None:
+                    gathered = g
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -574,7 +602,8 @@ def main():
                                    + f" ({desc})",
                        "blocks_per_gpu": len(blocks), "cols": args.cols, "seqs": args.seqs, "samples": args.samples,
                        "seed_base": args.seed_base, "sharding": f"blocks x{world}",
-                       "exchange": ("all-gather of " + args.exchange) if multi else "none"},
+                       "exchange": (("all-gather of " + args.exchange + (", step i's gather overlapped with the scoring of step i + 1 (all complete "
+                                     "inside the timed region)" if overlap is not None else "")) if multi else "none")},
             "value_definition": "resident: inputs in HBM when the timed region starts (bench contract); the host-inclusive pipeline is stream.value",
             "roofline": roofline_object(blocks, args.samples, null_ms, kernel_name, args.config, default_workload and world == 1),
             "device_ms_per_step": {k: v / args.steps for k, v in tk.items()},

@@ -211,7 +211,9 @@ struct rc_ctx {
   int tailSharing = 1;        // k_null: items taken near the end of the queues are shared part by part with workgroups that have run out of work (RC_TAIL_SHARING=0: off)
   int nativeWavesPerCU = 8;   // persistent wavefronts of k_native_dp per CU (RC_NATIVE_WAVES_PER_CU): it runs beside k_null and should not crowd it out
   size_t genericScratchWords = static_cast<size_t>(1) << 30;   // uint32 of staging scratch one k_null_generic launch may take: a twelfth of the device memory (24 GB of 288)
-  hipStream_t compute[2] = {nullptr, nullptr};   // null sampling + fit; consecutive batches alternate, so the tail of one overlaps the head of the next
+  static constexpr int kComputeStreams = 3;
+  hipStream_t compute[kComputeStreams] = {nullptr, nullptr, nullptr};   // null sampling + fit; consecutive batches take them in turn, so the tail of one overlaps the head of the next
+  int computeStreams = 2;                        // RC_COMPUTE_STREAMS (1..3).  A third one was measured: the third batch of a stream no longer waits behind the first one's tail and fit, but the chip is busy with the second by then (1250-block shard streamed: 7.85 ms either way)
   hipStream_t native = nullptr;    // table preparation and native-block kernels: small and latency-bound, they run beside the null sampling
   hipStream_t copy = nullptr;      // host -> device blob copies
   hipStream_t aux = nullptr;       // synchronous helpers (second-stage result copies, backtrack rows, stand-alone fits): never behind queued batches
@@ -395,8 +397,8 @@ int rc_ctx_create(int device, rc_ctx **out) {
   // serialises the native-block kernels behind k_null again -- seen under torch.distributed)
   int prioLow = 0, prioHigh = 0;
   HIP_TRY(hipDeviceGetStreamPriorityRange(&prioLow, &prioHigh));
-  HIP_TRY(hipStreamCreateWithPriority(&c->compute[0], hipStreamNonBlocking, prioLow));
-  HIP_TRY(hipStreamCreateWithPriority(&c->compute[1], hipStreamNonBlocking, prioLow));
+  for (int x = 0; x < rc_ctx::kComputeStreams; x++) HIP_TRY(hipStreamCreateWithPriority(&c->compute[x], hipStreamNonBlocking, prioLow));
+  if (const char *e = std::getenv("RC_COMPUTE_STREAMS")) c->computeStreams = std::max(1, std::min(rc_ctx::kComputeStreams, std::atoi(e)));
   HIP_TRY(hipStreamCreateWithPriority(&c->native, hipStreamNonBlocking, prioHigh));
   HIP_TRY(hipStreamCreateWithPriority(&c->copy, hipStreamNonBlocking, prioHigh));
   HIP_TRY(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prioHigh));
@@ -909,7 +911,7 @@ static int batch_run_async(rc_batch *b, bool streaming = false) {
   const int n = b->n, sampleN = b->par.sampleN;
   const int groups = (sampleN + kWave - 1) / kWave, Spad = groups * kWave;
   b->clamped = 0;
-  hipStream_t cs = c->compute[c->seq++ & 1];
+  hipStream_t cs = c->compute[c->seq++ % static_cast<unsigned>(c->computeStreams)];
   const uint8_t *blob = b->dblob.as<uint8_t>();
   const RunEnv R{b, c, cs, n, sampleN, groups, Spad, n * 6, table_ptrs(c, b->par.blosum), blob,
                  reinterpret_cast<const DevBlock *>(blob + b->oDblocks), reinterpret_cast<const int *>(blob + b->oOk),

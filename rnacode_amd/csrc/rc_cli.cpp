@@ -244,7 +244,7 @@ int main(int argc, char **argv) {
 
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double tMain = now();
-  double tRead = now(), tCtx = 0, tTrees = 0, tSubmit = 0, tWait = 0, tList = 0, tFetch = 0;
+  double tRead = now(), tCtx = 0, tTrees = 0, tTreeWait = 0, tSubmit = 0, tWait = 0, tList = 0, tFetch = 0;
   // the HIP runtime and the context come up (0.1-0.3 s) on a thread of their own while this one reads and parses the input
   rc_ctx *ctx = nullptr;
   int ctxRc = RC_OK;
@@ -356,9 +356,45 @@ int main(int argc, char **argv) {
     for (const Row &r : b.rows) need += r.name.size() + 32;
     cap = std::max(cap, static_cast<int>(need));
   }
-  std::vector<char> nwk;
-  std::vector<float> kap;
-  int next = 0, base = 0, fitted = 0;
+  int next = 0, base = 0;
+  // What treeML() hands over (RNAcode.c:153): tree + kappa, fitted on the GPU (one wavefront per block, latency-bound: a call costs
+  // about the same for 100 blocks as for the 2048 the chip holds at once) -- on a thread of its own, in chunks that run ahead of the
+  // scoring: 2048 blocks first so that the first sub-batches can go, then doubling up to 8192 (a remainder of less than half a
+  // chunk goes with the chunk before it).  The scoring loop below only waits when it has caught up with the fits.
+  std::mutex tm;
+  std::condition_variable tcv;
+  int fitted = trees.empty() ? 0 : n;      // blocks [0, fitted) have their tree (or a sidecar entry, or none to be had)
+  std::string treeErr;
+  std::thread treeThread;
+  if (trees.empty() && n > 0) treeThread = std::thread([&] {
+    std::vector<char> nwk;
+    std::vector<float> kap;
+    int at = 0;
+    for (int chunk = std::max(subBlocks, 2048); at < n; chunk = std::min(2 * chunk, std::max(subBlocks, 8192))) {
+      const int mf = (n - at <= chunk + chunk / 2) ? n - at : chunk;
+      nwk.assign(static_cast<size_t>(mf) * cap, 0);
+      kap.assign(mf, 0.0f);
+      const double t = now();
+      const int r = rc_fit_trees_device(ctx, rb.data() + at, mf, nwk.data(), cap, kap.data(), nullptr);
+      tTrees += now() - t;
+      if (r >= 0)
+        for (int i = 0; i < mf; i++) { blocks[at + i].tree = nwk.data() + static_cast<size_t>(i) * cap; blocks[at + i].kappa = kap[i]; }
+      {
+        std::lock_guard<std::mutex> lk(tm);
+        if (r < 0) { treeErr = rc_last_error(); fitted = n; }
+        else fitted = at + mf;
+      }
+      tcv.notify_all();
+      if (r < 0) return;
+      at += mf;
+    }
+  });
+  auto trees_ready = [&](int upto, bool wait) {   // are the trees of blocks [0, upto) there?
+    std::unique_lock<std::mutex> lk(tm);
+    if (wait) tcv.wait(lk, [&] { return fitted >= upto; });
+    if (!treeErr.empty()) { lk.unlock(); if (treeThread.joinable()) treeThread.join(); die(treeErr); }
+    return fitted >= upto;
+  };
   // The listing is written by a thread of its own, batch by batch in input order: formatting 10^5 lines takes as long as the GPU
   // needs for the blocks behind them, and this thread has the next sub-batch to prepare.
   struct Job {
@@ -401,22 +437,15 @@ int main(int argc, char **argv) {
   });
   while (next < n || rc_stream_pending(stream) > 0) {
     while (next < n && rc_stream_pending(stream) < 3) {
-      const int m = planAt < plan.size() ? std::min<int>(plan[planAt++], n - next) : n - next;
-      if (trees.empty() && next + m > fitted) {
-        // what treeML() hands over (RNAcode.c:153): tree + kappa, fitted on the GPU.  One wavefront per block, latency-bound:
-        // a call costs about the same for 100 blocks as for 2048 (the wavefronts the chip holds at once), so the fits
-        // run ahead of the scoring in chunks of 8192 blocks
-        // (a remainder of less than half a chunk goes with the chunk before it: a short call costs as much as a long one)
-        const int chunk = std::max(subBlocks, 8192);
-        const int mf = (n - fitted <= chunk + chunk / 2) ? n - fitted : chunk;
-        nwk.assign(static_cast<size_t>(mf) * cap, 0);
-        kap.assign(mf, 0.0f);
+      const int m = planAt < plan.size() ? std::min<int>(plan[planAt], n - next) : n - next;
+      // the fits have not got this far: take a finished batch first if there is one, else wait for them
+      if (!trees_ready(next + m, false)) {
+        if (rc_stream_pending(stream) > 0) break;
         const double t = now();
-        if (rc_fit_trees_device(ctx, rb.data() + fitted, mf, nwk.data(), cap, kap.data(), nullptr) < 0) die(rc_last_error());
-        tTrees += now() - t;
-        for (int i = 0; i < mf; i++) { blocks[fitted + i].tree = nwk.data() + static_cast<size_t>(i) * cap; blocks[fitted + i].kappa = kap[i]; }
-        fitted += mf;
+        trees_ready(next + m, true);
+        tTreeWait += now() - t;
       }
+      planAt++;
       for (int i = next; i < next + m; i++) { rb[i].newick = blocks[i].tree.empty() ? nullptr : blocks[i].tree.c_str(); rb[i].kappa = blocks[i].kappa; }
       const double t = now();
       if (rc_stream_submit(stream, rb.data() + next, m) != RC_OK) die(rc_last_error());
@@ -450,10 +479,11 @@ int main(int argc, char **argv) {
   { std::lock_guard<std::mutex> lk(jm); jobsDone = true; }
   jcv.notify_one();
   printer.join();
+  if (treeThread.joinable()) treeThread.join();
   rc_stream_destroy(stream);
   if (std::getenv("RC_CLI_TIMES"))
-    std::fprintf(stderr, "[rnacode_hip] read %.3f s, context (beside the reading) %.3f s, trees %.3f s, submit %.3f s, wait %.3f s, results %.3f s, listing (its own thread) %.3f s, main() so far %.3f s\n",
-                 tRead, tCtx, tTrees, tSubmit, tWait, tFetch, tList, now() - tMain);
+    std::fprintf(stderr, "[rnacode_hip] read %.3f s, context (beside the reading) %.3f s, trees (their own thread) %.3f s of which the scoring waited %.3f s, submit %.3f s, wait %.3f s, results %.3f s, listing (its own thread) %.3f s, main() so far %.3f s\n",
+                 tRead, tCtx, tTrees, tTreeWait, tSubmit, tWait, tFetch, tList, now() - tMain);
   if (list.fmt == 0) {   // RNAcode.c:223-228
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::fprintf(list.out, "\n%i alignment(s) scored in %.2f seconds. Parameters used:\nN=%i, Delta=%.2f, Omega=%.2f, omega=%.2f, stop penalty=%.2f\n\n",

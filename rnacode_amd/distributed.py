@@ -48,6 +48,52 @@ def all_gather_rows(local, counts: Sequence[int]):
 
 
 all_gather_maxima = all_gather_rows   # [n_r, sampleN] per-sample maxima
+
+
+class OverlappedGather:
+    """The path's one exchange with its wire time hidden: step i's all-gather runs while step i + 1 is being scored.
+
+    Two source tensors [rows, width] alternate.  `source(i)` is what step i's kernels write (the caller binds it with
+    rc_batch_bind_maxima / rc_stream_submit_bound); `launch(i)` starts the all-gather of that tensor without waiting for it
+    (RCCL runs it on its own stream over xGMI); `source(i + 2)` first waits, on the host, until gather i has read the buffer
+    -- the library's kernels run on streams RCCL knows nothing about, so the reuse rule is enforced here.  `finish()` waits
+    for everything and returns the last gathered tensor [world * rows, width].  Equal shards only (one fused
+    all_gather_into_tensor per step, no padding copies): ragged shards use all_gather_rows."""
+
+    def __init__(self, rows: int, width: int, device, dtype=None):
+        import torch
+        import torch.distributed as dist
+
+        self._dist = dist
+        self._torch = torch
+        dtype = dtype or torch.float32
+        world = dist.get_world_size()
+        self.src = [torch.empty((rows, width), dtype=dtype, device=device) for _ in range(2)]
+        self.out = [torch.empty((world * rows, width), dtype=dtype, device=device) for _ in range(2)]
+        self.work = [None, None]
+        self.last = None
+
+    def _wait(self, k: int):
+        w = self.work[k]
+        if w is not None:
+            w.wait()                                           # the current torch stream waits for the collective ...
+            if self.src[0].is_cuda:
+                self._torch.cuda.current_stream().synchronize()    # ... and the host for the stream (CPU backends: wait() blocks)
+            self.work[k] = None
+
+    def source(self, i: int):
+        self._wait(i & 1)
+        return self.src[i & 1]
+
+    def launch(self, i: int):
+        k = i & 1
+        self.work[k] = self._dist.all_gather_into_tensor(self.out[k], self.src[k], async_op=True)
+        self.last = k
+
+    def finish(self):
+        self._wait(0)
+        self._wait(1)
+        return None if self.last is None else self.out[self.last]
 all_gather_fits = all_gather_rows     # [n_r, 4] rows of rc_batch_fit_all
 
 

@@ -153,3 +153,46 @@ def test_sample_range_is_a_partition_in_wavefront_groups():
             assert r[0][0] == 0 and r[-1][1] == n
             assert all(r[i][1] == r[i + 1][0] for i in range(world - 1))
             assert all(lo % 64 == 0 for lo, _ in r if lo < n)
+
+
+def _overlap_worker(rank, world, port, steps, out_path):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from rnacode_amd import distributed as rd
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rows, width = 3, 5
+    og = rd.OverlappedGather(rows, width, "cpu")
+    seen = []
+    for i in range(steps):
+        src = og.source(i)                       # waits until gather i - 2 has read this buffer
+        src.copy_(torch.full((rows, width), float(100 * i + rank)))   # "step i's kernels write their maxima"
+        og.launch(i)
+        if i >= 1:                               # gather i - 1 is complete once source(i + 1) has been handed out; check it a step late
+            og._wait((i - 1) & 1)
+            seen.append(og.out[(i - 1) & 1].clone())
+    last = og.finish()
+    seen.append(last.clone())
+    if rank == 0:
+        np.save(out_path, torch.stack(seen).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_gather_alternates_two_buffers(tmp_path):
+    """rnacode_amd.distributed.OverlappedGather (bench.py --gpus N: step i's all-gather runs while step i + 1 is scored): every
+    step's gathered tensor holds that step's rows of every rank, in rank order, although only two source buffers exist."""
+    import torch.multiprocessing as mp
+
+    world, steps = 2, 5
+    out = str(tmp_path / "og.npy")
+    mp.spawn(_overlap_worker, args=(world, _free_port(), steps, out), nprocs=world, join=True)
+    got = np.load(out)
+    assert got.shape == (steps, world * 3, 5)
+    for i in range(steps):
+        for r in range(world):
+            assert (got[i, 3 * r:3 * r + 3] == 100 * i + r).all()

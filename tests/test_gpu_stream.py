@@ -403,19 +403,22 @@ def test_bench_under_torchrun_goes_through_rccl(tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    dump = str(tmp_path / "g.npy")
     env = dict(os.environ, RC_BENCH_FORCE_DIST="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--blocks", "40", "--samples", "128",
-                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--sub-batches", "2", "--dump-gathered", dump],
-                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-3000:]
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["config"]["exchange"] == "all-gather of maxima" and line["n_gpus"] == 1 and line["stream"]["value"] > 0
     one, m1 = _bench(tmp_path, 1, extra=("--blocks", "40", "--samples", "128"))
-    np.testing.assert_array_equal(np.load(dump), m1)
+    # default: step i's all-gather overlapped with step i + 1 (rnacode_amd.distributed.OverlappedGather); --no-overlap: one after the other
+    for extra, overlapped in ((), True), (("--no-overlap",), False):
+        dump = str(tmp_path / ("rccl_%d.npy" % overlapped))
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--blocks", "40", "--samples", "128",
+                            "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--sub-batches", "2", "--dump-gathered", dump, *extra],
+                           env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["config"]["exchange"].startswith("all-gather of maxima") and ("overlapped" in line["config"]["exchange"]) == overlapped
+        assert line["n_gpus"] == 1 and line["stream"]["value"] > 0
+        np.testing.assert_array_equal(np.load(dump), m1)
 
 
 def test_two_contexts_on_two_host_threads_do_not_interfere():
