@@ -500,6 +500,10 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
             constexpr int t = k % CPW;
             uint32_t addr;
             if constexpr (t == 0) addr = w[k / CPW]; else addr = w[k / CPW] >> (6 * t);   // bits [7:2] select the lane
+            if constexpr (kProfiling) {   // timing experiments (wrong results): RC_DEBUG_SKIP bit 2 no shifts, bit 3 one look-up per cell
+              if (A.debugSkip & 4) addr = w[k / CPW];
+              if ((A.debugSkip & 8) && k > 0) { asm volatile("" : : "v"(addr)); sig[k] = sig[0]; return; }
+            }
             const int lutv = R.template at<k>().lut;
             float got;
             asm volatile("ds_bpermute_b32 %0, %1, %2" : "=v"(got) : "v"(addr), "v"(lutv));

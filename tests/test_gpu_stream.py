@@ -522,3 +522,59 @@ def test_stream_of_mixed_sub_batches_equals_one_batch():
         assert at == len(blocks)
     st.close()
     ctx.close()
+
+
+def test_tail_sharing_on_and_off_give_the_same_results(monkeypatch):
+    """k_null's tail sharing: items taken near the end of the work queues are published and their strand x frame
+    parts claimed one by one, by the owner and by workgroups that have run out of work; partial maxima meet in an atomic max.  Batches
+    sized so that most or all items are shared (a little over one round of the chip's wavefront slots, several row-count classes side
+    by side, --stop-early rounds) must give, bit for bit, what RC_TAIL_SHARING=0 gives -- maxima, fits, HSS tables -- as one batch and
+    as a stream, and a sample of blocks must equal the CPU oracle."""
+    from oracle import binding as ob
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_block, synth_blocks
+    rng = np.random.RandomState(77)
+    cases = [
+        ("one class, 1.2 rounds", [b.upper() for b in synth_blocks(313, 6, 120, seed=3)], dict(sampleN=1000, seed_base=5)),
+        ("six classes side by side", [synth_block(rng, int(rng.randint(3, 9)), int(rng.randint(40, 130)), index=i, gaps=True).upper()
+                                      for i in range(900)], dict(sampleN=700, seed_base=9)),
+        ("stop-early rounds", [b.upper() for b in synth_blocks(400, 5, 90, seed=8)], dict(sampleN=1000, seed_base=11, stopEarly=1, cutoff=0.05)),
+    ]
+    monkeypatch.setenv("RC_STOP_MIN_ITEMS", "1")
+    got = {}
+    for sharing in ("1", "0"):
+        monkeypatch.setenv("RC_TAIL_SHARING", sharing)
+        c = api.Context(0)
+        for name, blocks, kw in cases:
+            p = api.default_params(**kw)
+            m = api.Marshalled(blocks)
+            m.set_trees()
+            b = api.Batch(c, m, p).run()
+            res = [b.maxScores_all().copy(), b.fits().copy(), [b.scoreAln(i) for i in range(0, b.n, 37)]]
+            b.close()
+            streamed = []
+            for sb in api.score_stream(c, m, p, [len(blocks) // 3, len(blocks) - len(blocks) // 3]):
+                streamed.append(sb.maxScores_all().copy())
+                sb.close()
+            res.append(np.concatenate(streamed))
+            got[(name, sharing)] = res
+        c.close()
+    for name, blocks, kw in cases:
+        on, off = got[(name, "1")], got[(name, "0")]
+        if not kw.get("stopEarly"):
+            np.testing.assert_array_equal(on[0], off[0], err_msg=name)
+            np.testing.assert_array_equal(on[3], off[3], err_msg=name + " (stream)")
+            np.testing.assert_array_equal(on[0], on[3], err_msg=name + " (stream vs batch)")
+        else:   # stopped blocks keep whatever samples their rounds reached; the fits' verdicts and the undecided blocks' rows must agree
+            np.testing.assert_array_equal(on[1][:, 0], off[1][:, 0], err_msg=name)
+            live = on[1][:, 0] == 1
+            np.testing.assert_array_equal(on[0][live], off[0][live], err_msg=name)
+        np.testing.assert_array_equal(on[1], off[1], err_msg=name + " (fits)")
+        assert on[2] == off[2], name
+    # and against the oracle: five blocks of the first case, their first 64 samples
+    name, blocks, kw = cases[0]
+    for i in (0, 77, 150, 233, 312):
+        blk = blocks[i]
+        want = ob.run_block([r.seq for r in blk.rows], [r.name for r in blk.rows], blk.rows[0].start, blk.rows[0].length, blk.tree, blk.kappa,
+                            ob.default_params(64), kw["seed_base"])
+        np.testing.assert_array_equal(got[(name, "1")][0][i][:64], np.float32(want.maxScores))
