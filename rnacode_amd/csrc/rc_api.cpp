@@ -207,6 +207,9 @@ struct rc_ctx {
   std::mutex treeMutex;
   int gridCapPerCU = 0;       // RC_GRID_CAP_PER_CU: at most this many k_null workgroups per CU (experiments on cache residency of the code scratch); 0 = what fits
   double splitFactor = 0.5;   // a k_null launch with fewer (block, sample group) items than this fraction of the chip's wavefront slots splits every item into its six strand x frame parts (RC_SPLIT_FACTOR)
+  int dualRows = 1;           // RC_DUAL_ROWS=0: never the two-row instantiations of k_null (A/B)
+  long long fatStreamMinBlocks = 1024;   // RC_FAT_STREAM_MIN_BLOCKS: a stream's sub-batch of fat classes takes the two-row path from this many blocks on
+  int nativeFirst = -1;       // RC_NATIVE_FIRST: 1 always queue a batch's native-block kernels in front of its k_null, 0 never (and no two-row k_null for fat classes); -1: for batches that take the fat path (see fat_class)
   int copyResults = 0;        // RC_COPY_RESULTS=1: the small results go back with hipMemcpyAsync instead of k_results_out (A/B)
   int tailSharing = 1;        // k_null: items taken near the end of the queues are shared part by part with workgroups that have run out of work (RC_TAIL_SHARING=0: off)
   int nativeWavesPerCU = 8;   // persistent wavefronts of k_native_dp per CU (RC_NATIVE_WAVES_PER_CU): it runs beside k_null and should not crowd it out
@@ -390,6 +393,9 @@ int rc_ctx_create(int device, rc_ctx **out) {
   if (const char *e = std::getenv("RC_NATIVE_WAVES_PER_CU")) c->nativeWavesPerCU = std::max(1, std::min(32, std::atoi(e)));
   if (const char *e = std::getenv("RC_TAIL_SHARING")) c->tailSharing = std::atoi(e) != 0;
   if (const char *e = std::getenv("RC_COPY_RESULTS")) c->copyResults = std::atoi(e) != 0;
+  if (const char *e = std::getenv("RC_NATIVE_FIRST")) c->nativeFirst = std::atoi(e) != 0;
+  if (const char *e = std::getenv("RC_DUAL_ROWS")) c->dualRows = std::atoi(e) != 0;
+  if (const char *e = std::getenv("RC_FAT_STREAM_MIN_BLOCKS")) c->fatStreamMinBlocks = std::max(0ll, std::atoll(e));
   if (const char *e = std::getenv("RC_GENERIC_SCRATCH_MB")) c->genericScratchWords = std::max<size_t>(1, static_cast<size_t>(std::atoll(e))) * (1u << 20) / sizeof(uint32_t);
   // non-blocking streams: no implicit ordering against the legacy default stream that a host framework in
   // the same process (torch, RCCL) may be using; the native stream gets the higher priority so that the
@@ -669,23 +675,43 @@ struct RunEnv {
   const DevBlock *dblocks;
   const int *okList, *classList;
   bool streaming;     // a sub-batch of a stream: others are queued behind it
+  bool nativeFirst;   // the native-block kernels run on this run's compute stream in front of k_null, with the chip to themselves
+  int nativeMode;     // native_grid's mode
+  bool fat;           // every class of the batch takes the two-row k_null (fat_class) and nothing runs beside it
 };
 }  // namespace
 
 // persistent workgroups of k_native_dp for `items` (block, strand x frame) items whose longest block has smax codons: each keeps 64 rows
 // of S (64 * smax floats), all of them together at most 2 GiB (very long blocks run on fewer workgroups)
-static size_t native_grid(const rc_ctx *c, size_t items, int smax) {
+// mode 0: beside a k_null that leaves registers free on every SIMD (RC_NATIVE_WAVES_PER_CU, 8); 1: with the chip to itself, every wavefront slot
+static size_t native_grid(const rc_ctx *c, size_t items, int smax, int mode = 0) {
   const size_t perGroup = static_cast<size_t>(kWave) * std::max(1, smax) * sizeof(float);
   const size_t byMemory = std::max<size_t>(1, (static_cast<size_t>(2) << 30) / perGroup);
-  return std::max<size_t>(1, std::min(std::min(items, static_cast<size_t>(c->nativeWavesPerCU) * c->numCU), byMemory));
+  const size_t perCU = mode == 1 ? 32 : static_cast<size_t>(c->nativeWavesPerCU);
+  return std::max<size_t>(1, std::min(std::min(items, perCU * c->numCU), byMemory));
+}
+
+// A k_null launch that walks two rows per pass (rc_null_kernel.h; N-1 <= kDualRowsMaxNK, codes staged in LDS) needs up to 127 VGPRs:
+// four such wavefronts take a SIMD's whole register file, and any other kernel's wavefront on that SIMD displaces one of them (measured:
+// the native-block kernels beside it, even one workgroup per CU, 42.5 -> 50.3 ms; an LDS request sized for 15 workgroups per CU did
+// not help).  So the two-row instantiations are used where nothing has to run beside them: in batches made of such classes only
+// ("fat": every class 3 <= N-1 <= 5 with LDS staging; N-1 = 2 needs 95 VGPRs, leaves a quarter of the registers free and is always
+// two-row), whose native-block kernels are queued in front of k_null on the same stream with every wavefront slot to themselves
+// (1.9 ms instead of 2.9 at C3) -- resident batches, and sub-batches of a stream that are long enough for the bubble this leaves at
+// every sub-batch boundary to be paid back (RC_FAT_STREAM_MIN_BLOCKS).  Everything else keeps the one-row instantiations (74 VGPRs)
+// and the small kernels beside them.
+static bool fat_class(const rc_batch *b, const rc_ctx *c, int NK, int maxL) {
+  if (NK < 3 || NK > kDualRowsMaxNK || b->allExact) return false;
+  const size_t lds = static_cast<size_t>(maxL / 3) * ((NK + 4) / 5) * kWave * sizeof(uint32_t);
+  return lds <= c->ldsMaxBytes;
 }
 
 static int launch_native_block(const RunEnv &R) {
   rc_batch *b = R.b; rc_ctx *c = R.c;
   // ---- native block: sigma -> DP per N-1 class -> scan, on the native stream: these kernels are small and
   // latency-bound, the null sampling fills the chip beside them; the fit waits for both
-  hipStream_t st = c->serialNative ? R.cs : c->native;
-  if (!c->serialNative) HIP_TRY(hipStreamWaitEvent(st, b->evStart, 0));
+  hipStream_t st = R.nativeFirst ? R.cs : c->native;
+  if (!R.nativeFirst) HIP_TRY(hipStreamWaitEvent(st, b->evStart, 0));
   HIP_TRY(b->evN0.record(st));
   NativeArgs na{};
   na.blob = b->dblob.as<uint8_t>(); na.dblocks = R.dblocks; na.blocks = R.okList; na.pair = R.tp.pair;
@@ -698,7 +724,7 @@ static int launch_native_block(const RunEnv &R) {
       if (kv.first == kGenericClass) continue;
       int smaxClass = 1;
       for (int bi : kv.second) smaxClass = std::max(smaxClass, b->meta[bi].L / 3);
-      const size_t grid = native_grid(c, kv.second.size() * 6, smaxClass);
+      const size_t grid = native_grid(c, kv.second.size() * 6, smaxClass, R.nativeMode);
       need = std::max(need, grid * kWave * smaxClass);
     }
     HIP_TRY(b->dnativeTile.ensure(std::max<size_t>(need, 4) * sizeof(float)));
@@ -725,7 +751,7 @@ static int launch_native_block(const RunEnv &R) {
     for (int bi : kv.second) smaxClass = std::max(smaxClass, b->meta[bi].L / 3);
     nc.nItems = static_cast<int>(kv.second.size()) * 6;
     nc.tileStride = static_cast<size_t>(kWave) * smaxClass;
-    const int grid = static_cast<int>(native_grid(c, static_cast<size_t>(nc.nItems), smaxClass));
+    const int grid = static_cast<int>(native_grid(c, static_cast<size_t>(nc.nItems), smaxClass, R.nativeMode));
     nc.tile = b->dnativeTile.as<float>();
     if (!launch_native_dp(kv.first, nc, grid, st))
       return fail(RC_ERR_UNSUPPORTED, "no native DP kernel for this number of rows");
@@ -854,7 +880,8 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
         if (p.NK == kGenericClass) b->nullKernel = "rc::k_null_generic";
         else {
           const bool ex = b->allExact || p.NK >= kFastRows;
-          b->nullKernel = "rc::k_null<" + std::to_string(p.NK) + (!ex && p.ldsBytes ? ", true" : ", false") + (ex ? ", true>" : ", false>");
+          const bool dual = !ex && c->dualRows && p.ldsBytes && p.ldsBytes <= 48 * 1024 && p.NK <= kDualRowsMaxNK && (p.NK == 2 || R.fat);
+          b->nullKernel = "rc::k_null<" + std::to_string(p.NK) + (!ex && p.ldsBytes ? ", true" : ", false") + (ex ? ", true" : ", false") + (dual ? ", true>" : ", false>");
         }
       }
     }
@@ -872,6 +899,7 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
     } else {
       a.skipMask = kFlagExact | extraSkip;
       a.workCounter = work + p.NK * 8;
+      a.dual = (c->dualRows && p.ldsBytes && p.NK <= kDualRowsMaxNK && (p.NK == 2 || R.fat)) ? 1 : 0;
       // tail sharing: one slot per workgroup of this launch in the zeroed dsteal area (see batch_run_async)
       if (c->tailSharing && !p.comboSplit && static_cast<size_t>(p.grid) <= steal_slots(c) && b->dsteal.p) {
         const size_t idx = static_cast<size_t>(phase) * b->classes.size() + pi;
@@ -887,6 +915,7 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
       e.skipMask = extraSkip;
       e.comboSplit = 0;
       e.steal = nullptr;
+      e.dual = 0;
       e.workCounter = work + kClassSlots * 8 + p.NK * 8;
       if (!launch_null(p.NK, e, p.gridExact, 0, true, st)) return fail(RC_ERR_UNSUPPORTED, "no null kernel for this number of rows");
     }
@@ -913,9 +942,19 @@ static int batch_run_async(rc_batch *b, bool streaming = false) {
   b->clamped = 0;
   hipStream_t cs = c->compute[c->seq++ % static_cast<unsigned>(c->computeStreams)];
   const uint8_t *blob = b->dblob.as<uint8_t>();
+  bool nativeFirst = c->serialNative != 0, allFat = !b->classes.empty();
+  for (auto &kv : b->classes) {
+    int maxLc = 0;
+    for (int bi : kv.second) maxLc = std::max(maxLc, b->meta[bi].L);
+    allFat = allFat && kv.first != kGenericClass && fat_class(b, c, kv.first, maxLc);
+  }
+  bool fat = allFat && c->nativeFirst != 0 && (!streaming || static_cast<long long>(b->okBlocks.size()) >= c->fatStreamMinBlocks);
+  if (c->nativeFirst == 1) nativeFirst = true;
+  if (fat) nativeFirst = true;
+  const int nativeMode = c->serialNative ? 0 : nativeFirst ? 1 : 0;
   const RunEnv R{b, c, cs, n, sampleN, groups, Spad, n * 6, table_ptrs(c, b->par.blosum), blob,
                  reinterpret_cast<const DevBlock *>(blob + b->oDblocks), reinterpret_cast<const int *>(blob + b->oOk),
-                 reinterpret_cast<const int *>(blob + b->oClass), streaming};
+                 reinterpret_cast<const int *>(blob + b->oClass), streaming, nativeFirst, nativeMode, fat};
   HIP_TRY(hipStreamWaitEvent(cs, b->evPrep, 0));   // upload + expected-score tables
   HIP_TRY(b->evStart.record(cs));
   if (!b->okBlocks.empty()) {
@@ -953,17 +992,18 @@ static int batch_run_async(rc_batch *b, bool streaming = false) {
         HIP_TRY(hipMemsetAsync(b->dsteal.p, 0, bytes, cs));
       }
     }
-    HIP_TRY(b->evS0.record(cs));   // the class launches of the first round fork from here: every memset above is behind it
     // the native block's kernels go first: queued behind k_null's persistent grid they would find no free wavefront slot until its
     // tail, and the fit waits for them (long blocks: 1000 blocks of 12 x 300 took 628 ms per step that way instead of 600)
     bool nativeQueued = true;
-    RC_TRY(launch_native_block(R));
+    if (R.nativeFirst) RC_TRY(launch_native_block(R));   // on this stream, in front of k_null (fat_class): not part of the sampling interval
+    HIP_TRY(b->evS0.record(cs));   // the class launches of the first round fork from here: every memset above is behind it
+    if (!R.nativeFirst) RC_TRY(launch_native_block(R));
     int round = 0;
     for (int lo = 0, hi = g1; lo < groups; round++) {
       if (round == c->stopRounds - 1) hi = groups;
       if (lo > 0 && !nativeQueued) { RC_TRY(launch_native_block(R)); nativeQueued = true; }   // the stop marks need the best native scores (evN1)
       if (lo > 0) {
-        if (!c->serialNative && lo == g1) HIP_TRY(hipStreamWaitEvent(cs, b->evN1, 0));   // best native scores
+        if (!R.nativeFirst && lo == g1) HIP_TRY(hipStreamWaitEvent(cs, b->evN1, 0));   // best native scores
         fa.firstN = std::min(sampleN, lo * kWave);
         launch_stop_mark(fa, static_cast<int>(b->okBlocks.size()), cs);
         HIP_TRY(b->evMid.record(cs));
@@ -975,7 +1015,7 @@ static int batch_run_async(rc_batch *b, bool streaming = false) {
     HIP_TRY(b->evS1.record(cs));
     if (!nativeQueued) RC_TRY(launch_native_block(R));
     // ---- EVD fit
-    if (!c->serialNative) HIP_TRY(hipStreamWaitEvent(cs, b->evN1, 0));   // native HSS of the native stream
+    if (!R.nativeFirst) HIP_TRY(hipStreamWaitEvent(cs, b->evN1, 0));   // native HSS of the native stream
     // (a batch of a stream: the next sub-batch's k_null will be holding the LDS by the time this fit runs)
     // (a small input -- a few dozen blocks -- is one sub-batch by itself and keeps the four-wavefront fit, whose latency is its run time)
     launch_evd_fit(fa, static_cast<int>(b->okBlocks.size()), c->inflight.load() == 0 && (!streaming || b->okBlocks.size() <= 64), cs); b->nl[4]++;

@@ -78,6 +78,7 @@ struct DevBlock {
 };
 
 // per-block flag word (device array next to the DevBlocks)
+constexpr int kDualRowsMaxNK = 5;        // k_null walks two rows of S per pass for blocks of up to this many sequences besides the reference (rc_null_kernel.h)
 constexpr uint32_t kFlagExact = 1u;     // score tables outside the range proven for div_by_nk -> scored by the EXACT instantiation
 constexpr uint32_t kFlagStopped = 2u;   // --stop-early: enough samples beat the native score, the remaining ones are not simulated
 

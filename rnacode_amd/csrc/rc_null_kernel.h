@@ -172,7 +172,7 @@ __device__ __forceinline__ void sample_scan_last(const SampleScan &st, float &be
 // Read-only inputs are separate __restrict__ kernel parameters (not members of the by-value
 // argument block) so that the compiler may prove them unclobbered and fetch the wave-uniform
 // block tables (z words, tree records, masks) with scalar loads.
-template <int NK, bool LDSC, bool EXACT>
+template <int NK, bool LDSC, bool EXACT, bool DUAL = false>
 __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restrict__ blob,
                                              const DevBlock *__restrict__ dblocks, const int *__restrict__ classBlocks,
                                              const uint32_t *__restrict__ flags, const uint32_t *__restrict__ Ustream, const uint8_t *__restrict__ pairTab,
@@ -182,6 +182,10 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
   constexpr int NCW = (NK + CPW - 1) / CPW;
   constexpr int ZW = (NK + 31) / 32;      // 64-bit words per z entry (2 bits per sequence)
   using Regs = KRegs<std::make_integer_sequence<int, NK>>;
+  // DUAL: two rows of S per pass (see "rows a and a + 1 together" below): for instantiations whose codes are staged in LDS and whose
+  // register budget has room for a second row's states and a 32-entry row buffer at four wavefronts per SIMD.  The host picks it per
+  // launch (NullArgs::dual): up to 127 VGPRs instead of 74, i.e. no other kernel shares a SIMD with four such wavefronts.
+  static_assert(!DUAL || (LDSC && !EXACT && NK <= kDualRowsMaxNK), "two rows per pass: LDS-staged codes, fast division, few sequences");
   // phase A: threshold table of the tree (nnodes x 64 B); phase B with LDSC: [site][NCW][64] sigma codes
   // of the current strand x frame
   extern __shared__ uint32_t lds_codes[];
@@ -500,10 +504,15 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
             constexpr int t = k % CPW;
             uint32_t addr;
             if constexpr (t == 0) addr = w[k / CPW]; else addr = w[k / CPW] >> (6 * t);   // bits [7:2] select the lane
-            if constexpr (kProfiling) {   // timing experiments (wrong results): RC_DEBUG_SKIP bit 2 no shifts, bit 3 one look-up per cell
-              if (A.debugSkip & 4) addr = w[k / CPW];
-              if ((A.debugSkip & 8) && k > 0) { asm volatile("" : : "v"(addr)); sig[k] = sig[0]; return; }
-            }
+            // timing experiments, never in the product build (wrong results; tools/ab_lookup.sh): what the address shifts and the
+            // look-ups themselves cost -- -DRC_EXP_NO_SHIFTS: every look-up uses the unshifted word; -DRC_EXP_ONE_LOOKUP: one
+            // ds_bpermute per cell instead of one per sequence (the shifts stay)
+#ifdef RC_EXP_NO_SHIFTS
+            addr = w[k / CPW];
+#endif
+#ifdef RC_EXP_ONE_LOOKUP
+            if constexpr (k > 0) { asm volatile("" : : "v"(addr)); sig[k] = sig[0]; return; }
+#endif
             const int lutv = R.template at<k>().lut;
             float got;
             asm volatile("ds_bpermute_b32 %0, %1, %2" : "=v"(got) : "v"(addr), "v"(lutv));
@@ -643,95 +652,396 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
         float two_v;
         asm volatile("v_mov_b32 %0, 2.0" : "=v"(two_v));
         const float negTie = -A.tieThr;
-        for (int a = 0; a < sites; a++) {
-          sample_scan_row_begin(st, best, static_cast<uint32_t>(a));
-          static_for<NK>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            auto &r = R.template at<k>();
-            r.s0 = r.s1 = r.s2 = 0.0f;
-          });
-          uint32_t wcur[NCW];
-          load_words(a, wcur);
-          const int jend = (a == sites - 1) ? sites - 1 : sites;   // the frame's final entry is handled below
-          int j = a;
-          float j2f = static_cast<float>(2 * a + 1);   // 2j + 1 of the cell being entered
-          {   // pristine segment: up to the row's first event
-            const int e = next_event(j, jend);
-            float wv = 0.0f;
-            asm volatile("v_mov_b32 %0, 0" : "=v"(wv));   // keep w a per-lane register (full-rate v_add/v_max operands)
-            for (; j < e; j++) {
-              const int jn = j + 1 < sites ? j + 1 : j;
-              uint32_t wnext[NCW];
-              if constexpr (!LDSC) load_words(jn, wnext);
-              if constexpr (kProfiling) statPristine++;
-              const float v = pristine_cell(wcur, wv, jn);
-              sample_scan_step(st, v, j2f, negTie);
-              asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
-              if constexpr (!LDSC) {
-#pragma unroll
-                for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
-              }
-            }
+        if constexpr (DUAL) {
+          // ---- Two rows per pass.  sigma of (site j, sequence k) is the same for every row a <= j, and the look-up -- a shift and a
+          // ds_bpermute per sequence -- is what the cell loop waits for most (tools/ab_lookup.sh: four of the five look-ups left out,
+          // 49.1 -> 43.7 ms).  Rows a and a + 1 therefore walk their common sites together on one set of look-ups.  getHSS reads the
+          // entries row by row, so row a's entries go through the scan as they are made and row a + 1's S values wait in a register
+          // buffer (32 floats, indexed with the wave-uniform site number: s_set_gpr_idx) until row a is done; a row longer than the
+          // buffer has its first cells made twice -- states only beside row a, then again with their scan when its turn comes.
+          // Every row's additions and maxima are the ones of the one-row loop in the same order: results are bit-identical.
+          // A pair needs a site a without a frame-shift event (both rows then change their cell kind at the same sites) and two more
+          // rows below it; other rows go alone.
+          typedef float RowBuf __attribute__((ext_vector_type(32)));
+          constexpr int kBuf = 32;
+          RowBuf buf = {};
+          Regs RB;   // row a + 1 (its lut members are not used)
+          auto pristine2 = [&](uint32_t (&w)[NCW], float &wvA, float &wvB, int jn, float &vB) -> float {
+            float sig[NK];
+            lookup(w, sig, jn, std::false_type{});
+            wvA = wvA + omega_v;
+            wvB = wvB + omega_v;
+            float sumA = 0.0f, sumB = 0.0f;
             static_for<NK>([&](auto kc) {
               constexpr int k = decltype(kc)::value;
-              auto &r = R.template at<k>();
-              r.s1 = r.s2 = wv;
+              auto &ra = R.template at<k>();
+              auto &rb = RB.template at<k>();
+              ra.s0 = ra.s0 + sig[k];
+              const float ma = fmaxf(ra.s0, wvA);
+              sumA = (k == 0) ? ma : sumA + ma;
+              rb.s0 = rb.s0 + sig[k];
+              const float mb = fmaxf(rb.s0, wvB);
+              sumB = (k == 0) ? mb : sumB + mb;
             });
-          }
-          while (j < jend) {
-            if ((zany[j >> 6] >> (j & 63)) & 1ull) {               // event codon
-              const int jn = j + 1 < sites ? j + 1 : j;
-              uint32_t wnext[NCW];
-              if constexpr (!LDSC) load_words(jn, wnext);
-              if constexpr (kProfiling) statEvent++;
-              const float v = event_cell(wcur, j, jn);
-              sample_scan_step(st, v, j2f, negTie);
-              asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
-              if constexpr (!LDSC) {
+            vB = finish(sumB);
+            return finish(sumA);
+          };
+          auto fast2 = [&](uint32_t (&w)[NCW], int jn, float &vB) -> float {
+            float sig[NK];
+            lookup(w, sig, jn, std::false_type{});
+            float sumA = 0.0f, sumB = 0.0f;
+            static_for<NK>([&](auto kc) {
+              constexpr int k = decltype(kc)::value;
+              auto &ra = R.template at<k>();
+              auto &rb = RB.template at<k>();
+              ra.s0 = ra.s0 + sig[k];
+              ra.s1 = ra.s1 + omega_v;
+              ra.s2 = ra.s2 + omega_v;
+              const float ma = fmaxf(fmaxf(ra.s0, ra.s1), ra.s2);
+              sumA = (k == 0) ? ma : sumA + ma;
+              rb.s0 = rb.s0 + sig[k];
+              rb.s1 = rb.s1 + omega_v;
+              rb.s2 = rb.s2 + omega_v;
+              const float mb = fmaxf(fmaxf(rb.s0, rb.s1), rb.s2);
+              sumB = (k == 0) ? mb : sumB + mb;
+            });
+            vB = finish(sumB);
+            return finish(sumA);
+          };
+          auto tail2 = [&](uint32_t (&w)[NCW], int jn, float &vB) -> float {
+            float sig[NK];
+            lookup(w, sig, jn, std::false_type{});
+            float sumA = 0.0f, sumB = 0.0f;
+            static_for<NK>([&](auto kc) {
+              constexpr int k = decltype(kc)::value;
+              auto &ra = R.template at<k>();
+              auto &rb = RB.template at<k>();
+              ra.s0 = ra.s0 + sig[k];
+              ra.s1 = ra.s1 + omega_v;
+              const float ma = fmaxf(ra.s0, ra.s1);
+              sumA = (k == 0) ? ma : sumA + ma;
+              rb.s0 = rb.s0 + sig[k];
+              rb.s1 = rb.s1 + omega_v;
+              const float mb = fmaxf(rb.s0, rb.s1);
+              sumB = (k == 0) ? mb : sumB + mb;
+            });
+            vB = finish(sumB);
+            return finish(sumA);
+          };
+          auto event2 = [&](uint32_t (&w)[NCW], int j, int jn, float &vB) -> float {
+            float sig[NK];
+            lookup(w, sig, jn, std::true_type{});
+            unsigned long long z[ZW];
 #pragma unroll
-                for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
-              }
-              j++;
-            }
-            const int e = next_event(j, jend);
-            if (e == jend) {                                       // no further event in this row: the tail
+            for (int x = 0; x < ZW; x++) z[x] = zbase[static_cast<size_t>(3 * j) * ZW + x];
+            float sumA = 0.0f, sumB = 0.0f;
+            static_for<NK>([&](auto kc) {
+              constexpr int k = decltype(kc)::value;
+              auto &ra = R.template at<k>();
+              auto &rb = RB.template at<k>();
+              const int zc = static_cast<int>((z[k >> 5] >> (2 * (k & 31))) & 3ull);
+              pair_step(zc, sig[k], Delta, Omega, omega, ra.s0, ra.s1, ra.s2);
+              const float ma = fmaxf(fmaxf(ra.s0, ra.s1), ra.s2);
+              sumA = (k == 0) ? ma : sumA + ma;
+              pair_step(zc, sig[k], Delta, Omega, omega, rb.s0, rb.s1, rb.s2);
+              const float mb = fmaxf(fmaxf(rb.s0, rb.s1), rb.s2);
+              sumB = (k == 0) ? mb : sumB + mb;
+            });
+            vB = finish(sumB);
+            return finish(sumA);
+          };
+          int a = 0;
+          int pendRow = -1, pendExtra = 0, pendN = 0;   // row a + 1 of the last pair: its first pendExtra cells are still to be made, then pendN buffered values to scan
+          while (a < sites || pendRow >= 0) {
+            if (pendRow < 0 && a + 2 < sites && !((zany[a >> 6] >> (a & 63)) & 1ull)) {
+              // ---- rows a and a + 1 together
+              sample_scan_row_begin(st, best, static_cast<uint32_t>(a));
               static_for<NK>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
                 auto &r = R.template at<k>();
-                r.s1 = fmaxf(r.s1, r.s2);
+                r.s0 = r.s1 = r.s2 = 0.0f;
+                auto &rb = RB.template at<k>();
+                rb.s0 = rb.s1 = rb.s2 = 0.0f;
               });
+              uint32_t wcur[NCW];
+              load_words(a, wcur);
+              int j = a;
+              float j2f = static_cast<float>(2 * a + 1);
+              float wvA = 0.0f, wvB = 0.0f;
+              asm volatile("v_mov_b32 %0, 0" : "=v"(wvA));
+              asm volatile("v_mov_b32 %0, 0" : "=v"(wvB));
+              {   // row a's first cell (site a: no event)
+                const float v = pristine_cell(wcur, wvA, a + 1);
+                sample_scan_step(st, v, j2f, negTie);
+                asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
+                j = a + 1;
+              }
+              const int extra = (sites - 1 - a > kBuf) ? sites - 1 - a - kBuf : 0;   // row a + 1 has sites - 1 - a cells: the last kBuf are buffered
+              const int b0 = a + 1 + extra;
+              auto keep = [&](float vB, int jj) {   // (a cell before b0 lands in entry 0 and is overwritten by the one that belongs there)
+                const int idx = jj > b0 ? jj - b0 : 0;
+                buf[idx] = vB;
+              };
+              {
+                const int e = next_event(j, sites);
+                for (; j < e; j++) {
+                  const int jn = j + 1 < sites ? j + 1 : j;
+                  float vB;
+                  const float v = pristine2(wcur, wvA, wvB, jn, vB);
+                  sample_scan_step(st, v, j2f, negTie);
+                  keep(vB, j);
+                  asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
+                }
+                static_for<NK>([&](auto kc) {
+                  constexpr int k = decltype(kc)::value;
+                  auto &r = R.template at<k>();
+                  r.s1 = r.s2 = wvA;
+                  auto &rb = RB.template at<k>();
+                  rb.s1 = rb.s2 = wvB;
+                });
+              }
+              while (j < sites) {
+                if ((zany[j >> 6] >> (j & 63)) & 1ull) {
+                  const int jn = j + 1 < sites ? j + 1 : j;
+                  float vB;
+                  const float v = event2(wcur, j, jn, vB);
+                  sample_scan_step(st, v, j2f, negTie);
+                  keep(vB, j);
+                  asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
+                  j++;
+                }
+                const int e = next_event(j, sites);
+                if (e == sites) {
+                  static_for<NK>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    auto &r = R.template at<k>();
+                    r.s1 = fmaxf(r.s1, r.s2);
+                    auto &rb = RB.template at<k>();
+                    rb.s1 = fmaxf(rb.s1, rb.s2);
+                  });
+                  for (; j < e; j++) {
+                    const int jn = j + 1 < sites ? j + 1 : j;
+                    float vB;
+                    const float v = tail2(wcur, jn, vB);
+                    sample_scan_step(st, v, j2f, negTie);
+                    keep(vB, j);
+                    asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
+                  }
+                }
+                for (; j < e; j++) {
+                  const int jn = j + 1 < sites ? j + 1 : j;
+                  float vB;
+                  const float v = fast2(wcur, jn, vB);
+                  sample_scan_step(st, v, j2f, negTie);
+                  keep(vB, j);
+                  asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
+                }
+              }
+#pragma unroll
+              for (int x = 0; x < NCW; x++) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wcur[x]));
+              sample_scan_row_end(st, static_cast<uint32_t>(a));
+              pendRow = a + 1; pendExtra = extra; pendN = sites - b0;
+              a += 2;
+            } else {
+              // ---- one row: row `a`, or the row left over from a pair (its first pendExtra cells, then its buffered values)
+              const bool pend = pendRow >= 0;
+              const int row = pend ? pendRow : a;
+              const int jend = pend ? row + pendExtra : ((row == sites - 1) ? sites - 1 : sites);
+              float j2f = static_cast<float>(2 * row + 1);
+                sample_scan_row_begin(st, best, static_cast<uint32_t>(row));
+                static_for<NK>([&](auto kc) {
+                  constexpr int k = decltype(kc)::value;
+                  auto &r = R.template at<k>();
+                  r.s0 = r.s1 = r.s2 = 0.0f;
+                });
+                uint32_t wcur[NCW];
+                load_words(row, wcur);
+                int j = row;
+                {   // pristine segment: up to the row's first event
+                  const int e = next_event(j, jend);
+                  float wv = 0.0f;
+                  asm volatile("v_mov_b32 %0, 0" : "=v"(wv));   // keep w a per-lane register (full-rate v_add/v_max operands)
+                  for (; j < e; j++) {
+                    const int jn = j + 1 < sites ? j + 1 : j;
+                    uint32_t wnext[NCW];
+                    if constexpr (!LDSC) load_words(jn, wnext);
+                    if constexpr (kProfiling) statPristine++;
+                    const float v = pristine_cell(wcur, wv, jn);
+                    sample_scan_step(st, v, j2f, negTie);
+                    asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
+                    if constexpr (!LDSC) {
+      #pragma unroll
+                      for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
+                    }
+                  }
+                  static_for<NK>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    auto &r = R.template at<k>();
+                    r.s1 = r.s2 = wv;
+                  });
+                }
+                while (j < jend) {
+                  if ((zany[j >> 6] >> (j & 63)) & 1ull) {               // event codon
+                    const int jn = j + 1 < sites ? j + 1 : j;
+                    uint32_t wnext[NCW];
+                    if constexpr (!LDSC) load_words(jn, wnext);
+                    if constexpr (kProfiling) statEvent++;
+                    const float v = event_cell(wcur, j, jn);
+                    sample_scan_step(st, v, j2f, negTie);
+                    asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
+                    if constexpr (!LDSC) {
+      #pragma unroll
+                      for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
+                    }
+                    j++;
+                  }
+                  const int e = next_event(j, jend);
+                  if (e == jend) {                                       // no further event in this row: the tail
+                    static_for<NK>([&](auto kc) {
+                      constexpr int k = decltype(kc)::value;
+                      auto &r = R.template at<k>();
+                      r.s1 = fmaxf(r.s1, r.s2);
+                    });
+                    for (; j < e; j++) {
+                      const int jn = j + 1 < sites ? j + 1 : j;
+                      uint32_t wnext[NCW];
+                      if constexpr (!LDSC) load_words(jn, wnext);
+                      if constexpr (kProfiling) statTail++;
+                      const float v = tail_cell(wcur, jn);
+                      sample_scan_step(st, v, j2f, negTie);
+                      asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
+                      if constexpr (!LDSC) {
+      #pragma unroll
+                        for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
+                      }
+                    }
+                  }
+                  for (; j < e; j++) {                                   // tight loop: no events
+                    const int jn = j + 1 < sites ? j + 1 : j;
+                    uint32_t wnext[NCW];
+                    if constexpr (!LDSC) load_words(jn, wnext);
+                    const float v = fast_cell(wcur, jn);
+                    sample_scan_step(st, v, j2f, negTie);
+                    asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
+                    if constexpr (!LDSC) {
+      #pragma unroll
+                      for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
+                    }
+                  }
+                }
+                if constexpr (LDSC) {   // the last cell's fetch-ahead must have landed before its registers are given away
+      #pragma unroll
+                  for (int x = 0; x < NCW; x++) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wcur[x]));
+                }
+              if (pend) {
+                // the buffered values, entry 0 first: unrolled, so that every entry is a register operand of its scan step (an
+                // indexed read costs three instructions and 9 cycles of the SIMD, tools/microbench_gpr_idx.hip)
+                [&]() {
+#pragma unroll
+                  for (int idx = 0; idx < kBuf; idx++) {
+                    if (idx >= pendN) return;
+                    sample_scan_step(st, buf[idx], j2f, negTie);
+                    asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
+                  }
+                }();
+                pendRow = -1;
+              } else {
+                a += 1;
+              }
+              sample_scan_row_end(st, static_cast<uint32_t>(row));
+            }
+          }
+        } else {
+          for (int a = 0; a < sites; a++) {
+            sample_scan_row_begin(st, best, static_cast<uint32_t>(a));
+            static_for<NK>([&](auto kc) {
+              constexpr int k = decltype(kc)::value;
+              auto &r = R.template at<k>();
+              r.s0 = r.s1 = r.s2 = 0.0f;
+            });
+            uint32_t wcur[NCW];
+            load_words(a, wcur);
+            const int jend = (a == sites - 1) ? sites - 1 : sites;   // the frame's final entry is handled below
+            int j = a;
+            float j2f = static_cast<float>(2 * a + 1);   // 2j + 1 of the cell being entered
+            {   // pristine segment: up to the row's first event
+              const int e = next_event(j, jend);
+              float wv = 0.0f;
+              asm volatile("v_mov_b32 %0, 0" : "=v"(wv));   // keep w a per-lane register (full-rate v_add/v_max operands)
               for (; j < e; j++) {
                 const int jn = j + 1 < sites ? j + 1 : j;
                 uint32_t wnext[NCW];
                 if constexpr (!LDSC) load_words(jn, wnext);
-                if constexpr (kProfiling) statTail++;
-                const float v = tail_cell(wcur, jn);
+                if constexpr (kProfiling) statPristine++;
+                const float v = pristine_cell(wcur, wv, jn);
                 sample_scan_step(st, v, j2f, negTie);
                 asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
                 if constexpr (!LDSC) {
-#pragma unroll
+  #pragma unroll
+                  for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
+                }
+              }
+              static_for<NK>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                auto &r = R.template at<k>();
+                r.s1 = r.s2 = wv;
+              });
+            }
+            while (j < jend) {
+              if ((zany[j >> 6] >> (j & 63)) & 1ull) {               // event codon
+                const int jn = j + 1 < sites ? j + 1 : j;
+                uint32_t wnext[NCW];
+                if constexpr (!LDSC) load_words(jn, wnext);
+                if constexpr (kProfiling) statEvent++;
+                const float v = event_cell(wcur, j, jn);
+                sample_scan_step(st, v, j2f, negTie);
+                asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
+                if constexpr (!LDSC) {
+  #pragma unroll
+                  for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
+                }
+                j++;
+              }
+              const int e = next_event(j, jend);
+              if (e == jend) {                                       // no further event in this row: the tail
+                static_for<NK>([&](auto kc) {
+                  constexpr int k = decltype(kc)::value;
+                  auto &r = R.template at<k>();
+                  r.s1 = fmaxf(r.s1, r.s2);
+                });
+                for (; j < e; j++) {
+                  const int jn = j + 1 < sites ? j + 1 : j;
+                  uint32_t wnext[NCW];
+                  if constexpr (!LDSC) load_words(jn, wnext);
+                  if constexpr (kProfiling) statTail++;
+                  const float v = tail_cell(wcur, jn);
+                  sample_scan_step(st, v, j2f, negTie);
+                  asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
+                  if constexpr (!LDSC) {
+  #pragma unroll
+                    for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
+                  }
+                }
+              }
+              for (; j < e; j++) {                                   // tight loop: no events
+                const int jn = j + 1 < sites ? j + 1 : j;
+                uint32_t wnext[NCW];
+                if constexpr (!LDSC) load_words(jn, wnext);
+                const float v = fast_cell(wcur, jn);
+                sample_scan_step(st, v, j2f, negTie);
+                asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
+                if constexpr (!LDSC) {
+  #pragma unroll
                   for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
                 }
               }
             }
-            for (; j < e; j++) {                                   // tight loop: no events
-              const int jn = j + 1 < sites ? j + 1 : j;
-              uint32_t wnext[NCW];
-              if constexpr (!LDSC) load_words(jn, wnext);
-              const float v = fast_cell(wcur, jn);
-              sample_scan_step(st, v, j2f, negTie);
-              asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
-              if constexpr (!LDSC) {
-#pragma unroll
-                for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
-              }
+            if constexpr (LDSC) {   // the last cell's fetch-ahead must have landed before its registers are given away
+  #pragma unroll
+              for (int x = 0; x < NCW; x++) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wcur[x]));
             }
+            sample_scan_row_end(st, static_cast<uint32_t>(a));
           }
-          if constexpr (LDSC) {   // the last cell's fetch-ahead must have landed before its registers are given away
-#pragma unroll
-            for (int x = 0; x < NCW; x++) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wcur[x]));
-          }
-          sample_scan_row_end(st, static_cast<uint32_t>(a));
         }
         sample_scan_last(st, best);   // entry (sites-1, sites-1): its own value can never be reported
       }
@@ -773,6 +1083,13 @@ inline void launch_null_one(const NullArgs &a, int grid, size_t ldsBytes, bool e
     hipLaunchKernelGGL((k_null<NK, false, true>), dim3(grid), dim3(64), 0, stream, a, a.blob, a.dblocks,
                        a.classBlocks, a.flags, a.U, a.pair, a.scratch, a.maxima);
   } else if (ldsBytes) {
+    if constexpr (NK <= kDualRowsMaxNK) {
+      if (a.dual && ldsBytes <= 48 * 1024) {
+        hipLaunchKernelGGL((k_null<NK, true, false, true>), dim3(grid), dim3(64), ldsBytes, stream, a, a.blob, a.dblocks,
+                           a.classBlocks, a.flags, a.U, a.pair, a.scratch, a.maxima);
+        return;
+      }
+    }
     if (ldsBytes > 48 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_null<NK, true, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsBytes));

@@ -4,7 +4,7 @@ k_null's cell loops only run at their measured rate while the compiler can prove
 reaches a branch through a vector register (round 3: a __shfl result deciding which item a workgroup helps with) turned every loop
 of the kernel into an exec-masked loop -- five more instructions per cell and 49 -> 65 ms per launch, with all parity tests green.
 This test compiles the N-1 = 2..6 unit the way the Makefile does and looks at the ISA of k_null<5, true, false> (the bench
-workload's instantiation)."""
+workload's instantiation): the one-row cell loops, and the loops that walk two rows on one set of look-ups."""
 import os
 import re
 import shutil
@@ -13,7 +13,8 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NAME = "_ZN2rc6k_nullILi5ELb1ELb0EEEvNS_8NullArgsEPKhPKNS_8DevBlockEPKiPKjSA_S3_PjPf"
+ONE_ROW = "_ZN2rc6k_nullILi5ELb1ELb0ELb0EEEvNS_8NullArgsEPKhPKNS_8DevBlockEPKiPKjSA_S3_PjPf"    # k_null<5, true, false, false>
+TWO_ROWS = "_ZN2rc6k_nullILi5ELb1ELb0ELb1EEEvNS_8NullArgsEPKhPKNS_8DevBlockEPKiPKjSA_S3_PjPf"   # k_null<5, true, false, true>
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
@@ -23,25 +24,40 @@ def test_k_null_cell_loops_are_wave_uniform_and_tight(tmp_path):
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "--cuda-device-only", "-S", *flags, "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "rnacode_amd", "csrc", "rc_null_a.hip"), "-o", str(out)])
     txt = out.read_text()
-    body = txt[txt.index(NAME + ":"):]
-    body = body[:body.index(".Lfunc_end")]
-    blocks, cur = [], None
-    for ln in body.split("\n"):
-        if re.match(r"^\.LBB\d+_\d+:", ln):
-            cur = []
-            blocks.append(cur)
-        elif cur is not None and ln.startswith("\t") and not ln.startswith(("\t.", "\t;")):
-            cur.append(ln.strip())
-    cells = [b for b in blocks if sum("ds_bpermute_b32" in x for x in b) == 5]   # one sigma look-up per sequence: a cell loop
-    # the four cell kinds: before the row's first frame-shift event, at an event, after the last one, between events
-    assert len(cells) == 4, [len(b) for b in cells]
-    for b in cells:
-        assert not any("exec" in x for x in b), "a cell loop manipulates exec: its trip count is no longer wave-uniform\n" + "\n".join(b)
-        assert not any(x.startswith(("scratch_", "buffer_")) for x in b)
-    # instructions per cell (round 2/3 builds: 50, 50, 53, 58)
-    assert sorted(len(b) for b in cells) <= [50, 50, 53, 58], sorted(len(b) for b in cells)
-    meta = txt[txt.index(".name:           " + NAME):]
-    vgprs = int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1))
-    assert vgprs <= 128, vgprs   # four wavefronts per SIMD (16 per CU is what the LDS allows)
-    head = txt[txt.rindex(".amdhsa_kernel " + NAME):]
-    assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", head).group(1)) == 0
+
+    def loops_of(name):
+        body = txt[txt.index(name + ":"):]
+        body = body[:body.index(".Lfunc_end")]
+        blocks, cur = [], None
+        for ln in body.split("\n"):
+            if re.match(r"^\.LBB\d+_\d+:", ln):
+                cur = []
+                blocks.append(cur)
+            elif cur is not None and ln.startswith("\t") and not ln.startswith(("\t.", "\t;")):
+                cur.append(ln.strip())
+        lookups = [b for b in blocks if sum("ds_bpermute_b32" in x for x in b) == 5]   # one sigma look-up per sequence: a cell (or cell pair) body
+        for b in lookups:
+            assert not any(re.match(r"s_\w+ exec\b", x) or "saveexec" in x for x in b), \
+                "a cell loop writes exec: its trip count is no longer wave-uniform\n" + "\n".join(b)
+            assert not any(x.startswith(("scratch_", "buffer_")) for x in b)
+        loops = [b for b in lookups if any(x.startswith("s_cbranch") for x in b[-3:])]
+        meta = txt[txt.index(".name:           " + name):]
+        vgprs = int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1))
+        head = txt[txt.rindex(".amdhsa_kernel " + name):]
+        assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", head).group(1)) == 0
+        return loops, vgprs
+
+    # one row per pass: the three straight-line cell kinds -- before the row's first frame-shift event, after its last one, between
+    # events (round 2/3 builds: 50, 53, 58 instructions per cell; the event cell branches per sequence and spans several blocks)
+    loops, vgprs = loops_of(ONE_ROW)
+    singles = [b for b in loops if len(b) <= 60 and sum(x.startswith("v_") for x in b) >= 25]
+    assert len(singles) == 3 and sorted(len(b) for b in singles) <= [50, 53, 58], sorted(len(b) for b in singles)
+    assert vgprs <= 80, vgprs        # leaves 192 VGPRs per SIMD to the kernels that run beside it
+    # two rows per pass: the pair loops keep row a + 1's S value with ONE indexed register move (s_set_gpr_idx)
+    # and never copy the 32-register row buffer: 75, 83, 91 instructions per TWO cells
+    loops, vgprs = loops_of(TWO_ROWS)
+    pairs = [b for b in loops if any("s_set_gpr_idx_on" in x for x in b)]
+    assert len(pairs) == 3 and sorted(len(b) for b in pairs) <= [75, 83, 91], sorted(len(b) for b in pairs)
+    for b in pairs:
+        assert sum("s_set_gpr_idx_on" in x for x in b) == 1 and not any(x.startswith("v_mov_b64") for x in b)
+    assert vgprs <= 128, vgprs       # four wavefronts per SIMD (16 per CU is what the LDS allows)

@@ -22,7 +22,7 @@ for name in ("fetch", "write"):
     tot = cnt = 0
     for f in glob.glob(f"{out}/{name}_cap{cap}/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            if "k_null<11, false, false>" in row["Kernel_Name"]:
+            if "k_null<11, false, false" in row["Kernel_Name"]:
                 tot += float(row["Counter_Value"]); cnt += 1
     res[name] = tot / max(cnt, 1) * 1024
 alg = d["roofline"]["algorithmic_bytes_per_launch"]
