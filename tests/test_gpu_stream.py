@@ -578,3 +578,38 @@ def test_tail_sharing_on_and_off_give_the_same_results(monkeypatch):
         want = ob.run_block([r.seq for r in blk.rows], [r.name for r in blk.rows], blk.rows[0].start, blk.rows[0].length, blk.tree, blk.kappa,
                             ob.default_params(64), kw["seed_base"])
         np.testing.assert_array_equal(got[(name, "1")][0][i][:64], np.float32(want.maxScores))
+
+
+def test_two_rows_per_pass_equal_one_row_per_pass_and_the_oracle(monkeypatch):
+    """k_null<N-1, true, false, DUAL>: rows a and a + 1 of S share their sigma look-ups, row a + 1's values wait in
+    a 32-register buffer.  Batches of ONE row count each (3..6 rows: the classes that take the two-row kernel; a batch of such classes
+    only also runs its native-block kernels first), gapped blocks of 30..156 columns -- up to 52 codon sites, so rows longer than the
+    buffer (their first cells are made twice), rows whose first site is a frame-shift event (they go alone) and pairs that change
+    their cell kind together all occur.  RC_DUAL_ROWS=0 must give the same maxima, fits and HSS tables bit for bit, and a sample of
+    blocks must equal the CPU oracle."""
+    from oracle import binding as ob
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_block
+    rng = np.random.RandomState(123)
+    cases = {n: [synth_block(rng, n, int(rng.randint(30, 157)), index=i, gaps=True).upper() for i in range(260)] for n in (3, 4, 5, 6)}
+    kw = dict(sampleN=600, seed_base=17)   # 2600 (block, 64-sample) items: whole items, not their strand x frame parts
+    got = {}
+    for dual in ("1", "0"):
+        monkeypatch.setenv("RC_DUAL_ROWS", dual)
+        c = api.Context(0)
+        for n, blocks in cases.items():
+            b = api.Batch(c, blocks, api.default_params(**kw)).run()
+            got[(n, dual)] = (b.maxScores_all().copy(), b.fits().copy(), [b.scoreAln(i) for i in range(0, b.n, 11)], b.null_kernel())
+            b.close()
+        c.close()
+    for n, blocks in cases.items():
+        on, off = got[(n, "1")], got[(n, "0")]
+        assert on[3].endswith(", true>") and off[3].endswith(", false>"), (on[3], off[3])   # the two instantiations really ran
+        np.testing.assert_array_equal(on[0], off[0], err_msg=f"{n} rows")
+        np.testing.assert_array_equal(on[1], off[1], err_msg=f"{n} rows (fits)")
+        assert on[2] == off[2]
+        for i in (0, 141, 259):
+            blk = blocks[i]
+            want = ob.run_block([r.seq for r in blk.rows], [r.name for r in blk.rows], blk.rows[0].start, blk.rows[0].length, blk.tree, blk.kappa,
+                                ob.default_params(64), kw["seed_base"])
+            np.testing.assert_array_equal(on[0][i][:64], np.float32(want.maxScores), err_msg=f"{n} rows, block {i}")
