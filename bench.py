@@ -33,6 +33,7 @@ Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import socket
@@ -154,16 +155,35 @@ def end_to_end_leg(blocks, sampleN, seed, runs=5):
         os.rmdir(d)
 
 
+LAST_STEP_MS = []   # per-step times of the last timed_region (diagnostics: a mean hides a stalled step)
+
+
 def timed_region(step, min_s, min_steps=3):
     """Run `step` until at least min_s seconds and min_steps steps have passed; (seconds, steps)."""
     n = 0
-    t0 = time.perf_counter()
-    while True:
-        step()
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt >= min_s and n >= min_steps:
-            return dt, n
+    del LAST_STEP_MS[:]
+    gc.collect()
+    gc.disable()   # this process holds millions of Python objects (the synthetic blocks): a full collection in the middle of a step takes 0.3-2 s
+    try:
+        t0 = time.perf_counter()
+        prev = t0
+        while True:
+            step()
+            n += 1
+            now = time.perf_counter()
+            LAST_STEP_MS.append((now - prev) * 1e3)
+            prev = now
+            dt = now - t0
+            if dt >= min_s and n >= min_steps:
+                return dt, n
+    finally:
+        gc.enable()
+
+
+def spread():
+    """min / median / max of the last timed region's steps, ms"""
+    x = sorted(LAST_STEP_MS)
+    return {"min": x[0], "median": x[len(x) // 2], "max": x[-1]} if x else None
 
 
 def resident_leg(api, ctx, blocks, params, min_s, warmup=2):
@@ -184,7 +204,11 @@ def resident_leg(api, ctx, blocks, params, min_s, warmup=2):
     kernel = batch.null_kernel()
     _, cs = batch.work()
     batch.close()
-    return dt / n * 1e3, acc["null"] / acc["n"] / acc["launches"], kernel, cs, n, m
+    resident_leg.spread = spread()
+    resident_leg.spread["mean"] = dt / n * 1e3
+    # the MEDIAN step (a stalled step -- before the collector was switched off around the timed regions, single steps took 0.3-2 s
+    # now and then -- would shift a three-second mean by tens of per cent; min / median / max / mean are reported)
+    return resident_leg.spread["median"], acc["null"] / acc["n"] / acc["launches"], kernel, cs, n, m
 
 
 def stream_leg(api, ctx, m, params, sub_blocks, min_s, depth=3, warmup=2):
@@ -200,7 +224,9 @@ def stream_leg(api, ctx, m, params, sub_blocks, min_s, depth=3, warmup=2):
         step()
     dt, n = timed_region(step, min_s)
     st.close()
-    return dt / n * 1e3, n
+    stream_leg.spread = spread()
+    stream_leg.spread["mean"] = dt / n * 1e3
+    return stream_leg.spread["median"], n   # the median pass, see resident_leg
 
 
 def cpu_baseline(blocks, sampleN, seed, target_s=12.0):
@@ -455,6 +481,8 @@ def main():
         for _ in range(args.warmup):
             step()
         sync()
+        gc.collect()
+        gc.disable()   # see timed_region
         t0 = time.perf_counter()
         tk = {"total": 0.0, "mt_stream": 0.0, "null": 0.0, "native": 0.0, "evd_fit": 0.0}
         nlaunch = {}
@@ -467,6 +495,7 @@ def main():
                 nlaunch = nl
         sync()
         elapsed = time.perf_counter() - t0
+        gc.enable()
         if multi:
             elapsed = rd.max_over_ranks(elapsed, device=coll_dev)
         return elapsed, tk, nlaunch
@@ -485,6 +514,8 @@ def main():
             slices = [(lo, min(len(blocks), lo + big)) for lo in range(0, len(blocks), big)] * args.steps
             slices = [(0, sub_sizes[0])] + ([(sub_sizes[0], slices[0][1])] if slices[0][1] > sub_sizes[0] else []) + slices[1:]
             sent = 0
+            gc.collect()
+            gc.disable()
             t0 = time.perf_counter()
             while sent < len(slices) or stream.pending:
                 while sent < len(slices) and stream.pending < stream.depth:
@@ -494,6 +525,7 @@ def main():
                 sb.fits()
                 sb.close()
             c_elapsed = time.perf_counter() - t0
+            gc.enable()
 
     # N > 1 under strong scaling: also the weak-scaling figure (every rank its own --blocks blocks, generator seed 1 + rank),
     # as an extra key: the per-GPU work then equals the N = 1 run's, which is what separates kernel scaling from shard size
@@ -541,28 +573,19 @@ def main():
         ctx.set_host_threads(t8)
         sh_ms, sh_null, sh_kernel, sh_units, sh_steps, sh_m = resident_leg(api, ctx, blocks[lo:hi], params, args.extra_seconds)
         sh_sub = api.stream_plan(ctx, params, hi - lo, 1)
+        sh_res_spread = resident_leg.spread
         sh_stream_ms, sh_passes = stream_leg(api, ctx, sh_m, params, sh_sub, args.extra_seconds)
         legs["shard"] = {
             "blocks": hi - lo, "of": len(blocks), "ranks": 8, "host_threads": t8, "usable_cpus": cpus,
-            "ms_per_step": sh_ms, "steps": sh_steps, "kernel_ms": sh_null, "ideal_ms": main_ms / 8,
+            "ms_per_step": sh_ms, "ms_per_step_spread": sh_res_spread, "steps": sh_steps, "kernel_ms": sh_null, "ideal_ms": main_ms / 8,
             "efficiency": (main_ms / 8) / sh_ms, "value": sh_units / (sh_ms * 1e-3),
-            "stream": {"ms_per_step": sh_stream_ms, "passes": sh_passes, "frac_of_resident": sh_ms / sh_stream_ms, "sub_batches": sh_sub,
+            "stream": {"ms_per_step": sh_stream_ms, "ms_per_step_spread": stream_leg.spread, "passes": sh_passes, "frac_of_resident": sh_ms / sh_stream_ms, "sub_batches": sh_sub,
                        "efficiency": (main_ms / 8) / sh_stream_ms},
-            "note": "efficiency = (ms per step of the whole 10 000-block workload on this GPU / 8) / ms per step of the shard: what strong "
+            "note": "ms_per_step of the extra legs is the MEDIAN step of the timed region (min / median / max / mean in ms_per_step_spread); "
+                    "efficiency = (ms per step of the whole 10 000-block workload on this GPU / 8) / ms per step of the shard: what strong "
                     "scaling to eight GPUs can reach before the all-gather; the stream prepares its blocks on usable_cpus // 8 host threads"}
         ctx.set_host_threads(threads)
         del sh_m
-        # ---- c5: the long-block slice of configs[4]
-        nb5, cols5, seqs5, n5, desc5 = CONFIGS["c5"]
-        t0 = time.perf_counter()
-        blocks5 = [b.upper() for b in synth_blocks(nb5, seqs5, cols5, seed=1)]
-        gen5 = time.perf_counter() - t0
-        params5 = api.default_params(sampleN=n5, seed_base=args.seed_base)
-        c5_ms, c5_null, c5_kernel, c5_units, c5_steps, c5_m = resident_leg(api, ctx, blocks5, params5, args.extra_seconds, warmup=1)
-        legs["c5"] = {"workload": f"synthetic MAF {nb5} blocks x {cols5} cols x {seqs5} seqs, --num-samples {n5} ({desc5})",
-                      "value": c5_units / (c5_ms * 1e-3), "unit": "alignment-columns*samples/s", "ms_per_step": c5_ms, "steps": c5_steps,
-                      "generate_s": gen5, "roofline": roofline_object(blocks5, n5, c5_null, c5_kernel, "c5", True)}
-        del c5_m, blocks5
         # ---- mixed: ten row-count classes, ragged lengths, as a stream from host blocks
         import numpy as _np
         from rnacode_amd.synth import synth_block
@@ -571,6 +594,7 @@ def main():
         mixed = [synth_block(rng, int(rng.randint(3, 13)), int(rng.randint(60, 201)), index=i, gaps=True).upper() for i in range(10000)]
         genm = time.perf_counter() - t0
         mx_ms, mx_null, mx_kernel, mx_units, mx_steps, mx_m = resident_leg(api, ctx, mixed, params, args.extra_seconds, warmup=2)
+        mx_res_spread = resident_leg.spread
         classes = len({b.n for b in mixed})
         mx_sub = api.stream_plan(ctx, params, len(mixed), classes)
         # (three warm-up passes: the stream's three batch objects each grow their multi-GB staging areas to the largest sub-batch once)
@@ -578,10 +602,23 @@ def main():
         legs["mixed"] = {"workload": "synthetic MAF 10000 blocks of 3..12 rows x 60..200 cols, --num-samples %d" % args.samples,
                          "row_count_classes": classes, "value": mx_units / (mx_stream_ms * 1e-3), "unit": "alignment-columns*samples/s",
                          "ms_per_step": mx_stream_ms, "passes": mx_passes, "blocks_per_sub_batch": mx_sub, "host_threads": threads,
-                         "resident": {"ms_per_step": mx_ms, "steps": mx_steps, "value": mx_units / (mx_ms * 1e-3)},
-                         "generate_s": genm, "note": "value = the streamed rate (host rc_block arrays -> fitted results on the host)"}
+                         "ms_per_step_spread": stream_leg.spread,
+                         "resident": {"ms_per_step": mx_ms, "steps": mx_steps, "value": mx_units / (mx_ms * 1e-3), "ms_per_step_spread": mx_res_spread},
+                         "generate_s": genm, "note": "value = the streamed rate (host rc_block arrays -> fitted results on the host), from the median pass"}
         del mx_m, mixed
 
+        # ---- c5: the long-block slice of configs[4] (last: 0.6 s launches at the HBM roof; the legs after it ran a few per cent slower)
+        nb5, cols5, seqs5, n5, desc5 = CONFIGS["c5"]
+        t0 = time.perf_counter()
+        blocks5 = [b.upper() for b in synth_blocks(nb5, seqs5, cols5, seed=1)]
+        gen5 = time.perf_counter() - t0
+        params5 = api.default_params(sampleN=n5, seed_base=args.seed_base)
+        c5_ms, c5_null, c5_kernel, c5_units, c5_steps, c5_m = resident_leg(api, ctx, blocks5, params5, args.extra_seconds, warmup=1)
+        legs["c5"] = {"workload": f"synthetic MAF {nb5} blocks x {cols5} cols x {seqs5} seqs, --num-samples {n5} ({desc5})",
+                      "value": c5_units / (c5_ms * 1e-3), "unit": "alignment-columns*samples/s", "ms_per_step": c5_ms, "ms_per_step_spread": resident_leg.spread,
+                      "steps": c5_steps,
+                      "generate_s": gen5, "roofline": roofline_object(blocks5, n5, c5_null, c5_kernel, "c5", True)}
+        del c5_m, blocks5
     if rank == 0:
         null_ms = tk["null"] / args.steps / max(1, nlaunch.get("null", 1))   # average duration of one k_null launch
         desc = CONFIGS[args.config][4]
