@@ -208,7 +208,7 @@ struct rc_ctx {
   int gridCapPerCU = 0;       // RC_GRID_CAP_PER_CU: at most this many k_null workgroups per CU (experiments on cache residency of the code scratch); 0 = what fits
   double splitFactor = 0.5;   // a k_null launch with fewer (block, sample group) items than this fraction of the chip's wavefront slots splits every item into its six strand x frame parts (RC_SPLIT_FACTOR)
   int dualRows = 1;           // RC_DUAL_ROWS=0: never the two-row instantiations of k_null (A/B)
-  long long fatStreamMinBlocks = 1024;   // RC_FAT_STREAM_MIN_BLOCKS: a stream's sub-batch of fat classes takes the two-row path from this many blocks on
+  long long fatStreamMinItems = 16384;   // RC_FAT_STREAM_MIN_ITEMS: a stream's sub-batch of fat classes takes the two-row path from this many (block, 64-sample group) items on: four rounds of the chip's wavefront slots (1024 blocks at n = 1000)
   int nativeFirst = -1;       // RC_NATIVE_FIRST: 1 always queue a batch's native-block kernels in front of its k_null, 0 never (and no two-row k_null for fat classes); -1: for batches that take the fat path (see fat_class)
   int copyResults = 0;        // RC_COPY_RESULTS=1: the small results go back with hipMemcpyAsync instead of k_results_out (A/B)
   int tailSharing = 1;        // k_null: items taken near the end of the queues are shared part by part with workgroups that have run out of work (RC_TAIL_SHARING=0: off)
@@ -395,7 +395,7 @@ int rc_ctx_create(int device, rc_ctx **out) {
   if (const char *e = std::getenv("RC_COPY_RESULTS")) c->copyResults = std::atoi(e) != 0;
   if (const char *e = std::getenv("RC_NATIVE_FIRST")) c->nativeFirst = std::atoi(e) != 0;
   if (const char *e = std::getenv("RC_DUAL_ROWS")) c->dualRows = std::atoi(e) != 0;
-  if (const char *e = std::getenv("RC_FAT_STREAM_MIN_BLOCKS")) c->fatStreamMinBlocks = std::max(0ll, std::atoll(e));
+  if (const char *e = std::getenv("RC_FAT_STREAM_MIN_ITEMS")) c->fatStreamMinItems = std::max(0ll, std::atoll(e));
   if (const char *e = std::getenv("RC_GENERIC_SCRATCH_MB")) c->genericScratchWords = std::max<size_t>(1, static_cast<size_t>(std::atoll(e))) * (1u << 20) / sizeof(uint32_t);
   // non-blocking streams: no implicit ordering against the legacy default stream that a host framework in
   // the same process (torch, RCCL) may be using; the native stream gets the higher priority so that the
@@ -698,7 +698,7 @@ static size_t native_grid(const rc_ctx *c, size_t items, int smax, int mode = 0)
 // ("fat": every class 3 <= N-1 <= 5 with LDS staging; N-1 = 2 needs 95 VGPRs, leaves a quarter of the registers free and is always
 // two-row), whose native-block kernels are queued in front of k_null on the same stream with every wavefront slot to themselves
 // (1.9 ms instead of 2.9 at C3) -- resident batches, and sub-batches of a stream that are long enough for the bubble this leaves at
-// every sub-batch boundary to be paid back (RC_FAT_STREAM_MIN_BLOCKS).  Everything else keeps the one-row instantiations (74 VGPRs)
+// every sub-batch boundary to be paid back (RC_FAT_STREAM_MIN_ITEMS).  Everything else keeps the one-row instantiations (74 VGPRs)
 // and the small kernels beside them.
 static bool fat_class(const rc_batch *b, const rc_ctx *c, int NK, int maxL) {
   if (NK < 3 || NK > kDualRowsMaxNK || b->allExact) return false;
@@ -948,7 +948,7 @@ static int batch_run_async(rc_batch *b, bool streaming = false) {
     for (int bi : kv.second) maxLc = std::max(maxLc, b->meta[bi].L);
     allFat = allFat && kv.first != kGenericClass && fat_class(b, c, kv.first, maxLc);
   }
-  bool fat = allFat && c->nativeFirst != 0 && (!streaming || static_cast<long long>(b->okBlocks.size()) >= c->fatStreamMinBlocks);
+  bool fat = allFat && c->nativeFirst != 0 && (!streaming || static_cast<long long>(b->okBlocks.size()) * groups >= c->fatStreamMinItems);
   if (c->nativeFirst == 1) nativeFirst = true;
   if (fat) nativeFirst = true;
   const int nativeMode = c->serialNative ? 0 : nativeFirst ? 1 : 0;

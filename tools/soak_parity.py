@@ -1,6 +1,7 @@
 """Randomised parity soak: random block shapes, sample counts, seeds and parameters through the HIP path and the
 oracle until the time budget is used up; any difference in per-sample maxima, HSS tables or fit results is printed.
-usage: python tools/soak_parity.py [seconds] [rng_seed] [wide]     wide: 65..300 rows only (the kernels for more than 64 rows)"""
+usage: python tools/soak_parity.py [seconds] [rng_seed] [wide|fat]     wide: 65..300 rows only (the kernels for more than 64 rows);
+       fat: one row count per batch, 3..6 rows, up to 156 columns (the batches that take k_null's two-rows-per-pass instantiations)"""
 import re
 import sys
 import time
@@ -22,6 +23,7 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
+    fat = len(sys.argv) > 3 and sys.argv[3] == "fat"
     ctx = api.Context(0)
     t0 = time.time()
     rounds = blocks_done = bad = paths = 0
@@ -38,9 +40,13 @@ def main():
         elif r < 0.3:
             pars = dict(blosum=90)
         blocks = []
+        fat_n = int(rng.choice([3, 4, 5, 6]))
         for i in range(int(rng.randint(1, 6 if wide else 25))):
             n = int(rng.choice([3, 3, 4, 5, 6, 6, 7, 8, 10, 12, 17, 32, 33, 40, 64, 65, 90, 130]))
             cols = int(rng.choice([9, 12, 30, 45, 60, 90, 120, 150, 200, 301]))
+            if fat:
+                n = fat_n
+                cols = int(rng.choice([9, 12, 30, 45, 60, 90, 99, 120, 150, 156]))
             if wide:
                 n = int(rng.choice([65, 66, 70, 90, 128, 129, 200, 300]))
                 cols = int(rng.choice([9, 30, 60, 99, 120, 150, 200]))
