@@ -594,6 +594,7 @@ def test_two_rows_per_pass_equal_one_row_per_pass_and_the_oracle(monkeypatch):
     cases = {n: [synth_block(rng, n, int(rng.randint(30, 157)), index=i, gaps=True).upper() for i in range(260)] for n in (3, 4, 5, 6)}
     kw = dict(sampleN=600, seed_base=17)   # 2600 (block, 64-sample) items: whole items, not their strand x frame parts
     got = {}
+    monkeypatch.delenv("RC_NATIVE_FIRST", raising=False)   # (0 would forbid the two-row kernel for these classes: the name check below wants it)
     for dual in ("1", "0"):
         monkeypatch.setenv("RC_DUAL_ROWS", dual)
         c = api.Context(0)
