@@ -220,6 +220,8 @@ struct rc_ctx {
   hipStream_t native = nullptr;    // table preparation and native-block kernels: small and latency-bound, they run beside the null sampling
   hipStream_t copy = nullptr;      // host -> device blob copies
   hipStream_t aux = nullptr;       // synchronous helpers (second-stage result copies, backtrack rows, stand-alone fits): never behind queued batches
+  int prioLow = 0, prioHigh = 0;   // stream priorities (compute streams low, the small latency-bound work high)
+  std::mutex streamMutex;          // ctx_stream
   std::vector<hipStream_t> classStreams;   // k_null launches of different row-count classes, when a batch has several
   unsigned seq = 0;
   CodeTables ct62{62}, ct90{90};
@@ -245,6 +247,20 @@ struct rc_ctx {
   std::unique_ptr<Pool> pool;
   std::atomic<int> inflight{0};   // batches between run_async and wait
 };
+
+// the context's streams, created on first use (see rc_ctx_create); which: 0..2 compute, 3 native, 4 copy, 5 aux
+static hipStream_t ctx_stream(rc_ctx *c, int which) {
+  hipStream_t *slot = which < rc_ctx::kComputeStreams ? &c->compute[which] : which == 3 ? &c->native : which == 4 ? &c->copy : &c->aux;
+  std::lock_guard<std::mutex> lk(c->streamMutex);
+  if (!*slot) {
+    (void)hipSetDevice(c->device);
+    if (hipStreamCreateWithPriority(slot, hipStreamNonBlocking, which < rc_ctx::kComputeStreams ? c->prioLow : c->prioHigh) != hipSuccess) *slot = nullptr;
+  }
+  return *slot;
+}
+static hipStream_t stream_native(rc_ctx *c) { return ctx_stream(c, 3); }
+static hipStream_t stream_copy(rc_ctx *c) { return ctx_stream(c, 4); }
+static hipStream_t stream_aux(rc_ctx *c) { return ctx_stream(c, 5); }
 
 // layout of rc_ctx::d_tables
 struct TablePtrs { const uint8_t *pair; const int *pep; const int *blosum; const CodeInfo *info; };
@@ -403,11 +419,11 @@ int rc_ctx_create(int device, rc_ctx **out) {
   // serialises the native-block kernels behind k_null again -- seen under torch.distributed)
   int prioLow = 0, prioHigh = 0;
   HIP_TRY(hipDeviceGetStreamPriorityRange(&prioLow, &prioHigh));
-  for (int x = 0; x < rc_ctx::kComputeStreams; x++) HIP_TRY(hipStreamCreateWithPriority(&c->compute[x], hipStreamNonBlocking, prioLow));
   if (const char *e = std::getenv("RC_COMPUTE_STREAMS")) c->computeStreams = std::max(1, std::min(rc_ctx::kComputeStreams, std::atoi(e)));
-  HIP_TRY(hipStreamCreateWithPriority(&c->native, hipStreamNonBlocking, prioHigh));
-  HIP_TRY(hipStreamCreateWithPriority(&c->copy, hipStreamNonBlocking, prioHigh));
-  HIP_TRY(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, prioHigh));
+  // The streams are created when they are first used (ctx_stream): a HIP stream with a hardware queue of its own costs 10 ms to create,
+  // six of them were 60 ms of every context -- a fifth of the stand-alone driver's run on a 10 000-block input -- and a run of fat batches
+  // (rc_api.cpp, fat_class) never touches the native-block stream, a single batch never the second compute stream.
+  c->prioLow = prioLow; c->prioHigh = prioHigh;
   trace("ctx: streams", nullptr);
   c->serialNative = std::getenv("RC_SERIAL_NATIVE") ? 1 : 0;   // profiling: one kernel at a time, clean per-kernel intervals
   c->stopTwoRoundsMinItems = 4LL * c->numCU * 16;   // the chip filled four times over
@@ -590,7 +606,8 @@ static int batch_upload(rc_batch *b) {
   HIP_TRY(b->dexact.ensure(nn * sizeof(int)));
   HIP_TRY(b->dcounters.ensure(kCntTotal * sizeof(uint32_t)));
   // copy and table kernels share one stream of their own: batch i+1's tables are made while batch i is being scored
-  hipStream_t ps = c->copy;
+  hipStream_t ps = stream_copy(c);
+  if (!ps) return fail(RC_ERR_DEVICE, "hipStreamCreate failed");
   HIP_TRY(hipMemcpyAsync(b->dblob.p, b->hblob.p, b->hostUsed, hipMemcpyHostToDevice, ps));
   HIP_TRY(b->evUp.record(ps));
   HIP_TRY(b->evPrep0.record(ps));
@@ -710,7 +727,8 @@ static int launch_native_block(const RunEnv &R) {
   rc_batch *b = R.b; rc_ctx *c = R.c;
   // ---- native block: sigma -> DP per N-1 class -> scan, on the native stream: these kernels are small and
   // latency-bound, the null sampling fills the chip beside them; the fit waits for both
-  hipStream_t st = R.nativeFirst ? R.cs : c->native;
+  hipStream_t st = R.nativeFirst ? R.cs : stream_native(c);
+  if (!st) return fail(RC_ERR_DEVICE, "hipStreamCreate failed");
   if (!R.nativeFirst) HIP_TRY(hipStreamWaitEvent(st, b->evStart, 0));
   HIP_TRY(b->evN0.record(st));
   NativeArgs na{};
@@ -940,7 +958,8 @@ static int batch_run_async(rc_batch *b, bool streaming = false) {
   const int n = b->n, sampleN = b->par.sampleN;
   const int groups = (sampleN + kWave - 1) / kWave, Spad = groups * kWave;
   b->clamped = 0;
-  hipStream_t cs = c->compute[c->seq++ % static_cast<unsigned>(c->computeStreams)];
+  hipStream_t cs = ctx_stream(c, static_cast<int>(c->seq++ % static_cast<unsigned>(c->computeStreams)));
+  if (!cs) return fail(RC_ERR_DEVICE, "hipStreamCreate failed");
   const uint8_t *blob = b->dblob.as<uint8_t>();
   bool nativeFirst = c->serialNative != 0, allFat = !b->classes.empty();
   for (auto &kv : b->classes) {
@@ -1102,8 +1121,8 @@ static int batch_wait(rc_batch *b) {
       // on the helper stream: the compute streams may already hold the kernels of later batches
       PinBuf more;
       HIP_TRY(more.ensure(sizeof(DevHss) * nrec));
-      HIP_TRY(hipMemcpyAsync(more.p, b->dhssPacked.p, sizeof(DevHss) * nrec, hipMemcpyDeviceToHost, c->aux));
-      HIP_TRY(hipStreamSynchronize(c->aux));
+      HIP_TRY(hipMemcpyAsync(more.p, b->dhssPacked.p, sizeof(DevHss) * nrec, hipMemcpyDeviceToHost, stream_aux(c)));
+      HIP_TRY(hipStreamSynchronize(stream_aux(c)));
       b->hssRec.assign(more.as<DevHss>(), more.as<DevHss>() + nrec);
     } else if (nrec) {
       b->hssRec.assign(b->hpacked.as<DevHss>(), b->hpacked.as<DevHss>() + nrec);
@@ -1147,7 +1166,7 @@ static void trace_device(rc_batch *b) {
   static Event ref;
   static double refHostUs = 0.0;
   if (!ref.e) {
-    if (ref.record(b->ctx->aux) != hipSuccess || hipEventSynchronize(ref) != hipSuccess) return;
+    if (ref.record(stream_aux(b->ctx)) != hipSuccess || hipEventSynchronize(ref) != hipSuccess) return;
     refHostUs = trace_now_us();
     std::fprintf(stderr, "[rc device clock: reference recorded now; a batch finished before it shows negative offsets]\n");
   }
@@ -1512,7 +1531,7 @@ int rc_batch_backtrack(const rc_batch *b, int32_t blk, int32_t strand, int32_t o
   const uint64_t *zw = zwv.data();
   DevBuf d_out;
   HIP_TRY(d_out.ensure(sizeof(float) * NK * 3 * steps));
-  hipStream_t st = c->aux;
+  hipStream_t st = stream_aux(c);
   launch_sk_row(b->dblob.as<uint8_t>(), reinterpret_cast<const DevBlock *>(b->dblob.as<uint8_t>() + b->oDblocks), blk, strand, opt_b, opt_i,
                 d_out.as<float>(), steps, st);
   std::vector<float> sk(static_cast<size_t>(NK) * 3 * steps);
@@ -1735,16 +1754,16 @@ int rc_fit_trees_device(rc_ctx *c, const rc_block *blocks, int32_t n_blocks, cha
     fill();
     for (auto &x : th) x.join();
   }
-  HIP_TRY(hipMemcpyAsync(d_jobs.p, jobs.data(), sizeof(TreeJob) * nj, hipMemcpyHostToDevice, c->aux));
-  HIP_TRY(hipMemcpyAsync(d_in.p, c->treeInPin.p, in_bytes, hipMemcpyHostToDevice, c->aux));
+  HIP_TRY(hipMemcpyAsync(d_jobs.p, jobs.data(), sizeof(TreeJob) * nj, hipMemcpyHostToDevice, stream_aux(c)));
+  HIP_TRY(hipMemcpyAsync(d_in.p, c->treeInPin.p, in_bytes, hipMemcpyHostToDevice, stream_aux(c)));
   for (size_t ch = 0; ch + 1 < chunkStart.size(); ch++) {
     const int q0 = chunkStart[ch], q1 = chunkStart[ch + 1];
     launch_tree_fit(static_cast<const TreeJob *>(d_jobs.p) + q0, q1 - q0, static_cast<const uint8_t *>(d_in.p), static_cast<double *>(d_work.p),
-                    static_cast<TreeOut *>(d_out.p), static_cast<double *>(d_res.p), c->aux);
+                    static_cast<TreeOut *>(d_out.p), static_cast<double *>(d_res.p), stream_aux(c));
   }
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(c->treeResPin.p, d_res.p, sizeof(double) * res_doubles, hipMemcpyDeviceToHost, c->aux));
-  HIP_TRY(hipStreamSynchronize(c->aux));
+  HIP_TRY(hipMemcpyAsync(c->treeResPin.p, d_res.p, sizeof(double) * res_doubles, hipMemcpyDeviceToHost, stream_aux(c)));
+  HIP_TRY(hipStreamSynchronize(stream_aux(c)));
   const double *res = c->treeResPin.as<double>();
   std::atomic<int> done{0};
   {
@@ -1797,9 +1816,9 @@ int rc_evd_fit(rc_ctx *c, const double *x, int32_t n, double *mu, double *lambda
   HIP_TRY(hipMalloc(&d_x, sizeof(double) * n));
   HIP_TRY(hipMalloc(&d_o, sizeof(FitOut)));
   HIP_TRY(hipMemcpy(d_x, x, sizeof(double) * n, hipMemcpyHostToDevice));
-  launch_evd_fit_f64(d_x, n, d_o, c->aux);
+  launch_evd_fit_f64(d_x, n, d_o, stream_aux(c));
   FitOut o;
-  hipError_t e = hipStreamSynchronize(c->aux);
+  hipError_t e = hipStreamSynchronize(stream_aux(c));
   if (e == hipSuccess) e = hipMemcpy(&o, d_o, sizeof o, hipMemcpyDeviceToHost);
   (void)hipFree(d_x); (void)hipFree(d_o);
   if (e != hipSuccess) return fail(RC_ERR_DEVICE, hipGetErrorString(e));
@@ -1813,8 +1832,8 @@ int rc_mt_stream(rc_ctx *c, uint32_t seed, uint32_t *out, int32_t n) {
   HIP_TRY(hipSetDevice(c->device));
   uint32_t *d = nullptr;
   HIP_TRY(hipMalloc(&d, sizeof(uint32_t) * n));
-  launch_mt_stream(seed, 1, n, d, c->aux);
-  hipError_t e = hipStreamSynchronize(c->aux);
+  launch_mt_stream(seed, 1, n, d, stream_aux(c));
+  hipError_t e = hipStreamSynchronize(stream_aux(c));
   if (e == hipSuccess) e = hipMemcpy(out, d, sizeof(uint32_t) * n, hipMemcpyDeviceToHost);
   (void)hipFree(d);
   if (e != hipSuccess) return fail(RC_ERR_DEVICE, hipGetErrorString(e));
