@@ -1184,6 +1184,10 @@ int rc_stream_create(rc_ctx *ctx, const rc_params *par, int32_t depth, rc_stream
   if (par->sampleN < 1) return fail(RC_ERR_ARG, "sampleN must be >= 1");
   rc_stream *s = new rc_stream();
   s->ctx = ctx; s->par = *par; s->depth = depth;
+  // the HIP streams its sub-batches will use, now rather than inside the first submits (10 ms each): a driver creates its rc_stream
+  // while something else is still on the way (the stand-alone driver: the first chunk of tree fits)
+  (void)stream_copy(ctx);
+  for (int x = 0; x < std::min(depth, ctx->computeStreams); x++) (void)ctx_stream(ctx, x);
   *out = s;
   return RC_OK;
 }

@@ -346,8 +346,7 @@ int main(int argc, char **argv) {
     subBlocks = 2048;
   }
   size_t planAt = 0;
-  rc_stream *stream = nullptr;
-  if (rc_stream_create(ctx, &par, 3, &stream) != RC_OK) die(rc_last_error());
+  rc_stream *stream = nullptr;   // (created below, beside the first tree fits: it brings up the HIP streams of the scoring pipeline)
   // per block: room for the longest Newick text -- per tip its name, ':' and a "%f" length, per internal node two brackets, a comma
   // and a length (a "%f" of a length <= 100 has at most 10 characters)
   int cap = 64;
@@ -389,6 +388,7 @@ int main(int argc, char **argv) {
       at += mf;
     }
   });
+  if (rc_stream_create(ctx, &par, 3, &stream) != RC_OK) { if (treeThread.joinable()) treeThread.join(); die(rc_last_error()); }
   auto trees_ready = [&](int upto, bool wait) {   // are the trees of blocks [0, upto) there?
     std::unique_lock<std::mutex> lk(tm);
     if (wait) tcv.wait(lk, [&] { return fitted >= upto; });
