@@ -175,11 +175,9 @@ __device__ __forceinline__ void sample_scan_last(const SampleScan &st, float &be
 // (The instantiations that read their codes from L2 live on occupancy -- 4000 blocks x 150 columns x 9 rows: 49.4 ms at 20 workgroups
 // per CU, 64.0 at 12 -- so those for 6..8 other sequences, 81-85 VGPRs by themselves, are compiled for six wavefronts per SIMD (80
 // VGPRs, 0 / 2 / 5 spilled registers) and ask for the LDS their phase A really needs, not the 8 KB of the largest tree: 24 workgroups
-// per CU instead of 20, 7 / 8 / 9 rows 44.5 -> 41.2, 46.2 -> 43.8, 49.3 -> 47.2 ms.  Those for 10..12, 98-113 VGPRs, for five: 96 VGPRs with 3 / 19 / 27
-// spilled registers, 20 workgroups per CU instead of 16: 11 / 12 / 13 rows 58.4 -> 55.5, 68.8 -> 67.1, 72.3 -> 71.5 ms; the C5 shape, at its
-// HBM roof, is unchanged.)
+// per CU instead of 20, 7 / 8 / 9 rows 44.5 -> 41.2, 46.2 -> 43.8, 49.3 -> 47.2 ms.)
 template <int NK, bool LDSC, bool EXACT, bool DUAL = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!LDSC && !EXACT && NK >= 6 && NK <= 8) ? 6 : (!LDSC && !EXACT && NK >= 10 && NK <= 12) ? 5 : 1))) void k_null(NullArgs A, const uint8_t *__restrict__ blob,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!LDSC && !EXACT && NK >= 6 && NK <= 8) ? 6 : 1))) void k_null(NullArgs A, const uint8_t *__restrict__ blob,
                                              const DevBlock *__restrict__ dblocks, const int *__restrict__ classBlocks,
                                              const uint32_t *__restrict__ flags, const uint32_t *__restrict__ Ustream, const uint8_t *__restrict__ pairTab,
                                              uint32_t *__restrict__ scratch, float *__restrict__ maxima) {
