@@ -172,12 +172,8 @@ __device__ __forceinline__ void sample_scan_last(const SampleScan &st, float &be
 // Read-only inputs are separate __restrict__ kernel parameters (not members of the by-value
 // argument block) so that the compiler may prove them unclobbered and fetch the wave-uniform
 // block tables (z words, tree records, masks) with scalar loads.
-// (The instantiations that read their codes from L2 live on occupancy -- 4000 blocks x 150 columns x 9 rows: 49.4 ms at 20 workgroups
-// per CU, 64.0 at 12 -- so those for 6..8 other sequences, 81-85 VGPRs by themselves, are compiled for six wavefronts per SIMD (80
-// VGPRs, 0 / 2 / 5 spilled registers) and ask for the LDS their phase A really needs, not the 8 KB of the largest tree: 24 workgroups
-// per CU instead of 20, 7 / 8 / 9 rows 44.5 -> 41.2, 46.2 -> 43.8, 49.3 -> 47.2 ms.)
 template <int NK, bool LDSC, bool EXACT, bool DUAL = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!LDSC && !EXACT && NK >= 6 && NK <= 8) ? 6 : 1))) void k_null(NullArgs A, const uint8_t *__restrict__ blob,
+__global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restrict__ blob,
                                              const DevBlock *__restrict__ dblocks, const int *__restrict__ classBlocks,
                                              const uint32_t *__restrict__ flags, const uint32_t *__restrict__ Ustream, const uint8_t *__restrict__ pairTab,
                                              uint32_t *__restrict__ scratch, float *__restrict__ maxima) {
@@ -1069,7 +1065,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!LDSC && !E
 
 // launch / occupancy of one N-1 value, used by the range units
 // dynamic LDS of the instantiations that do not stage codes: phase A's threshold table (64 B per node) + pair table
-template <int NK> constexpr size_t phase_a_lds() { return static_cast<size_t>(2 * (NK + 1)) * 64 + 64 * 64; }   // 2N - 1 nodes x 64 B of thresholds, the codon-pair table
+template <int NK> constexpr size_t phase_a_lds() { return NK < kFastRows ? static_cast<size_t>(kPhaseALds) : static_cast<size_t>(2 * (NK + 1)) * 64 + 64 * 64; }
 
 template <int NK>
 inline int null_occupancy_one(size_t ldsBytes) {
