@@ -99,22 +99,40 @@ def measured_traffic(config, kernel):
 
 
 def roofline_object(blocks, sampleN, null_ms, kernel, config, with_traffic):
-    """The contract's roofline object for one k_null launch of `null_ms` ms over `blocks` (algorithmic work: SURVEY.md section 8d)."""
+    """The contract's roofline object for one k_null launch of `null_ms` ms over `blocks` (algorithmic work: SURVEY.md section 8d).
+    Two roofs are evaluated and `bound` names the one that binds: "valu" -- the FP32 add/max issue peak against the algorithmic
+    flops -- or "hbm" -- the counter-measured HBM-side traffic against 8 TB/s.  The path has no dense contraction (no MFMA) and by the
+    algorithmic bytes it is far from HBM (230-590 flop/B); it only becomes HBM-bound where a kernel re-reads its sigma codes from
+    memory (the long-block shape).  The top-level achieved/peak/unit/frac describe the binding roof; the other one is the sub-object."""
     by, fl = algorithmic_work(blocks, sampleN)
-    ach = by / (null_ms * 1e-3) / 1e9
+    sec = null_ms * 1e-3
+    ach_gbs = by / sec / 1e9
     traffic, src = measured_traffic(config, kernel) if with_traffic else (None, "not the profiled configuration")
-    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_source": src, "kernel": kernel, "kernel_ms": null_ms, "algorithmic_bytes_per_launch": by,
-            "valu": {"achieved_gops": fl / (null_ms * 1e-3) / 1e9, "peak_gops": VALU_PEAK_GOPS,
-                     "frac": fl / (null_ms * 1e-3) / 1e9 / VALU_PEAK_GOPS, "algorithmic_flops_per_launch": fl}}
+    hbm = {"achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": by,
+           "traffic": traffic, "traffic_source": src,
+           "traffic_gbs": None if traffic is None else traffic / sec / 1e9,
+           "traffic_frac_of_peak": None if traffic is None else traffic / sec / 1e9 / HBM_PEAK_GBS,
+           "traffic_over_algorithmic": None if traffic is None else traffic / by}
+    ach_tops = fl / sec / 1e12
+    valu = {"achieved": ach_tops, "peak": VALU_PEAK_GOPS / 1e3, "unit": "TFLOP/s", "frac": ach_tops / (VALU_PEAK_GOPS / 1e3),
+            "algorithmic_flops_per_launch": fl,
+            "peak_definition": "FP32 add/max wave-instruction issue: 256 CU x 4 SIMD x 64 lanes / 2 cycles x 2.4 GHz (no FMA, no packed math in max-plus chains)"}
+    hbm_binds = hbm["traffic_frac_of_peak"] is not None and hbm["traffic_frac_of_peak"] > valu["frac"]
+    top = hbm if hbm_binds else valu
+    return {"bound": "hbm" if hbm_binds else "valu", "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
+            "traffic": traffic, "traffic_source": src, "kernel": kernel, "kernel_ms": null_ms,
+            "binding_rule": "hbm if measured traffic / time / 8 TB/s exceeds the FP32 issue fraction, else valu",
+            "hbm": hbm, "valu": valu}
 
 
-def end_to_end_leg(blocks, sampleN, seed, runs=5):
+def end_to_end_leg(blocks, sampleN, seed, runs=5, repeat=1):
     """SURVEY.md section 8d's metric as the reference's driver would be timed (RNAcode.c:115-228: read -> tree -> models -> score ->
     sample -> print): the native stand-alone driver as a fresh process on a MAF file, trees and kappa fitted on the GPU (no sidecar),
     the tabular listing read from its standard output.  Wall time from exec to the LAST OUTPUT BYTE (end of file on the pipe: the
     driver closes its output when the listing is complete; the kernel then takes another 0.1 s to release the process's GPU
-    resources, reported as wall_s_to_exit).  Runs before this process touches a GPU; a short pause separates the runs."""
+    resources, reported as wall_s_to_exit).  Runs before this process touches a GPU; a short pause separates the runs.
+    repeat > 1: the file holds the blocks `repeat` times over (a 100 000-block file from the 10 000 generated blocks: what the fixed
+    costs -- process start, HIP context, first tree chunk -- amount to on an input of configs[4]'s block count)."""
     from rnacode_amd.synth import to_maf
     exe = os.path.join(ROOT, "rnacode_amd", "rnacode_hip")
     if not os.path.exists(exe):
@@ -122,9 +140,14 @@ def end_to_end_leg(blocks, sampleN, seed, runs=5):
     d = tempfile.mkdtemp(prefix="rc_e2e_")
     maf = os.path.join(d, "in.maf")
     try:
+        text = to_maf(blocks)
         with open(maf, "w") as fh:
-            fh.write(to_maf(blocks))
-        units = sum(b.cols for b in blocks) * sampleN
+            fh.write(text)
+            body = text[text.index("\n") + 1:]      # without the "##maf" header line
+            for _ in range(repeat - 1):
+                fh.write(body)
+        del text
+        units = sum(b.cols for b in blocks) * sampleN * repeat
         walls, exits, stages, hss_lines = [], [], [], 0
         for _ in range(runs):
             time.sleep(0.3)
@@ -145,7 +168,7 @@ def end_to_end_leg(blocks, sampleN, seed, runs=5):
         med = order[runs // 2]
         return {"value": units / walls[med], "unit": "alignment-columns*samples/s", "wall_s_median": walls[med], "wall_s_best": walls[order[0]],
                 "wall_s_all": walls, "wall_s_to_exit_all": exits, "stages_of_median_run": stages[med], "stages_of_best_run": stages[order[0]],
-                "hss_lines": hss_lines, "maf_bytes": os.path.getsize(maf), "blocks": len(blocks), "samples": sampleN, "runs": runs,
+                "hss_lines": hss_lines, "maf_bytes": os.path.getsize(maf), "blocks": len(blocks) * repeat, "samples": sampleN, "runs": runs,
                 "includes": "process start, library load, HIP context, MAF parsing, tree + kappa fits on the GPU (k_tree_fit, no sidecar), block "
                             "preparation, scoring, sampling, fits, p-values, the tabular listing written to standard output and read by this process",
                 "note": "fresh process per run, 0.3 s apart; wall = exec to end of the listing on the pipe; value = units / median wall"}
@@ -153,6 +176,69 @@ def end_to_end_leg(blocks, sampleN, seed, runs=5):
         if os.path.exists(maf):
             os.unlink(maf)
         os.rmdir(d)
+
+
+FILE_LEGS = {
+    # BASELINE.json configs[0] and [1]: the two inputs the reference ships, scored with the trees and kappa its own PhyML step
+    # gave (the sidecar fields of the committed goldens -- data, the reference itself is not read at run time)
+    "c1": ("coding_aln_n100", "examples/coding.aln (ClustalW, 8 rows x 137 cols) --num-samples 100 (BASELINE.json configs[0])"),
+    "c2": ("genomic_preprocessed_n1000", "examples/genomic-preprocessed.maf (34 blocks, 33 scored) --num-samples 1000 (BASELINE.json configs[1])"),
+}
+
+
+def golden_blocks(name):
+    """(blocks, samples, seed_base, params) of a committed fixture under tests/golden/."""
+    import gzip
+    from rnacode_amd.alnio import AlnBlock, AlnRow
+    with gzip.open(os.path.join(ROOT, "tests", "golden", name + ".json.gz"), "rb") as fh:
+        doc = json.loads(fh.read().decode())
+    blocks = []
+    for e in doc["blocks"]:
+        inp, ref = e["input"], e["ref"]
+        rows = [AlnRow(r["name"], r["seq"], r["start"], r["length"], r["strand"], r["full_length"]) for r in inp["rows"]]
+        blocks.append(AlnBlock(rows, inp["id"], ref.get("tree", inp.get("tree")), ref.get("kappa", inp.get("kappa"))).upper())
+    return blocks, int(doc["samples"]), int(doc["seed_base"]), dict(doc.get("params") or {})
+
+
+def file_leg(api, ctx, key, min_s=1.0):
+    """Latency of one shipped input file, trees given: (a) as ONE batch through rc_batch_* (create = host preparation + upload + table
+    kernels, run, HSS lists with p-values), (b) block by block in the order the reference's main loop makes its calls through the shim
+    of integration/score_hip_shim.c (RNAcode.c:164-216: getModels -> scoreAln -> getExtremeValuePars per block, each block a batch of
+    one).  The footer the reference prints (RNAcode.c:225-228) times the same span plus file parsing and PhyML."""
+    name, desc = FILE_LEGS[key]
+    blocks, n, seed, pk = golden_blocks(name)
+    params = api.default_params(sampleN=n, seed_base=seed, **pk)
+    scored = [b for b in blocks if b.tree is not None and b.n >= 3]
+    units = sum(b.cols for b in scored) * n
+
+    def as_batch():
+        batch = api.Batch(ctx, blocks, params).run()
+        for i in range(batch.n):
+            if batch.status(i) == api.RC_OK:
+                batch.scoreAln(i)
+        batch.close()
+
+    def per_block():
+        for b in scored:
+            batch = api.Batch(ctx, [b], params)      # make_batch (getModels, first call)
+            batch.getModels(0)
+            batch.run()                              # scoreAln
+            batch.scoreAln(0)
+            batch.getExtremeValuePars(0)             # getExtremeValuePars
+            batch.close()
+
+    out = {"workload": desc, "blocks": len(blocks), "scored_blocks": len(scored), "samples": n, "units": units, "unit": "alignment-columns*samples/s"}
+    for label, fn in (("batch", as_batch), ("per_block_shim_sequence", per_block)):
+        fn()
+        dt, k = timed_region(fn, min_s)
+        sp = spread()
+        out[label] = {"ms_per_file": sp["median"], "ms_per_file_spread": sp, "files": k, "value": units / (sp["median"] * 1e-3)}
+    out["value"] = out["batch"]["value"]
+    out["ms_per_file"] = out["batch"]["ms_per_file"]
+    out["note"] = ("latency per file with a warm context, trees and kappa from the fixture (the reference's own PhyML results); value = "
+                   "units / median latency of the one-batch form; these inputs cannot fill one GPU (33 blocks x 16 sample groups = 528 "
+                   "work items on 4096 wavefront slots)")
+    return out, scored, n, seed
 
 
 LAST_STEP_MS = []   # per-step times of the last timed_region (diagnostics: a mean hides a stalled step)
@@ -229,54 +315,130 @@ def stream_leg(api, ctx, m, params, sub_blocks, min_s, depth=3, warmup=2):
     return stream_leg.spread["median"], n   # the median pass, see resident_leg
 
 
-def cpu_baseline(blocks, sampleN, seed, target_s=12.0):
+def continuous_leg(api, ctx, m, n_blocks, params, first_sizes, steady, min_s, depth=3):
+    """The blocks of `m` submitted over and over as ONE stream for about min_s seconds: the first pass in the ramped sub-batches
+    `first_sizes` (a cold pipeline), every later pass in sub-batches of `steady` blocks (the previous pass's last sub-batch is still in
+    flight when the next pass starts, so nothing has to start early).  (ms per pass over the whole region, fill and drain included; passes)"""
+    st = api.Stream(ctx, params, depth)
+    first = []
+    lo = 0
+    for sz in first_sizes:
+        first.append((lo, lo + sz)); lo += sz
+    later = [(lo, min(n_blocks, lo + steady)) for lo in range(0, n_blocks, steady)]
+
+    def run(seconds):
+        sent_passes = 0
+        queue = list(first)
+        gc.collect()
+        gc.disable()
+        try:
+            t0 = time.perf_counter()
+            while True:
+                if not queue:
+                    if time.perf_counter() - t0 >= seconds and sent_passes >= 3:
+                        break
+                    queue = list(later)
+                while queue and st.pending < st.depth:
+                    a, b = queue.pop(0)
+                    st.submit(m, a, b)
+                    if not queue:
+                        sent_passes += 1
+                sb = st.next()
+                sb.fits()
+                sb.close()
+            while st.pending:
+                sb = st.next()
+                sb.fits()
+                sb.close()
+            return time.perf_counter() - t0, sent_passes
+        finally:
+            gc.enable()
+
+    run(0.2)                      # buffers grown, kernels loaded
+    dt, passes = run(min_s)
+    st.close()
+    return dt / passes * 1e3, passes
+
+
+def _harness_path():
+    return os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+
+
+def _run_reference(sub, n, seed):
+    """Wall seconds of the unmodified reference objects (oracle/_ref/ref_harness) on the blocks `sub` at n samples, one thread."""
+    from rnacode_amd.alnio import write_harness_blocks
+    with tempfile.NamedTemporaryFile("w", suffix=".blk", delete=False) as fh:
+        path = fh.name
+    try:
+        write_harness_blocks(sub, path)
+        t0 = time.perf_counter()
+        subprocess.check_output([_harness_path(), path, "--samples", str(n), "--seed", str(seed), "--no-backtrack", "--no-digest"])
+        return time.perf_counter() - t0
+    finally:
+        os.unlink(path)
+
+
+def _run_port(sub, n, seed):
+    from oracle import binding as ob
+    t0 = time.perf_counter()
+    for b in sub:
+        ob.run_block([r.seq for r in b.rows], [r.name for r in b.rows], b.rows[0].start, b.rows[0].length,
+                     b.tree, b.kappa, ob.default_params(n), seed)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(blocks, sampleN, seed, target_s=12.0, max_n=None, what="the workload"):
     """The unmodified reference objects (oracle/_ref/ref_harness, kind "reference") on a bounded
     sample of the same workload, single thread (the reference has no threading).  The sample is sized
     from a two-block probe so that it takes about target_s seconds on whatever host this runs on.
+    max_n bounds the sample count of the run itself (C5's n = 10 000 takes a minute per block on one core): the rate
+    is per (column x sample) and the null loop is linear in n (score.c:1004-1048), which `sample` then states.
     Falls back to the oracle restatement (kind "port") only if the harness binary did not travel."""
-    harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
-    from rnacode_amd.alnio import write_harness_blocks
-
-    def run_reference(sub):
-        with tempfile.NamedTemporaryFile("w", suffix=".blk", delete=False) as fh:
-            path = fh.name
-        try:
-            write_harness_blocks(sub, path)
-            t0 = time.perf_counter()
-            subprocess.check_output([harness, path, "--samples", str(sampleN), "--seed", str(seed), "--no-backtrack"])
-            return time.perf_counter() - t0
-        finally:
-            os.unlink(path)
-
-    def run_port(sub):
-        from oracle import binding as ob
-        t0 = time.perf_counter()
-        for b in sub:
-            ob.run_block([r.seq for r in b.rows], [r.name for r in b.rows], b.rows[0].start, b.rows[0].length,
-                         b.tree, b.kappa, ob.default_params(sampleN), seed)
-        return time.perf_counter() - t0
-
-    kind, run = ("reference", run_reference) if os.path.exists(harness) else ("port", run_port)
-    probe_n = min(sampleN, 1000)
-    t0 = time.perf_counter()
-    if kind == "reference":   # probe at a bounded sample count (C5: n = 10 000 would take a minute per block)
-        with tempfile.NamedTemporaryFile("w", suffix=".blk", delete=False) as fh:
-            path = fh.name
-        try:
-            write_harness_blocks(blocks[:2], path)
-            subprocess.check_output([harness, path, "--samples", str(probe_n), "--seed", str(seed), "--no-backtrack"])
-        finally:
-            os.unlink(path)
-        probe = (time.perf_counter() - t0) / 2.0 * (sampleN / probe_n)
-    else:
-        probe = run(blocks[:2]) / 2.0
+    kind, run = ("reference", _run_reference) if os.path.exists(_harness_path()) else ("port", _run_port)
+    n_run = min(sampleN, max_n) if max_n else sampleN
+    probe_n = min(n_run, 1000 if kind == "reference" else n_run)
+    probe = run(blocks[:2], probe_n, seed) / 2.0 * (n_run / probe_n)
     nblk = max(1, min(len(blocks), int(target_s / max(probe, 1e-3))))
     sub = blocks[:nblk]
-    dt = run(sub)
-    units = sum(b.cols for b in sub) * sampleN
-    return dict(value=units / dt, unit="alignment-columns*samples/s", cores=1, kind=kind,
-                sample=f"first {nblk} blocks of the workload at n={sampleN}, {dt:.1f} s; tree and kappa given to the harness, "
+    dt = run(sub, n_run, seed)
+    units = sum(b.cols for b in sub) * n_run
+    cut = "" if n_run == sampleN else f" (of the workload's {sampleN}: the sampling loop is linear in n)"
+    return dict(value=units / dt, unit="alignment-columns*samples/s", cores=1, kind=kind, blocks=nblk, seconds=dt,
+                sample=f"first {nblk} blocks of {what} at n={n_run}{cut}, {dt:.1f} s; tree and kappa given to the harness, "
                        f"so PhyML's share (1-2 % of the reference's run time, SURVEY.md section 6) is not in it")
+
+
+def cpu_baseline_all_cores(blocks, sampleN, seed, per_core_blocks, cores):
+    """BASELINE.md section 3.3 / SURVEY.md section 8d(ii): the reference has no threads, but blocks are independent, so the fair
+    many-core figure is one reference process per usable core over a split block list.  Core c gets blocks
+    [c * per_core_blocks, (c + 1) * per_core_blocks) of the workload; wall time = start of the first process to the exit of the last."""
+    from rnacode_amd.alnio import write_harness_blocks
+    if not os.path.exists(_harness_path()):
+        return {"error": "oracle/_ref/ref_harness did not travel: no all-cores reference baseline"}
+    cores = max(1, min(cores, len(blocks) // max(1, per_core_blocks)))
+    d = tempfile.mkdtemp(prefix="rc_cpu_")
+    paths = []
+    try:
+        for c in range(cores):
+            paths.append(os.path.join(d, f"part{c}.blk"))
+            write_harness_blocks(blocks[c * per_core_blocks:(c + 1) * per_core_blocks], paths[-1])
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([_harness_path(), p, "--samples", str(sampleN), "--seed", str(seed), "--no-backtrack", "--no-digest"],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for p in paths]
+        rcs = [p.wait() for p in procs]
+        dt = time.perf_counter() - t0
+        if any(rcs):
+            return {"error": f"a reference process exited with {max(rcs)}"}
+        sub = blocks[:cores * per_core_blocks]
+        units = sum(b.cols for b in sub) * sampleN
+        return dict(value=units / dt, unit="alignment-columns*samples/s", cores=cores, kind="reference", blocks=len(sub), seconds=dt,
+                    sample=f"{cores} reference processes side by side (one per usable CPU of this host), {per_core_blocks} blocks each = the first "
+                           f"{len(sub)} blocks of the workload at n={sampleN}, {dt:.1f} s of wall time; tree and kappa given")
+    finally:
+        for p in paths:
+            if os.path.exists(p):
+                os.unlink(p)
+        os.rmdir(d)
 
 
 def free_port():
@@ -307,8 +469,13 @@ def parse_args():
                          "block, written by the kernel straight into the gathered tensor) or only the per-block fit results "
                          "(16 B per block: enough for p-values, since every rank fits its own blocks on the device)")
     ap.add_argument("--no-overlap", action="store_true",
-                    help="N > 1: wait for every step's all-gather before the next step starts (default: step i's gather runs over "
-                         "xGMI while step i + 1 is scored; all of them are complete when the timed region ends)")
+                    help="N > 1: wait for every step's all-gather before the next step starts")
+    ap.add_argument("--overlap", action="store_true",
+                    help="N > 1: step i's gather runs over xGMI while step i + 1 is scored; all of them are complete when the timed region "
+                         "ends.  Default (neither flag): both orders are timed during the warm-up and the faster one runs the timed region "
+                         "(RCCL's all-gather is a kernel of its own: beside a k_null that holds every register of a SIMD it may cost more "
+                         "than it hides; config.exchange reports both timings and the choice)")
+    ap.add_argument("--ab-steps", type=int, default=0, help="steps per order in that warm-up comparison (0: max(3, --warmup))")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
                     help="strong (default): --blocks in total, split across the ranks (BASELINE configs[3]); weak: --blocks per GPU")
     ap.add_argument("--no-weak", action="store_true", help="N > 1, strong scaling: skip the extra weak-scaling measurement")
@@ -359,6 +526,12 @@ def main():
                 local_rank %= ndev
                 coll_dev = f"cuda:{local_rank}"
             torch.cuda.set_device(local_rank)
+            # The path's one collective moves 5 MB per rank (configs[3]).  RCCL's all-gather is a CU kernel with one workgroup per
+            # channel; its default channel count (tuned for GB-sized tensors) would put tens of workgroups beside k_null, whose
+            # two-row instantiation holds every VGPR of the SIMDs it runs on.  Two channels keep the gather on one or two CUs; the
+            # ring is per-link bound at this size anyway.  An explicit setting in the environment wins.
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", "2")
+            os.environ.setdefault("NCCL_MIN_NCHANNELS", "1")
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import numpy as np
@@ -382,11 +555,45 @@ def main():
     default_workload = (args.blocks, args.cols, args.seqs, args.samples) == CONFIGS[args.config][:4]
     extras = single and not args.no_extra and default_workload and args.config == "c3"
     cpu = None
+    cpu_all = None
+    legs = {}
+    mixed = blocks5 = None
+    genm = gen5 = 0.0
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if extras:
+        # the other workloads of the extra legs, generated now: their CPU baselines run before this process creates its HIP context
+        import numpy as _np
+        from rnacode_amd.synth import synth_block
+        rng = _np.random.RandomState(5)
+        t0 = time.perf_counter()
+        mixed = [synth_block(rng, int(rng.randint(3, 13)), int(rng.randint(60, 201)), index=i, gaps=True).upper() for i in range(10000)]
+        genm = time.perf_counter() - t0
+        nb5, cols5, seqs5, n5, desc5 = CONFIGS["c5"]
+        t0 = time.perf_counter()
+        blocks5 = [b.upper() for b in synth_blocks(nb5, seqs5, cols5, seed=1)]
+        gen5 = time.perf_counter() - t0
     if single and not args.no_cpu_baseline:
         cpu = cpu_baseline(blocks, args.samples, args.seed_base)
-    legs = {}
+        if extras and "blocks" in cpu:
+            try:   # the cgroup quota, where there is one (what rc_host_cpus reports as well)
+                with open("/sys/fs/cgroup/cpu.max") as fh:
+                    q, per = fh.read().split()[:2]
+                    if q != "max":
+                        usable = max(1, min(usable, -(-int(q) // int(per))))
+            except Exception:   # noqa: BLE001
+                pass
+            cpu_all = cpu_baseline_all_cores(blocks, args.samples, args.seed_base, cpu["blocks"], usable)
+            legs["cpu_baselines"] = {
+                "mixed": cpu_baseline(mixed, args.samples, args.seed_base, target_s=8.0, what="the mixed workload"),
+                "c5": cpu_baseline(blocks5, CONFIGS["c5"][3], args.seed_base, target_s=8.0, max_n=1000, what="the c5 workload"),
+            }
+            for key, (gname, _) in FILE_LEGS.items():
+                gb, gn, gseed, _pk = golden_blocks(gname)
+                gb = [b for b in gb if b.tree is not None and b.n >= 3]
+                legs["cpu_baselines"][key] = cpu_baseline(gb, gn, gseed, target_s=8.0, what=f"tests/golden/{gname}")
     if extras:
         legs["end_to_end"] = end_to_end_leg(blocks, args.samples, args.seed_base)
+        legs["end_to_end_100k"] = end_to_end_leg(blocks, args.samples, args.seed_base, runs=3, repeat=10)
 
     ctx = api.Context(local_rank)
     cpus = api.lib().rc_host_cpus()
@@ -402,24 +609,35 @@ def main():
 
     gathered = None
     mine = None
-    # The exchange overlapped with the next step (equal shards, maxima, RCCL): two source tensors alternate, step i's all-gather is
-    # started without waiting for it, and the tensor is written again (step i + 2) only after that gather has read it.
+    # The exchange, two orders (equal shards, maxima, RCCL):
+    #   overlapped -- two source tensors alternate, step i's all-gather is started without waiting for it and runs while step i + 1
+    #                 is scored; a tensor is written again (step i + 2) only after the gather that read it has finished;
+    #   synchronous -- every step waits for its gather.
+    # Which one is faster depends on what RCCL's gather kernel costs beside k_null (see --overlap): unless forced, both are timed during
+    # the warm-up and the faster one runs the timed region (`mode`).
     overlap = None
+    mode = {"overlap": False}
     step_no = 0
+    can_overlap = multi and args.exchange == "maxima" and coll_dev != "cpu" and len(set(counts)) == 1
+    if os.environ.get("RC_BENCH_TEST_OVERLAP_ON_CPU") and multi and args.exchange == "maxima" and len(set(counts)) == 1:
+        can_overlap = True   # test hook: the overlapped order over gloo (CPU tensors), so that a box without N GPUs covers both branches
     if multi and args.exchange == "maxima":
-        if not args.no_overlap and coll_dev != "cpu" and len(set(counts)) == 1:
-            overlap = rd.OverlappedGather(len(blocks), args.samples, f"cuda:{local_rank}")
+        dev = f"cuda:{local_rank}"
+        if can_overlap and not args.no_overlap:
+            overlap = rd.OverlappedGather(len(blocks), args.samples, dev, stage_on_cpu=(coll_dev == "cpu"))
             mine = overlap.src[0]
+            mode["overlap"] = True
         else:
-            mine = torch.empty((len(blocks), args.samples), dtype=torch.float32, device=f"cuda:{local_rank}")
+            mine = torch.empty((len(blocks), args.samples), dtype=torch.float32, device=dev)
         batch.bind_maxima(mine.data_ptr())
 
-    def exchange(fit_rows):
+    def exchange(fit_rows, src=None):
         """The path's one exchange (RCCL over xGMI): results of all blocks on every rank.  Synchronised before it
         returns: the next step overwrites the gathered buffer's source on the library's own streams."""
         nonlocal gathered
         if args.exchange == "maxima":
-            gathered = rd.all_gather_maxima(mine if coll_dev != "cpu" else mine.cpu(), counts)
+            src = mine if src is None else src
+            gathered = rd.all_gather_maxima(src if coll_dev != "cpu" else src.cpu(), counts)
         else:
             fits = torch.from_numpy(fit_rows).to(coll_dev, non_blocking=True)
             gathered = rd.all_gather_fits(fits, counts)
@@ -429,9 +647,13 @@ def main():
     def resident_step():
         nonlocal step_no
         if overlap is not None:
-            batch.bind_maxima(overlap.source(step_no).data_ptr())   # (waits for the gather of two steps ago, long done)
-            batch.run()                  # synchronous: this step's maxima are complete in the tensor
-            overlap.launch(step_no)      # their all-gather runs while the next step is scored
+            src = overlap.source(step_no)    # (waits for the gather of two steps ago, long done)
+            batch.bind_maxima(src.data_ptr())
+            batch.run()                      # synchronous: this step's maxima are complete in the tensor
+            if mode["overlap"]:
+                overlap.launch(step_no)      # their all-gather runs while the next step is scored
+            else:
+                exchange(None, src)
             step_no += 1
             return
         batch.run()                      # synchronous: kernels done, small results on the host
@@ -455,7 +677,10 @@ def main():
             rows.append(sb.fits())       # (evd_rc, mu, lambda, better) per block: what a caller needs for p-values
             sb.close()                   # buffers back to the stream
         if overlap is not None:
-            overlap.launch(step_no)
+            if mode["overlap"]:
+                overlap.launch(step_no)
+            else:
+                exchange(None, src)
             step_no += 1
         elif multi:
             exchange(np.concatenate(rows) if args.exchange == "fits" else None)
@@ -466,16 +691,57 @@ def main():
         if multi:
             if overlap is not None:          # every all-gather started so far is complete before the clock is read
                 g = overlap.finish()
-                if g is not None:
+                if g is not None and mode["overlap"]:
                     gathered = g
-            torch.cuda.synchronize()
+            if coll_dev != "cpu":
+                torch.cuda.synchronize()
             dist.barrier()
-            torch.cuda.synchronize()
+            if coll_dev != "cpu":
+                torch.cuda.synchronize()
 
     if multi:   # RCCL's first collective builds its rings: keep that out of the timed steps even with --warmup 0
         probe = torch.zeros((1, 4), dtype=torch.float32, device=coll_dev)
         rd.all_gather_rows(probe, [1] * world)
         sync()
+
+    # ---- which order of the exchange?  k steps of each between barriers, the slowest rank's time decides (every rank takes the same branch)
+    exchange_ab = None
+    if overlap is not None and not args.overlap:
+        k = args.ab_steps or max(3, args.warmup)
+        t_ab = {}
+        for name, flag in (("synchronous", False), ("overlapped", True), ("synchronous_again", False)):
+            mode["overlap"] = flag
+            resident_step()              # one untimed step per order: its first gather may still build something
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                resident_step()
+            sync()
+            t_ab[name] = rd.max_over_ranks((time.perf_counter() - t0) / k * 1e3, device=coll_dev)
+        t_sync = min(t_ab["synchronous"], t_ab["synchronous_again"])   # the second run of it guards against a warm-up effect in the first
+        mode["overlap"] = bool(t_ab["overlapped"] < t_sync)
+        exchange_ab = {"ms_per_step_synchronous": t_sync, "ms_per_step_overlapped": t_ab["overlapped"], "steps_each": k,
+                       "all_timings_ms": t_ab, "chosen": "overlapped" if mode["overlap"] else "synchronous"}
+    elif overlap is not None:
+        exchange_ab = {"chosen": "overlapped", "forced": "--overlap"}
+    elif multi and args.exchange == "maxima":
+        exchange_ab = {"chosen": "synchronous", "forced": "--no-overlap" if args.no_overlap else "ragged shards or a CPU backend"}
+
+    # ---- the devices the ranks sit on: the SCALE record must show N distinct GPUs
+    devices_seen = None
+    if multi:
+        me = {"rank": rank, "local_rank": local_rank, "host": socket.gethostname()}
+        try:
+            pr = torch.cuda.get_device_properties(local_rank)
+            me["name"] = pr.name
+            me["uuid"] = str(getattr(pr, "uuid", "")) or None
+            me["pci"] = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
+        except Exception as e:   # noqa: BLE001
+            me["error"] = repr(e)
+        seen = [None] * dist.get_world_size()
+        dist.all_gather_object(seen, me)
+        ids = [(d.get("host"), d.get("uuid") or d.get("pci") or d.get("local_rank")) for d in seen]
+        devices_seen = {"n_ranks_seen": dist.get_world_size(), "distinct_devices": len(set(ids)), "ranks": seen}
 
     def timed(step, collect_timing):
         for _ in range(args.warmup):
@@ -567,6 +833,9 @@ def main():
     kernel_name = batch.null_kernel()
     if extras:
         main_ms = elapsed / args.steps * 1e3
+        # ---- c1, c2: the two inputs the reference ships (BASELINE.json configs[0], [1]), latency per file
+        for key in FILE_LEGS:
+            legs[key], _, _, _ = file_leg(api, ctx, key)
         # ---- shard: what ONE of eight ranks holds under configs[3] (strong scaling), with an eighth of the host's CPUs
         lo, hi = rd.shard_range(len(blocks), 0, 8)
         t8 = max(1, cpus // 8)
@@ -575,24 +844,25 @@ def main():
         sh_sub = api.stream_plan(ctx, params, hi - lo, 1)
         sh_res_spread = resident_leg.spread
         sh_stream_ms, sh_passes = stream_leg(api, ctx, sh_m, params, sh_sub, args.extra_seconds)
+        sh_stream_spread = stream_leg.spread
+        sh_cont_ms, sh_cont_passes = continuous_leg(api, ctx, sh_m, hi - lo, params, sh_sub, hi - lo, args.extra_seconds)
         legs["shard"] = {
             "blocks": hi - lo, "of": len(blocks), "ranks": 8, "host_threads": t8, "usable_cpus": cpus,
             "ms_per_step": sh_ms, "ms_per_step_spread": sh_res_spread, "steps": sh_steps, "kernel_ms": sh_null, "ideal_ms": main_ms / 8,
             "efficiency": (main_ms / 8) / sh_ms, "value": sh_units / (sh_ms * 1e-3),
-            "stream": {"ms_per_step": sh_stream_ms, "ms_per_step_spread": stream_leg.spread, "passes": sh_passes, "frac_of_resident": sh_ms / sh_stream_ms, "sub_batches": sh_sub,
-                       "efficiency": (main_ms / 8) / sh_stream_ms},
+            "stream": {"ms_per_step": sh_stream_ms, "ms_per_step_spread": sh_stream_spread, "passes": sh_passes, "frac_of_resident": sh_ms / sh_stream_ms, "sub_batches": sh_sub,
+                       "efficiency": (main_ms / 8) / sh_stream_ms,
+                       "continuous": {"ms_per_step": sh_cont_ms, "passes": sh_cont_passes, "frac_of_resident": sh_ms / sh_cont_ms,
+                                      "efficiency": (main_ms / 8) / sh_cont_ms, "sub_batches_first_pass": sh_sub, "sub_batch_later_passes": hi - lo,
+                                      "note": "the shard's blocks submitted pass after pass as ONE stream (what a rank sees on a long input): the "
+                                              "pipeline fills once, every later pass is one sub-batch queued while its predecessor is scored; "
+                                              "ms per pass = whole region / passes, fill and drain included"}},
             "note": "ms_per_step of the extra legs is the MEDIAN step of the timed region (min / median / max / mean in ms_per_step_spread); "
                     "efficiency = (ms per step of the whole 10 000-block workload on this GPU / 8) / ms per step of the shard: what strong "
                     "scaling to eight GPUs can reach before the all-gather; the stream prepares its blocks on usable_cpus // 8 host threads"}
         ctx.set_host_threads(threads)
         del sh_m
         # ---- mixed: ten row-count classes, ragged lengths, as a stream from host blocks
-        import numpy as _np
-        from rnacode_amd.synth import synth_block
-        rng = _np.random.RandomState(5)
-        t0 = time.perf_counter()
-        mixed = [synth_block(rng, int(rng.randint(3, 13)), int(rng.randint(60, 201)), index=i, gaps=True).upper() for i in range(10000)]
-        genm = time.perf_counter() - t0
         mx_ms, mx_null, mx_kernel, mx_units, mx_steps, mx_m = resident_leg(api, ctx, mixed, params, args.extra_seconds, warmup=2)
         mx_res_spread = resident_leg.spread
         classes = len({b.n for b in mixed})
@@ -608,10 +878,6 @@ def main():
         del mx_m, mixed
 
         # ---- c5: the long-block slice of configs[4] (last: 0.6 s launches at the HBM roof; the legs after it ran a few per cent slower)
-        nb5, cols5, seqs5, n5, desc5 = CONFIGS["c5"]
-        t0 = time.perf_counter()
-        blocks5 = [b.upper() for b in synth_blocks(nb5, seqs5, cols5, seed=1)]
-        gen5 = time.perf_counter() - t0
         params5 = api.default_params(sampleN=n5, seed_base=args.seed_base)
         c5_ms, c5_null, c5_kernel, c5_units, c5_steps, c5_m = resident_leg(api, ctx, blocks5, params5, args.extra_seconds, warmup=1)
         legs["c5"] = {"workload": f"synthetic MAF {nb5} blocks x {cols5} cols x {seqs5} seqs, --num-samples {n5} ({desc5})",
@@ -641,7 +907,7 @@ def main():
                        "blocks_per_gpu": len(blocks), "cols": args.cols, "seqs": args.seqs, "samples": args.samples,
                        "seed_base": args.seed_base, "sharding": f"blocks x{world}",
                        "exchange": (("all-gather of " + args.exchange + (", step i's gather overlapped with the scoring of step i + 1 (all complete "
-                                     "inside the timed region)" if overlap is not None else "")) if multi else "none")},
+                                     "inside the timed region)" if (overlap is not None and mode["overlap"]) else ", every step waits for its gather")) if multi else "none")},
             "value_definition": "resident: inputs in HBM when the timed region starts (bench contract); the host-inclusive pipeline is stream.value",
             "roofline": roofline_object(blocks, args.samples, null_ms, kernel_name, args.config, default_workload and world == 1),
             "device_ms_per_step": {k: v / args.steps for k, v in tk.items()},
@@ -675,6 +941,24 @@ def main():
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]
+        per_leg = legs.pop("cpu_baselines", None)
+        if per_leg:
+            for k, v in per_leg.items():
+                if k in legs and isinstance(legs[k], dict):
+                    legs[k]["cpu_baseline"] = v
+                    if "value" in v and legs[k].get("value"):
+                        legs[k]["speedup_vs_cpu_baseline"] = legs[k]["value"] / v["value"]
+        if cpu_all is not None:
+            out["cpu_baseline_all_cores"] = cpu_all
+            if "value" in cpu_all:
+                out["speedup_vs_cpu_baseline_all_cores"] = value / cpu_all["value"]
+        if devices_seen is not None:
+            out["n_ranks_seen"] = devices_seen["n_ranks_seen"]
+            out["devices"] = devices_seen
+        if multi and coll_dev != "cpu":
+            out["config"]["rccl_env"] = {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS")}
+        if exchange_ab is not None:
+            out["config"]["exchange_ab"] = exchange_ab
         for k, v in legs.items():
             out[k] = v
         print(json.dumps(out))

@@ -32,9 +32,10 @@ extern "C" {
 /* Two further bounds on a block's size.  (1) Device memory: the MT19937 streams of a block take 4 bytes x (2 rows - 1) x columns x
  * samples (padded to 64); a block for which that exceeds a quarter of the device memory (MI355X: rows x columns x samples > ~9e9,
  * e.g. 500 rows x 18 000 columns at 1000 samples) gets RC_ERR_UNSUPPORTED with a reason, the other blocks of the batch are scored.
- * (2) Bit parity of the base frequencies: the reference counts residues in float counters, which stop at 2^24 (score.c:255-280);
- * the library reproduces that saturation, so frequencies match the reference for any size, but such blocks (more than 16.7 million
- * residues) are beyond (1) for any useful sample count anyway. */
+ * (2) Bit parity of the base frequencies: the reference counts each of the four residues in a float counter, which stops at 2^24,
+ * and divides by an integer total converted to float once (score.c:255-280); the library reproduces both (counts clamped to 2^24,
+ * the total unclamped), so frequencies match the reference for any size -- a block only gets there with more than 16.7 million
+ * residues of one kind. */
 
 /* Scoring parameters: the members of `parameters pars` (src/RNAcode.h:29-54) that the
  * scoring path reads (score.c:415,419,508-533,842,992,1040), plus the seed base that

@@ -66,27 +66,44 @@ struct Event {
 struct Retired {
   std::mutex m;
   std::vector<std::pair<void *, bool>> list;   // pointer, pinned host memory?
-  void add(void *p, bool host) { std::lock_guard<std::mutex> lk(m); list.emplace_back(p, host); }
+  size_t bytes = 0;
+  void add(void *p, bool host, size_t n) { std::lock_guard<std::mutex> lk(m); list.emplace_back(p, host); bytes += n; }
   void drain() {
     std::vector<std::pair<void *, bool>> take;
-    { std::lock_guard<std::mutex> lk(m); take.swap(list); }
+    { std::lock_guard<std::mutex> lk(m); take.swap(list); bytes = 0; }
     for (auto &e : take) { if (e.second) (void)hipHostFree(e.first); else (void)hipFree(e.first); }
   }
   bool empty() { std::lock_guard<std::mutex> lk(m); return list.empty(); }
+  size_t held() { std::lock_guard<std::mutex> lk(m); return bytes; }
 };
+// Buffers that belong to no context yet retire here; a batch's buffers are pointed at their context's list when the batch is bound
+// to it (rc_batch::adopt): one context's wait then never frees -- and device-synchronises for -- another context's leftovers.
 Retired g_retired;
+
+// An allocation that fails while outgrown buffers are still parked (a stream kept at depth 3 never has "nothing in flight") gets a
+// second try after the device has drained and the parked buffers are gone.
+template <typename Alloc> hipError_t alloc_with_retry(Retired *ret, Alloc alloc) {
+  hipError_t r = alloc();
+  if (r == hipSuccess || (ret->empty() && g_retired.empty())) return r;
+  (void)hipGetLastError();
+  (void)hipDeviceSynchronize();
+  ret->drain();
+  g_retired.drain();
+  return alloc();
+}
 
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
+  Retired *retired = &g_retired;
   ~DevBuf() { release(); }
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
   hipError_t ensure(size_t bytes) {
     if (bytes <= cap && p) return hipSuccess;
-    if (p) g_retired.add(p, false);
+    if (p) retired->add(p, false, cap);
     p = nullptr; cap = 0;
     const size_t want = std::max<size_t>(bytes + bytes / 8, 256);
-    hipError_t r = hipMalloc(&p, want);
+    hipError_t r = alloc_with_retry(retired, [&] { return hipMalloc(&p, want); });
     if (r == hipSuccess) cap = want; else p = nullptr;
     return r;
   }
@@ -95,14 +112,15 @@ struct DevBuf {
 struct PinBuf {
   void *p = nullptr;
   size_t cap = 0;
+  Retired *retired = &g_retired;
   ~PinBuf() { release(); }
   void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
   hipError_t ensure(size_t bytes) {
     if (bytes <= cap && p) return hipSuccess;
-    if (p) g_retired.add(p, true);
+    if (p) retired->add(p, true, cap);
     p = nullptr; cap = 0;
     const size_t want = std::max<size_t>(bytes + bytes / 8, 4096);
-    hipError_t r = hipHostMalloc(&p, want, hipHostMallocDefault);
+    hipError_t r = alloc_with_retry(retired, [&] { return hipHostMalloc(&p, want, hipHostMallocDefault); });
     if (r == hipSuccess) cap = want; else p = nullptr;
     return r;
   }
@@ -211,6 +229,7 @@ struct rc_ctx {
   long long fatStreamMinItems = 16384;   // RC_FAT_STREAM_MIN_ITEMS: a stream's sub-batch of fat classes takes the two-row path from this many (block, 64-sample group) items on: four rounds of the chip's wavefront slots (1024 blocks at n = 1000)
   int nativeFirst = -1;       // RC_NATIVE_FIRST: 1 always queue a batch's native-block kernels in front of its k_null, 0 never (and no two-row k_null for fat classes); -1: for batches that take the fat path (see fat_class)
   int copyResults = 0;        // RC_COPY_RESULTS=1: the small results go back with hipMemcpyAsync instead of k_results_out (A/B)
+  int tailRelease = 0;        // RC_TAIL_RELEASE=agent: late items are published with an agent-scope release (see k_null); default workgroup scope
   int tailSharing = 1;        // k_null: items taken near the end of the queues are shared part by part with workgroups that have run out of work (RC_TAIL_SHARING=0: off)
   int nativeWavesPerCU = 8;   // persistent wavefronts of k_native_dp per CU (RC_NATIVE_WAVES_PER_CU): it runs beside k_null and should not crowd it out
   size_t genericScratchWords = static_cast<size_t>(1) << 30;   // uint32 of staging scratch one k_null_generic launch may take: a twelfth of the device memory (24 GB of 288)
@@ -220,6 +239,7 @@ struct rc_ctx {
   hipStream_t native = nullptr;    // table preparation and native-block kernels: small and latency-bound, they run beside the null sampling
   hipStream_t copy = nullptr;      // host -> device blob copies
   hipStream_t aux = nullptr;       // synchronous helpers (second-stage result copies, backtrack rows, stand-alone fits): never behind queued batches
+  hipStream_t tree = nullptr;      // rc_fit_trees_device: 25-40 ms kernels of a driver's tree-fit thread, kept off the helper stream
   int prioLow = 0, prioHigh = 0;   // stream priorities (compute streams low, the small latency-bound work high)
   std::mutex streamMutex;          // ctx_stream
   std::vector<hipStream_t> classStreams;   // k_null launches of different row-count classes, when a batch has several
@@ -246,11 +266,15 @@ struct rc_ctx {
   int hostThreads = 0;
   std::unique_ptr<Pool> pool;
   std::atomic<int> inflight{0};   // batches between run_async and wait
+  std::shared_ptr<Retired> retired = std::make_shared<Retired>();   // outgrown buffers of this context's batches (shared: a batch may outlive its context)
+  size_t retiredCapBytes = 0;     // more than this parked while batches are in flight: the next wait drains (and stalls) once; 1/16 of the device memory
 };
 
-// the context's streams, created on first use (see rc_ctx_create); which: 0..2 compute, 3 native, 4 copy, 5 aux
+// the context's streams, created on first use (see rc_ctx_create); which: 0..2 compute, 3 native, 4 copy, 5 aux, 6 tree fits
+// nullptr if the stream cannot be created: callers return RC_ERR_DEVICE (a null handle would be the legacy default stream, which
+// does not order against the non-blocking ones)
 static hipStream_t ctx_stream(rc_ctx *c, int which) {
-  hipStream_t *slot = which < rc_ctx::kComputeStreams ? &c->compute[which] : which == 3 ? &c->native : which == 4 ? &c->copy : &c->aux;
+  hipStream_t *slot = which < rc_ctx::kComputeStreams ? &c->compute[which] : which == 3 ? &c->native : which == 4 ? &c->copy : which == 5 ? &c->aux : &c->tree;
   std::lock_guard<std::mutex> lk(c->streamMutex);
   if (!*slot) {
     (void)hipSetDevice(c->device);
@@ -261,6 +285,10 @@ static hipStream_t ctx_stream(rc_ctx *c, int which) {
 static hipStream_t stream_native(rc_ctx *c) { return ctx_stream(c, 3); }
 static hipStream_t stream_copy(rc_ctx *c) { return ctx_stream(c, 4); }
 static hipStream_t stream_aux(rc_ctx *c) { return ctx_stream(c, 5); }
+static hipStream_t stream_tree(rc_ctx *c) { return ctx_stream(c, 6); }
+#define RC_STREAM_TRY(var, expr)                                                               \
+  hipStream_t var = (expr);                                                                    \
+  if (!var) return fail(RC_ERR_DEVICE, "hipStreamCreateWithPriority failed")
 
 // layout of rc_ctx::d_tables
 struct TablePtrs { const uint8_t *pair; const int *pep; const int *blosum; const CodeInfo *info; };
@@ -315,6 +343,15 @@ struct rc_batch {
   std::string nullKernel;   // the k_null instantiation that did most of the last run's sampling, as rocprofv3 prints it
   double nullKernelCost = 0.0;
   rc_stream *owner = nullptr;
+  std::shared_ptr<Retired> retiredKeep;   // the context's list of outgrown buffers (kept alive: a batch may be destroyed after its context)
+  // bind the batch to its context: from now on its buffers, when outgrown, are parked in that context's list
+  void adopt(rc_ctx *c) {
+    ctx = c; device = c->device; retiredKeep = c->retired;
+    Retired *r = retiredKeep.get();
+    for (DevBuf *d : {&dblob, &dmaxima, &dhss, &dhssCount, &dhssPacked, &dhssOffsets, &dfit, &dflags, &dexact, &dcounters, &dscratch, &dnativeScratch,
+                      &dnativeTile, &dsteal}) d->retired = r;
+    for (PinBuf *h : {&hblob, &hstage, &hpacked}) h->retired = r;
+  }
 };
 
 struct rc_stream {
@@ -364,6 +401,7 @@ void rc_ctx_destroy(rc_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
+  c->retired->drain();
   g_retired.drain();
   c->pool.reset();
   if (kProfiling && c->d_cellStats.p) {
@@ -379,6 +417,7 @@ void rc_ctx_destroy(rc_ctx *c) {
   if (c->native) (void)hipStreamDestroy(c->native);
   if (c->copy) (void)hipStreamDestroy(c->copy);
   if (c->aux) (void)hipStreamDestroy(c->aux);
+  if (c->tree) (void)hipStreamDestroy(c->tree);
   for (hipStream_t st : c->classStreams) (void)hipStreamDestroy(st);
   delete c;
 }
@@ -401,6 +440,9 @@ int rc_ctx_create(int device, rc_ctx **out) {
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   c->numCU = prop.multiProcessorCount;
   c->totalMem = prop.totalGlobalMem;
+  c->retiredCapBytes = prop.totalGlobalMem / 16;
+  for (DevBuf *d : {&c->treeJobs, &c->treeIn, &c->treeWork, &c->treeOut, &c->treeRes, &c->d_tables, &c->d_cellStats}) d->retired = c->retired.get();
+  for (PinBuf *h : {&c->treeInPin, &c->treeResPin}) h->retired = c->retired.get();
   c->genericScratchWords = std::max<size_t>(static_cast<size_t>(1) << 30, prop.totalGlobalMem / 12 / sizeof(uint32_t));
   c->togetherWords = std::max<size_t>(static_cast<size_t>(1) << 30, prop.totalGlobalMem / 36 / sizeof(uint32_t));   // 8 GB of 288: allocating more costs a short run more than it gains (tools/cli_mixed_sweep.sh)
   if (const char *e = std::getenv("RC_TOGETHER_MAX_MB")) c->togetherWords = static_cast<size_t>(std::max(0ll, std::atoll(e))) * (1u << 20) / sizeof(uint32_t);
@@ -408,6 +450,7 @@ int rc_ctx_create(int device, rc_ctx **out) {
   if (const char *e = std::getenv("RC_SPLIT_FACTOR")) c->splitFactor = std::max(0.0, std::atof(e));
   if (const char *e = std::getenv("RC_NATIVE_WAVES_PER_CU")) c->nativeWavesPerCU = std::max(1, std::min(32, std::atoi(e)));
   if (const char *e = std::getenv("RC_TAIL_SHARING")) c->tailSharing = std::atoi(e) != 0;
+  if (const char *e = std::getenv("RC_TAIL_RELEASE")) c->tailRelease = std::strcmp(e, "agent") == 0;
   if (const char *e = std::getenv("RC_COPY_RESULTS")) c->copyResults = std::atoi(e) != 0;
   if (const char *e = std::getenv("RC_NATIVE_FIRST")) c->nativeFirst = std::atoi(e) != 0;
   if (const char *e = std::getenv("RC_DUAL_ROWS")) c->dualRows = std::atoi(e) != 0;
@@ -643,7 +686,7 @@ int rc_batch_create(rc_ctx *ctx, const rc_block *blocks, int32_t n_blocks, const
   *out = nullptr;
   std::unique_ptr<rc_batch, void (*)(rc_batch *)> guard(new rc_batch(), rc_batch_destroy);   // released on success only
   rc_batch *b = guard.get();
-  b->ctx = ctx; b->device = ctx->device;
+  b->adopt(ctx);
   RC_TRY(batch_prepare(b, blocks, n_blocks, par));
   RC_TRY(batch_upload(b));
   *out = guard.release();
@@ -923,6 +966,7 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
         const size_t idx = static_cast<size_t>(phase) * b->classes.size() + pi;
         if ((idx + 1) * steal_words(c) * sizeof(uint32_t) <= b->dsteal.cap) a.steal = b->dsteal.as<unsigned int>() + idx * steal_words(c);
         a.stealWait = R.streaming ? 0 : 1;
+        a.stealRelease = c->tailRelease;
       }
       if (!launch_null(p.NK, a, p.grid, p.ldsBytes, false, st)) return fail(RC_ERR_UNSUPPORTED, "no null kernel for this number of rows");
       b->nl[2]++;
@@ -1090,7 +1134,9 @@ static int batch_wait(rc_batch *b) {
   rc_ctx *c = b->ctx;
   HIP_TRY(hipSetDevice(c->device));
   hipError_t e = hipEventSynchronize(b->evDone);
-  if (c->inflight.fetch_sub(1) == 1 && !g_retired.empty()) g_retired.drain();   // nothing in flight: releasing outgrown buffers stalls nobody
+  // nothing in flight: releasing outgrown buffers stalls nobody.  A stream kept full never gets there: once the parked buffers
+  // exceed a sixteenth of the device memory they are released anyway (one stall, instead of holding every generation of a growing buffer)
+  if (c->inflight.fetch_sub(1) == 1 || c->retired->held() > c->retiredCapBytes) { if (!c->retired->empty()) c->retired->drain(); }
   b->state = rc_batch::READY;   // a failed run may be repeated
   if (e != hipSuccess) return fail(RC_ERR_DEVICE, std::string("hipEventSynchronize: ") + hipGetErrorString(e));
   HIP_TRY(hipGetLastError());
@@ -1121,8 +1167,9 @@ static int batch_wait(rc_batch *b) {
       // on the helper stream: the compute streams may already hold the kernels of later batches
       PinBuf more;
       HIP_TRY(more.ensure(sizeof(DevHss) * nrec));
-      HIP_TRY(hipMemcpyAsync(more.p, b->dhssPacked.p, sizeof(DevHss) * nrec, hipMemcpyDeviceToHost, stream_aux(c)));
-      HIP_TRY(hipStreamSynchronize(stream_aux(c)));
+      RC_STREAM_TRY(aux, stream_aux(c));
+      HIP_TRY(hipMemcpyAsync(more.p, b->dhssPacked.p, sizeof(DevHss) * nrec, hipMemcpyDeviceToHost, aux));
+      HIP_TRY(hipStreamSynchronize(aux));
       b->hssRec.assign(more.as<DevHss>(), more.as<DevHss>() + nrec);
     } else if (nrec) {
       b->hssRec.assign(b->hpacked.as<DevHss>(), b->hpacked.as<DevHss>() + nrec);
@@ -1166,7 +1213,8 @@ static void trace_device(rc_batch *b) {
   static Event ref;
   static double refHostUs = 0.0;
   if (!ref.e) {
-    if (ref.record(stream_aux(b->ctx)) != hipSuccess || hipEventSynchronize(ref) != hipSuccess) return;
+    hipStream_t aux = stream_aux(b->ctx);
+    if (!aux || ref.record(aux) != hipSuccess || hipEventSynchronize(ref) != hipSuccess) return;
     refHostUs = trace_now_us();
     std::fprintf(stderr, "[rc device clock: reference recorded now; a batch finished before it shows negative offsets]\n");
   }
@@ -1237,7 +1285,7 @@ int rc_stream_submit_bound(rc_stream *s, const rc_block *blocks, int32_t n_block
   if (static_cast<int>(s->inflight.size()) >= s->depth) return fail(RC_ERR_ARG, "stream is full: take a finished batch with rc_stream_next first");
   rc_batch *b = nullptr;
   if (!s->spare.empty()) { b = s->spare.back(); s->spare.pop_back(); }
-  else { b = new rc_batch(); b->ctx = s->ctx; b->device = s->ctx->device; b->owner = s; }
+  else { b = new rc_batch(); b->adopt(s->ctx); b->owner = s; }
   if (g_no_stream_cache && s->inflight.empty() && s->ctx->inflight.load() == 0) s->ctx->U_valid = false;   // a new pass over the stream
   if (maxima_device_ptr) { b->dmaxima.release(); b->maxPtr = static_cast<float *>(maxima_device_ptr); b->maximaExternal = true; }
   else if (b->maximaExternal) { b->maxPtr = nullptr; b->maximaExternal = false; }
@@ -1535,7 +1583,7 @@ int rc_batch_backtrack(const rc_batch *b, int32_t blk, int32_t strand, int32_t o
   const uint64_t *zw = zwv.data();
   DevBuf d_out;
   HIP_TRY(d_out.ensure(sizeof(float) * NK * 3 * steps));
-  hipStream_t st = stream_aux(c);
+  RC_STREAM_TRY(st, stream_aux(c));
   launch_sk_row(b->dblob.as<uint8_t>(), reinterpret_cast<const DevBlock *>(b->dblob.as<uint8_t>() + b->oDblocks), blk, strand, opt_b, opt_i,
                 d_out.as<float>(), steps, st);
   std::vector<float> sk(static_cast<size_t>(NK) * 3 * steps);
@@ -1758,16 +1806,17 @@ int rc_fit_trees_device(rc_ctx *c, const rc_block *blocks, int32_t n_blocks, cha
     fill();
     for (auto &x : th) x.join();
   }
-  HIP_TRY(hipMemcpyAsync(d_jobs.p, jobs.data(), sizeof(TreeJob) * nj, hipMemcpyHostToDevice, stream_aux(c)));
-  HIP_TRY(hipMemcpyAsync(d_in.p, c->treeInPin.p, in_bytes, hipMemcpyHostToDevice, stream_aux(c)));
+  RC_STREAM_TRY(ts, stream_tree(c));
+  HIP_TRY(hipMemcpyAsync(d_jobs.p, jobs.data(), sizeof(TreeJob) * nj, hipMemcpyHostToDevice, ts));
+  HIP_TRY(hipMemcpyAsync(d_in.p, c->treeInPin.p, in_bytes, hipMemcpyHostToDevice, ts));
   for (size_t ch = 0; ch + 1 < chunkStart.size(); ch++) {
     const int q0 = chunkStart[ch], q1 = chunkStart[ch + 1];
     launch_tree_fit(static_cast<const TreeJob *>(d_jobs.p) + q0, q1 - q0, static_cast<const uint8_t *>(d_in.p), static_cast<double *>(d_work.p),
-                    static_cast<TreeOut *>(d_out.p), static_cast<double *>(d_res.p), stream_aux(c));
+                    static_cast<TreeOut *>(d_out.p), static_cast<double *>(d_res.p), ts);
   }
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(c->treeResPin.p, d_res.p, sizeof(double) * res_doubles, hipMemcpyDeviceToHost, stream_aux(c)));
-  HIP_TRY(hipStreamSynchronize(stream_aux(c)));
+  HIP_TRY(hipMemcpyAsync(c->treeResPin.p, d_res.p, sizeof(double) * res_doubles, hipMemcpyDeviceToHost, ts));
+  HIP_TRY(hipStreamSynchronize(ts));
   const double *res = c->treeResPin.as<double>();
   std::atomic<int> done{0};
   {
@@ -1815,14 +1864,15 @@ float rc_pvalue(float score, float mu, float lambda) { return pvalue_of(score, m
 int rc_evd_fit(rc_ctx *c, const double *x, int32_t n, double *mu, double *lambda) {
   if (!c || !x || n < 1) return fail(RC_ERR_ARG, "bad argument");
   HIP_TRY(hipSetDevice(c->device));
+  RC_STREAM_TRY(aux, stream_aux(c));
   double *d_x = nullptr;
   FitOut *d_o = nullptr;
   HIP_TRY(hipMalloc(&d_x, sizeof(double) * n));
   HIP_TRY(hipMalloc(&d_o, sizeof(FitOut)));
   HIP_TRY(hipMemcpy(d_x, x, sizeof(double) * n, hipMemcpyHostToDevice));
-  launch_evd_fit_f64(d_x, n, d_o, stream_aux(c));
+  launch_evd_fit_f64(d_x, n, d_o, aux);
   FitOut o;
-  hipError_t e = hipStreamSynchronize(stream_aux(c));
+  hipError_t e = hipStreamSynchronize(aux);
   if (e == hipSuccess) e = hipMemcpy(&o, d_o, sizeof o, hipMemcpyDeviceToHost);
   (void)hipFree(d_x); (void)hipFree(d_o);
   if (e != hipSuccess) return fail(RC_ERR_DEVICE, hipGetErrorString(e));
@@ -1834,10 +1884,11 @@ int rc_evd_fit(rc_ctx *c, const double *x, int32_t n, double *mu, double *lambda
 int rc_mt_stream(rc_ctx *c, uint32_t seed, uint32_t *out, int32_t n) {
   if (!c || !out || n < 1) return fail(RC_ERR_ARG, "bad argument");
   HIP_TRY(hipSetDevice(c->device));
+  RC_STREAM_TRY(aux, stream_aux(c));
   uint32_t *d = nullptr;
   HIP_TRY(hipMalloc(&d, sizeof(uint32_t) * n));
-  launch_mt_stream(seed, 1, n, d, stream_aux(c));
-  hipError_t e = hipStreamSynchronize(stream_aux(c));
+  launch_mt_stream(seed, 1, n, d, aux);
+  hipError_t e = hipStreamSynchronize(aux);
   if (e == hipSuccess) e = hipMemcpy(out, d, sizeof(uint32_t) * n, hipMemcpyDeviceToHost);
   (void)hipFree(d);
   if (e != hipSuccess) return fail(RC_ERR_DEVICE, hipGetErrorString(e));

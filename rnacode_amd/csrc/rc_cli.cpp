@@ -47,10 +47,14 @@ struct Block {
 
 std::thread *g_ctxThread = nullptr;   // the thread that brings up the HIP context: an exit waits for it
 
+// Leaves at once, like the success path: other threads (tree fits with kernels in flight, the printer) may still be running, and
+// std::exit would run the HIP runtime's teardown and the static destructors under them.
 [[noreturn]] void die(const std::string &msg) {
-  if (g_ctxThread && g_ctxThread->joinable()) g_ctxThread->join();
+  if (g_ctxThread && g_ctxThread->joinable() && g_ctxThread->get_id() != std::this_thread::get_id()) g_ctxThread->join();
   std::fprintf(stderr, "ERROR: %s\n", msg.c_str());
-  std::exit(1);
+  std::fflush(stdout);
+  std::fflush(stderr);
+  _exit(1);
 }
 
 std::vector<std::string> fields(const std::string &line) {

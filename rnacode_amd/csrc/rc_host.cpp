@@ -146,9 +146,10 @@ bool parse_newick(const char *s, Tree &t, std::string &err) {
 // countFreqsMono (score.c:255-280): all rows, '-' skipped, unknown characters count as A.  One pass over the
 // forward rows gives both strands: the reverse complement (rnaz_utils.c:316-348) maps T,U->A, A->T, C<->G and
 // leaves everything else -- which the count files under A -- unchanged.
-// The reference's counters are floats incremented by one: such a counter stops at 2^24 (16777216 + 1 rounds back to
-// 16777216), and so does its float total.  Integer counts clamped to 2^24 are the same numbers (a block reaches that only
-// beyond 16.7 million residues; RC_MAX_ROWS x RC_MAX_COLS allows 32.7 million).
+// The reference's four counters are floats incremented by one: such a counter stops at 2^24 (16777216 + 1 rounds back to
+// 16777216).  Its total is an unsigned long (`counter`) converted to float once for the division and does NOT saturate.  Integer
+// counts clamped to 2^24 over float(total) are therefore the same numbers (a block gets there only beyond 16.7 million residues of
+// one kind; RC_MAX_ROWS x RC_MAX_COLS allows 32.7 million).
 static void mono_freqs_both(const uint8_t *chars, size_t nchars, float fwd[4], float rev[4]) {
   unsigned long cnt[256];
   std::memset(cnt, 0, sizeof cnt);
@@ -158,7 +159,7 @@ static void mono_freqs_both(const uint8_t *chars, size_t nchars, float fwd[4], f
   const unsigned long other = total - a - c - g - t;       // N and the rest: index 0 on both strands
   const unsigned long f[4] = {a + other, c, g, t}, r[4] = {t + other, g, c, a};
   const unsigned long sat = 1ul << 24;
-  const float totalf = static_cast<float>(std::min(total, sat));
+  const float totalf = static_cast<float>(total);          // (float)counter, score.c:279
   for (int i = 0; i < 4; i++) {
     fwd[i] = static_cast<float>(std::min(f[i], sat)) / totalf;
     rev[i] = static_cast<float>(std::min(r[i], sat)) / totalf;

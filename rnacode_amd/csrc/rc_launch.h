@@ -39,6 +39,7 @@ struct NullArgs {
   unsigned int *workCounter;  // [8], zeroed before the launch: next unclaimed work item of each XCD queue
   unsigned int *steal;        // tail sharing (see k_null): 16 + 4 x grid words, zeroed before the launch; null = off
   int dual;                   // 1: the instantiation that walks two rows of S per pass (N-1 <= kDualRowsMaxNK, codes staged in LDS)
+  int stealRelease;           // how a late item's codes are published to helpers: 0 workgroup-scope release (same-XCD helpers read them from the shared L2), 1 agent-scope release (the documented cross-CU form: writes the L2's dirty lines back)
   int stealWait;              // 1: a workgroup without work waits for owners that are still simulating a late item; 0: it leaves at once (a stream: the next sub-batch's workgroups want its place)
   int debugSkip;              // RC_PROFILING builds only: bit0 skip the DP/scan phase, bit1 skip simulation
   unsigned long long *cellStats;   // RC_PROFILING builds only: [0] wavefront-cells, [1] of those with no lane's sum > 0, [2] lanes with sum > 0, [3..5] cells before the row's first event / at events / after its last

@@ -429,7 +429,15 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
       }
       // The codes only have to reach this XCD's L2 (the L1 writes through): helpers are taken from the same XCD.  A device-scope
       // release would write back the whole L2 -- for every late item, and in a stream of small sub-batches most items are late.
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      // That shortcut is what gfx942 / gfx950 do (write-through vector L1, one L2 per XCD, XCC_ID names the L2 domain), not what the
+      // memory model promises: A.stealRelease = 1 (RC_TAIL_RELEASE=agent) takes the documented agent-scope release instead
+      // (MI355X_MICROARCH.md, inter-workgroup visibility), and tests/test_gpu_stream.py holds a stress test that would catch a
+      // toolchain or firmware that breaks the shortcut.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
+#error "k_null's tail sharing publishes with a workgroup-scope release; that is only known to reach other CUs on gfx942 / gfx950"
+#endif
+      if (A.stealRelease) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_s_waitcnt(0);
       if (lane == 0) {
         atomicExch(A.steal + kStealHdr + blockIdx.x, 1u);

@@ -60,7 +60,7 @@ class OverlappedGather:
     for everything and returns the last gathered tensor [world * rows, width].  Equal shards only (one fused
     all_gather_into_tensor per step, no padding copies): ragged shards use all_gather_rows."""
 
-    def __init__(self, rows: int, width: int, device, dtype=None):
+    def __init__(self, rows: int, width: int, device, dtype=None, stage_on_cpu: bool = False):
         import torch
         import torch.distributed as dist
 
@@ -69,7 +69,11 @@ class OverlappedGather:
         dtype = dtype or torch.float32
         world = dist.get_world_size()
         self.src = [torch.empty((rows, width), dtype=dtype, device=device) for _ in range(2)]
-        self.out = [torch.empty((world * rows, width), dtype=dtype, device=device) for _ in range(2)]
+        # stage_on_cpu (tests on a box with fewer GPUs than ranks): the kernels still write device tensors, the collective runs on
+        # host copies over a CPU backend
+        self.stage = stage_on_cpu and self.src[0].is_cuda
+        out_dev = "cpu" if self.stage else device
+        self.out = [torch.empty((world * rows, width), dtype=dtype, device=out_dev) for _ in range(2)]
         self.work = [None, None]
         self.last = None
 
@@ -77,7 +81,7 @@ class OverlappedGather:
         w = self.work[k]
         if w is not None:
             w.wait()                                           # the current torch stream waits for the collective ...
-            if self.src[0].is_cuda:
+            if self.out[0].is_cuda:
                 self._torch.cuda.current_stream().synchronize()    # ... and the host for the stream (CPU backends: wait() blocks)
             self.work[k] = None
 
@@ -87,13 +91,16 @@ class OverlappedGather:
 
     def launch(self, i: int):
         k = i & 1
-        self.work[k] = self._dist.all_gather_into_tensor(self.out[k], self.src[k], async_op=True)
+        src = self.src[k].cpu() if self.stage else self.src[k]
+        self.work[k] = self._dist.all_gather_into_tensor(self.out[k], src, async_op=True)
         self.last = k
 
     def finish(self):
         self._wait(0)
         self._wait(1)
         return None if self.last is None else self.out[self.last]
+
+
 all_gather_fits = all_gather_rows     # [n_r, 4] rows of rc_batch_fit_all
 
 

@@ -373,8 +373,19 @@ def test_bench_starts_its_own_ranks_and_two_hip_ranks_gather_the_single_rank_res
     assert two["weak_scaling"]["blocks_per_gpu"] == 50 and two["weak_scaling"]["value"] > 0
     assert m1.shape == (50, 192)
     np.testing.assert_array_equal(m1, m2)
+    assert two["n_ranks_seen"] == 2 and len(two["devices"]["ranks"]) == 2 and two["config"]["exchange_ab"]["chosen"] == "synchronous"
     fits, mf = _bench(tmp_path, 2, extra=("--exchange", "fits"), env_extra={"RC_BENCH_TEST_BACKEND": "gloo"})
     assert mf.shape == (50, 4) and (mf[:, 0] == 1).all()
+    # the overlapped order and the warm-up comparison of the two orders with two ranks (the collective staged through host copies over gloo)
+    hook = {"RC_BENCH_TEST_BACKEND": "gloo", "RC_BENCH_TEST_OVERLAP_ON_CPU": "1"}
+    for extra, want in (("--overlap",), "overlapped"), (("--no-overlap",), "synchronous"), ((), None):
+        line, mo = _bench(tmp_path, 2, extra=extra, env_extra=hook)
+        ab = line["config"]["exchange_ab"]
+        if want is None:
+            assert ab["chosen"] in ("overlapped", "synchronous") and ab["ms_per_step_overlapped"] > 0 and ab["ms_per_step_synchronous"] > 0
+        else:
+            assert ab["chosen"] == want
+        np.testing.assert_array_equal(m1, mo)
 
 
 def test_bench_refuses_a_world_that_does_not_match_gpus(tmp_path):
@@ -407,17 +418,28 @@ def test_bench_under_torchrun_goes_through_rccl(tmp_path):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     one, m1 = _bench(tmp_path, 1, extra=("--blocks", "40", "--samples", "128"))
-    # default: step i's all-gather overlapped with step i + 1 (rnacode_amd.distributed.OverlappedGather); --no-overlap: one after the other
-    for extra, overlapped in ((), True), (("--no-overlap",), False):
-        dump = str(tmp_path / ("rccl_%d.npy" % overlapped))
+    # --overlap: step i's all-gather overlapped with step i + 1 (rnacode_amd.distributed.OverlappedGather); --no-overlap: one after the
+    # other; neither: both orders timed during the warm-up, the faster one runs the timed region (config.exchange_ab says which)
+    for extra, overlapped in (("--overlap",), True), (("--no-overlap",), False), ((), None):
+        dump = str(tmp_path / ("rccl_%s.npy" % overlapped))
         r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                             "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--blocks", "40", "--samples", "128",
                             "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--sub-batches", "2", "--dump-gathered", dump, *extra],
                            env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
         assert r.returncode == 0, r.stderr[-3000:]
         line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        ab = line["config"]["exchange_ab"]
+        if overlapped is None:
+            assert ab["ms_per_step_synchronous"] > 0 and ab["ms_per_step_overlapped"] > 0 and ab["steps_each"] >= 3
+            overlapped = ab["chosen"] == "overlapped"
+            assert overlapped == (ab["ms_per_step_overlapped"] < ab["ms_per_step_synchronous"])
+        else:
+            assert ab["chosen"] == ("overlapped" if overlapped else "synchronous") and "forced" in ab
         assert line["config"]["exchange"].startswith("all-gather of maxima") and ("overlapped" in line["config"]["exchange"]) == overlapped
         assert line["n_gpus"] == 1 and line["stream"]["value"] > 0
+        # the line proves which devices the ranks sat on, and the RCCL channel cap is recorded
+        assert line["n_ranks_seen"] == 1 and line["devices"]["distinct_devices"] == 1 and len(line["devices"]["ranks"]) == 1
+        assert line["config"]["rccl_env"]["NCCL_MAX_NCHANNELS"] == "2"
         np.testing.assert_array_equal(np.load(dump), m1)
 
 
@@ -614,3 +636,70 @@ def test_two_rows_per_pass_equal_one_row_per_pass_and_the_oracle(monkeypatch):
             want = ob.run_block([r.seq for r in blk.rows], [r.name for r in blk.rows], blk.rows[0].start, blk.rows[0].length, blk.tree, blk.kappa,
                                 ob.default_params(64), kw["seed_base"])
             np.testing.assert_array_equal(on[0][i][:64], np.float32(want.maxScores), err_msg=f"{n} rows, block {i}")
+
+
+def test_tail_sharing_stress_every_item_late(monkeypatch):
+    """k_null's tail sharing hands an owner's sigma codes to helper workgroups of the same XCD behind a WORKGROUP-scope release (the L1
+    writes through, owner and helper share an L2): what gfx950 does, not what the memory model promises.  This is
+    the tripwire for a toolchain or firmware that changes it.  One workgroup per CU (RC_GRID_CAP_PER_CU=1) and a little more than one
+    item per workgroup, no strand x frame split: EVERY item is late, is published, and has its six parts claimed by its owner and by the
+    workgroups that found the queues empty -- on every launch, hundreds of launches, the staging scratch rewritten with other blocks'
+    codes each time (a stream recycles its three batch objects; resident batches are re-run in turn), both code-word paths (LDS-staged
+    and from L2).  Every launch must reproduce the maxima computed with sharing off, bit for bit; a stale code word shows as a wrong
+    maximum.  The documented agent-scope form (RC_TAIL_RELEASE=agent) is held to the same."""
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_blocks
+    monkeypatch.setenv("RC_GRID_CAP_PER_CU", "1")
+    monkeypatch.setenv("RC_SPLIT_FACTOR", "0")
+    shapes = [(6, 120), (4, 90), (8, 150), (12, 100), (3, 60), (10, 201)]
+    n = 320                                    # five sample groups x 60 blocks = 300 items on 256 workgroups
+    sets = []
+    for t, (rows, cols) in enumerate(shapes):
+        m = api.Marshalled([b.upper() for b in synth_blocks(60, rows, cols, seed=900 + t)])
+        m.set_trees()
+        sets.append(m)
+    p = api.default_params(sampleN=n, seed_base=3)
+    monkeypatch.setenv("RC_TAIL_SHARING", "0")
+    c0 = api.Context(0)
+    want = []
+    for m in sets:
+        b = api.Batch(c0, m, p).run()
+        want.append(b.maxScores_all().copy())
+        b.close()
+    c0.close()
+    monkeypatch.setenv("RC_TAIL_SHARING", "1")
+    launches = 0
+    for release in ("workgroup", "agent"):
+        monkeypatch.setenv("RC_TAIL_RELEASE", release)
+        c = api.Context(0)
+        st = api.Stream(c, p, 3)
+        for rep in range(25 if release == "workgroup" else 6):           # streamed: helpers leave at once (stealWait = 0)
+            order = np.random.RandomState(rep).permutation(len(sets))
+            pend = []
+
+            def take():
+                k = pend.pop(0)
+                sb = st.next()
+                np.testing.assert_array_equal(sb.maxScores_all(), want[k], err_msg=f"{release}, stream pass {rep}, shape {shapes[k]}")
+                sb.close()
+
+            for k in order:
+                if st.pending >= st.depth:
+                    take()
+                    launches += 1
+                st.submit(sets[k], 0, 60)
+                pend.append(k)
+            while pend:
+                take()
+                launches += 1
+        st.close()
+        batches = [api.Batch(c, m, p) for m in sets]                      # resident: helpers wait for owners that are still simulating
+        for rep in range(20 if release == "workgroup" else 5):
+            for k, b in enumerate(batches):
+                b.run()
+                np.testing.assert_array_equal(b.maxScores_all(), want[k], err_msg=f"{release}, resident run {rep}, shape {shapes[k]}")
+                launches += 1
+        for b in batches:
+            b.close()
+        c.close()
+    assert launches >= 300

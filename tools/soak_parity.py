@@ -1,7 +1,8 @@
 """Randomised parity soak: random block shapes, sample counts, seeds and parameters through the HIP path and the
 oracle until the time budget is used up; any difference in per-sample maxima, HSS tables or fit results is printed.
 usage: python tools/soak_parity.py [seconds] [rng_seed] [wide|fat]     wide: 65..300 rows only (the kernels for more than 64 rows);
-       fat: one row count per batch, 3..6 rows, up to 156 columns (the batches that take k_null's two-rows-per-pass instantiations)"""
+       fat: one row count per batch, 3..6 rows, up to 156 columns (the batches that take k_null's two-rows-per-pass instantiations)
+tests/test_gpu_soak.py runs a bounded slice of every mode under pytest -m gpu (soak(budget, seed, mode, max_blocks))."""
 import re
 import sys
 import time
@@ -19,15 +20,15 @@ def key(h):
     return (-h["score"], h["strand"], h["frame"], h["start"], h["end"])
 
 
-def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-    rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-    wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
-    fat = len(sys.argv) > 3 and sys.argv[3] == "fat"
+def soak(budget=60.0, rng_seed=1, mode="", max_blocks=None, log=print):
+    """(batches, blocks compared, mismatches, backtrack paths compared); stops at the time budget or after max_blocks blocks."""
+    rng = np.random.RandomState(rng_seed)
+    wide = mode == "wide"
+    fat = mode == "fat"
     ctx = api.Context(0)
     t0 = time.time()
     rounds = blocks_done = bad = paths = 0
-    while time.time() - t0 < budget:
+    while time.time() - t0 < budget and (max_blocks is None or blocks_done < max_blocks):
         rounds += 1
         n_samples = int(rng.choice([1, 2, 63, 64, 65, 100, 129, 200, 333]))
         seed = int(rng.randint(1, 2 ** 31 - 1))
@@ -119,11 +120,19 @@ def main():
             blocks_done += 1
             if not ok:
                 bad += 1
-                print(f"MISMATCH round {rounds} block {i}: {b.n} x {b.cols}, n={n_samples}, seed={seed}, pars={pars}")
+                log(f"MISMATCH round {rounds} block {i}: {b.n} x {b.cols}, n={n_samples}, seed={seed}, pars={pars}")
         for pb in parts:
             pb.close()
-    print(f"soak: {rounds} batches, {blocks_done} blocks compared in {time.time() - t0:.0f} s, {bad} mismatches; {paths} backtrack paths compared")
-    return 1 if bad else 0
+    ctx.close()
+    log(f"soak{' ' + mode if mode else ''}: {rounds} batches, {blocks_done} blocks compared in {time.time() - t0:.0f} s, {bad} mismatches; {paths} backtrack paths compared")
+    return rounds, blocks_done, bad, paths
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    mode = sys.argv[3] if len(sys.argv) > 3 else ""
+    return 1 if soak(budget, seed, mode)[2] else 0
 
 
 if __name__ == "__main__":
