@@ -28,6 +28,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <vector>
 
 #include "../../include/rnacode_hip.h"
@@ -229,7 +230,7 @@ struct rc_ctx {
   long long fatStreamMinItems = 16384;   // RC_FAT_STREAM_MIN_ITEMS: a stream's sub-batch of fat classes takes the two-row path from this many (block, 64-sample group) items on: four rounds of the chip's wavefront slots (1024 blocks at n = 1000)
   int nativeFirst = -1;       // RC_NATIVE_FIRST: 1 always queue a batch's native-block kernels in front of its k_null, 0 never (and no two-row k_null for fat classes); -1: for batches that take the fat path (see fat_class)
   int copyResults = 0;        // RC_COPY_RESULTS=1: the small results go back with hipMemcpyAsync instead of k_results_out (A/B)
-  int tailRelease = 0;        // RC_TAIL_RELEASE=agent: late items are published with an agent-scope release (see k_null); default workgroup scope
+  int tailRelease = 1;        // how k_null publishes a late item's codes: 1 agent-scope release (the documented cross-CU hand-off), 0 workgroup scope (RC_TAIL_RELEASE=workgroup: what gfx950 needs in practice, 1-1.5 % faster on streams of small sub-batches, not guaranteed)
   int tailSharing = 1;        // k_null: items taken near the end of the queues are shared part by part with workgroups that have run out of work (RC_TAIL_SHARING=0: off)
   int nativeWavesPerCU = 8;   // persistent wavefronts of k_native_dp per CU (RC_NATIVE_WAVES_PER_CU): it runs beside k_null and should not crowd it out
   size_t genericScratchWords = static_cast<size_t>(1) << 30;   // uint32 of staging scratch one k_null_generic launch may take: a twelfth of the device memory (24 GB of 288)
@@ -256,6 +257,11 @@ struct rc_ctx {
   Event U_ready;
   float tieThr = 0.0f;
   std::map<std::pair<int, size_t>, int> occ;   // (N-1, LDS bytes) -> resident workgroups per CU of k_null
+  struct PlainPlan { int occ; size_t lds; int hiOcc; };
+  std::map<std::tuple<int, int, int>, PlainPlan> plainPlans;   // (N-1, tree nodes, high-occupancy wanted) -> launch shape of a k_null that reads its codes from L2
+  size_t ldsPerCU = 160 * 1024;
+  int suffixCache = 1;          // RC_SUFFIX_CACHE=0: the launches that read their codes from L2 keep none of them in LDS (A/B)
+  int highOccupancy = 1;        // RC_HIGH_OCCUPANCY: 1 k_null_occ (one more wavefront per SIMD) for batches of one row-count class, 0 never, 2 always (A/B)
   size_t ldsMaxBytes = 13312;   // per wavefront: >= 12 wavefronts per CU; measured crossover against reading the codes from L2 (cols 150: 52.0 vs 54.0 ms, cols 180: 41.5 vs 39.3 ms)
   int debugSkip = 0;
   DevBuf d_cellStats;              // RC_PROFILING builds with RC_CELL_STATS=1: k_null's cell counters, printed when the context goes
@@ -450,7 +456,10 @@ int rc_ctx_create(int device, rc_ctx **out) {
   if (const char *e = std::getenv("RC_SPLIT_FACTOR")) c->splitFactor = std::max(0.0, std::atof(e));
   if (const char *e = std::getenv("RC_NATIVE_WAVES_PER_CU")) c->nativeWavesPerCU = std::max(1, std::min(32, std::atoi(e)));
   if (const char *e = std::getenv("RC_TAIL_SHARING")) c->tailSharing = std::atoi(e) != 0;
-  if (const char *e = std::getenv("RC_TAIL_RELEASE")) c->tailRelease = std::strcmp(e, "agent") == 0;
+  if (const char *e = std::getenv("RC_TAIL_RELEASE")) c->tailRelease = std::strcmp(e, "workgroup") != 0;
+  if (const char *e = std::getenv("RC_SUFFIX_CACHE")) c->suffixCache = std::atoi(e) != 0;
+  if (const char *e = std::getenv("RC_HIGH_OCCUPANCY")) c->highOccupancy = std::max(0, std::min(2, std::atoi(e)));
+  if (prop.maxSharedMemoryPerMultiProcessor > 0) c->ldsPerCU = prop.maxSharedMemoryPerMultiProcessor;
   if (const char *e = std::getenv("RC_COPY_RESULTS")) c->copyResults = std::atoi(e) != 0;
   if (const char *e = std::getenv("RC_NATIVE_FIRST")) c->nativeFirst = std::atoi(e) != 0;
   if (const char *e = std::getenv("RC_DUAL_ROWS")) c->dualRows = std::atoi(e) != 0;
@@ -831,10 +840,35 @@ static int launch_native_block(const RunEnv &R) {
 static size_t steal_slots(const rc_ctx *c) { return static_cast<size_t>(c->numCU) * 32; }
 static size_t steal_words(const rc_ctx *c) { return 16 + 4 * steal_slots(c); }   // header, claim words, (block, group) pairs, list of published slots
 
+// Launch shape of a k_null that reads its code words from L2 (rc_null_kernel.h): which build -- k_null_occ, one more wavefront per SIMD,
+// for batches of one row-count class: round 3 measured +1..7 % there and -5 % on a stream of ten classes, whose small kernels ran in the
+// registers those wavefronts take --, how many workgroups per CU, and how much LDS each gets: what phase A needs at least, and with the
+// suffix cache everything the occupancy leaves (160 KB / workgroups per CU), which phase B fills with the most re-read code words.
+static rc_ctx::PlainPlan plain_plan(rc_ctx *c, int NK, int maxNodes, bool wantHi) {
+  const auto key = std::make_tuple(NK, maxNodes, wantHi ? 1 : 0);
+  auto it = c->plainPlans.find(key);
+  if (it != c->plainPlans.end()) return it->second;
+  rc_ctx::PlainPlan pp{0, 0, 0};
+  for (int hi = wantHi ? 1 : 0; hi >= 0 && pp.occ <= 0; hi--) {
+    const size_t minLds = hi ? al256(static_cast<size_t>(maxNodes) * 64 + 64 * 64) : static_cast<size_t>(kPhaseALds);
+    const int occ = null_occupancy_plain(NK, minLds, hi);
+    if (occ <= 0) continue;
+    size_t lds = minLds;
+    if (c->suffixCache) {
+      size_t budget = (c->ldsPerCU / static_cast<size_t>(occ)) & ~static_cast<size_t>(255);
+      while (budget > minLds && null_occupancy_plain(NK, budget, hi) < occ) budget -= 256;
+      lds = std::max(budget, minLds);
+    }
+    pp = rc_ctx::PlainPlan{occ, lds, hi};
+  }
+  c->plainPlans[key] = pp;
+  return pp;
+}
+
 static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t extraSkip, size_t *sizeOnly = nullptr) {
   rc_batch *b = R.b; rc_ctx *c = R.c;
   const int groupsHere = gHi - gLo;
-  struct Plan { int NK, grid, gridExact, comboSplit; size_t stride, ldsBytes, need; double itemCost; };
+  struct Plan { int NK, grid, gridExact, comboSplit; size_t stride, ldsBytes, need; double itemCost; int hiOcc, cacheSites; size_t plainLds; };
   std::vector<Plan> plans;
   size_t needSum = 0, needMax = 0;
   // Several row-count classes: first planned as launches that run side by side (no strand x frame split: together they fill the chip);
@@ -882,6 +916,16 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
     if (!c->occ.count(key)) c->occ[key] = null_occupancy(p.NK, p.ldsBytes);
     if (c->occ[key] <= 0 && p.ldsBytes) { p.ldsBytes = 0; const std::pair<int, size_t> k2(p.NK, 0); if (!c->occ.count(k2)) c->occ[k2] = null_occupancy(p.NK, 0); }
     int occ = std::max(1, c->occ[std::pair<int, size_t>(p.NK, p.ldsBytes)]);
+    if (!p.ldsBytes && !exactOnly) {   // codes from L2
+      int maxNodes = 0;
+      for (int bi : kv.second) maxNodes = std::max(maxNodes, b->db[bi].nnodes);
+      const bool wantHi = c->highOccupancy == 2 || (c->highOccupancy == 1 && b->classes.size() == 1);
+      const rc_ctx::PlainPlan pp = plain_plan(c, p.NK, maxNodes, wantHi);
+      if (pp.occ > 0) {
+        occ = pp.occ; p.hiOcc = pp.hiOcc; p.plainLds = pp.lds;
+        p.cacheSites = c->suffixCache ? static_cast<int>(pp.lds / (static_cast<size_t>(NCW) * kWave * sizeof(uint32_t))) : 0;
+      }
+    }
     if (c->gridCapPerCU > 0) occ = std::min(occ, c->gridCapPerCU);
     int items = static_cast<int>(kv.second.size()) * groupsHere;
     // small batches: split every item into its six strand x frame parts to fill the chip
@@ -942,7 +986,8 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
         else {
           const bool ex = b->allExact || p.NK >= kFastRows;
           const bool dual = !ex && c->dualRows && p.ldsBytes && p.ldsBytes <= 48 * 1024 && p.NK <= kDualRowsMaxNK && (p.NK == 2 || R.fat);
-          b->nullKernel = "rc::k_null<" + std::to_string(p.NK) + (!ex && p.ldsBytes ? ", true" : ", false") + (ex ? ", true" : ", false") + (dual ? ", true>" : ", false>");
+          if (!ex && !p.ldsBytes && p.hiOcc) b->nullKernel = "rc::k_null_occ<" + std::to_string(p.NK) + ">";
+          else b->nullKernel = "rc::k_null<" + std::to_string(p.NK) + (!ex && p.ldsBytes ? ", true" : ", false") + (ex ? ", true" : ", false") + (dual ? ", true>" : ", false>");
         }
       }
     }
@@ -961,6 +1006,7 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
       a.skipMask = kFlagExact | extraSkip;
       a.workCounter = work + p.NK * 8;
       a.dual = (c->dualRows && p.ldsBytes && p.NK <= kDualRowsMaxNK && (p.NK == 2 || R.fat)) ? 1 : 0;
+      a.hiOcc = p.hiOcc; a.plainLds = static_cast<int>(p.plainLds); a.cacheSites = p.cacheSites;
       // tail sharing: one slot per workgroup of this launch in the zeroed dsteal area (see batch_run_async)
       if (c->tailSharing && !p.comboSplit && static_cast<size_t>(p.grid) <= steal_slots(c) && b->dsteal.p) {
         const size_t idx = static_cast<size_t>(phase) * b->classes.size() + pi;
@@ -977,7 +1023,7 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
       e.skipMask = extraSkip;
       e.comboSplit = 0;
       e.steal = nullptr;
-      e.dual = 0;
+      e.dual = 0; e.hiOcc = 0; e.plainLds = 0; e.cacheSites = 0;
       e.workCounter = work + kClassSlots * 8 + p.NK * 8;
       if (!launch_null(p.NK, e, p.gridExact, 0, true, st)) return fail(RC_ERR_UNSUPPORTED, "no null kernel for this number of rows");
     }

@@ -626,7 +626,7 @@ void launch_mt_stream(uint32_t seedBase, int Spad, int D, uint32_t *U, hipStream
 }
 
 // k_null is instantiated in eight units (rc_null_a..h.hip), one per range of N-1; e..h hold the wide blocks (N-1 >= 32)
-#define RC_NULL_UNIT(S) int null_occupancy_##S(int, size_t); bool launch_null_##S(int, const NullArgs &, int, size_t, bool, hipStream_t);
+#define RC_NULL_UNIT(S) int null_occupancy_##S(int, size_t); int null_occupancy_plain_##S(int, size_t, int); bool launch_null_##S(int, const NullArgs &, int, size_t, bool, hipStream_t);
 RC_NULL_UNIT(a) RC_NULL_UNIT(b) RC_NULL_UNIT(c) RC_NULL_UNIT(d) RC_NULL_UNIT(e) RC_NULL_UNIT(f) RC_NULL_UNIT(g) RC_NULL_UNIT(h)
 #undef RC_NULL_UNIT
 
@@ -636,6 +636,12 @@ int null_occupancy(int NK, size_t ldsBytes) {
        : NK <= 21 ? null_occupancy_c(NK, ldsBytes) : NK <= 31 ? null_occupancy_d(NK, ldsBytes)
        : NK <= 39 ? null_occupancy_e(NK, ldsBytes) : NK <= 47 ? null_occupancy_f(NK, ldsBytes)
        : NK <= 55 ? null_occupancy_g(NK, ldsBytes) : null_occupancy_h(NK, ldsBytes);
+}
+
+int null_occupancy_plain(int NK, size_t dynLds, int hiOcc) {
+  if (NK < 2 || NK >= kFastRows) return 0;
+  return NK <= 6 ? null_occupancy_plain_a(NK, dynLds, hiOcc) : NK <= 12 ? null_occupancy_plain_b(NK, dynLds, hiOcc)
+       : NK <= 21 ? null_occupancy_plain_c(NK, dynLds, hiOcc) : null_occupancy_plain_d(NK, dynLds, hiOcc);
 }
 
 // N-1 >= 32: only the EXACT instantiation without code staging exists (ldsBytes and exact are ignored)

@@ -38,6 +38,9 @@ struct NullArgs {
   int comboSplit;             // 1: items are (block, group, strand x frame); maxima combined by atomic max
   unsigned int *workCounter;  // [8], zeroed before the launch: next unclaimed work item of each XCD queue
   unsigned int *steal;        // tail sharing (see k_null): 16 + 4 x grid words, zeroed before the launch; null = off
+  int cacheSites;             // codes from L2: the words of the last cacheSites sites of a strand x frame are kept in LDS (0: none)
+  int plainLds;               // host only: dynamic LDS bytes of a launch that reads its codes from L2 (phase A's tables, then the suffix cache); 0: the default
+  int hiOcc;                  // host only: 1 = launch k_null_occ (one more wavefront per SIMD), where this N-1 has one
   int dual;                   // 1: the instantiation that walks two rows of S per pass (N-1 <= kDualRowsMaxNK, codes staged in LDS)
   int stealRelease;           // how a late item's codes are published to helpers: 0 workgroup-scope release (same-XCD helpers read them from the shared L2), 1 agent-scope release (the documented cross-CU form: writes the L2's dirty lines back)
   int stealWait;              // 1: a workgroup without work waits for owners that are still simulating a late item; 0: it leaves at once (a stream: the next sub-batch's workgroups want its place)
@@ -127,6 +130,7 @@ void launch_tree_fit(const TreeJob *jobs, int njobs, const uint8_t *in, double *
 void launch_mt_stream(uint32_t seedBase, int Spad, int D, uint32_t *U, hipStream_t stream);
 void launch_prep(const PrepArgs &a, hipStream_t stream);   // k_prep_models, then k_prep_lut
 int null_occupancy(int NK, size_t ldsBytes);   // resident workgroups per CU (0 = cannot launch)
+int null_occupancy_plain(int NK, size_t dynLds, int hiOcc);   // the same for a launch that reads its codes from L2 with dynLds bytes of LDS; hiOcc: k_null_occ (0 if N-1 has none)
 bool launch_null(int NK, const NullArgs &a, int grid, size_t ldsBytes, bool exact, hipStream_t stream);
 void launch_native_sigma(const NativeArgs &a, int nblocks, hipStream_t stream);
 bool launch_native_dp(int NK, const NativeArgs &a, int grid, hipStream_t stream);   // a.nItems items over `grid` persistent workgroups

@@ -172,11 +172,13 @@ __device__ __forceinline__ void sample_scan_last(const SampleScan &st, float &be
 // Read-only inputs are separate __restrict__ kernel parameters (not members of the by-value
 // argument block) so that the compiler may prove them unclobbered and fetch the wave-uniform
 // block tables (z words, tree records, masks) with scalar loads.
-template <int NK, bool LDSC, bool EXACT, bool DUAL = false>
-__global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restrict__ blob,
-                                             const DevBlock *__restrict__ dblocks, const int *__restrict__ classBlocks,
-                                             const uint32_t *__restrict__ flags, const uint32_t *__restrict__ Ustream, const uint8_t *__restrict__ pairTab,
-                                             uint32_t *__restrict__ scratch, float *__restrict__ maxima) {
+// (The body is a device function so that two kernels can share it: k_null, and k_null_occ, the same code compiled for more
+// wavefronts per SIMD -- see below.)
+template <int NK, bool LDSC, bool EXACT, bool DUAL>
+__device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__restrict__ blob,
+                                          const DevBlock *__restrict__ dblocks, const int *__restrict__ classBlocks,
+                                          const uint32_t *__restrict__ flags, const uint32_t *__restrict__ Ustream, const uint8_t *__restrict__ pairTab,
+                                          uint32_t *__restrict__ scratch, float *__restrict__ maxima) {
   constexpr int N = NK + 1;
   constexpr int CPW = 5;                  // 6-bit sigma codes per 32-bit word
   constexpr int NCW = (NK + CPW - 1) / CPW;
@@ -186,6 +188,7 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
   // register budget has room for a second row's states and a 32-entry row buffer at four wavefronts per SIMD.  The host picks it per
   // launch (NullArgs::dual): up to 127 VGPRs instead of 74, i.e. no other kernel shares a SIMD with four such wavefronts.
   static_assert(!DUAL || (LDSC && !EXACT && NK <= kDualRowsMaxNK), "two rows per pass: LDS-staged codes, fast division, few sequences");
+  static_assert(!(LDSC && EXACT), "the EXACT instantiation uses no LDS");
   // phase A: threshold table of the tree (nnodes x 64 B); phase B with LDSC: [site][NCW][64] sigma codes
   // of the current strand x frame
   extern __shared__ uint32_t lds_codes[];
@@ -427,12 +430,13 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
         __hip_atomic_store(A.steal + kStealHdr + G + 2 * blockIdx.x, static_cast<unsigned int>(bi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(A.steal + kStealHdr + G + 2 * blockIdx.x + 1, static_cast<unsigned int>(grp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      // The codes only have to reach this XCD's L2 (the L1 writes through): helpers are taken from the same XCD.  A device-scope
-      // release would write back the whole L2 -- for every late item, and in a stream of small sub-batches most items are late.
-      // That shortcut is what gfx942 / gfx950 do (write-through vector L1, one L2 per XCD, XCC_ID names the L2 domain), not what the
-      // memory model promises: A.stealRelease = 1 (RC_TAIL_RELEASE=agent) takes the documented agent-scope release instead
-      // (MI355X_MICROARCH.md, inter-workgroup visibility), and tests/test_gpu_stream.py holds a stress test that would catch a
-      // toolchain or firmware that breaks the shortcut.
+      // Publishing the codes: an agent-scope release (A.stealRelease = 1, the default) is the documented hand-off to another CU
+      // (MI355X_MICROARCH.md, inter-workgroup visibility): it writes this XCD's dirty L2 lines back.  The codes only have to reach
+      // this XCD's L2, though -- helpers are taken from the same XCD, and the L1 writes through --, so a workgroup-scope release
+      // (RC_TAIL_RELEASE=workgroup) does in practice on gfx942 / gfx950 what is needed, without the write-back: measured 1-1.5 %
+      // faster on a stream of small sub-batches (1250-block shard 7.8 against 7.9 ms per pass, 313 resident blocks 1.91 against
+      // 1.94 ms), nothing on a 10 000-block batch.  Not worth an undocumented dependency: kept as a switch, and
+      // tests/test_gpu_stream.py::test_tail_sharing_stress_every_item_late holds both forms to bit-identical results.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
 #error "k_null's tail sharing publishes with a workgroup-scope release; that is only known to reach other CUs on gfx942 / gfx950"
 #endif
@@ -480,16 +484,54 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
         const uint32_t *__restrict__ cbase = cod + (static_cast<size_t>(s * L1 + 3 + f) * NCW) * kWave + lane;  // site j: + j*3*NCW*64
         const unsigned long long *__restrict__ zbase = zw + static_cast<size_t>(s * L1 + 3 + f) * ZW;               // site j: [3j * ZW + word]
         const unsigned long long *__restrict__ zany = zmask + static_cast<size_t>(s * 3 + f) * zmWords;            // bit j: some z != 0 at site j
+        // Codes from L2 (the strand x frame's words do not fit the LDS at the occupancy this kernel needs): row a reads the words of
+        // the sites a..sites-1, so site j is read by j + 1 rows -- the LAST sites are the ones read most.  Whatever LDS the launch
+        // was given beyond phase A's tables (A.cacheSites sites' worth) therefore holds the words of the frame's suffix [jc, sites);
+        // the rows read those from LDS and only the sites before jc from L2 (C5, 100 sites, 13 of them cached: 24 % of the reads;
+        // 8 rows x 150 columns, 16 of 50: 55 %).
+        int jc = sites;
         if constexpr (LDSC) {
           for (int idx = 0; idx < sites * NCW; idx++)
             lds_codes[idx * kWave + lane] = cbase[static_cast<size_t>(idx / NCW) * 3 * NCW * kWave + (idx % NCW) * kWave];
           __builtin_amdgcn_s_waitcnt(0);   // everything landed: the row loops below issue no vector memory ops
+        } else if constexpr (!EXACT) {
+          jc = sites - (A.cacheSites < sites ? A.cacheSites : sites);
+          for (int idx = jc * NCW; idx < sites * NCW; idx++)
+            lds_codes[(idx - jc * NCW) * kWave + lane] = cbase[static_cast<size_t>(idx / NCW) * 3 * NCW * kWave + (idx % NCW) * kWave];
+          __builtin_amdgcn_s_waitcnt(0);
         }
-        auto load_words = [&](int j, uint32_t (&w)[NCW]) {
+        const uint32_t ldsLane = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_codes)) + static_cast<uint32_t>(lane) * 4u;
+        // codes from L2: the wave-uniform part of the code words' address (scalar registers) and the lane's byte offset
+        const uint32_t *__restrict__ sbase = cod + (static_cast<size_t>(s * L1 + 3 + f) * NCW) * kWave;
+        const uint32_t laneOff = static_cast<uint32_t>(lane) * 4u;
+        // asm fetches of a site's code words: the compiler does not know them as memory operations and places no waits of its own
+        auto fetch_lds = [&](uint32_t (&w)[NCW], uint32_t at) {
 #pragma unroll
-          for (int x = 0; x < NCW; x++) {
-            if constexpr (LDSC) w[x] = lds_codes[(j * NCW + x) * kWave + lane];
-            else w[x] = cbase[(static_cast<size_t>(j) * 3 * NCW + x) * kWave];
+          for (int x = 0; x < NCW; x++) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(w[x]) : "v"(at), "n"(x * kWave * 4));
+        };
+        auto fetch_global = [&](uint32_t (&w)[NCW], const uint32_t *p) {   // p: wave-uniform, settled in scalar registers five wait states ago
+          const uint32_t lo = laneOff + 0u;   // (a copy: an asm operand alone does not make a generic lambda capture the variable)
+#pragma unroll
+          for (int x = 0; x < NCW; x++) asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(w[x]) : "v"(lo), "s"(p), "n"(x * kWave * 4));
+        };
+        // the words of site j, complete when it returns (a row's first site)
+        auto load_words = [&](int j, uint32_t (&w)[NCW]) {
+          if constexpr (LDSC) {
+#pragma unroll
+            for (int x = 0; x < NCW; x++) w[x] = lds_codes[(j * NCW + x) * kWave + lane];
+          } else if constexpr (!EXACT) {
+            if (j >= jc) {   // wave-uniform
+              fetch_lds(w, ldsLane + static_cast<uint32_t>(j - jc) * (NCW * kWave * 4u));
+            } else {
+              const uint32_t *p = sbase + static_cast<size_t>(j) * (3 * NCW * kWave);
+              asm volatile("s_nop 4" : "+s"(p));   // a VMEM instruction must not read an SGPR within five wait states of the scalar write
+              fetch_global(w, p);
+            }
+#pragma unroll
+            for (int x = 0; x < NCW; x++) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(w[x]));
+          } else {
+#pragma unroll
+            for (int x = 0; x < NCW; x++) w[x] = cbase[(static_cast<size_t>(j) * 3 * NCW + x) * kWave];
           }
         };
         // sigma of every sequence at the site whose code words are w: a 64-entry table look-up per
@@ -501,15 +543,27 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
         // right after the look-ups have been issued (they read w at issue): no second register set and
         // no copy per cell.  LDS operations complete in order, so lgkmcnt(NCW) leaves exactly those
         // NCW reads in flight; the next call starts by waiting for them.
-        const uint32_t ldsLane = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_codes)) + static_cast<uint32_t>(lane) * 4u;
-        auto lookup = [&](uint32_t (&w)[NCW], float (&sig)[NK], int jn, auto scalarLoadsNearby) {
+        // Codes from L2 (neither staged nor EXACT): the same scheme with global loads.  The words of site jn are fetched INTO w behind
+        // the look-ups -- from the LDS suffix cache if jn >= jc, else with global_load_dword (scalar base + lane offset: the address
+        // costs no vector instruction) -- and the NEXT call starts by waiting for them: a whole cell of other work hides the L2 / HBM
+        // latency.  (As plain C++ loads into a second register set the compiler's own wait-count placement waited for them twenty
+        // instructions after they had been issued: its analysis merges the loop-entry state, where the first words are still on
+        // their way, into the loop.)
+        auto lookup = [&](uint32_t (&w)[NCW], float (&sig)[NK], int jn, auto scalarLoadsNearby, auto kind) {   // (kind: unused)
           if constexpr (LDSC) {
 #pragma unroll
             for (int x = 0; x < NCW; x++) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[x]));
           }
+          // the global fetch's scalar base, settled HERE: a VMEM instruction must not read an SGPR within five wait states of the scalar
+          // instruction that wrote it, and the compiler's hazard recognizer does not look inside inline asm -- the look-ups below lie between
+          const uint32_t *pnext = sbase + static_cast<size_t>(jn) * (3 * NCW * kWave);
+          if constexpr (!LDSC && !EXACT) asm volatile("" : "+s"(pnext));
           static_for<NK>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             constexpr int t = k % CPW;
+            // codes from L2: the words were fetched by the previous call and arrive in order -- wait for each one where it is first used
+            // (any LDS read of the suffix cache was covered by that call's closing wait)
+            if constexpr (!LDSC && !EXACT && t == 0) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[k / CPW]) : "n"(NCW - 1 - k / CPW));
             uint32_t addr;
             if constexpr (t == 0) addr = w[k / CPW]; else addr = w[k / CPW] >> (6 * t);   // bits [7:2] select the lane
             // timing experiments, never in the product build (wrong results; tools/ab_lookup.sh): what the address shifts and the
@@ -526,35 +580,47 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
             asm volatile("ds_bpermute_b32 %0, %1, %2" : "=v"(got) : "v"(addr), "v"(lutv));
             sig[k] = got;
           });
-          if constexpr (LDSC) {
-            const uint32_t at = ldsLane + static_cast<uint32_t>(jn) * (NCW * kWave * 4u);
-#pragma unroll
-            for (int x = 0; x < NCW; x++) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(w[x]) : "v"(at), "n"(x * kWave * 4));
-          }
-          {   // one wait for the look-ups; operands of the last code word pin its position
+          // one wait for the look-ups; operands of the last code word pin its position.  leave: LDS reads that were issued behind
+          // the look-ups and may stay in flight (LDS operations complete in order)
+          auto wait_lookups = [&](auto leave) {
             constexpr int k0 = (NCW - 1) * CPW;
-            constexpr int cnt = NK - k0;
-            float a0 = sig[k0], a1 = sig[cnt > 1 ? k0 + 1 : k0], a2 = sig[cnt > 2 ? k0 + 2 : k0], a3 = sig[cnt > 3 ? k0 + 3 : k0],
-                  a4 = sig[cnt > 4 ? k0 + 4 : k0];
+            constexpr int cnt = NK - k0;   // look-ups of the last code word: 1..5, each one an operand of the wait (no padding copies)
             // (scalar loads share the counter and may complete out of order: where the compiler could have one
             // in flight -- the event cell reads z -- wait for everything)
-            if constexpr (LDSC && !decltype(scalarLoadsNearby)::value)
-              asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4) : "n"(NCW));
-            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4));
-            if constexpr (cnt > 1) sig[k0 + 1] = a1;
-            if constexpr (cnt > 2) sig[k0 + 2] = a2;
-            if constexpr (cnt > 3) sig[k0 + 3] = a3;
-            if constexpr (cnt > 4) sig[k0 + 4] = a4;
+            constexpr int left = (decltype(leave)::value > 0 && !decltype(scalarLoadsNearby)::value) ? decltype(leave)::value : 0;
+            if constexpr (cnt == 1) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(sig[k0]) : "n"(left));
+            else if constexpr (cnt == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(sig[k0]), "+v"(sig[k0 + 1]) : "n"(left));
+            else if constexpr (cnt == 3) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(sig[k0]), "+v"(sig[k0 + 1]), "+v"(sig[k0 + 2]) : "n"(left));
+            else if constexpr (cnt == 4)
+              asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(sig[k0]), "+v"(sig[k0 + 1]), "+v"(sig[k0 + 2]), "+v"(sig[k0 + 3]) : "n"(left));
+            else
+              asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(sig[k0]), "+v"(sig[k0 + 1]), "+v"(sig[k0 + 2]), "+v"(sig[k0 + 3]), "+v"(sig[k0 + 4]) : "n"(left));
             // earlier words: make their values depend on the wait as well (no instruction emitted)
             static_for<NK>([&](auto kc) {
               constexpr int k = decltype(kc)::value;
               if constexpr (k < k0) {
                 float b = sig[k];
-                asm volatile("" : "+v"(b), "+v"(a0));
+                asm volatile("" : "+v"(b), "+v"(sig[k0]));
                 sig[k] = b;
               }
             });
-            sig[k0] = a0;
+          };
+          if constexpr (LDSC) {
+            fetch_lds(w, ldsLane + static_cast<uint32_t>(jn) * (NCW * kWave * 4u));
+            wait_lookups(std::integral_constant<int, NCW>{});
+          } else if constexpr (!EXACT) {
+            // the fetch goes out as early as it can (the look-ups have read w when they were issued): the next call waits for it, and
+            // nearly a whole cell of other work lies between
+            // Which of the two is decided per cell by a wave-uniform branch.  (Cutting every row loop at jc - 1 instead, so that each
+            // loop has one kind of fetch compiled in, was built and taken back: with two loops per span and two event cells the
+            // register allocator moved w between registers at the joins -- BEFORE the wait that makes w valid --, results were wrong
+            // wherever a row had frame-shift events, and the launches were 5-12 % slower on top.)  The wait for the look-ups is common
+            // to both arms and behind them (inside the arms its register ties became eleven moves per arm); it covers the LDS arm's reads.
+            if (jn >= jc) fetch_lds(w, ldsLane + static_cast<uint32_t>(jn - jc) * (NCW * kWave * 4u));
+            else fetch_global(w, pnext);
+            wait_lookups(std::integral_constant<int, 0>{});
+          } else {
+            wait_lookups(std::integral_constant<int, 0>{});
           }
         };
         // Only positive S values ever reach a sample's result (getHSS ignores the rest and the frame's
@@ -580,9 +646,9 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
           }
         };
         // codon without a frame shift in any sequence (z == 0 for all k, score.c:506-510): straight-line
-        auto fast_cell = [&](uint32_t (&w)[NCW], int jn) -> float {
+        auto fast_cell = [&](uint32_t (&w)[NCW], int jn, auto kind) -> float {
           float sig[NK];
-          lookup(w, sig, jn, std::false_type{});
+          lookup(w, sig, jn, std::false_type{}, kind);
           float sum = 0.0f;
           static_for<NK>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
@@ -598,9 +664,9 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
         // the same before the row has met its first event: states 1 and 2 of EVERY sequence have only
         // ever received "+ omega" from 0, so they all hold the one value w (identical operations on
         // identical operands); MAX3(s0, w, w) = max(s0, w).  w advances once per codon.
-        auto pristine_cell = [&](uint32_t (&w)[NCW], float &wv, int jn) -> float {
+        auto pristine_cell = [&](uint32_t (&w)[NCW], float &wv, int jn, auto kind) -> float {
           float sig[NK];
-          lookup(w, sig, jn, std::false_type{});
+          lookup(w, sig, jn, std::false_type{}, kind);
           wv = wv + omega_v;
           float sum = 0.0f;
           static_for<NK>([&](auto kc) {
@@ -616,9 +682,9 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
         // row and are never read individually again, so one value per sequence, t = max(s1, s2), stands for both:
         // fl(max(s1, s2) + omega) == max(fl(s1 + omega), fl(s2 + omega)) because x -> fl(x + omega) is monotone, and
         // MAX3(s0, s1, s2) == max(s0, t).  The caller folds s2 into s1 first; one add per sequence and codon less.
-        auto tail_cell = [&](uint32_t (&w)[NCW], int jn) -> float {
+        auto tail_cell = [&](uint32_t (&w)[NCW], int jn, auto kind) -> float {
           float sig[NK];
-          lookup(w, sig, jn, std::false_type{});
+          lookup(w, sig, jn, std::false_type{}, kind);
           float sum = 0.0f;
           static_for<NK>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
@@ -631,9 +697,9 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
           return finish(sum);
         };
         // codon where some sequence has z != 0 (score.c:512-533), wave-uniform branch per sequence
-        auto event_cell = [&](uint32_t (&w)[NCW], int j, int jn) -> float {
+        auto event_cell = [&](uint32_t (&w)[NCW], int j, int jn, auto kind) -> float {
           float sig[NK];
-          lookup(w, sig, jn, std::true_type{});
+          lookup(w, sig, jn, std::true_type{}, kind);
           unsigned long long z[ZW];
 #pragma unroll
           for (int x = 0; x < ZW; x++) z[x] = zbase[static_cast<size_t>(3 * j) * ZW + x];
@@ -676,7 +742,7 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
           Regs RB;   // row a + 1 (its lut members are not used)
           auto pristine2 = [&](uint32_t (&w)[NCW], float &wvA, float &wvB, int jn, float &vB) -> float {
             float sig[NK];
-            lookup(w, sig, jn, std::false_type{});
+            lookup(w, sig, jn, std::false_type{}, std::true_type{});
             wvA = wvA + omega_v;
             wvB = wvB + omega_v;
             float sumA = 0.0f, sumB = 0.0f;
@@ -696,7 +762,7 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
           };
           auto fast2 = [&](uint32_t (&w)[NCW], int jn, float &vB) -> float {
             float sig[NK];
-            lookup(w, sig, jn, std::false_type{});
+            lookup(w, sig, jn, std::false_type{}, std::true_type{});
             float sumA = 0.0f, sumB = 0.0f;
             static_for<NK>([&](auto kc) {
               constexpr int k = decltype(kc)::value;
@@ -718,7 +784,7 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
           };
           auto tail2 = [&](uint32_t (&w)[NCW], int jn, float &vB) -> float {
             float sig[NK];
-            lookup(w, sig, jn, std::false_type{});
+            lookup(w, sig, jn, std::false_type{}, std::true_type{});
             float sumA = 0.0f, sumB = 0.0f;
             static_for<NK>([&](auto kc) {
               constexpr int k = decltype(kc)::value;
@@ -738,7 +804,7 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
           };
           auto event2 = [&](uint32_t (&w)[NCW], int j, int jn, float &vB) -> float {
             float sig[NK];
-            lookup(w, sig, jn, std::true_type{});
+            lookup(w, sig, jn, std::true_type{}, std::true_type{});
             unsigned long long z[ZW];
 #pragma unroll
             for (int x = 0; x < ZW; x++) z[x] = zbase[static_cast<size_t>(3 * j) * ZW + x];
@@ -779,7 +845,7 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
               asm volatile("v_mov_b32 %0, 0" : "=v"(wvA));
               asm volatile("v_mov_b32 %0, 0" : "=v"(wvB));
               {   // row a's first cell (site a: no event)
-                const float v = pristine_cell(wcur, wvA, a + 1);
+                const float v = pristine_cell(wcur, wvA, a + 1, std::true_type{});
                 sample_scan_step(st, v, j2f, negTie);
                 asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
                 j = a + 1;
@@ -872,12 +938,12 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
                   for (; j < e; j++) {
                     const int jn = j + 1 < sites ? j + 1 : j;
                     uint32_t wnext[NCW];
-                    if constexpr (!LDSC) load_words(jn, wnext);
+                    if constexpr (EXACT) load_words(jn, wnext);
                     if constexpr (kProfiling) statPristine++;
-                    const float v = pristine_cell(wcur, wv, jn);
+                    const float v = pristine_cell(wcur, wv, jn, std::true_type{});
                     sample_scan_step(st, v, j2f, negTie);
                     asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
-                    if constexpr (!LDSC) {
+                    if constexpr (EXACT) {
       #pragma unroll
                       for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
                     }
@@ -892,12 +958,12 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
                   if ((zany[j >> 6] >> (j & 63)) & 1ull) {               // event codon
                     const int jn = j + 1 < sites ? j + 1 : j;
                     uint32_t wnext[NCW];
-                    if constexpr (!LDSC) load_words(jn, wnext);
+                    if constexpr (EXACT) load_words(jn, wnext);
                     if constexpr (kProfiling) statEvent++;
-                    const float v = event_cell(wcur, j, jn);
+                    const float v = event_cell(wcur, j, jn, std::true_type{});
                     sample_scan_step(st, v, j2f, negTie);
                     asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
-                    if constexpr (!LDSC) {
+                    if constexpr (EXACT) {
       #pragma unroll
                       for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
                     }
@@ -913,12 +979,12 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
                     for (; j < e; j++) {
                       const int jn = j + 1 < sites ? j + 1 : j;
                       uint32_t wnext[NCW];
-                      if constexpr (!LDSC) load_words(jn, wnext);
+                      if constexpr (EXACT) load_words(jn, wnext);
                       if constexpr (kProfiling) statTail++;
-                      const float v = tail_cell(wcur, jn);
+                      const float v = tail_cell(wcur, jn, std::true_type{});
                       sample_scan_step(st, v, j2f, negTie);
                       asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
-                      if constexpr (!LDSC) {
+                      if constexpr (EXACT) {
       #pragma unroll
                         for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
                       }
@@ -927,19 +993,22 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
                   for (; j < e; j++) {                                   // tight loop: no events
                     const int jn = j + 1 < sites ? j + 1 : j;
                     uint32_t wnext[NCW];
-                    if constexpr (!LDSC) load_words(jn, wnext);
-                    const float v = fast_cell(wcur, jn);
+                    if constexpr (EXACT) load_words(jn, wnext);
+                    const float v = fast_cell(wcur, jn, std::true_type{});
                     sample_scan_step(st, v, j2f, negTie);
                     asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
-                    if constexpr (!LDSC) {
+                    if constexpr (EXACT) {
       #pragma unroll
                       for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
                     }
                   }
                 }
-                if constexpr (LDSC) {   // the last cell's fetch-ahead must have landed before its registers are given away
+                if constexpr (!EXACT) {   // the last cell's fetch-ahead must have landed before its registers are given away
       #pragma unroll
-                  for (int x = 0; x < NCW; x++) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wcur[x]));
+                  for (int x = 0; x < NCW; x++) {
+                    if constexpr (LDSC) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wcur[x]));
+                    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(wcur[x]));
+                  }
                 }
               if (pend) {
                 // the buffered values, entry 0 first: unrolled, so that every entry is a register operand of its scan step (an
@@ -972,23 +1041,31 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
             const int jend = (a == sites - 1) ? sites - 1 : sites;   // the frame's final entry is handled below
             int j = a;
             float j2f = static_cast<float>(2 * a + 1);   // 2j + 1 of the cell being entered
+            // cells j .. e - 1 through body(kind)
+            auto span = [&](int e, auto &&body) {
+              for (; j < e; j++) body(std::true_type{});
+            };
+            // one cell: the site whose words are fetched behind the look-ups, EXACT's second register set, the cell, its scan step
+            auto one = [&](auto kind, auto &&cell) {
+              const int jn = j + 1 < sites ? j + 1 : j;
+              uint32_t wnext[NCW];
+              if constexpr (EXACT) load_words(jn, wnext);
+              const float v = cell(jn, kind);
+              sample_scan_step(st, v, j2f, negTie);
+              asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
+              if constexpr (EXACT) {
+#pragma unroll
+                for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
+              }
+            };
             {   // pristine segment: up to the row's first event
               const int e = next_event(j, jend);
               float wv = 0.0f;
               asm volatile("v_mov_b32 %0, 0" : "=v"(wv));   // keep w a per-lane register (full-rate v_add/v_max operands)
-              for (; j < e; j++) {
-                const int jn = j + 1 < sites ? j + 1 : j;
-                uint32_t wnext[NCW];
-                if constexpr (!LDSC) load_words(jn, wnext);
+              span(e, [&](auto kind) {
                 if constexpr (kProfiling) statPristine++;
-                const float v = pristine_cell(wcur, wv, jn);
-                sample_scan_step(st, v, j2f, negTie);
-                asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
-                if constexpr (!LDSC) {
-  #pragma unroll
-                  for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
-                }
-              }
+                one(kind, [&](int jn, auto kd) { return pristine_cell(wcur, wv, jn, kd); });
+              });
               static_for<NK>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
                 auto &r = R.template at<k>();
@@ -997,17 +1074,9 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
             }
             while (j < jend) {
               if ((zany[j >> 6] >> (j & 63)) & 1ull) {               // event codon
-                const int jn = j + 1 < sites ? j + 1 : j;
-                uint32_t wnext[NCW];
-                if constexpr (!LDSC) load_words(jn, wnext);
                 if constexpr (kProfiling) statEvent++;
-                const float v = event_cell(wcur, j, jn);
-                sample_scan_step(st, v, j2f, negTie);
-                asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
-                if constexpr (!LDSC) {
-  #pragma unroll
-                  for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
-                }
+                const int jj = j;
+                one(std::true_type{}, [&](int jn, auto kd) { return event_cell(wcur, jj, jn, kd); });
                 j++;
               }
               const int e = next_event(j, jend);
@@ -1017,36 +1086,21 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
                   auto &r = R.template at<k>();
                   r.s1 = fmaxf(r.s1, r.s2);
                 });
-                for (; j < e; j++) {
-                  const int jn = j + 1 < sites ? j + 1 : j;
-                  uint32_t wnext[NCW];
-                  if constexpr (!LDSC) load_words(jn, wnext);
+                span(e, [&](auto kind) {
                   if constexpr (kProfiling) statTail++;
-                  const float v = tail_cell(wcur, jn);
-                  sample_scan_step(st, v, j2f, negTie);
-                  asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
-                  if constexpr (!LDSC) {
-  #pragma unroll
-                    for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
-                  }
-                }
+                  one(kind, [&](int jn, auto kd) { return tail_cell(wcur, jn, kd); });
+                });
               }
-              for (; j < e; j++) {                                   // tight loop: no events
-                const int jn = j + 1 < sites ? j + 1 : j;
-                uint32_t wnext[NCW];
-                if constexpr (!LDSC) load_words(jn, wnext);
-                const float v = fast_cell(wcur, jn);
-                sample_scan_step(st, v, j2f, negTie);
-                asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
-                if constexpr (!LDSC) {
-  #pragma unroll
-                  for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
-                }
-              }
+              span(e, [&](auto kind) {                               // tight loop: no events
+                one(kind, [&](int jn, auto kd) { return fast_cell(wcur, jn, kd); });
+              });
             }
-            if constexpr (LDSC) {   // the last cell's fetch-ahead must have landed before its registers are given away
-  #pragma unroll
-              for (int x = 0; x < NCW; x++) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wcur[x]));
+            if constexpr (!EXACT) {   // the last cell's fetch-ahead must have landed before its registers are given away
+#pragma unroll
+              for (int x = 0; x < NCW; x++) {
+                if constexpr (LDSC) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wcur[x]));
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(wcur[x]));
+              }
             }
             sample_scan_row_end(st, static_cast<uint32_t>(a));
           }
@@ -1070,9 +1124,34 @@ __global__ __launch_bounds__(64) void k_null(NullArgs A, const uint8_t *__restri
   }
 }
 
+template <int NK, bool LDSC, bool EXACT, bool DUAL = false>
+__global__ __launch_bounds__(64)
+void k_null(NullArgs A, const uint8_t *__restrict__ blob,
+                                             const DevBlock *__restrict__ dblocks, const int *__restrict__ classBlocks,
+                                             const uint32_t *__restrict__ flags, const uint32_t *__restrict__ Ustream, const uint8_t *__restrict__ pairTab,
+                                             uint32_t *__restrict__ scratch, float *__restrict__ maxima) {
+  null_body<NK, LDSC, EXACT, DUAL>(A, blob, dblocks, classBlocks, flags, Ustream, pairTab, scratch, maxima);
+}
+
+// The instantiations that read their code words from L2 live on occupancy (4000 blocks x 150 columns x 9 rows: 49.4 ms at 20
+// workgroups per CU, 64.0 at 12).  k_null_occ<NK> is k_null<NK, false, false> compiled for one more wavefront per SIMD than its
+// registers allow by themselves: 6..8 other sequences (81-85 VGPRs) for six (80 VGPRs, a handful of spills: 24 workgroups per CU
+// instead of 20), 10..12 (101-113 VGPRs) for five (96 VGPRs: 20 instead of 16).  Round 3 measured +1..7 % on uniform batches and
+// -5 % on a stream of ten row-count classes, whose native-block, table and fit kernels ran in the registers these wavefronts take --
+// so the host launches it only for batches of ONE row-count class (rc_api.cpp, high_occupancy_class).
+constexpr int hi_occ_waves(int NK) { return (NK >= 6 && NK <= 8) ? 6 : (NK >= 10 && NK <= 12) ? 5 : 0; }
+template <int NK>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(hi_occ_waves(NK) ? hi_occ_waves(NK) : 1)))
+void k_null_occ(NullArgs A, const uint8_t *__restrict__ blob, const DevBlock *__restrict__ dblocks, const int *__restrict__ classBlocks,
+                const uint32_t *__restrict__ flags, const uint32_t *__restrict__ Ustream, const uint8_t *__restrict__ pairTab,
+                uint32_t *__restrict__ scratch, float *__restrict__ maxima) {
+  null_body<NK, false, false, false>(A, blob, dblocks, classBlocks, flags, Ustream, pairTab, scratch, maxima);
+}
+
 
 // launch / occupancy of one N-1 value, used by the range units
-// dynamic LDS of the instantiations that do not stage codes: phase A's threshold table (64 B per node) + pair table
+// dynamic LDS of the instantiations that do not stage codes: at least phase A's threshold table (64 B per node) + pair table; the
+// host may give more (NullArgs::plainLds), which phase B uses as its suffix cache
 template <int NK> constexpr size_t phase_a_lds() { return NK < kFastRows ? static_cast<size_t>(kPhaseALds) : static_cast<size_t>(2 * (NK + 1)) * 64 + 64 * 64; }
 
 template <int NK>
@@ -1080,6 +1159,18 @@ inline int null_occupancy_one(size_t ldsBytes) {
   int nb = 0;
   hipError_t e = ldsBytes ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_null<NK, true, false>, 64, ldsBytes)
                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_null<NK, false, false>, 64, phase_a_lds<NK>());
+  if (e != hipSuccess) return 0;
+  return nb;
+}
+// codes from L2 with `dynLds` bytes of dynamic LDS; hiOcc: the k_null_occ build (0 if this N-1 has none)
+template <int NK>
+inline int null_occupancy_plain_one(size_t dynLds, int hiOcc) {
+  int nb = 0;
+  hipError_t e;
+  if (hiOcc) {
+    if constexpr (hi_occ_waves(NK) != 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_null_occ<NK>, 64, dynLds);
+    else return 0;
+  } else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_null<NK, false, false>, 64, dynLds);
   if (e != hipSuccess) return 0;
   return nb;
 }
@@ -1104,7 +1195,15 @@ inline void launch_null_one(const NullArgs &a, int grid, size_t ldsBytes, bool e
     hipLaunchKernelGGL((k_null<NK, true, false>), dim3(grid), dim3(64), ldsBytes, stream, a, a.blob, a.dblocks,
                        a.classBlocks, a.flags, a.U, a.pair, a.scratch, a.maxima);
   } else {
-    hipLaunchKernelGGL((k_null<NK, false, false>), dim3(grid), dim3(64), phase_a_lds<NK>(), stream, a, a.blob, a.dblocks,
+    const size_t dyn = a.plainLds ? static_cast<size_t>(a.plainLds) : phase_a_lds<NK>();
+    if constexpr (hi_occ_waves(NK) != 0) {
+      if (a.hiOcc) {
+        hipLaunchKernelGGL((k_null_occ<NK>), dim3(grid), dim3(64), dyn, stream, a, a.blob, a.dblocks,
+                           a.classBlocks, a.flags, a.U, a.pair, a.scratch, a.maxima);
+        return;
+      }
+    }
+    hipLaunchKernelGGL((k_null<NK, false, false>), dim3(grid), dim3(64), dyn, stream, a, a.blob, a.dblocks,
                        a.classBlocks, a.flags, a.U, a.pair, a.scratch, a.maxima);
   }
 }
@@ -1122,7 +1221,12 @@ inline void launch_null_one(const NullArgs &a, int grid, size_t ldsBytes, bool e
       return launch_rec_##SUFFIX<NK + 1>(nk, a, grid, lds, exact, st);                               \
     }                                                                                                \
   }                                                                                                  \
+  template <int NK> static int occp_rec_##SUFFIX(int nk, size_t lds, int hiOcc) {                    \
+    if constexpr (NK > HI) return 0;                                                                 \
+    else return nk == NK ? null_occupancy_plain_one<NK>(lds, hiOcc) : occp_rec_##SUFFIX<NK + 1>(nk, lds, hiOcc); \
+  }                                                                                                  \
   int null_occupancy_##SUFFIX(int nk, size_t lds) { return occ_rec_##SUFFIX<LO>(nk, lds); }          \
+  int null_occupancy_plain_##SUFFIX(int nk, size_t lds, int hiOcc) { return occp_rec_##SUFFIX<LO>(nk, lds, hiOcc); } \
   bool launch_null_##SUFFIX(int nk, const NullArgs &a, int grid, size_t lds, bool exact, hipStream_t st) { \
     return launch_rec_##SUFFIX<LO>(nk, a, grid, lds, exact, st);                                     \
   }
@@ -1155,6 +1259,7 @@ inline void launch_null_one(const NullArgs &a, int grid, size_t ldsBytes, bool e
     }                                                                                                \
   }                                                                                                  \
   int null_occupancy_##SUFFIX(int nk, size_t) { return occ_rec_##SUFFIX<LO>(nk); }                   \
+  int null_occupancy_plain_##SUFFIX(int, size_t, int) { return 0; }                                  \
   bool launch_null_##SUFFIX(int nk, const NullArgs &a, int grid, size_t, bool, hipStream_t st) {     \
     return launch_rec_##SUFFIX<LO>(nk, a, grid, st);                                                 \
   }

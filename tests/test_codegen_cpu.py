@@ -61,3 +61,38 @@ def test_k_null_cell_loops_are_wave_uniform_and_tight(tmp_path):
     for b in pairs:
         assert sum("s_set_gpr_idx_on" in x for x in b) == 1 and not any(x.startswith("v_mov_b64") for x in b)
     assert vgprs <= 128, vgprs       # four wavefronts per SIMD (16 per CU is what the LDS allows)
+
+
+PLAIN = "_ZN2rc6k_nullILi6ELb0ELb0ELb0EEEvNS_8NullArgsEPKhPKNS_8DevBlockEPKiPKjSA_S3_PjPf"      # k_null<6, false, false, false>
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_codes_from_l2_cell_keeps_its_fetched_words_in_place(tmp_path):
+    """k_null<N-1, false, false> fetches the next cell's code words with asm loads INTO the registers the look-ups have just read, and
+    the next cell waits for them (rc_null_kernel.h, lookup).  The compiler does not know those registers are pending: a copy out of
+    one of them before that wait reads garbage.  A build that cut the row loops by kind of fetch had exactly that (a v_mov at a join,
+    in front of the wait) and got every row with a frame-shift event wrong; the parity suite caught it, this test names the cause.
+    In the kernel's DP phase no v_mov may read a register that an asm fetch writes, and each cell loop holds its own fetches."""
+    out = tmp_path / "rc_null_a.s"
+    flags = "-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize".split()
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "--cuda-device-only", "-S", *flags, "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "rnacode_amd", "csrc", "rc_null_a.hip"), "-o", str(out)])
+    txt = out.read_text()
+    body = txt[txt.index(PLAIN + ":"):]
+    body = body[:body.index(".Lfunc_end")]
+    ins = [ln.strip() for ln in body.split("\n") if ln.startswith("\t") and not ln.startswith(("\t.", "\t;"))]
+    first = next(i for i, x in enumerate(ins) if x.startswith("ds_bpermute_b32"))
+    dp = ins[first:]
+    fetched = set()
+    for x in dp:
+        m = re.match(r"global_load_dword (v\d+), v\d+, s\[\d+:\d+\]", x)      # the saddr form only the asm fetch uses
+        if m:
+            fetched.add(m.group(1))
+    assert fetched, "no asm fetch found: has the kernel changed?"
+    copies = [x for x in dp if re.match(r"v_mov_b32(_e32)? v\d+, (v\d+)$", x) and x.split(", ")[1] in fetched]
+    assert not copies, "the compiler copies a register that an asm fetch leaves pending:\n" + "\n".join(copies[:10])
+    n_fetch = sum(1 for x in dp if re.match(r"global_load_dword v\d+, v\d+, s\[", x))
+    n_cache = sum(1 for x in dp if x.startswith("ds_read_b32"))
+    assert n_fetch >= 8 and n_cache >= 8      # four kinds of cell, two code words each, both arms
+    meta = txt[txt.index(".name:           " + PLAIN):]
+    assert int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1)) <= 80      # six wavefronts per SIMD

@@ -43,7 +43,7 @@ def test_soak_slice(monkeypatch, mode, env, blocks):
 
 
 KNOBS = [
-    {"RC_TAIL_SHARING": "0"}, {"RC_TAIL_RELEASE": "agent"}, {"RC_DUAL_ROWS": "0"}, {"RC_NATIVE_FIRST": "0"}, {"RC_NATIVE_FIRST": "1"},
+    {"RC_TAIL_SHARING": "0"}, {"RC_TAIL_RELEASE": "workgroup"}, {"RC_DUAL_ROWS": "0"}, {"RC_NATIVE_FIRST": "0"}, {"RC_NATIVE_FIRST": "1"},
     {"RC_FAT_STREAM_MIN_ITEMS": "0"}, {"RC_COPY_RESULTS": "1"}, {"RC_COMPUTE_STREAMS": "1"}, {"RC_COMPUTE_STREAMS": "3"},
     {"RC_HOST_THREADS": "1", "RC_SPLIT_FACTOR": "0"}, {"RC_SPLIT_FACTOR": "100"}, {"RC_NATIVE_WAVES_PER_CU": "1"},
     {"RC_NATIVE_WAVES_PER_CU": "32"}, {"RC_TOGETHER_MAX_MB": "0"}, {"RC_STOP_ROUNDS": "6", "RC_STOP_MIN_ITEMS": "0"},

@@ -639,14 +639,14 @@ def test_two_rows_per_pass_equal_one_row_per_pass_and_the_oracle(monkeypatch):
 
 
 def test_tail_sharing_stress_every_item_late(monkeypatch):
-    """k_null's tail sharing hands an owner's sigma codes to helper workgroups of the same XCD behind a WORKGROUP-scope release (the L1
-    writes through, owner and helper share an L2): what gfx950 does, not what the memory model promises.  This is
-    the tripwire for a toolchain or firmware that changes it.  One workgroup per CU (RC_GRID_CAP_PER_CU=1) and a little more than one
-    item per workgroup, no strand x frame split: EVERY item is late, is published, and has its six parts claimed by its owner and by the
-    workgroups that found the queues empty -- on every launch, hundreds of launches, the staging scratch rewritten with other blocks'
-    codes each time (a stream recycles its three batch objects; resident batches are re-run in turn), both code-word paths (LDS-staged
-    and from L2).  Every launch must reproduce the maxima computed with sharing off, bit for bit; a stale code word shows as a wrong
-    maximum.  The documented agent-scope form (RC_TAIL_RELEASE=agent) is held to the same."""
+    """k_null's tail sharing hands an owner's sigma codes to helper workgroups of the same XCD: by default behind an agent-scope
+    release (the documented cross-CU hand-off), with RC_TAIL_RELEASE=workgroup behind a workgroup-scope one (the L1 writes through,
+    owner and helper share an L2: what gfx950 does, not what the memory model promises).  This is the tripwire
+    for both.  One workgroup per CU (RC_GRID_CAP_PER_CU=1) and a little more than one item per workgroup, no strand x frame split:
+    EVERY item is late, is published, and has its six parts claimed by its owner and by the workgroups that found the queues empty --
+    on every launch, hundreds of launches, the staging scratch rewritten with other blocks' codes each time (a stream recycles its
+    three batch objects; resident batches are re-run in turn), both code-word paths (LDS-staged and from L2).  Every launch must
+    reproduce the maxima computed with sharing off, bit for bit; a stale code word shows as a wrong maximum."""
     from rnacode_amd import api
     from rnacode_amd.synth import synth_blocks
     monkeypatch.setenv("RC_GRID_CAP_PER_CU", "1")
@@ -673,7 +673,7 @@ def test_tail_sharing_stress_every_item_late(monkeypatch):
         monkeypatch.setenv("RC_TAIL_RELEASE", release)
         c = api.Context(0)
         st = api.Stream(c, p, 3)
-        for rep in range(25 if release == "workgroup" else 6):           # streamed: helpers leave at once (stealWait = 0)
+        for rep in range(14):                                             # streamed: helpers leave at once (stealWait = 0)
             order = np.random.RandomState(rep).permutation(len(sets))
             pend = []
 
@@ -694,7 +694,7 @@ def test_tail_sharing_stress_every_item_late(monkeypatch):
                 launches += 1
         st.close()
         batches = [api.Batch(c, m, p) for m in sets]                      # resident: helpers wait for owners that are still simulating
-        for rep in range(20 if release == "workgroup" else 5):
+        for rep in range(12):
             for k, b in enumerate(batches):
                 b.run()
                 np.testing.assert_array_equal(b.maxScores_all(), want[k], err_msg=f"{release}, resident run {rep}, shape {shapes[k]}")
