@@ -904,7 +904,7 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
       continue;
     }
     const int NCW = (p.NK + 4) / 5;   // 5 six-bit sigma codes per word
-    p.stride = static_cast<size_t>(2) * (maxLc + 1) * NCW * kWave;
+    p.stride = static_cast<size_t>(2) * (maxLc + 1) * code_pos_words(p.NK);   // both strands, positions 0..L, [word][lane] with a narrow last word (rc_device.h)
     // sigma codes of one strand x frame are staged in LDS when that still leaves >= 12 wavefronts per
     // CU (RC_LDS_MAX_BYTES overrides the per-wavefront budget); otherwise they are read from the
     // per-workgroup scratch in global memory.
@@ -923,7 +923,7 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
       const rc_ctx::PlainPlan pp = plain_plan(c, p.NK, maxNodes, wantHi);
       if (pp.occ > 0) {
         occ = pp.occ; p.hiOcc = pp.hiOcc; p.plainLds = pp.lds;
-        p.cacheSites = c->suffixCache ? static_cast<int>(pp.lds / (static_cast<size_t>(NCW) * kWave * sizeof(uint32_t))) : 0;
+        p.cacheSites = c->suffixCache ? static_cast<int>(pp.lds / (static_cast<size_t>(code_pos_words(p.NK)) * sizeof(uint32_t))) : 0;
       }
     }
     if (c->gridCapPerCU > 0) occ = std::min(occ, c->gridCapPerCU);

@@ -77,6 +77,12 @@ struct DevBlock {
   uint64_t off_sigma;    // f32[2][NK][L+1] native sigma (k_native_sigma)
 };
 
+// k_null's staging scratch: the sigma codes of one (strand, reference position) for the 64 samples of a wavefront -- five 6-bit codes
+// per dword, [word][lane]; the LAST word of a position is stored as a byte or a halfword where it holds only one or two codes.
+constexpr int code_words(int NK) { return (NK + 4) / 5; }
+constexpr int code_tail_bytes(int NK) { return NK - 5 * (code_words(NK) - 1) == 1 ? 1 : NK - 5 * (code_words(NK) - 1) == 2 ? 2 : 4; }
+constexpr int code_pos_words(int NK) { return (code_words(NK) - 1) * kWave + code_tail_bytes(NK) * (kWave / 4); }   // dwords per (strand, position)
+
 // per-block flag word (device array next to the DevBlocks)
 constexpr int kDualRowsMaxNK = 5;        // k_null walks two rows of S per pass for blocks of up to this many sequences besides the reference (rc_null_kernel.h)
 constexpr uint32_t kFlagExact = 1u;     // score tables outside the range proven for div_by_nk -> scored by the EXACT instantiation

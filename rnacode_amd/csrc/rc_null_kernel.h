@@ -182,6 +182,13 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
   constexpr int N = NK + 1;
   constexpr int CPW = 5;                  // 6-bit sigma codes per 32-bit word
   constexpr int NCW = (NK + CPW - 1) / CPW;
+  // The last code word of a site holds CNT = NK - 5 (NCW - 1) codes; with one or two codes it is kept as a byte or a halfword in the
+  // staging scratch (a field shifted down by 6t is a look-up address either way: one code is (code << 2) < 256): a site of twelve rows
+  // takes 9 bytes per sample instead of 12, one of seven rows 5 instead of 8 -- that much less to write, to re-read from L2, and to hold
+  // in the suffix cache.  Layout per (strand, position): [NCW - 1][64] dwords, then [64] tail values of LB bytes.  (code_layout, rc_device.h)
+  constexpr int LB = code_tail_bytes(NK);
+  constexpr int PSW = code_pos_words(NK);                  // dwords per (strand, position)
+  using TailT = std::conditional_t<LB == 1, uint8_t, std::conditional_t<LB == 2, uint16_t, uint32_t>>;
   constexpr int ZW = (NK + 31) / 32;      // 64-bit words per z entry (2 bits per sequence)
   using Regs = KRegs<std::make_integer_sequence<int, NK>>;
   // DUAL: two rows of S per pass (see "rows a and a + 1 together" below): for instantiations whose codes are staged in LDS and whose
@@ -414,8 +421,13 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
                     wr |= static_cast<uint32_t>(pairLut[aR * 64 + bR]) << (6 * c + 2);
                   }
                 }
-                cod[(static_cast<size_t>(0 * L1 + i) * NCW + w) * kWave + lane] = wf;
-                cod[(static_cast<size_t>(1 * L1 + ip) * NCW + w) * kWave + lane] = wr;
+                if (w < NCW - 1) {
+                  cod[static_cast<size_t>(0 * L1 + i) * PSW + w * kWave + lane] = wf;
+                  cod[static_cast<size_t>(1 * L1 + ip) * PSW + w * kWave + lane] = wr;
+                } else {
+                  reinterpret_cast<TailT *>(cod + static_cast<size_t>(0 * L1 + i) * PSW + (NCW - 1) * kWave)[lane] = static_cast<TailT>(wf);
+                  reinterpret_cast<TailT *>(cod + static_cast<size_t>(1 * L1 + ip) * PSW + (NCW - 1) * kWave)[lane] = static_cast<TailT>(wr);
+                }
               }
             }
           }
@@ -481,38 +493,65 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
         }
         const int sites = (L - f) / 3;
         if (sites <= 0) continue;
-        const uint32_t *__restrict__ cbase = cod + (static_cast<size_t>(s * L1 + 3 + f) * NCW) * kWave + lane;  // site j: + j*3*NCW*64
+        // the code words of this strand x frame: site j at position 3 + f + 3 j of the strand (wave-uniform base, the lane added per access)
+        const uint32_t *__restrict__ sbase = cod + static_cast<size_t>(s * L1 + 3 + f) * PSW;
+        constexpr int kSiteWords = 3 * PSW;                   // dwords from one site of a frame to the next
+        auto word_at = [&](int j, int x) -> uint32_t {        // word x of site j from the staging scratch
+          const uint32_t *p = sbase + static_cast<size_t>(j) * kSiteWords;
+          if (x < NCW - 1) return p[x * kWave + lane];
+          return static_cast<uint32_t>(reinterpret_cast<const TailT *>(p + (NCW - 1) * kWave)[lane]);
+        };
         const unsigned long long *__restrict__ zbase = zw + static_cast<size_t>(s * L1 + 3 + f) * ZW;               // site j: [3j * ZW + word]
         const unsigned long long *__restrict__ zany = zmask + static_cast<size_t>(s * 3 + f) * zmWords;            // bit j: some z != 0 at site j
         // Codes from L2 (the strand x frame's words do not fit the LDS at the occupancy this kernel needs): row a reads the words of
         // the sites a..sites-1, so site j is read by j + 1 rows -- the LAST sites are the ones read most.  Whatever LDS the launch
-        // was given beyond phase A's tables (A.cacheSites sites' worth) therefore holds the words of the frame's suffix [jc, sites);
-        // the rows read those from LDS and only the sites before jc from L2 (C5, 100 sites, 13 of them cached: 24 % of the reads;
-        // 8 rows x 150 columns, 16 of 50: 55 %).
+        // was given beyond phase A's tables (A.cacheSites sites' worth) therefore holds the words of the frame's suffix [jc, sites),
+        // in the scratch's own layout (narrow tail values); the rows read those from LDS and only the sites before jc from L2 (C5, 100
+        // sites, 17 of them cached: 31 % of the reads; 8 rows x 150 columns, 21 of 50: 67 %).
         int jc = sites;
-        if constexpr (LDSC) {
-          for (int idx = 0; idx < sites * NCW; idx++)
-            lds_codes[idx * kWave + lane] = cbase[static_cast<size_t>(idx / NCW) * 3 * NCW * kWave + (idx % NCW) * kWave];
+        constexpr int kCacheSiteBytes = PSW * 4;              // bytes of one cached site
+        if constexpr (LDSC) {                                 // staged: all dwords, [site][NCW][64] (conflict-free ds_read_b32)
+          for (int idx = 0; idx < sites * NCW; idx++) lds_codes[idx * kWave + lane] = word_at(idx / NCW, idx % NCW);
           __builtin_amdgcn_s_waitcnt(0);   // everything landed: the row loops below issue no vector memory ops
         } else if constexpr (!EXACT) {
           jc = sites - (A.cacheSites < sites ? A.cacheSites : sites);
-          for (int idx = jc * NCW; idx < sites * NCW; idx++)
-            lds_codes[(idx - jc * NCW) * kWave + lane] = cbase[static_cast<size_t>(idx / NCW) * 3 * NCW * kWave + (idx % NCW) * kWave];
+          for (int j = jc; j < sites; j++) {
+            uint32_t *dst = lds_codes + (j - jc) * PSW;
+#pragma unroll
+            for (int x = 0; x < NCW - 1; x++) dst[x * kWave + lane] = word_at(j, x);
+            reinterpret_cast<TailT *>(dst + (NCW - 1) * kWave)[lane] = static_cast<TailT>(word_at(j, NCW - 1));
+          }
           __builtin_amdgcn_s_waitcnt(0);
         }
-        const uint32_t ldsLane = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_codes)) + static_cast<uint32_t>(lane) * 4u;
-        // codes from L2: the wave-uniform part of the code words' address (scalar registers) and the lane's byte offset
-        const uint32_t *__restrict__ sbase = cod + (static_cast<size_t>(s * L1 + 3 + f) * NCW) * kWave;
-        const uint32_t laneOff = static_cast<uint32_t>(lane) * 4u;
+        const uint32_t ldsBase = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_codes));
+        const uint32_t ldsLane = ldsBase + static_cast<uint32_t>(lane) * 4u;                                  // a lane's dwords
+        const uint32_t ldsTail = ldsBase + (NCW - 1) * kWave * 4u + static_cast<uint32_t>(lane) * LB;         // its tail value (suffix cache)
+        const uint32_t laneOff = static_cast<uint32_t>(lane) * 4u, laneTail = static_cast<uint32_t>(lane) * LB;
         // asm fetches of a site's code words: the compiler does not know them as memory operations and places no waits of its own
-        auto fetch_lds = [&](uint32_t (&w)[NCW], uint32_t at) {
+        auto fetch_staged = [&](uint32_t (&w)[NCW], int j) {        // LDSC: [site][NCW][64] dwords
+          const uint32_t at = ldsLane + static_cast<uint32_t>(j) * (NCW * kWave * 4u);
 #pragma unroll
           for (int x = 0; x < NCW; x++) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(w[x]) : "v"(at), "n"(x * kWave * 4));
         };
-        auto fetch_global = [&](uint32_t (&w)[NCW], const uint32_t *p) {   // p: wave-uniform, settled in scalar registers five wait states ago
-          const uint32_t lo = laneOff + 0u;   // (a copy: an asm operand alone does not make a generic lambda capture the variable)
+        auto fetch_cached = [&](uint32_t (&w)[NCW], int j) {        // suffix cache: site j >= jc, the scratch's layout
+          const uint32_t off = static_cast<uint32_t>(j - jc) * kCacheSiteBytes;
+          if constexpr (NCW > 1) {
+            const uint32_t at = ldsLane + off;
 #pragma unroll
-          for (int x = 0; x < NCW; x++) asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(w[x]) : "v"(lo), "s"(p), "n"(x * kWave * 4));
+            for (int x = 0; x < NCW - 1; x++) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(w[x]) : "v"(at), "n"(x * kWave * 4));
+          }
+          const uint32_t att = ldsTail + off;
+          if constexpr (LB == 1) asm volatile("ds_read_u8 %0, %1" : "=v"(w[NCW - 1]) : "v"(att));
+          else if constexpr (LB == 2) asm volatile("ds_read_u16 %0, %1" : "=v"(w[NCW - 1]) : "v"(att));
+          else asm volatile("ds_read_b32 %0, %1" : "=v"(w[NCW - 1]) : "v"(att));
+        };
+        auto fetch_global = [&](uint32_t (&w)[NCW], const uint32_t *p) {   // p: wave-uniform, settled in scalar registers five wait states ago
+          const uint32_t lo = laneOff + 0u, lt = laneTail + 0u;   // (copies: an asm operand alone does not make a generic lambda capture the variable)
+#pragma unroll
+          for (int x = 0; x < NCW - 1; x++) asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(w[x]) : "v"(lo), "s"(p), "n"(x * kWave * 4));
+          if constexpr (LB == 1) asm volatile("global_load_ubyte %0, %1, %2 offset:%3" : "=v"(w[NCW - 1]) : "v"(lt), "s"(p), "n"((NCW - 1) * kWave * 4));
+          else if constexpr (LB == 2) asm volatile("global_load_ushort %0, %1, %2 offset:%3" : "=v"(w[NCW - 1]) : "v"(lt), "s"(p), "n"((NCW - 1) * kWave * 4));
+          else asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(w[NCW - 1]) : "v"(lt), "s"(p), "n"((NCW - 1) * kWave * 4));
         };
         // the words of site j, complete when it returns (a row's first site)
         auto load_words = [&](int j, uint32_t (&w)[NCW]) {
@@ -521,9 +560,9 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
             for (int x = 0; x < NCW; x++) w[x] = lds_codes[(j * NCW + x) * kWave + lane];
           } else if constexpr (!EXACT) {
             if (j >= jc) {   // wave-uniform
-              fetch_lds(w, ldsLane + static_cast<uint32_t>(j - jc) * (NCW * kWave * 4u));
+              fetch_cached(w, j);
             } else {
-              const uint32_t *p = sbase + static_cast<size_t>(j) * (3 * NCW * kWave);
+              const uint32_t *p = sbase + static_cast<size_t>(j) * kSiteWords;
               asm volatile("s_nop 4" : "+s"(p));   // a VMEM instruction must not read an SGPR within five wait states of the scalar write
               fetch_global(w, p);
             }
@@ -531,7 +570,7 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
             for (int x = 0; x < NCW; x++) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(w[x]));
           } else {
 #pragma unroll
-            for (int x = 0; x < NCW; x++) w[x] = cbase[(static_cast<size_t>(j) * 3 * NCW + x) * kWave];
+            for (int x = 0; x < NCW; x++) w[x] = word_at(j, x);
           }
         };
         // sigma of every sequence at the site whose code words are w: a 64-entry table look-up per
@@ -556,7 +595,7 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
           }
           // the global fetch's scalar base, settled HERE: a VMEM instruction must not read an SGPR within five wait states of the scalar
           // instruction that wrote it, and the compiler's hazard recognizer does not look inside inline asm -- the look-ups below lie between
-          const uint32_t *pnext = sbase + static_cast<size_t>(jn) * (3 * NCW * kWave);
+          const uint32_t *pnext = sbase + static_cast<size_t>(jn) * kSiteWords;
           if constexpr (!LDSC && !EXACT) asm volatile("" : "+s"(pnext));
           static_for<NK>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
@@ -606,7 +645,7 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
             });
           };
           if constexpr (LDSC) {
-            fetch_lds(w, ldsLane + static_cast<uint32_t>(jn) * (NCW * kWave * 4u));
+            fetch_staged(w, jn);
             wait_lookups(std::integral_constant<int, NCW>{});
           } else if constexpr (!EXACT) {
             // the fetch goes out as early as it can (the look-ups have read w when they were issued): the next call waits for it, and
@@ -616,7 +655,7 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
             // register allocator moved w between registers at the joins -- BEFORE the wait that makes w valid --, results were wrong
             // wherever a row had frame-shift events, and the launches were 5-12 % slower on top.)  The wait for the look-ups is common
             // to both arms and behind them (inside the arms its register ties became eleven moves per arm); it covers the LDS arm's reads.
-            if (jn >= jc) fetch_lds(w, ldsLane + static_cast<uint32_t>(jn - jc) * (NCW * kWave * 4u));
+            if (jn >= jc) fetch_cached(w, jn);
             else fetch_global(w, pnext);
             wait_lookups(std::integral_constant<int, 0>{});
           } else {
