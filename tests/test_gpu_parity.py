@@ -312,7 +312,7 @@ def test_native_cli_matches_reference_listing_and_python_cli(tmp_path):
     doc = load_golden("coding_aln_n100")
     b = block_from_golden(doc["blocks"][0])
     aln = tmp_path / "in.aln"
-    aln.write_text("CLUSTAL W (1.83) multiple sequence alignment\n\n" + "".join(f"{r.name:<40s}{r.seq}\n" for r in b.rows) + "\n")
+    aln.write_text("CLUSTAL W (1.83) multiple sequence alignment\n\n" + "".join(f"{r.name:<40s} {r.seq}\n" for r in b.rows) + "\n")
     r = subprocess.run([exe, str(aln), "-n", "100", "-t"], capture_output=True, text=True, timeout=300)
     pyo = tmp_path / "py2.txt"
     assert r.returncode == 0 and cli.main([str(aln), "-n", "100", "-t", "-o", str(pyo)]) == 0
@@ -906,3 +906,125 @@ def test_malformed_blocks_among_good_ones_do_not_disturb_them(ctx):
                 assert np.isfinite(batch.maxScores(i)).all()
     assert api.RC_ERR_ARG in statuses and api.RC_ERR_SKIP in statuses
     batch.close(); clean.close()
+
+
+def _write_inputs(tmp_path, name):
+    """(command-line head, golden) for a reference-scored fixture: its blocks as a file, its PhyML trees as the sidecar."""
+    from rnacode_amd.synth import to_maf
+    doc = load_golden(name)
+    blocks = [block_from_golden(e) for e in doc["blocks"]]
+    side = tmp_path / f"{name}.trees.tsv"
+    side.write_text("".join("-\n" if "skipped" in e["ref"] else f"{e['ref']['tree']}\t{e['ref']['kappa']!r}\n" for e in doc["blocks"]))
+    if all(r.start == 0 and r.length == 0 for b in blocks for r in b.rows):   # a ClustalW input (coding.aln): one block
+        path = tmp_path / f"{name}.aln"
+        path.write_text("CLUSTAL W (1.83) multiple sequence alignment\n\n" + "".join(f"{r.name:<40s} {r.seq}\n" for r in blocks[0].rows) + "\n")
+    else:
+        path = tmp_path / f"{name}.maf"
+        path.write_text(to_maf(blocks))
+    return [str(path), "--trees", str(side), "-n", str(doc["samples"]), "--seed-base", str(doc["seed_base"])], doc
+
+
+@pytest.mark.parametrize("name", ["eps_coding_aln_n100", "eps_genomic_preprocessed_n100"])
+def test_native_cli_draws_the_reference_plots(tmp_path, name):
+    """rnacode_hip --eps (rc_eps.h on rc_batch_backtrack + rc_code_tables): the hss-<n>.eps files the unmodified reference wrote
+    (src/postscript.c compiled into the harness: goldens eps_*), byte for byte and under the same counters; the whole directory equal
+    to the Python driver's; and the same again from two contexts (--gpus 2 --devices 0,0)."""
+    import os
+    import subprocess
+
+    from conftest import ROOT
+    from rnacode_amd import cli
+    exe = os.path.join(ROOT, "rnacode_amd", "rnacode_hip")
+    doc = load_golden(name)
+    head, _ = _write_inputs(tmp_path, doc["base"])
+    runs = {}
+    for tag, extra in (("one", []), ("two", ["--gpus", "2", "--devices", "0,0", "--sub-blocks", "7"])):
+        d = tmp_path / f"plots_{tag}"
+        r = subprocess.run([exe, *head, "-e", "-i", repr(doc["eps_cutoff"]), "-d", str(d), "-o", str(tmp_path / f"list_{tag}.txt"), *extra],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        runs[tag] = {p.name: p.read_text() for p in d.iterdir()}
+    counter = lambda n: int(n[4:-4])
+    assert sorted(runs["one"], key=counter) == doc["names"]            # which HSS get a plot, and under which counter
+    for k, want in doc["files"].items():
+        assert runs["one"][k] == want, k
+    assert runs["two"] == runs["one"]
+    pyd = tmp_path / "plots_py"
+    assert cli.main([*head, "-e", "-i", repr(doc["eps_cutoff"]), "-d", str(pyd), "-o", str(tmp_path / "list_py.txt")]) == 0
+    assert {p.name: p.read_text() for p in pyd.iterdir()} == runs["one"]
+    strip = lambda t: [l for l in t.splitlines() if "alignment(s) scored in" not in l]
+    assert strip((tmp_path / "list_py.txt").read_text()) == strip((tmp_path / "list_one.txt").read_text())
+
+
+def test_native_cli_on_several_gpus_writes_the_single_gpu_listing(tmp_path):
+    """rnacode_hip --gpus N inside one process (SURVEY.md section 8e without a collective library): N contexts on N host threads.
+    On the one GPU of a test box, --gpus 2 / 3 --devices 0,0[,0] must write the single-context listing byte for byte
+    (a) for a many-block input, whose sub-batches are dealt to the contexts in turn -- trees fitted by each context for its own
+    sub-batches, one writer, the hit counter running across blocks in input order -- and (b) for few-block inputs, where every context
+    simulates a slice of every block's sample range (seed_base + first sample) and the slices are fitted after they meet on the host:
+    the shipped coding.aln and three blocks of genomic-preprocessed.maf, with --stop-early and with plots as well."""
+    import os
+    import subprocess
+
+    from conftest import ROOT
+    from rnacode_amd.synth import synth_block, to_maf
+    exe = os.path.join(ROOT, "rnacode_amd", "rnacode_hip")
+
+    def run(args, **kw):
+        r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=900, **kw)
+        assert r.returncode == 0, r.stderr
+        return r
+
+    # (a) 700 blocks of 3..7 rows, a few of them unscorable (two rows; too short)
+    rng = np.random.RandomState(99)
+    blocks = [synth_block(rng, int(rng.randint(3, 8)), int(rng.randint(30, 120)), index=i, gaps=True).upper() for i in range(700)]
+    for k in (13, 350):
+        blocks[k].rows = blocks[k].rows[:2]
+    maf = tmp_path / "many.maf"
+    maf.write_text(to_maf(blocks))
+    for fmt in (["-t"], ["-g"], ["-t", "-b"], ["-t", "-r", "-p", "0.5"]):
+        one = run([str(maf), "-n", "200", *fmt])
+        for extra in (["--gpus", "2", "--devices", "0,0"], ["--gpus", "3", "--devices", "0,0,0", "--sub-blocks", "37"]):
+            got = run([str(maf), "-n", "200", *fmt, *extra])
+            assert got.stdout == one.stdout and one.stdout.count("\n") > 100, (fmt, extra)
+            assert sorted(got.stderr.splitlines()) == sorted(one.stderr.splitlines())   # the "Skipping alignment" notes
+    one = run([str(maf), "-n", "200"])
+    two = run([str(maf), "-n", "200", "--gpus", "2", "--devices", "0,0"], env=dict(os.environ, RC_CLI_TIMES="1"))
+    strip = lambda t: [l for l in t.splitlines() if "alignment(s) scored in" not in l]
+    assert strip(one.stdout) == strip(two.stdout)
+    assert "2 GPUs" in two.stderr and "dealt to the GPUs in turn" in two.stderr
+    # (b) few blocks: the sample range is split
+    head, doc = _write_inputs(tmp_path, "coding_aln_n100")
+    one = run([*head, "-t"])
+    for extra in (["--gpus", "2", "--devices", "0,0"],):
+        got = run([*head, "-t", *extra], env=dict(os.environ, RC_CLI_TIMES="1"))
+        assert got.stdout == one.stdout and "sample ranges over the GPUs" in got.stderr
+    base = load_golden("genomic_preprocessed_n1000")
+    three = dict(base, blocks=[e for e in base["blocks"] if "skipped" not in e["ref"]][:3])
+    from rnacode_amd.synth import to_maf as _to_maf
+    blocks3 = [block_from_golden(e) for e in three["blocks"]]
+    m3 = tmp_path / "three.maf"
+    m3.write_text(_to_maf(blocks3))
+    s3 = tmp_path / "three.tsv"
+    s3.write_text("".join(f"{e['ref']['tree']}\t{e['ref']['kappa']!r}\n" for e in three["blocks"]))
+    for flags in (["-t"], ["-t", "-s", "-p", "0.05"], ["-t", "-e", "-i", "0.9"]):
+        outs = []
+        for tag, extra in (("one", []), ("two", ["--gpus", "2", "--devices", "0,0"]), ("four", ["--gpus", "4", "--devices", "0,0,0,0"])):
+            d = tmp_path / f"p_{tag}_{len(flags)}"
+            r = run([str(m3), "--trees", str(s3), "-n", "1000", "--seed-base", "42", *flags, *(["-d", str(d)] if "-e" in flags else []), *extra])
+            outs.append((r.stdout, {p.name: p.read_text() for p in d.iterdir()} if "-e" in flags else None))
+        assert outs[0] == outs[1] == outs[2], flags
+        assert outs[0][0].count("\n") >= 3
+    # ... and the p-values of that listing are the reference's (the fit of the gathered rows, through rc_evd_fit)
+    r = run([str(m3), "--trees", str(s3), "-n", "1000", "--seed-base", "42", "-t", "--gpus", "2", "--devices", "0,0"])
+    want = {}
+    for e in three["blocks"]:
+        for h in e["ref"]["hss"]:
+            want[(e["input"]["rows"][0]["name"], h["strand"], h["frame"] + 1, h["startSite"] + 1, h["endSite"] + 1)] = h
+    seen = 0
+    for line in r.stdout.splitlines():
+        f = line.split("\t")
+        h = want[(f[6], f[1], int(f[2]), int(f[4]), int(f[5]))]
+        assert abs(float(f[9]) - h["score"]) < 1e-3 and close_p(float(f[10]), float("%.3e" % h["pvalue"]) if h["pvalue"] < 0.001 else float("%.3f" % h["pvalue"]), rel=2e-3)
+        seen += 1
+    assert seen >= 3
