@@ -1020,11 +1020,11 @@ def test_native_cli_on_several_gpus_writes_the_single_gpu_listing(tmp_path):
     want = {}
     for e in three["blocks"]:
         for h in e["ref"]["hss"]:
-            want[(e["input"]["rows"][0]["name"], h["strand"], h["frame"] + 1, h["startSite"] + 1, h["endSite"] + 1)] = h
+            want[(e["input"]["rows"][0]["name"], h["strand"], h["frame"] + 1, h["startSite"] + 1, h["endSite"] + 1, h["startGenomic"])] = h
     seen = 0
     for line in r.stdout.splitlines():
         f = line.split("\t")
-        h = want[(f[6], f[1], int(f[2]), int(f[4]), int(f[5]))]
+        h = want[(f[6], f[1], int(f[2]), int(f[4]), int(f[5]), int(f[7]))]
         assert abs(float(f[9]) - h["score"]) < 1e-3 and close_p(float(f[10]), float("%.3e" % h["pvalue"]) if h["pvalue"] < 0.001 else float("%.3f" % h["pvalue"]), rel=2e-3)
         seen += 1
     assert seen >= 3
