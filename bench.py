@@ -14,12 +14,21 @@ driver's torchrun it just runs as one rank.  The 10 000 blocks are split across 
 configs[3]; `--scaling weak` gives every rank its own 10 000), no data-path collective, and every step ends
 with the path's one exchange: an RCCL all-gather of the per-sample maxima.
 
-With one GPU and no flags the same JSON line also carries four further legs, each with a timed region of about three seconds
+With one GPU and no flags the same JSON line also carries further legs, each with a timed region of about three seconds
 (`--no-extra` leaves them out): `end_to_end` -- the native driver rnacode_amd/rnacode_hip as a fresh process on a 10 000-block
-MAF file, wall time from exec to exit, trees fitted on the GPU (no sidecar): SURVEY.md section 8d's metric with I/O included
-(RNAcode.c:115-228); `shard` -- the 1250 blocks ONE of eight ranks holds under configs[3], resident and streamed with an eighth
-of the host's CPUs; `c5` -- the long-block slice of configs[4] with a roofline object of its own; `mixed` -- a stream of
-10 000 blocks of 3..12 rows and 60..200 columns (ten row-count classes).
+MAF file, wall time from exec to the last output byte, trees fitted on the GPU (no sidecar): SURVEY.md section 8d's metric with I/O
+included (RNAcode.c:115-228) -- and `end_to_end_100k`, the same on a 100 000-block file (what the fixed costs amortise to);
+`c1`, `c2` -- BASELINE.json configs[0] and [1], the two inputs the reference ships (tests/golden/*.json.gz hold them with the
+reference's own trees): latency per file as one batch and block by block in the shim's call sequence; `shard` -- the 1250 blocks ONE
+of eight ranks holds under configs[3], resident, streamed pass by pass and as one continuous stream, with an eighth of the host's
+CPUs; `c5` -- the long-block slice of configs[4] with a roofline object of its own; `mixed` -- a stream of 10 000 blocks of 3..12
+rows and 60..200 columns (ten row-count classes).  `cpu_baseline` (the unmodified reference objects, one core) has a sibling for
+every leg, and `cpu_baseline_all_cores` runs one reference process per usable CPU over a split block list.
+
+With N > 1 the line proves where the ranks sat (`n_ranks_seen`, `devices`: the UUIDs gathered from every rank), records RCCL's channel
+cap (`config.rccl_env`), and says which order of the exchange ran the timed region (`config.exchange_ab`: overlapped with the next
+step or waited for -- both are timed during the warm-up unless --overlap / --no-overlap forces one); `native_driver_multi_gpu` is the
+native driver's own `--gpus N` mode on the whole input file, run by rank 0 while the others wait on the host.
 
 A step is one pass of the hot path over this rank's blocks.  Two measurements per run, K steps each:
   * resident (`value`, the contract's definition: inputs in HBM when the timed region starts): MT19937
@@ -50,7 +59,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 VALU_PEAK_GOPS = 78643.2       # 256 CU x 4 SIMD x 64 lanes / 2 cycles x 2.4 GHz (v_add/v_max wave64 = 2 cyc/SIMD)
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 CONFIGS = {
     # name: (blocks, cols, seqs, samples, description)
@@ -81,7 +90,7 @@ def measured_traffic(config, kernel):
     (MI355X_MICROARCH.md, HBM), so the read side is doubled.  `kernel` is the instantiation this run just timed
     (rc_batch_null_kernel): a profile of another kernel is refused.  (None, reason) if no usable profile is committed."""
     why = "no committed profile"
-    for rnd in (PROFILE_ROUND, "r02", "r01"):
+    for rnd in (PROFILE_ROUND, "r03", "r02", "r01"):
         for name in (f"k_null_{config}_pmc.json", "k_null_pmc.json" if config == "c3" else None):
             if not name:
                 continue
@@ -125,7 +134,7 @@ def roofline_object(blocks, sampleN, null_ms, kernel, config, with_traffic):
             "hbm": hbm, "valu": valu}
 
 
-def end_to_end_leg(blocks, sampleN, seed, runs=5, repeat=1):
+def end_to_end_leg(blocks, sampleN, seed, runs=5, repeat=1, extra_args=()):
     """SURVEY.md section 8d's metric as the reference's driver would be timed (RNAcode.c:115-228: read -> tree -> models -> score ->
     sample -> print): the native stand-alone driver as a fresh process on a MAF file, trees and kappa fitted on the GPU (no sidecar),
     the tabular listing read from its standard output.  Wall time from exec to the LAST OUTPUT BYTE (end of file on the pipe: the
@@ -152,7 +161,7 @@ def end_to_end_leg(blocks, sampleN, seed, runs=5, repeat=1):
         for _ in range(runs):
             time.sleep(0.3)
             t0 = time.perf_counter()
-            p = subprocess.Popen([exe, maf, "-n", str(sampleN), "-t", "--seed-base", str(seed)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+            p = subprocess.Popen([exe, maf, "-n", str(sampleN), "-t", "--seed-base", str(seed), *extra_args], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                                  env=dict(os.environ, RC_CLI_TIMES="1"))
             out = p.stdout.read()                      # until the driver closes its output
             walls.append(time.perf_counter() - t0)
@@ -823,6 +832,31 @@ def main():
         wbatch.close()
         del wmine
 
+    # ---- N > 1: the native driver's own multi-GPU mode (rnacode_hip --gpus N: N contexts in ONE process, no collective library) on the
+    # whole input as a file, measured by rank 0 while the other ranks wait on the host (a store key, not a collective: nothing of
+    # theirs runs on the GPUs meanwhile).  A fresh process per run, wall time to the last output byte, as the one-GPU end_to_end leg.
+    native_multi = None
+    native_hook = bool(os.environ.get("RC_BENCH_TEST_NATIVE_MULTI"))   # test hook: this leg on a box with one GPU (every context on device 0), any workload
+    if world > 1 and args.scaling == "strong" and not args.no_extra and ((coll_dev != "cpu" and default_workload) or native_hook):
+        store = dist.distributed_c10d._get_default_store()
+        if rank == 0:
+            try:
+                if torch.cuda.device_count() < world and not native_hook:
+                    native_multi = {"skipped": f"this process sees {torch.cuda.device_count()} device(s), not {world}: the launcher masks the GPUs per rank"}
+                else:
+                    full = [b.upper() for b in synth_blocks(args.blocks, args.seqs, args.cols, seed=1)]
+                    native_multi = {"gpus_1": end_to_end_leg(full, args.samples, args.seed_base, runs=3),
+                                    f"gpus_{world}": end_to_end_leg(full, args.samples, args.seed_base, runs=3,
+                                                                    extra_args=["--gpus", str(world)] + (["--devices", ",".join(["0"] * world)] if native_hook else [])),
+                                    "note": "rnacode_amd/rnacode_hip on the 10 000-block MAF, trees fitted on the GPUs, fresh process per run; "
+                                            "gpus_1 beside it on device 0 for the ratio; the other ranks of this job hold their contexts but run nothing"}
+                    del full
+            except Exception as e:   # noqa: BLE001 -- this leg must never cost the run its line
+                native_multi = {"error": repr(e)}
+            store.set("rc_native_multi_done", "1")
+        else:
+            store.wait(["rc_native_multi_done"])
+
     sa, cs = batch.work()
     if multi:   # units of all ranks (shards may differ by one block under strong scaling)
         tot = torch.tensor([float(cs), float(sa)], dtype=torch.float64, device=coll_dev)
@@ -938,6 +972,8 @@ def main():
                 "excludes": "file parsing and tree fitting (sidecar trees, as for the cpu_baseline)"}
         if weak is not None:
             out["weak_scaling"] = weak
+        if native_multi is not None:
+            out["native_driver_multi_gpu"] = native_multi
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]

@@ -376,6 +376,10 @@ def test_bench_starts_its_own_ranks_and_two_hip_ranks_gather_the_single_rank_res
     assert two["n_ranks_seen"] == 2 and len(two["devices"]["ranks"]) == 2 and two["config"]["exchange_ab"]["chosen"] == "synchronous"
     fits, mf = _bench(tmp_path, 2, extra=("--exchange", "fits"), env_extra={"RC_BENCH_TEST_BACKEND": "gloo"})
     assert mf.shape == (50, 4) and (mf[:, 0] == 1).all()
+    # N > 1 also times the native driver's own --gpus N mode on the whole input (rank 0, the others wait on the host)
+    line, _ = _bench(tmp_path, 2, env_extra={"RC_BENCH_TEST_BACKEND": "gloo", "RC_BENCH_TEST_NATIVE_MULTI": "1"})
+    nm = line["native_driver_multi_gpu"]
+    assert nm["gpus_1"]["value"] > 0 and nm["gpus_2"]["value"] > 0 and nm["gpus_2"]["hss_lines"] == nm["gpus_1"]["hss_lines"] > 0, nm
     # the overlapped order and the warm-up comparison of the two orders with two ranks (the collective staged through host copies over gloo)
     hook = {"RC_BENCH_TEST_BACKEND": "gloo", "RC_BENCH_TEST_OVERLAP_ON_CPU": "1"}
     for extra, want in (("--overlap",), "overlapped"), (("--no-overlap",), "synchronous"), ((), None):
