@@ -650,6 +650,11 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
           } else if constexpr (!EXACT) {
             // the fetch goes out as early as it can (the look-ups have read w when they were issued): the next call waits for it, and
             // nearly a whole cell of other work lies between
+            // (Also built and taken back: the sites before jc through a RING of four LDS slots filled by LDS-DMA -- global_load_lds_*,
+            // memory -> LDS with no register in between, three cells ahead --, so that a cell only ever reads LDS and no register holds
+            // data the compiler does not know to be pending.  Bit-exact on the suite, and slower: 7 / 12 / 13 rows x 150 columns
+            // 36.6 / 65.4 / 69.3 -> 39.0 / 69.9 / 74.1 ms, C5 587 -> 644 ms (profiles/r04/ab_l2path_v5_*): three 256-byte DMA pieces per
+            // cell cost more issue time than the deeper prefetch gains, and the ring's 3 KB come out of the suffix cache.)
             // Which of the two is decided per cell by a wave-uniform branch.  (Cutting every row loop at jc - 1 instead, so that each
             // loop has one kind of fetch compiled in, was built and taken back: with two loops per span and two event cells the
             // register allocator moved w between registers at the joins -- BEFORE the wait that makes w valid --, results were wrong
