@@ -903,10 +903,15 @@ def main():
         mx_sub = api.stream_plan(ctx, params, len(mixed), classes)
         # (three warm-up passes: the stream's three batch objects each grow their multi-GB staging areas to the largest sub-batch once)
         mx_stream_ms, mx_passes = stream_leg(api, ctx, mx_m, params, mx_sub, args.extra_seconds, warmup=3)
+        mx_stream_spread = stream_leg.spread
+        mx_cont_ms, mx_cont_passes = continuous_leg(api, ctx, mx_m, len(mixed), params, mx_sub, max(mx_sub), args.extra_seconds)
         legs["mixed"] = {"workload": "synthetic MAF 10000 blocks of 3..12 rows x 60..200 cols, --num-samples %d" % args.samples,
                          "row_count_classes": classes, "value": mx_units / (mx_stream_ms * 1e-3), "unit": "alignment-columns*samples/s",
                          "ms_per_step": mx_stream_ms, "passes": mx_passes, "blocks_per_sub_batch": mx_sub, "host_threads": threads,
-                         "ms_per_step_spread": stream_leg.spread,
+                         "ms_per_step_spread": mx_stream_spread,
+                         "continuous": {"ms_per_step": mx_cont_ms, "passes": mx_cont_passes, "value": mx_units / (mx_cont_ms * 1e-3),
+                                        "sub_batch_later_passes": max(mx_sub),
+                                        "note": "the 10 000 blocks pass after pass as ONE stream: the pipeline fills once"},
                          "resident": {"ms_per_step": mx_ms, "steps": mx_steps, "value": mx_units / (mx_ms * 1e-3), "ms_per_step_spread": mx_res_spread},
                          "generate_s": genm, "note": "value = the streamed rate (host rc_block arrays -> fitted results on the host), from the median pass"}
         del mx_m, mixed

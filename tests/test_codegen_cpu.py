@@ -64,6 +64,86 @@ def test_k_null_cell_loops_are_wave_uniform_and_tight(tmp_path):
 
 
 PLAIN = "_ZN2rc6k_nullILi6ELb0ELb0ELb0EEEvNS_8NullArgsEPKhPKNS_8DevBlockEPKiPKjSA_S3_PjPf"      # k_null<6, false, false, false>
+OCC6 = "_ZN2rc10k_null_occILi6EEEvNS_8NullArgsEPKhPKNS_8DevBlockEPKiPKjSA_S3_PjPf"             # k_null_occ<6>
+_FETCH = re.compile(r"(?:global_load_(?:dword|ubyte|ushort) (v\d+), v\d+, s\[\d+:\d+\]|ds_read_(?:b32|u8|u16) (v\d+), v\d+)")
+
+
+def _compile_unit(tmp_path, unit):
+    out = tmp_path / (unit + ".s")
+    flags = "-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize".split()
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "--cuda-device-only", "-S", *flags, "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "rnacode_amd", "csrc", unit + ".hip"), "-o", str(out)])
+    return out.read_text()
+
+
+def _audit_pending_registers(txt, name):
+    """In every innermost loop of kernel `name` that holds asm fetches (the cell loops: look-ups, then the next site's words loaded INTO
+    the registers just read, waited for by the next cell), no instruction of the loop -- and none between the loop's exits and the
+    row's closing wait -- may copy (v_mov) or spill (scratch_store) a register such a fetch writes: the compiler does not know the
+    data is still on its way.  Returns the number of loops audited and the fetch instructions seen."""
+    body = txt[txt.index(name + ":"):]
+    body = body[:body.index(".Lfunc_end")]
+    blocks, order = {}, []
+    cur, hdr = None, None
+    for ln in body.split("\n"):
+        m = re.match(r"^(\.LBB\d+_\d+):\s*(?:;.*Header=(BB\d+_\d+) Depth=(\d+))?", ln)
+        if m:
+            cur = m.group(1)
+            blocks[cur] = {"ins": [], "header": ("." + "L" + m.group(2)) if m.group(2) else None, "depth": int(m.group(3) or 0), "asm": []}
+            order.append(cur)
+            continue
+        m = re.match(r"^; %bb\.\d+:\s*;.*Header=(BB\d+_\d+) Depth=(\d+)", ln)
+        if m and cur is not None:   # an unlabelled block of the same loop: keep appending
+            continue
+        if cur is not None and ln.startswith("\t") and not ln.startswith(("\t.", "\t;")):
+            blocks[cur]["ins"].append(ln.strip())
+    loops = {}
+    for lab in order:
+        b = blocks[lab]
+        h = b["header"] or lab
+        loops.setdefault(h, []).append(lab)
+    audited = fetches = 0
+    for h, labs in loops.items():
+        ins = [x for lab in labs for x in blocks[lab]["ins"]]
+        if not any(x.startswith("ds_bpermute_b32") for x in ins):
+            continue
+        regs = set()
+        for x in ins:
+            m = _FETCH.match(x)
+            if m:
+                regs.add(m.group(1) or m.group(2))
+                fetches += 1
+        if not regs:
+            continue
+        audited += 1
+
+        def bad(x):
+            if re.match(r"v_mov_b32(_e32)? v\d+, (v\d+)$", x) and x.split(", ")[1] in regs:
+                return True
+            return x.startswith("scratch_store") and any(re.search(r"\b%s\b" % r, x) for r in regs)
+        viol = [x for x in ins if bad(x)]
+        # behind the loop's exits, up to the wait that closes the row
+        for lab in labs:
+            for x in blocks[lab]["ins"]:
+                m = re.match(r"s_cbranch_\w+ (\.LBB\d+_\d+)|s_branch (\.LBB\d+_\d+)", x)
+                tgt = m and (m.group(1) or m.group(2))
+                if tgt and tgt not in labs and tgt in blocks:
+                    k = order.index(tgt)
+                    seen = 0
+                    while k < len(order) and seen < 120:
+                        stop = False
+                        for y in blocks[order[k]]["ins"]:
+                            seen += 1
+                            if y.startswith("s_waitcnt") and "vmcnt(0)" in y:
+                                stop = True
+                                break
+                            if bad(y):
+                                viol.append(order[k] + ": " + y)
+                        if stop or order[k] in labs:
+                            break
+                        k += 1
+        assert not viol, name + ": a register an asm fetch leaves pending is copied or spilled:\n" + "\n".join(viol[:10])
+    return audited, fetches
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
@@ -71,29 +151,24 @@ def test_codes_from_l2_cell_keeps_its_fetched_words_in_place(tmp_path):
     """k_null<N-1, false, false> fetches the next cell's code words with asm loads INTO the registers the look-ups have just read, and
     the next cell waits for them (rc_null_kernel.h, lookup).  The compiler does not know those registers are pending: a copy out of
     one of them before that wait reads garbage.  A build that cut the row loops by kind of fetch had exactly that (a v_mov at a join,
-    in front of the wait) and got every row with a frame-shift event wrong; the parity suite caught it, this test names the cause.
-    In the kernel's DP phase no v_mov may read a register that an asm fetch writes, and each cell loop holds its own fetches."""
-    out = tmp_path / "rc_null_a.s"
-    flags = "-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize".split()
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "--cuda-device-only", "-S", *flags, "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "rnacode_amd", "csrc", "rc_null_a.hip"), "-o", str(out)])
-    txt = out.read_text()
+    in front of the wait) and got every row with a frame-shift event wrong; the parity suite caught it, this test names the cause."""
+    txt = _compile_unit(tmp_path, "rc_null_a")
+    for name in (PLAIN, OCC6):     # (k_null_occ<6>: the same code compiled for 80 registers, a few of them spilled)
+        audited, fetches = _audit_pending_registers(txt, name)
+        assert audited >= 4 and fetches >= 16, (name, audited, fetches)     # four kinds of cell, two code words each, both arms
     body = txt[txt.index(PLAIN + ":"):]
     body = body[:body.index(".Lfunc_end")]
-    ins = [ln.strip() for ln in body.split("\n") if ln.startswith("\t") and not ln.startswith(("\t.", "\t;"))]
-    first = next(i for i, x in enumerate(ins) if x.startswith("ds_bpermute_b32"))
-    dp = ins[first:]
-    fetched = set()
-    for x in dp:
-        m = re.match(r"global_load_(?:dword|ubyte|ushort) (v\d+), v\d+, s\[\d+:\d+\]", x)      # the saddr form only the asm fetch uses
-        if m:
-            fetched.add(m.group(1))
-    assert fetched, "no asm fetch found: has the kernel changed?"
-    copies = [x for x in dp if re.match(r"v_mov_b32(_e32)? v\d+, (v\d+)$", x) and x.split(", ")[1] in fetched]
-    assert not copies, "the compiler copies a register that an asm fetch leaves pending:\n" + "\n".join(copies[:10])
-    n_fetch = sum(1 for x in dp if re.match(r"global_load_(dword|ubyte|ushort) v\d+, v\d+, s\[", x))
-    n_cache = sum(1 for x in dp if x.startswith(("ds_read_b32", "ds_read_u8", "ds_read_u16")))
-    assert n_fetch >= 8 and n_cache >= 8      # four kinds of cell, two code words each (a dword and a byte: six codes), both arms
-    assert any(x.startswith("global_load_ubyte") for x in dp) and any(x.startswith("ds_read_u8") for x in dp)   # the narrow tail word
+    assert "global_load_ubyte" in body and "ds_read_u8" in body      # the narrow tail word (six codes: a dword and a byte)
     meta = txt[txt.index(".name:           " + PLAIN):]
     assert int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1)) <= 96      # five wavefronts per SIMD
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_no_pending_fetch_register_is_copied_or_spilled_at_twelve_rows(tmp_path):
+    """The same audit for the instantiations BASELINE configs[4] runs (12 rows: k_null<11, false, false> and k_null_occ<11>, the
+    latter compiled for 96 registers with some twenty spilled)."""
+    txt = _compile_unit(tmp_path, "rc_null_b")
+    names = re.findall(r"\.amdhsa_kernel (\S+)", txt)
+    for want in ("k_nullILi11ELb0ELb0ELb0E", "k_null_occILi11E"):
+        audited, fetches = _audit_pending_registers(txt, next(n for n in names if want in n))
+        assert audited >= 4 and fetches >= 24, (want, audited, fetches)
