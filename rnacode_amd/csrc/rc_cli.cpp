@@ -57,6 +57,8 @@ struct Block {
   int index = 0;        // position in the input file (the --trees sidecar has one entry per block READ, before --limit drops any)
 };
 
+double now();
+double g_t0 = 0.0;   // start of main
 std::thread *g_ctxThread = nullptr;   // the thread that brings up the HIP context: an exit waits for it
 
 // Leaves at once, like the success path: other threads (tree fits with kernels in flight, the printer) may still be running, and
@@ -83,28 +85,82 @@ void check_equal(const Block &b) {
 }
 
 // Blocks of a MAF stream: 's' lines need exactly 7 fields; 'i', 'e', 'q' and comment lines are skipped; a block ends at the
-// next 'a' line (rnaz_utils.c:132-234)
-std::vector<Block> read_maf(const std::vector<std::string> &lines) {
-  std::vector<Block> out;
+// next 'a' line (rnaz_utils.c:132-234).  One pass over the file's bytes, fields cut at white space in place (a 94 MB file of
+// 100 000 blocks: 0.34 s with a string per line and a stream per line's fields, the largest serial stage of the run).
+void read_maf_range(const char *p, const char *end, std::vector<Block> &out) {
   Block cur;
-  for (const std::string &line : lines) {
-    const std::vector<std::string> f = fields(line);
-    if (f.empty() || f[0][0] == '#') continue;
-    if (f[0] == "i" || f[0] == "e" || f[0] == "q") continue;
-    if (f[0] == "s") {
-      if (f.size() != 7) die("Invalid MAF format (number of fields in 's' line not correct)");
-      if (f[4][0] != '+' && f[4][0] != '-') die("Invalid MAF format (strand)");
-      Row r;
-      r.name = f[1]; r.seq = f[6]; r.start = std::atoi(f[2].c_str()); r.length = std::atoi(f[3].c_str()); r.strand = f[4][0];
-      cur.rows.push_back(r);
+  auto space = [](char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; };
+  while (p < end) {
+    const char *eol = static_cast<const char *>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
+    if (!eol) eol = end;
+    const char *f[8][2];   // up to eight fields: begin, end
+    int nf = 0;
+    for (const char *q = p; q < eol;) {
+      while (q < eol && space(*q)) q++;
+      if (q >= eol) break;
+      const char *b0 = q;
+      if (nf == 6) {   // the seventh field of an 's' line is the sequence, nearly always the rest of the line: look for white space in bulk
+        const char *e = eol;
+        while (e > b0 && space(e[-1])) e--;
+        const size_t len = static_cast<size_t>(e - b0);
+        if (!std::memchr(b0, ' ', len) && !std::memchr(b0, '\t', len) && !std::memchr(b0, '\r', len) && !std::memchr(b0, '\v', len) && !std::memchr(b0, '\f', len)) {
+          f[6][0] = b0; f[6][1] = e; nf = 7;
+          break;
+        }
+      }
+      while (q < eol && !space(*q)) q++;
+      if (nf < 8) { f[nf][0] = b0; f[nf][1] = q; }
+      nf++;
+    }
+    p = eol < end ? eol + 1 : end;
+    if (nf == 0 || f[0][0][0] == '#') continue;
+    const bool one = f[0][1] - f[0][0] == 1;
+    const char tag = one ? f[0][0][0] : 0;
+    if (tag == 'i' || tag == 'e' || tag == 'q') continue;
+    if (tag == 's') {
+      if (nf != 7) die("Invalid MAF format (number of fields in 's' line not correct)");
+      if (f[4][0][0] != '+' && f[4][0][0] != '-') die("Invalid MAF format (strand)");
+      cur.rows.emplace_back();
+      Row &r = cur.rows.back();
+      r.name.assign(f[1][0], f[1][1]); r.seq.assign(f[6][0], f[6][1]);
+      r.start = std::atoi(f[2][0]); r.length = std::atoi(f[3][0]);   // (atoi stops at the white space behind the field)
+      r.strand = f[4][0][0];
       continue;
     }
-    if (f[0] == "a") {
-      if (!cur.rows.empty()) { check_equal(cur); out.push_back(cur); }
+    if (tag == 'a') {
+      if (!cur.rows.empty()) { check_equal(cur); out.push_back(std::move(cur)); }
       cur = Block();
     }
   }
-  if (!cur.rows.empty()) { check_equal(cur); out.push_back(cur); }
+  if (!cur.rows.empty()) { check_equal(cur); out.push_back(std::move(cur)); }
+}
+
+// A large file is cut at lines that start with "a" + white space -- where a block ends for the sequential reader too -- and the
+// pieces are parsed side by side.
+std::vector<Block> read_maf(const std::string &text) {
+  const char *p = text.data(), *end = p + text.size();
+  unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 8u);
+  if (text.size() < (4u << 20)) nt = 1;
+  std::vector<const char *> cut{p};
+  for (unsigned t = 1; t < nt; t++) {
+    const char *q = p + text.size() / nt * t;
+    while (q + 2 < end) {
+      q = static_cast<const char *>(std::memchr(q, '\n', static_cast<size_t>(end - q)));
+      if (!q || q + 2 >= end) { q = end; break; }
+      if (q[1] == 'a' && (q[2] == ' ' || q[2] == '\t' || q[2] == '\n' || q[2] == '\r')) { q++; break; }
+      q++;
+    }
+    if (q + 2 >= end) break;
+    if (q > cut.back()) cut.push_back(q);
+  }
+  cut.push_back(end);
+  std::vector<std::vector<Block>> part(cut.size() - 1);
+  std::vector<std::thread> th;
+  for (size_t t = 1; t + 1 < cut.size(); t++) th.emplace_back([&, t] { read_maf_range(cut[t], cut[t + 1], part[t]); });
+  read_maf_range(cut[0], cut[1], part[0]);
+  for (auto &x : th) x.join();
+  std::vector<Block> out = std::move(part[0]);
+  for (size_t t = 1; t < part.size(); t++) for (Block &b : part[t]) out.push_back(std::move(b));
   return out;
 }
 
@@ -140,16 +196,27 @@ std::vector<Block> read_clustal(const std::vector<std::string> &lines) {
   return out;
 }
 
-std::vector<Block> read_alignment(std::istream &in) {
-  std::vector<std::string> lines;
-  std::string line;
-  while (std::getline(in, line)) lines.push_back(line);
-  for (const std::string &l : lines) {
-    if (l.find_first_not_of(" \t\r\n") == std::string::npos) continue;
-    if (l.compare(0, 7, "CLUSTAL") == 0) return read_clustal(lines);
-    break;
+std::vector<Block> read_alignment(FILE *in) {
+  std::string text;
+  struct stat sp;
+  if (fstat(fileno(in), &sp) == 0 && S_ISREG(sp.st_mode) && sp.st_size > 0) {   // a regular file: one read into a buffer of its size
+    text.resize(static_cast<size_t>(sp.st_size));
+    const size_t got = std::fread(&text[0], 1, text.size(), in);
+    text.resize(got);
   }
-  return read_maf(lines);
+  char buf[1 << 16];
+  for (size_t k; (k = std::fread(buf, 1, sizeof buf, in)) > 0;) text.append(buf, k);
+  if (std::getenv("RC_CLI_TIMES")) std::fprintf(stderr, "[rnacode_hip] %.1f MB in memory at %.3f s\n", text.size() / 1e6, now() - g_t0);
+  size_t at = text.find_first_not_of(" \t\r\n");
+  if (at != std::string::npos) at = text.rfind('\n', at) == std::string::npos ? 0 : text.rfind('\n', at) + 1;   // start of the first non-blank line
+  if (at != std::string::npos && text.compare(at, 7, "CLUSTAL") == 0) {
+    std::vector<std::string> lines;
+    std::istringstream is(text);
+    std::string line;
+    while (std::getline(is, line)) lines.push_back(line);
+    return read_clustal(lines);
+  }
+  return read_maf(text);
 }
 
 // printResults (misc.c:392-552); the HSS counter runs across blocks and is not advanced after a --best-only break
@@ -631,6 +698,7 @@ int main(int argc, char **argv) {
   } else for (int g = 0; g < gpus; g++) devices.push_back(gpus == 1 ? device : g);
 
   const double tMain = now();
+  g_t0 = tMain;
   double tRead = now();
   // the HIP runtime and the contexts come up (0.1-0.3 s) on threads of their own while this one reads and parses the input
   std::vector<Worker> W(gpus);
@@ -652,14 +720,16 @@ int main(int argc, char **argv) {
   });
   g_ctxThread = &ctxThread;
   std::vector<Block> &blocks = R.blocks;
-  if (file.empty() || file == "-") blocks = read_alignment(std::cin);
+  if (file.empty() || file == "-") blocks = read_alignment(stdin);
   else {
-    std::ifstream in(file);
+    FILE *in = std::fopen(file.c_str(), "rb");
     if (!in) die("Could not open input file " + file);
     blocks = read_alignment(in);
+    std::fclose(in);
   }
   const int nRead = static_cast<int>(blocks.size());
   for (int i = 0; i < nRead; i++) blocks[i].index = i;
+  if (std::getenv("RC_CLI_TIMES")) std::fprintf(stderr, "[rnacode_hip] %d blocks read and parsed in %.3f s\n", nRead, now() - tRead);
   if (list.eps)   // the plots show the rows as main() leaves them: upper-cased (RNAcode.c:121-128; the library upper-cases its own copy)
     for (Block &b : blocks) for (Row &r : b.rows) for (char &c : r.seq) c = static_cast<char>(std::toupper(static_cast<unsigned char>(c)));
   if (!limit.empty()) {   // pruneAln (rnaz_utils.c:724-752, RNAcode.c:130-132): rows whose name starts with a listed string stay
