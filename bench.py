@@ -845,11 +845,14 @@ def main():
                     native_multi = {"skipped": f"this process sees {torch.cuda.device_count()} device(s), not {world}: the launcher masks the GPUs per rank"}
                 else:
                     full = [b.upper() for b in synth_blocks(args.blocks, args.seqs, args.cols, seed=1)]
-                    native_multi = {"gpus_1": end_to_end_leg(full, args.samples, args.seed_base, runs=3),
-                                    f"gpus_{world}": end_to_end_leg(full, args.samples, args.seed_base, runs=3,
+                    rep = 1 if native_hook else 10   # 100 000 blocks: on 10 000 the fixed costs (process start, HIP contexts) are most of the run
+                    native_multi = {"gpus_1": end_to_end_leg(full, args.samples, args.seed_base, runs=3, repeat=rep),
+                                    f"gpus_{world}": end_to_end_leg(full, args.samples, args.seed_base, runs=3, repeat=rep,
                                                                     extra_args=["--gpus", str(world)] + (["--devices", ",".join(["0"] * world)] if native_hook else [])),
-                                    "note": "rnacode_amd/rnacode_hip on the 10 000-block MAF, trees fitted on the GPUs, fresh process per run; "
-                                            "gpus_1 beside it on device 0 for the ratio; the other ranks of this job hold their contexts but run nothing"}
+                                    "note": "rnacode_amd/rnacode_hip on a 100 000-block MAF (the workload's blocks ten times over), trees fitted on the GPUs, "
+                                            "fresh process per run; gpus_1 beside it on device 0 for the ratio; reading the file (one thread ... eight "
+                                            "parser threads) and writing the listing (one thread, input order) do not shard; the other ranks of this job "
+                                            "hold their contexts but run nothing"}
                     del full
             except Exception as e:   # noqa: BLE001 -- this leg must never cost the run its line
                 native_multi = {"error": repr(e)}
