@@ -12,6 +12,13 @@
 // tile computed in full (35 % more steps at this length: 1.68 s), groups of eight steps skipped past the row end (2.1 s: the
 // branches cost more than the steps), the next sequence's loads issued during the current one's steps (1.7-2.2 s: 13 more live
 // registers, and the pass is issue-bound, not latency-bound), tiles of 16 or 24 end codons, 3 or 5 wavefronts per SIMD.
+// Round 4, measured and taken back: the thirteen operands of a sequence's pass (sigma table entry, eight code words,
+// frame-shift word, three parked states) fetched one sequence AHEAD with the look-ups in two halves of sixteen -- 256 blocks of
+// 100 x 300 at n = 1000: 412 -> 628 ms at four wavefronts per SIMD (51 spilled registers), 565 at three, 580 at two.  The counters say
+// the pass is neither issue-bound (0.33 VALU instructions per ns and SIMD, C3: 0.71) nor short of bandwidth (3.2 TB/s); what it waits
+// for is the round trip of the parked states and code words at four wavefronts per SIMD, and the registers that would hide it are
+// the ones the tile's 32 sums occupy.  The form that would fix it keeps the states of <= 16 sequences resident over a whole row
+// and carries the per-cell k-sum between chunks of sequences (ascending k, as the reference adds): another kernel.
 // It is the slow, complete path for rare inputs; the division is the plain '/'.
 #pragma once
 #include "rc_null_kernel.h"
