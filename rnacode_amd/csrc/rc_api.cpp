@@ -93,18 +93,64 @@ template <typename Alloc> hipError_t alloc_with_retry(Retired *ret, Alloc alloc)
   return alloc();
 }
 
+// Buffers of destroyed batches, kept by their context for the next batch: hipFree / hipHostFree synchronise the device and
+// hipMalloc / hipHostMalloc take 50-300 us each, and a caller that makes one batch per alignment block (the reference's main loop through
+// the shim, RNAcode.c:164-216) paid both fourteen times per block -- 0.6 ms of the 1.6 ms a one-block batch took, 1.1 of 6.3 ms for
+// genomic-preprocessed.maf.  A buffer is handed out again for requests between a quarter of its size and its size.  Bounded
+// (a sixteenth of the device memory, 1 GB of pinned memory, 256 buffers); what does not fit is freed as before.  The pool outlives
+// its context while batches still point at it (a batch may be destroyed after its context).
+struct BufPool {
+  struct Slot { void *p; size_t cap; };
+  std::mutex m;
+  std::vector<Slot> dev, host;
+  size_t devBytes = 0, hostBytes = 0, devCap = static_cast<size_t>(1) << 30, hostCap = static_cast<size_t>(1) << 30;
+  bool closed = false;   // the context is gone: nothing is kept any more
+  void *take(bool pinned, size_t want, size_t *got) {
+    std::lock_guard<std::mutex> lk(m);
+    std::vector<Slot> &v = pinned ? host : dev;
+    int best = -1;
+    for (size_t i = 0; i < v.size(); i++)
+      if (v[i].cap >= want && v[i].cap / 4 <= want && (best < 0 || v[i].cap < v[static_cast<size_t>(best)].cap)) best = static_cast<int>(i);
+    if (best < 0) return nullptr;
+    Slot s = v[static_cast<size_t>(best)];
+    v.erase(v.begin() + best);
+    (pinned ? hostBytes : devBytes) -= s.cap;
+    *got = s.cap;
+    return s.p;
+  }
+  bool give(bool pinned, void *p, size_t cap) {
+    std::lock_guard<std::mutex> lk(m);
+    std::vector<Slot> &v = pinned ? host : dev;
+    size_t &bytes = pinned ? hostBytes : devBytes;
+    if (closed || v.size() >= 256 || bytes + cap > (pinned ? hostCap : devCap)) return false;
+    v.push_back(Slot{p, cap});
+    bytes += cap;
+    return true;
+  }
+  void drain(bool close) {
+    std::vector<Slot> d, h;
+    { std::lock_guard<std::mutex> lk(m); d.swap(dev); h.swap(host); devBytes = hostBytes = 0; closed = closed || close; }
+    for (auto &s : d) (void)hipFree(s.p);
+    for (auto &s : h) (void)hipHostFree(s.p);
+  }
+  ~BufPool() { drain(true); }
+};
+
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
   Retired *retired = &g_retired;
+  BufPool *pool = nullptr;
   ~DevBuf() { release(); }
-  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  void release() { if (p && !(pool && pool->give(false, p, cap))) (void)hipFree(p); p = nullptr; cap = 0; }
   hipError_t ensure(size_t bytes) {
     if (bytes <= cap && p) return hipSuccess;
     if (p) retired->add(p, false, cap);
     p = nullptr; cap = 0;
     const size_t want = std::max<size_t>(bytes + bytes / 8, 256);
+    if (pool && (p = pool->take(false, want, &cap))) return hipSuccess;
     hipError_t r = alloc_with_retry(retired, [&] { return hipMalloc(&p, want); });
+    if (r != hipSuccess && pool) { pool->drain(false); r = hipMalloc(&p, want); }
     if (r == hipSuccess) cap = want; else p = nullptr;
     return r;
   }
@@ -114,14 +160,17 @@ struct PinBuf {
   void *p = nullptr;
   size_t cap = 0;
   Retired *retired = &g_retired;
+  BufPool *pool = nullptr;
   ~PinBuf() { release(); }
-  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+  void release() { if (p && !(pool && pool->give(true, p, cap))) (void)hipHostFree(p); p = nullptr; cap = 0; }
   hipError_t ensure(size_t bytes) {
     if (bytes <= cap && p) return hipSuccess;
     if (p) retired->add(p, true, cap);
     p = nullptr; cap = 0;
     const size_t want = std::max<size_t>(bytes + bytes / 8, 4096);
+    if (pool && (p = pool->take(true, want, &cap))) return hipSuccess;
     hipError_t r = alloc_with_retry(retired, [&] { return hipHostMalloc(&p, want, hipHostMallocDefault); });
+    if (r != hipSuccess && pool) { pool->drain(false); r = hipHostMalloc(&p, want, hipHostMallocDefault); }
     if (r == hipSuccess) cap = want; else p = nullptr;
     return r;
   }
@@ -273,6 +322,8 @@ struct rc_ctx {
   std::unique_ptr<Pool> pool;
   std::atomic<int> inflight{0};   // batches between run_async and wait
   std::shared_ptr<Retired> retired = std::make_shared<Retired>();   // outgrown buffers of this context's batches (shared: a batch may outlive its context)
+  std::shared_ptr<BufPool> bufPool = std::make_shared<BufPool>();   // buffers of destroyed batches, for the next ones (RC_BUFFER_POOL=0: off)
+  int poolEnabled = 1;
   size_t retiredCapBytes = 0;     // more than this parked while batches are in flight: the next wait drains (and stalls) once; 1/16 of the device memory
 };
 
@@ -350,13 +401,15 @@ struct rc_batch {
   double nullKernelCost = 0.0;
   rc_stream *owner = nullptr;
   std::shared_ptr<Retired> retiredKeep;   // the context's list of outgrown buffers (kept alive: a batch may be destroyed after its context)
-  // bind the batch to its context: from now on its buffers, when outgrown, are parked in that context's list
+  std::shared_ptr<BufPool> poolKeep;      // ... and its pool of buffers of destroyed batches
+  // bind the batch to its context: from now on its buffers, when outgrown, are parked in that context's list, and come from and go
+  // back to its pool
   void adopt(rc_ctx *c) {
-    ctx = c; device = c->device; retiredKeep = c->retired;
+    ctx = c; device = c->device; retiredKeep = c->retired; poolKeep = c->poolEnabled ? c->bufPool : nullptr;
     Retired *r = retiredKeep.get();
     for (DevBuf *d : {&dblob, &dmaxima, &dhss, &dhssCount, &dhssPacked, &dhssOffsets, &dfit, &dflags, &dexact, &dcounters, &dscratch, &dnativeScratch,
-                      &dnativeTile, &dsteal}) d->retired = r;
-    for (PinBuf *h : {&hblob, &hstage, &hpacked}) h->retired = r;
+                      &dnativeTile, &dsteal}) { d->retired = r; d->pool = poolKeep.get(); }
+    for (PinBuf *h : {&hblob, &hstage, &hpacked}) { h->retired = r; h->pool = poolKeep.get(); }
   }
 };
 
@@ -409,6 +462,7 @@ void rc_ctx_destroy(rc_ctx *c) {
   (void)hipDeviceSynchronize();
   c->retired->drain();
   g_retired.drain();
+  c->bufPool->drain(true);
   c->pool.reset();
   if (kProfiling && c->d_cellStats.p) {
     unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
@@ -447,6 +501,8 @@ int rc_ctx_create(int device, rc_ctx **out) {
   c->numCU = prop.multiProcessorCount;
   c->totalMem = prop.totalGlobalMem;
   c->retiredCapBytes = prop.totalGlobalMem / 16;
+  c->bufPool->devCap = prop.totalGlobalMem / 16;
+  if (const char *e = std::getenv("RC_BUFFER_POOL")) c->poolEnabled = std::atoi(e) != 0;
   for (DevBuf *d : {&c->treeJobs, &c->treeIn, &c->treeWork, &c->treeOut, &c->treeRes, &c->d_tables, &c->d_cellStats}) d->retired = c->retired.get();
   for (PinBuf *h : {&c->treeInPin, &c->treeResPin}) h->retired = c->retired.get();
   c->genericScratchWords = std::max<size_t>(static_cast<size_t>(1) << 30, prop.totalGlobalMem / 12 / sizeof(uint32_t));

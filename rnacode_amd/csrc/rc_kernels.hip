@@ -550,14 +550,23 @@ __global__ __launch_bounds__(THREADS) void k_evd_fit(FitArgs A) {
   const DevBlock *db = A.dblocks + bi;
   const float *x = A.maxima + static_cast<size_t>(db->out_index) * A.sampleN;
   const float maxNative = best_native(A, bi);     // every thread: a few records
-  double better = 0, z0 = 0, z1 = 0, z2 = 0;
-  for (int i = threadIdx.x; i < A.sampleN; i += THREADS) better += (x[i] > maxNative) ? 1.0 : 0.0;   // samples not simulated hold -1
-  fit_sum4<THREADS>(better, z0, z1, z2, sh);
+  double better = 0, scored = 0, z1 = 0, z2 = 0;
+  for (int i = threadIdx.x; i < A.sampleN; i += THREADS) {
+    better += (x[i] > maxNative) ? 1.0 : 0.0;   // samples not simulated hold -1
+    scored += (x[i] != -1.0f) ? 1.0 : 0.0;
+  }
+  fit_sum4<THREADS>(better, scored, z1, z2, sh);
   FitOut o;
   o.better = static_cast<int>(better);
   o.rc = -1; o.mu = 0; o.lambda = 0;
   const bool stopped = A.stopEarly && (o.better > A.stopCutoff);  // score.c:1040-1042
-  if (!stopped) {
+  // No sample has a high-scoring segment (every maximum is the -1 of score.c:1028: a block of one or two codons).  EVDMaxLikelyFit then
+  // evaluates Lawless 4.1.6 some 1100 times to no avail -- f(lambda) = (1/lambda + 1) - 1 > 0 for every lambda it tries: Newton doubles
+  // lambda until exp overflows and the sums turn NaN (100 steps), the bracketing walks right from 0.2 to 100 in steps of 0.1 and
+  // gives up (extreme_fit.c:193-216) -- and returns 0.  Same verdict here without the walk: it was 1.2 of the 4 ms that
+  // genomic-preprocessed.maf (one such block among 33) takes.
+  const bool nothingScored = scored == 0.0;
+  if (!stopped && !nothingScored) {
     double mu, lambda;
     if (evd_fit_block<THREADS>(x, A.sampleN, sh, &mu, &lambda) == 1) { o.rc = 1; o.mu = mu; o.lambda = lambda; }
   }
