@@ -838,7 +838,11 @@ def main():
     native_multi = None
     native_hook = bool(os.environ.get("RC_BENCH_TEST_NATIVE_MULTI"))   # test hook: this leg on a box with one GPU (every context on device 0), any workload
     if world > 1 and args.scaling == "strong" and not args.no_extra and ((coll_dev != "cpu" and default_workload) or native_hook):
-        store = dist.distributed_c10d._get_default_store()
+        # the other ranks wait at a barrier of a gloo group: on the host, with nothing of theirs spinning on a GPU meanwhile
+        try:
+            host_group = dist.new_group(backend="gloo")
+        except Exception:   # noqa: BLE001 -- no gloo here: wait in the default group instead (its barrier kernel occupies a CU or two)
+            host_group = None
         if rank == 0:
             try:
                 if torch.cuda.device_count() < world and not native_hook:
@@ -856,9 +860,7 @@ def main():
                     del full
             except Exception as e:   # noqa: BLE001 -- this leg must never cost the run its line
                 native_multi = {"error": repr(e)}
-            store.set("rc_native_multi_done", "1")
-        else:
-            store.wait(["rc_native_multi_done"])
+        dist.barrier(group=host_group)
 
     sa, cs = batch.work()
     if multi:   # units of all ranks (shards may differ by one block under strong scaling)
