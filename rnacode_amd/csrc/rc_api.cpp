@@ -1107,15 +1107,19 @@ static int batch_run_async(rc_batch *b, bool streaming = false) {
   hipStream_t cs = ctx_stream(c, static_cast<int>(c->seq++ % static_cast<unsigned>(c->computeStreams)));
   if (!cs) return fail(RC_ERR_DEVICE, "hipStreamCreate failed");
   const uint8_t *blob = b->dblob.as<uint8_t>();
-  bool nativeFirst = c->serialNative != 0, allFat = !b->classes.empty();
+  bool nativeFirst = c->serialNative != 0, allFat = !b->classes.empty(), wide = false;
   for (auto &kv : b->classes) {
     int maxLc = 0;
     for (int bi : kv.second) maxLc = std::max(maxLc, b->meta[bi].L);
     allFat = allFat && kv.first != kGenericClass && fat_class(b, c, kv.first, maxLc);
+    wide = wide || kv.first == kGenericClass;
   }
   bool fat = allFat && c->nativeFirst != 0 && (!streaming || static_cast<long long>(b->okBlocks.size()) * groups >= c->fatStreamMinItems);
   if (c->nativeFirst == 1) nativeFirst = true;
   if (fat) nativeFirst = true;
+  // k_null_generic's persistent grid takes every register of the chip as well (128 VGPRs, four wavefronts per SIMD): native-block
+  // kernels queued beside it either wait for its tail or, worse, get in first and keep part of its workgroups out for their whole run
+  if (wide && c->nativeFirst != 0) nativeFirst = true;
   const int nativeMode = c->serialNative ? 0 : nativeFirst ? 1 : 0;
   const RunEnv R{b, c, cs, n, sampleN, groups, Spad, n * 6, table_ptrs(c, b->par.blosum), blob,
                  reinterpret_cast<const DevBlock *>(blob + b->oDblocks), reinterpret_cast<const int *>(blob + b->oOk),

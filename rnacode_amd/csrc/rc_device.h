@@ -75,6 +75,7 @@ struct DevBlock {
   uint64_t off_zmask;    // u64[2][3][zm_words] bit j of (strand, frame): some sequence has z != 0 at codon site j (k_prep_gaps)
   uint64_t off_lut;      // f32[2][NK][64] sigma value per code (k_prep_lut)
   uint64_t off_sigma;    // f32[2][NK][L+1] native sigma (k_native_sigma)
+  uint64_t off_chain;    // f32[L/3 + 40] W[3 + t] = omega added t times to 0 (W[0..3] = 0): the gap states of a sequence without a frame shift, t cells into a row (k_prep_lut; k_null_generic)
 };
 
 // k_null's staging scratch: the sigma codes of one (strand, reference position) for the 64 samples of a wavefront -- five 6-bit codes

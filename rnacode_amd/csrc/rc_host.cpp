@@ -379,7 +379,7 @@ namespace {
 // section sizes of one block in the two blob parts
 struct Sections {
   size_t nodes, qtip, qtip16, chars, models, hostTotal;
-  size_t charsRev, refcol, zw, mask, zmask, lut, sigma, devTotal;
+  size_t charsRev, refcol, zw, mask, zmask, lut, sigma, chain, devTotal;
   Sections(int N, int cols, int L, int nnodes) {
     const size_t NK = static_cast<size_t>(N) - 1, L1 = static_cast<size_t>(L) + 1, ncw = (NK + 4) / 5, zww = (NK + 31) / 32;
     const size_t zmw = (static_cast<size_t>(L) / 3 + 63) / 64;
@@ -396,7 +396,8 @@ struct Sections {
     zmask = al16(6 * zmw * 8);
     lut = al16(2 * NK * kLutSize * 4);
     sigma = al16(2 * NK * L1 * 4);
-    devTotal = charsRev + refcol + zw + mask + zmask + lut + sigma;
+    chain = al16((static_cast<size_t>(L) / 3 + 40) * 4);
+    devTotal = charsRev + refcol + zw + mask + zmask + lut + sigma + chain;
   }
 };
 }  // namespace
@@ -472,7 +473,8 @@ int prepare_block(const rc_block &in, const rc_params &par, const PairTable &pt,
   d.off_mask = o; o += sec.mask;
   d.off_zmask = o; o += sec.zmask;
   d.off_lut = o; o += sec.lut;
-  d.off_sigma = o;
+  d.off_sigma = o; o += sec.sigma;
+  d.off_chain = o;
 
   d.N = N; d.NK = NK; d.cols = cols; d.L = L;
   d.nnodes = t.nnodes;

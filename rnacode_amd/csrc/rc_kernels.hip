@@ -190,6 +190,16 @@ __global__ __launch_bounds__(64) void k_prep_lut(PrepArgs A) {   // one wavefron
     lut[idx] = v;
     mine |= !in_div_range_dev(v);
   }
+  if (N >= A.genericMinRows && threadIdx.x == 0) {   // k_null_generic's running sums of omega, added the way the DP adds them
+    float *W = reinterpret_cast<float *>(A.blob + db->off_chain);
+    const int nW = db->L / 3 + 40;
+    const float omega = db->omega;
+    float c = 0.0f;
+    for (int i = 0; i < nW; i++) {
+      if (i > 3) c = c + omega;
+      W[i] = c;
+    }
+  }
   const bool bad = __ballot(mine) != 0ull;
   if (threadIdx.x == 0 && bad) {
     A.flags[bi] |= kFlagExact;

@@ -27,8 +27,9 @@ namespace rc {
 
 // scratch layout of one workgroup (bytes), for a class whose largest block has N rows, L reference residues, nn tree nodes
 struct GenericLayout {
-  size_t offCodes;   // u32 [6][NK][nW][64]    sigma codes per strand x frame and sequence, four consecutive codons per word (byte j & 3)
-  size_t offState;   // f32 [3][NK][64]        DP states of every sequence at the last tile boundary
+  size_t offCodes;   // u32 [6][NK][nW][64]    sigma codes x 4 per strand x frame and sequence, four consecutive codons per word (byte j & 3)
+  size_t offState;   // f32 [2][3][NK][64]     DP states of every sequence at the last tile boundary, for the two rows of a pass
+  size_t offRow;     // f32 [L/3 + 8][64]      the second row's S values, kept until the first row has gone through the scan
   size_t total;
   int nW;            // code words per (strand x frame, sequence): a tile reads eight words from any codon on, so 31 codons of padding
   __host__ __device__ GenericLayout(int N, int L, int nn) {
@@ -37,11 +38,116 @@ struct GenericLayout {
     offCodes = 0;
     offState = (offCodes + 6 * NK * static_cast<size_t>(nW) * kWave * sizeof(uint32_t) + 255) & ~static_cast<size_t>(255);
     (void)nn;
-    total = (offState + 3 * NK * kWave * sizeof(float) + 255) & ~static_cast<size_t>(255);
+    offRow = (offState + 2 * 3 * NK * kWave * sizeof(float) + 255) & ~static_cast<size_t>(255);
+    total = (offRow + (static_cast<size_t>(L) / 3 + 8) * kWave * sizeof(float) + 255) & ~static_cast<size_t>(255);
   }
 };
 
 constexpr int kGenericTile = 32;
+#ifndef RC_GENERIC_WAVES
+#define RC_GENERIC_WAVES 4   // wavefronts per SIMD of k_null_generic
+#endif
+
+// The cell sums of a tile as distinct scalar members, not an array: an array becomes one 32-register tuple, and every join of the
+// three kinds of pass then copies all of it (the same lesson as KRegs in rc_null_kernel.h).
+template <int U> struct CellSum { float v; };
+template <typename Seq> struct CellSums;
+template <int... U> struct CellSums<std::integer_sequence<int, U...>> : CellSum<U>... {
+  template <int I> __device__ __forceinline__ float &at() { return static_cast<CellSum<I> &>(*this).v; }
+};
+
+// Eight cells of one sequence.  The look-ups first -- the sequence's 64-entry sigma table is spread over the lanes in `lut`, a code
+// is stored times four, one per byte, and ds_bpermute_b32 reads address bits 2..7 only (tools/mb_bpermute_addr.hip), so the code
+// word itself, or the word shifted right by 8, 16, 24, is the address -- then the cells; m0..m7 receive max(s0, s1, s2) of each
+// cell.  Written out because the compiler, given the same in C++, waits for every look-up right behind its issue.  The sums are
+// not touched here: every kind of pass hands its m values to ONE add8 behind the join -- with an update of the sums in each kind
+// the register allocator keeps two sets of sums and copies all of them at both ends of every pass.
+#define RC_LOOKUPS8                                  \
+  "ds_bpermute_b32 %[m0], %[wa], %[lut]\n\t"         \
+  "v_lshrrev_b32 %[m1], 8, %[wa]\n\t"                \
+  "v_lshrrev_b32 %[m2], 16, %[wa]\n\t"               \
+  "ds_bpermute_b32 %[m1], %[m1], %[lut]\n\t"         \
+  "v_lshrrev_b32 %[m3], 24, %[wa]\n\t"               \
+  "ds_bpermute_b32 %[m2], %[m2], %[lut]\n\t"         \
+  "v_lshrrev_b32 %[m5], 8, %[wb]\n\t"                \
+  "ds_bpermute_b32 %[m3], %[m3], %[lut]\n\t"         \
+  "v_lshrrev_b32 %[m6], 16, %[wb]\n\t"               \
+  "ds_bpermute_b32 %[m4], %[wb], %[lut]\n\t"         \
+  "v_lshrrev_b32 %[m7], 24, %[wb]\n\t"               \
+  "ds_bpermute_b32 %[m5], %[m5], %[lut]\n\t"         \
+  "ds_bpermute_b32 %[m6], %[m6], %[lut]\n\t"         \
+  "ds_bpermute_b32 %[m7], %[m7], %[lut]\n\t"
+#define RC_M_OUT [m0] "=&v"(m0), [m1] "=&v"(m1), [m2] "=&v"(m2), [m3] "=&v"(m3), [m4] "=&v"(m4), [m5] "=&v"(m5), [m6] "=&v"(m6), [m7] "=&v"(m7)
+#define RC_WAIT4 "s_waitcnt lgkmcnt(4)\n\t"
+#define RC_WAIT0 "s_waitcnt lgkmcnt(0)\n\t"
+
+// a sequence that has met no frame shift in this row: s1 == s2 == w, the row's running sum of omega (the same number in every
+// lane and for every such sequence; kept in a VGPR and advanced here -- a table of it in SGPRs costs more than the adds)
+// (o0..o3: what the first four cells add to w -- omega, or zero for the cells before the row's start in its first tile)
+__device__ __forceinline__ void shared_cells8(float &s0, float &w, float &m0, float &m1, float &m2, float &m3, float &m4, float &m5, float &m6,
+                                              float &m7, uint32_t wa, uint32_t wb, int lut, float omega, float o0, float o1, float o2, float o3) {
+#define RC_CELL(N, OM) \
+  "v_add_f32 %[s0], %[s0], %[m" #N "]\n\t"      \
+  "v_add_f32 %[w], %[" #OM "], %[w]\n\t"        \
+  "v_max_f32 %[m" #N "], %[w], %[s0]\n\t"
+  asm volatile(RC_LOOKUPS8 RC_WAIT4 RC_CELL(0, o0) RC_CELL(1, o1) RC_CELL(2, o2) RC_CELL(3, o3) RC_WAIT0 RC_CELL(4, om) RC_CELL(5, om)
+               RC_CELL(6, om) RC_CELL(7, om)
+               : [s0] "+v"(s0), [w] "+v"(w), RC_M_OUT
+               : [wa] "v"(wa), [wb] "v"(wb), [lut] "v"(lut), [om] "s"(omega), [o0] "s"(o0), [o1] "s"(o1), [o2] "s"(o2), [o3] "s"(o3));
+#undef RC_CELL
+}
+
+// two rows a, a + 1 of such a sequence on one set of look-ups (sigma of cell j is the same for every row): row a + 1 is one cell
+// behind in w -- wx holds row a's w on entry and on exit, row a + 1 uses the value of the cell before
+__device__ __forceinline__ void dual_cells8(float &sa, float &sb, float &wx, float &m0, float &m1, float &m2, float &m3, float &m4, float &m5,
+                                            float &m6, float &m7, float &n0, float &n1, float &n2, float &n3, float &n4, float &n5, float &n6,
+                                            float &n7, uint32_t wa, uint32_t wb, int lut, float omega, float o0, float o1, float o2, float o3) {
+  float wy;
+#define RC_CELL(N, NEW, OLD, OM) \
+  "v_add_f32 %[sa], %[sa], %[m" #N "]\n\t"      \
+  "v_add_f32 %[sb], %[sb], %[m" #N "]\n\t"      \
+  "v_add_f32 %[" #NEW "], %[" #OM "], %[" #OLD "]\n\t" \
+  "v_max_f32 %[m" #N "], %[" #NEW "], %[sa]\n\t" \
+  "v_max_f32 %[n" #N "], %[" #OLD "], %[sb]\n\t"
+  asm volatile(RC_LOOKUPS8 RC_WAIT4 RC_CELL(0, wy, wx, o0) RC_CELL(1, wx, wy, o1) RC_CELL(2, wy, wx, o2) RC_CELL(3, wx, wy, o3) RC_WAIT0
+               RC_CELL(4, wy, wx, om) RC_CELL(5, wx, wy, om) RC_CELL(6, wy, wx, om) RC_CELL(7, wx, wy, om)
+               : [sa] "+v"(sa), [sb] "+v"(sb), [wx] "+v"(wx), [wy] "=&v"(wy), RC_M_OUT, [n0] "=&v"(n0), [n1] "=&v"(n1), [n2] "=&v"(n2),
+                 [n3] "=&v"(n3), [n4] "=&v"(n4), [n5] "=&v"(n5), [n6] "=&v"(n6), [n7] "=&v"(n7)
+               : [wa] "v"(wa), [wb] "v"(wb), [lut] "v"(lut), [om] "s"(omega), [o0] "s"(o0), [o1] "s"(o1), [o2] "s"(o2), [o3] "s"(o3));
+#undef RC_CELL
+}
+
+// a sequence that has met a frame shift earlier in the row but has none in these cells: three states
+__device__ __forceinline__ void general_cells8(float &s0, float &s1, float &s2, float &m0, float &m1, float &m2, float &m3, float &m4, float &m5,
+                                               float &m6, float &m7, uint32_t wa, uint32_t wb, int lut, float omega) {
+#define RC_CELL(N) \
+  "v_add_f32 %[s0], %[s0], %[m" #N "]\n\t"      \
+  "v_add_f32 %[s1], %[om], %[s1]\n\t"           \
+  "v_add_f32 %[s2], %[om], %[s2]\n\t"           \
+  "v_max3_f32 %[m" #N "], %[s0], %[s1], %[s2]\n\t"
+  asm volatile(RC_LOOKUPS8 RC_WAIT4 RC_CELL(0) RC_CELL(1) RC_CELL(2) RC_CELL(3) RC_WAIT0 RC_CELL(4) RC_CELL(5) RC_CELL(6) RC_CELL(7)
+               : [s0] "+v"(s0), [s1] "+v"(s1), [s2] "+v"(s2), RC_M_OUT
+               : [wa] "v"(wa), [wb] "v"(wb), [lut] "v"(lut), [om] "s"(omega));
+#undef RC_CELL
+}
+
+// only the look-ups: the cells of a tile in which the sequence does have a frame shift are compiler-made
+__device__ __forceinline__ void lookup8(uint32_t wa, uint32_t wb, int lut, float &m0, float &m1, float &m2, float &m3, float &m4, float &m5, float &m6, float &m7) {
+  asm volatile(RC_LOOKUPS8 RC_WAIT0 : RC_M_OUT : [wa] "v"(wa), [wb] "v"(wb), [lut] "v"(lut));
+}
+#undef RC_LOOKUPS8
+#undef RC_M_OUT
+#undef RC_WAIT4
+#undef RC_WAIT0
+
+// the one place where the cell sums of a tile change (score.c:512: sum += m)
+__device__ __forceinline__ void add8(float &c0, float &c1, float &c2, float &c3, float &c4, float &c5, float &c6, float &c7,
+                                     float m0, float m1, float m2, float m3, float m4, float m5, float m6, float m7) {
+  asm volatile("v_add_f32 %0, %0, %8\n\tv_add_f32 %1, %1, %9\n\tv_add_f32 %2, %2, %10\n\tv_add_f32 %3, %3, %11\n\t"
+               "v_add_f32 %4, %4, %12\n\tv_add_f32 %5, %5, %13\n\tv_add_f32 %6, %6, %14\n\tv_add_f32 %7, %7, %15\n\t"
+               : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7)
+               : "v"(m0), "v"(m1), "v"(m2), "v"(m3), "v"(m4), "v"(m5), "v"(m6), "v"(m7));
+}
 
 // LDS of one workgroup: the node states of the site being simulated, 2 bits each, 16 nodes per word [ceil(nn/16)][64], then the
 // last three states of every row, 6 bits in a byte [N][64]
@@ -49,7 +155,7 @@ __host__ __device__ inline size_t generic_lds_bytes(int N, int nn) {
   return (static_cast<size_t>((nn + 15) >> 4) * sizeof(uint32_t) + static_cast<size_t>(N)) * kWave;
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_null_generic(NullArgs A, const uint8_t *__restrict__ blob, const DevBlock *__restrict__ dblocks,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GENERIC_WAVES, RC_GENERIC_WAVES))) void k_null_generic(NullArgs A, const uint8_t *__restrict__ blob, const DevBlock *__restrict__ dblocks,
                                                      const int *__restrict__ classBlocks, const uint32_t *__restrict__ flags,
                                                      const uint32_t *__restrict__ Ustream, const uint8_t *__restrict__ pairTab,
                                                      uint8_t *__restrict__ scratch, float *__restrict__ maxima) {
@@ -98,7 +204,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     // ---- simulate the L reference-residue columns (evolve.c:416-433) and emit sigma codes for both strands
     unsigned int clamped = 0;
     for (int r = 0; r < N; r++) win[r * kWave] = 0;
+#if defined(RC_GENERIC_EXPERIMENT) && (RC_GENERIC_EXPERIMENT & 8)
+    for (int i = 1; i <= 0; i++) {
+#else
     for (int i = 1; i <= L; i++) {
+#endif
       const size_t ubase = static_cast<size_t>(refcol[i]) * A.Spad + sidx;
       const size_t qstride = static_cast<size_t>(cols) * A.Spad;
       uint32_t cur = 0;   // the word of node states being filled (nodes come parents first)
@@ -145,36 +255,62 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           const uint32_t b = win[(k + 1) * kWave];
           const uint32_t bF = b & mF, bR = (codon_flip(b) ^ 63u) & mR;
           // column i closes codon j = i/3 - 1 of frame i % 3 (i = 3j + 3 + f)
-          codes[(((static_cast<size_t>(0 + i % 3) * NK + k) * lay.nW + ((i / 3 - 1) >> 2)) * kWave + lane) * 4 + ((i / 3 - 1) & 3)] = pairTab[aF * 64 + bF];
-          codes[(((static_cast<size_t>(3 + ip % 3) * NK + k) * lay.nW + ((ip / 3 - 1) >> 2)) * kWave + lane) * 4 + ((ip / 3 - 1) & 3)] = pairTab[aR * 64 + bR];
+          codes[(((static_cast<size_t>(0 + i % 3) * NK + k) * lay.nW + ((i / 3 - 1) >> 2)) * kWave + lane) * 4 + ((i / 3 - 1) & 3)] = static_cast<uint8_t>(pairTab[aF * 64 + bF] << 2);
+          codes[(((static_cast<size_t>(3 + ip % 3) * NK + k) * lay.nW + ((ip / 3 - 1) >> 2)) * kWave + lane) * 4 + ((ip / 3 - 1) & 3)] = static_cast<uint8_t>(pairTab[aR * 64 + bR] << 2);
         }
       }
     }
     if (clamped && sidx < A.sampleN && onlyCombo <= 0) atomicAdd(A.clampCount, static_cast<unsigned long long>(clamped));   // (the six parts of a split item redo the same simulation)
 
     // ---- both strands x 3 frames: DP over (start a, end j) + serial HSS scan (score.c:496-535, 830-845, 888-962)
+    // A sequence that has met no frame shift since the row's start has s1 == s2 == the row's running sum of omega, the same
+    // number for every such sequence and every sample: W[3 + t] after t cells (k_prep_lut, off_chain).  Its pass keeps s0 only,
+    // a cell is add / max against the wave-uniform W / add to the cell's sum, and only s0 is parked between tiles.  The first
+    // tile in which a sequence meets a frame shift, and every later tile of that row, takes the three-state pass.
+    // Rows go in pairs a, a + 1 (a even: both start in the same code word): where a sequence is in the first state in both, the
+    // two rows share its look-ups and its code words -- half the ds_bpermutes and half the code traffic, which are what bound the
+    // pass.  getHSS reads S row by row: row a's entries go through the scan as they are made, row a + 1's wait in `rowbuf`.
     float best = -1.0f;
     const float negTie = -A.tieThr;
+    const float *__restrict__ chainW = reinterpret_cast<const float *>(blob + db->off_chain);
+    const uint32_t zeroCodes = (static_cast<uint32_t>(db->code_zero) << 2) * 0x01010101u;   // four copies of the code whose sigma is 0
+    float *__restrict__ rowbuf = reinterpret_cast<float *>(mine + lay.offRow) + lane;
+    float *__restrict__ dpB = dp + static_cast<size_t>(3 * NK) * kWave;
+#if defined(RC_GENERIC_EXPERIMENT) && (RC_GENERIC_EXPERIMENT & 4)
+    for (int s = 0; s < 0; s++)
+#else
     for (int s = 0; s < 2; s++)
+#endif
       for (int f = 0; f < 3; f++) {
         const int sites = (L - f) / 3;
         if (sites <= 0) continue;
         if (onlyCombo >= 0 && onlyCombo != s * 3 + f) continue;
         SampleScan st{0.0f, 0.0f, 0u, 0u};
-        for (int a = 0; a < sites; a++) {
+        for (int a = 0; a < sites; a += 2) {
+          const int b = a + 1;   // the second row of the pair; b == sites: there is none
           sample_scan_row_begin(st, best, static_cast<uint32_t>(a));
-          const int jend = (a == sites - 1) ? sites - 1 : sites;   // the frame's final entry is never reported (score.c:892-900)
+          const int jendA = (a == sites - 1) ? sites - 1 : sites;   // the frame's final entry is never reported (score.c:892-900)
+          const int jendB = (b >= sites - 1) ? sites - 1 : sites;   // (b == sites: no cell passes b <= j < sites - 1)
+          uint32_t stickyA = 0u, stickyB = 0u;   // bit k & 31 of lane k >> 5: sequence k has met a frame shift in this row
           // tiles start at multiples of four codons (the code words hold four), so a row's first tile may begin before a
-          for (int j0 = a & ~3; j0 < jend; j0 += kGenericTile) {
-            float sum[kGenericTile];
+          for (int j0 = a & ~3; j0 < jendA; j0 += kGenericTile) {
+            const bool first = j0 <= a, more = j0 + kGenericTile < jendA;
+            const int loA = first ? a - j0 : 0, hiA = jendA - j0 < kGenericTile ? jendA - j0 : kGenericTile;
+            const int loB = first ? b - j0 : 0, hiB = jendB - j0 < kGenericTile ? (jendB - j0 > 0 ? jendB - j0 : 0) : kGenericTile;
+            const uint32_t validA = (hiA == kGenericTile ? 0xffffffffu : (1u << hiA) - 1u) & ~((1u << loA) - 1u);   // bit u: a <= j0 + u < jendA
+            const uint32_t validB = hiB > loB ? (hiB == kGenericTile ? 0xffffffffu : (1u << hiB) - 1u) & ~((1u << loB) - 1u) : 0u;
+            if (validA == 0u) break;   // the frame's last row: its only cell is the unreported final entry
+            const int ng = (hiA + 7) >> 3;   // groups of eight cells; the cells of the last group past the row's end are computed and dropped
+            CellSums<std::make_integer_sequence<int, kGenericTile>> sumA, sumB;
+            static_for<kGenericTile>([&](auto uc) {   // score.c:509: sum = 0, then += in the order k = 0, 1, ...
+              sumA.template at<decltype(uc)::value>() = 0.0f;
+              sumB.template at<decltype(uc)::value>() = 0.0f;
+            });
+            const float wInA = chainW[j0 - a + 3], wInB = chainW[j0 - a + 2];   // the rows' running sums of omega before the tile's first cell
+            float oA[4], oB[4];   // what the tile's first four cells add to them: nothing before the row's start
 #pragma unroll
-            for (int u = 0; u < kGenericTile; u++) sum[u] = 0.0f;
-            const bool first = j0 <= a, more = j0 + kGenericTile < jend;
-            const int lo = first ? a - j0 : 0, hi = jend - j0 < kGenericTile ? jend - j0 : kGenericTile;
-            const uint32_t valid = (hi == kGenericTile ? 0xffffffffu : (1u << hi) - 1u) & ~((1u << lo) - 1u);   // bit u: a <= j0 + u < jend
-            if (valid == 0u) break;   // the frame's last row: its only cell is the unreported final entry
-            const bool full = valid == 0xffffffffu;
-            const int jl = (j0 + (lane & (kGenericTile - 1)) < jend) ? j0 + (lane & (kGenericTile - 1)) : jend - 1;   // this lane's end codon for the z fetch
+            for (int u = 0; u < 4; u++) { oA[u] = u < loA ? 0.0f : omega; oB[u] = u < loB ? 0.0f : omega; }
+            const int jl = (j0 + (lane & (kGenericTile - 1)) < jendA) ? j0 + (lane & (kGenericTile - 1)) : jendA - 1;   // this lane's end codon for the z fetch
             for (int k = 0; k < NK; k++) {
               const int lutv = __float_as_int(lut[(static_cast<size_t>(s) * NK + k) * kLutSize + lane]);
               const uint32_t *__restrict__ ck = reinterpret_cast<const uint32_t *>(codes) + ((static_cast<size_t>(s * 3 + f) * NK + k) * lay.nW + (j0 >> 2)) * kWave + lane;
@@ -182,46 +318,122 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
               // turn the 2-bit values into wave-uniform masks -- almost always both zero (a sequence has few frame shifts)
               const unsigned long long zword = zw[(static_cast<size_t>(s * L1 + 3 + f) + static_cast<size_t>(3 * jl)) * ZW + (k >> 5)];
               const uint32_t zcl = static_cast<uint32_t>(zword >> (2 * (k & 31))) & 3u;
-              float *__restrict__ dk = dp + static_cast<size_t>(k) * kWave + lane;
-              float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
-              if (!first) { s0 = dk[0]; s1 = dk[static_cast<size_t>(NK) * kWave]; s2 = dk[static_cast<size_t>(2 * NK) * kWave]; }
+              float *__restrict__ dkA = dp + static_cast<size_t>(k) * kWave + lane;
+              float *__restrict__ dkB = dpB + static_cast<size_t>(k) * kWave + lane;
               uint32_t cw[kGenericTile / 4];
 #pragma unroll
               for (int w = 0; w < kGenericTile / 4; w++) cw[w] = ck[w * kWave];
-              float sig[kGenericTile];
+#if defined(RC_GENERIC_EXPERIMENT) && (RC_GENERIC_EXPERIMENT & 1)
 #pragma unroll
-              for (int u = 0; u < kGenericTile; u++)
-                sig[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(static_cast<int>(((cw[u >> 2] >> (8 * (u & 3))) & 0xffu) << 2), lutv));
-              const uint32_t z0 = static_cast<uint32_t>(__ballot(zcl & 1u)) & valid, z1 = static_cast<uint32_t>(__ballot(zcl & 2u)) & valid;
-              // FULL: all kGenericTile end codons exist (no guards); CLEAN: no frame shift of this sequence among them
-              auto steps = [&](auto fullTag, auto cleanTag) {
-                constexpr bool FULL = decltype(fullTag)::value, CLEAN = decltype(cleanTag)::value;
-#pragma unroll
-                for (int u = 0; u < kGenericTile; u++) {
-                  if (FULL || ((valid >> u) & 1u)) {
-                    if constexpr (CLEAN) { s0 = s0 + sig[u]; s1 = s1 + omega; s2 = s2 + omega; }
-                    else pair_step(static_cast<int>(((z0 >> u) & 1u) | (((z1 >> u) & 1u) << 1)), sig[u], Delta, Omega, omega, s0, s1, s2);
-                    const float m = fmaxf(fmaxf(s0, s1), s2);
-                    sum[u] = (k == 0) ? m : sum[u] + m;
-                  }
+              for (int w = 0; w < kGenericTile / 4; w++) cw[w] = (static_cast<uint32_t>(lane * 0x01010101u + k + w) & 0x3f3f3f3fu) << 2;   // timing only: no code traffic
+#endif
+              const uint32_t zz0 = static_cast<uint32_t>(__ballot(zcl & 1u)), zz1 = static_cast<uint32_t>(__ballot(zcl & 2u));
+              const uint32_t swA = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(stickyA), k >> 5));
+              const uint32_t swB = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(stickyB), k >> 5));
+              const bool wasA = ((swA >> (k & 31)) & 1u) != 0u, evA = ((zz0 | zz1) & validA) != 0u;
+              const bool wasB = ((swB >> (k & 31)) & 1u) != 0u, evB = ((zz0 | zz1) & validB) != 0u;
+              const bool sharedA = !wasA && !evA, sharedB = !wasB && !evB, dual = sharedA && sharedB;
+              float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
+              uint32_t cwA0 = cw[0], cwB0 = cw[0];   // the first word as the two rows see it
+#if defined(RC_GENERIC_EXPERIMENT) && (RC_GENERIC_EXPERIMENT & 2)
+              if (!first && k == 1000000) {   // timing only: no parked states
+#else
+              if (!first) {
+#endif
+                a0 = dkA[0];
+                b0 = dkB[0];
+                if (!sharedA) {
+                  a1 = a2 = wInA;
+                  if (wasA) { a1 = dkA[static_cast<size_t>(NK) * kWave]; a2 = dkA[static_cast<size_t>(2 * NK) * kWave]; }
                 }
-              };
-              if ((z0 | z1) == 0u) {
-                if (full) steps(std::true_type{}, std::true_type{}); else steps(std::false_type{}, std::true_type{});
+                if (!sharedB) {
+                  b1 = b2 = wInB;
+                  if (wasB) { b1 = dkB[static_cast<size_t>(NK) * kWave]; b2 = dkB[static_cast<size_t>(2 * NK) * kWave]; }
+                }
               } else {
-                steps(std::false_type{}, std::false_type{});
+                // the cells before a row's start add sigma = 0, so that s0 stays zero (the three-state pass skips them instead)
+                if (sharedA && loA != 0) cwA0 = (cw[0] & (0xffffffffu << (8 * loA))) | (zeroCodes >> (32 - 8 * loA));
+                if (sharedB) cwB0 = (cw[0] & (0xffffffffu << (8 * loB))) | (zeroCodes >> (32 - 8 * loB));   // (loB is 1 or 3)
+                // both rows on row a's word: row a + 1 starts at minus sigma of cell a, and is exactly zero behind that cell
+                if (dual) b0 = -__int_as_float(__builtin_amdgcn_ds_bpermute(static_cast<int>(cw[0] >> (8 * loA)), lutv));
               }
-              if (more) { dk[0] = s0; dk[static_cast<size_t>(NK) * kWave] = s1; dk[static_cast<size_t>(2 * NK) * kWave] = s2; }
+              float wA = wInA, wB = wInB;   // (a row in the first state only)
+              static_for<kGenericTile / 8>([&](auto gc) {
+                constexpr int g = decltype(gc)::value, u0 = 8 * g;
+                if (g == 0 || g < ng) {
+                  float m[8], n[8];
+                  const uint32_t cA = g == 0 ? cwA0 : cw[2 * g], cB = g == 0 ? cwB0 : cw[2 * g];
+                  if (__builtin_expect(dual, 1)) {
+                    dual_cells8(a0, b0, wA, m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], n[0], n[1], n[2], n[3], n[4], n[5], n[6], n[7], cA,
+                                cw[2 * g + 1], lutv, omega, g == 0 ? oA[0] : omega, g == 0 ? oA[1] : omega, g == 0 ? oA[2] : omega,
+                                g == 0 ? oA[3] : omega);
+                  } else {
+                    // one row after the other
+                    auto row = [&](bool shared, bool ev, uint32_t valid, uint32_t w0, const float (&o)[4], float &w, float &s0, float &s1, float &s2, float (&mm)[8]) {
+                      if (shared) {
+                        shared_cells8(s0, w, mm[0], mm[1], mm[2], mm[3], mm[4], mm[5], mm[6], mm[7], w0, cw[2 * g + 1], lutv, omega, g == 0 ? o[0] : omega,
+                                      g == 0 ? o[1] : omega, g == 0 ? o[2] : omega, g == 0 ? o[3] : omega);
+                      } else if (!ev) {   // (never a row's first tile: that one is here only for an event)
+                        general_cells8(s0, s1, s2, mm[0], mm[1], mm[2], mm[3], mm[4], mm[5], mm[6], mm[7], w0, cw[2 * g + 1], lutv, omega);
+                      } else {
+                        lookup8(w0, cw[2 * g + 1], lutv, mm[0], mm[1], mm[2], mm[3], mm[4], mm[5], mm[6], mm[7]);
+                        static_for<8>([&](auto vc) {
+                          constexpr int v = decltype(vc)::value, u = u0 + v;
+                          const float sg = mm[v];
+                          mm[v] = 0.0f;   // a cell outside the row adds zero to a sum that is never read
+                          if ((valid >> u) & 1u) {
+                            pair_step(static_cast<int>(((zz0 >> u) & 1u) | (((zz1 >> u) & 1u) << 1)), sg, Delta, Omega, omega, s0, s1, s2);
+                            mm[v] = fmaxf(fmaxf(s0, s1), s2);
+                          }
+                        });
+                      }
+                    };
+                    row(sharedA, evA, validA, cA, oA, wA, a0, a1, a2, m);
+                    row(sharedB, evB, validB, cB, oB, wB, b0, b1, b2, n);
+                  }
+                  add8(sumA.template at<u0>(), sumA.template at<u0 + 1>(), sumA.template at<u0 + 2>(), sumA.template at<u0 + 3>(),
+                       sumA.template at<u0 + 4>(), sumA.template at<u0 + 5>(), sumA.template at<u0 + 6>(), sumA.template at<u0 + 7>(), m[0], m[1],
+                       m[2], m[3], m[4], m[5], m[6], m[7]);
+                  add8(sumB.template at<u0>(), sumB.template at<u0 + 1>(), sumB.template at<u0 + 2>(), sumB.template at<u0 + 3>(),
+                       sumB.template at<u0 + 4>(), sumB.template at<u0 + 5>(), sumB.template at<u0 + 6>(), sumB.template at<u0 + 7>(), n[0], n[1],
+                       n[2], n[3], n[4], n[5], n[6], n[7]);
+                }
+              });
+#if defined(RC_GENERIC_EXPERIMENT) && (RC_GENERIC_EXPERIMENT & 2)
+              if (more && k == 1000000) {
+#else
+              if (more) {
+#endif
+                dkA[0] = a0;
+                dkB[0] = b0;
+                if (!sharedA) { dkA[static_cast<size_t>(NK) * kWave] = a1; dkA[static_cast<size_t>(2 * NK) * kWave] = a2; }
+                if (!sharedB) { dkB[static_cast<size_t>(NK) * kWave] = b1; dkB[static_cast<size_t>(2 * NK) * kWave] = b2; }
+              }
+              if (evA && !wasA) stickyA |= (lane == (k >> 5)) ? 1u << (k & 31) : 0u;
+              if (evB && !wasB) stickyB |= (lane == (k >> 5)) ? 1u << (k & 31) : 0u;
             }
-#pragma unroll
-            for (int u = 0; u < kGenericTile; u++) {
-              if ((valid >> u) & 1u) {   // a <= j0 + u < jend
-                const float v = fmaxf(sum[u], Delta) / nkf;
+            static_for<kGenericTile>([&](auto uc) {
+              constexpr int u = decltype(uc)::value;
+              if ((validA >> u) & 1u) {   // a <= j0 + u < jendA
+                const float v = fmaxf(sumA.template at<u>(), Delta) / nkf;
                 sample_scan_step(st, v, static_cast<float>(2 * (j0 + u) + 1), negTie);
               }
-            }
+              if ((validB >> u) & 1u) rowbuf[static_cast<size_t>(j0 + u) * kWave] = fmaxf(sumB.template at<u>(), Delta) / nkf;
+            });
           }
           sample_scan_row_end(st, static_cast<uint32_t>(a));
+          if (b < sites) {   // row a + 1 through the scan, eight entries fetched at a time
+            sample_scan_row_begin(st, best, static_cast<uint32_t>(b));
+            for (int j = b; j < jendB; j += 8) {
+              float v[8];
+#pragma unroll
+              for (int t = 0; t < 8; t++) v[t] = rowbuf[static_cast<size_t>(j + t < jendB ? j + t : jendB - 1) * kWave];
+#pragma unroll
+              for (int t = 0; t < 8; t++)
+                if (j + t < jendB) sample_scan_step(st, v[t], static_cast<float>(2 * (j + t) + 1), negTie);
+            }
+            sample_scan_row_end(st, static_cast<uint32_t>(b));
+          }
         }
         sample_scan_last(st, best);
       }
