@@ -28,7 +28,7 @@ namespace rc {
 // scratch layout of one workgroup (bytes), for a class whose largest block has N rows, L reference residues, nn tree nodes
 struct GenericLayout {
   size_t offCodes;   // u32 [6][NK][nW][64]    sigma codes x 4 per strand x frame and sequence, four consecutive codons per word (byte j & 3)
-  size_t offState;   // f32 [2][3][NK][64]     DP states of every sequence at the last tile boundary, for the two rows of a pass
+  size_t offState;   // f32 [2][1 + 3 NK][64]  DP states of every sequence at the last tile boundary, for the two rows of a pass (row 0 of each: spare)
   size_t offRow;     // f32 [L/3 + 8][64]      the second row's S values, kept until the first row has gone through the scan
   size_t total;
   int nW;            // code words per (strand x frame, sequence): a tile reads eight words from any codon on, so 31 codons of padding
@@ -38,7 +38,7 @@ struct GenericLayout {
     offCodes = 0;
     offState = (offCodes + 6 * NK * static_cast<size_t>(nW) * kWave * sizeof(uint32_t) + 255) & ~static_cast<size_t>(255);
     (void)nn;
-    offRow = (offState + 2 * 3 * NK * kWave * sizeof(float) + 255) & ~static_cast<size_t>(255);
+    offRow = (offState + 2 * (3 * NK + 1) * kWave * sizeof(float) + 255) & ~static_cast<size_t>(255);
     total = (offRow + (static_cast<size_t>(L) / 3 + 8) * kWave * sizeof(float) + 255) & ~static_cast<size_t>(255);
   }
 };
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GENERIC_W
     uint8_t *__restrict__ codes = mine + lay.offCodes;
     uint32_t *nodeSt = ldsGeneric + lane;                                                                     // word w: [w * 64]
     uint8_t *win = reinterpret_cast<uint8_t *>(ldsGeneric + static_cast<size_t>((nnodes + 15) >> 4) * kWave) + lane;   // row r: [r * 64]
-    float *__restrict__ dp = reinterpret_cast<float *>(mine + lay.offState);
+    float *__restrict__ dp = reinterpret_cast<float *>(mine + lay.offState) + kWave;   // (the row in front: see the parked s0 below)
     const int sidx = grp * kWave + lane;
 
     // ---- simulate the L reference-residue columns (evolve.c:416-433) and emit sigma codes for both strands
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GENERIC_W
     const float *__restrict__ chainW = reinterpret_cast<const float *>(blob + db->off_chain);
     const uint32_t zeroCodes = (static_cast<uint32_t>(db->code_zero) << 2) * 0x01010101u;   // four copies of the code whose sigma is 0
     float *__restrict__ rowbuf = reinterpret_cast<float *>(mine + lay.offRow) + lane;
-    float *__restrict__ dpB = dp + static_cast<size_t>(3 * NK) * kWave;
+    float *__restrict__ dpB = dp + static_cast<size_t>(3 * NK + 1) * kWave;
 #if defined(RC_GENERIC_EXPERIMENT) && (RC_GENERIC_EXPERIMENT & 4)
     for (int s = 0; s < 0; s++)
 #else
@@ -311,18 +311,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GENERIC_W
 #pragma unroll
             for (int u = 0; u < 4; u++) { oA[u] = u < loA ? 0.0f : omega; oB[u] = u < loB ? 0.0f : omega; }
             const int jl = (j0 + (lane & (kGenericTile - 1)) < jendA) ? j0 + (lane & (kGenericTile - 1)) : jendA - 1;   // this lane's end codon for the z fetch
+            // The s0 values a pass parks are stored behind the NEXT pass's loads: vmcnt counts in order, so a wait for loads issued
+            // behind a store is also a wait for that store's round trip.
+            // Every pass stores (a wait that has to serve a path with the stores and one without is a wait for everything): the first
+            // one of a tile, and all of a row's last tile, into the spare row in front of the states.
+            float heldA = 0.0f, heldB = 0.0f;
+            const int heldStride = more ? kWave : 0;
             for (int k = 0; k < NK; k++) {
               const int lutv = __float_as_int(lut[(static_cast<size_t>(s) * NK + k) * kLutSize + lane]);
               const uint32_t *__restrict__ ck = reinterpret_cast<const uint32_t *>(codes) + ((static_cast<size_t>(s * 3 + f) * NK + k) * lay.nW + (j0 >> 2)) * kWave + lane;
-              // z of sequence k at the tile's end codons (score.c:506-533): lane u fetches the word of codon j0 + u, two ballots
-              // turn the 2-bit values into wave-uniform masks -- almost always both zero (a sequence has few frame shifts)
-              const unsigned long long zword = zw[(static_cast<size_t>(s * L1 + 3 + f) + static_cast<size_t>(3 * jl)) * ZW + (k >> 5)];
-              const uint32_t zcl = static_cast<uint32_t>(zword >> (2 * (k & 31))) & 3u;
               float *__restrict__ dkA = dp + static_cast<size_t>(k) * kWave + lane;
               float *__restrict__ dkB = dpB + static_cast<size_t>(k) * kWave + lane;
               uint32_t cw[kGenericTile / 4];
 #pragma unroll
               for (int w = 0; w < kGenericTile / 4; w++) cw[w] = ck[w * kWave];
+              // z of sequence k at the tile's end codons (score.c:506-533): lane u fetches the half word of codon j0 + u that holds it,
+              // two ballots turn the 2-bit values into wave-uniform masks -- almost always both zero (a sequence has few frame shifts)
+              // (fetched behind the code words: it is needed first, and a wait for it in front of their issue would be two round trips)
+              const uint32_t zhalf = reinterpret_cast<const uint32_t *>(zw)[((static_cast<size_t>(s * L1 + 3 + f) + static_cast<size_t>(3 * jl)) * ZW + (k >> 5)) * 2 + ((k >> 4) & 1)];
+              const uint32_t zcl = (zhalf >> (2 * (k & 15))) & 3u;
 #if defined(RC_GENERIC_EXPERIMENT) && (RC_GENERIC_EXPERIMENT & 1)
 #pragma unroll
               for (int w = 0; w < kGenericTile / 4; w++) cw[w] = (static_cast<uint32_t>(lane * 0x01010101u + k + w) & 0x3f3f3f3fu) << 2;   // timing only: no code traffic
@@ -330,34 +337,51 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GENERIC_W
               const uint32_t zz0 = static_cast<uint32_t>(__ballot(zcl & 1u)), zz1 = static_cast<uint32_t>(__ballot(zcl & 2u));
               const uint32_t swA = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(stickyA), k >> 5));
               const uint32_t swB = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(stickyB), k >> 5));
-              const bool wasA = ((swA >> (k & 31)) & 1u) != 0u, evA = ((zz0 | zz1) & validA) != 0u;
-              const bool wasB = ((swB >> (k & 31)) & 1u) != 0u, evB = ((zz0 | zz1) & validB) != 0u;
-              const bool sharedA = !wasA && !evA, sharedB = !wasB && !evB, dual = sharedA && sharedB;
+              // The scalar unit is shared by the CU's four SIMDs (tools/microbench.hip: 1.3 instructions per ns and CU) and is what
+              // bounds this loop: the two-row pass decides on ONE word; what the other passes need to know is worked out on their side
+              // of the branch (`fb`), behind an empty asm that keeps the compiler from hoisting it in front of the branch.
+              const uint32_t bitK = 1u << (k & 31);
+              const bool dual = (((zz0 | zz1) & validA) | ((swA | swB) & bitK)) == 0u;   // (validB is a subset of validA)
+              uint32_t fb = 0u;   // not dual: bit 0 row a in the first state, bit 1 row a + 1, bit 2 a frame shift of this sequence in row a's cells, bit 3 in row a + 1's
               float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
               uint32_t cwA0 = cw[0], cwB0 = cw[0];   // the first word as the two rows see it
-#if defined(RC_GENERIC_EXPERIMENT) && (RC_GENERIC_EXPERIMENT & 2)
-              if (!first && k == 1000000) {   // timing only: no parked states
-#else
-              if (!first) {
-#endif
-                a0 = dkA[0];
-                b0 = dkB[0];
-                if (!sharedA) {
-                  a1 = a2 = wInA;
-                  if (wasA) { a1 = dkA[static_cast<size_t>(NK) * kWave]; a2 = dkA[static_cast<size_t>(2 * NK) * kWave]; }
-                }
-                if (!sharedB) {
-                  b1 = b2 = wInB;
-                  if (wasB) { b1 = dkB[static_cast<size_t>(NK) * kWave]; b2 = dkB[static_cast<size_t>(2 * NK) * kWave]; }
+              if (__builtin_expect(dual, 1)) {
+                if (!first) {
+                  a0 = dkA[0];
+                  b0 = dkB[0];
+                } else {
+                  // the cells before the rows' start add sigma = 0, so that s0 stays zero; both rows go on row a's word: row a + 1
+                  // starts at minus sigma of cell a, and is exactly zero behind that cell
+                  if (loA != 0) cwA0 = (cw[0] & (0xffffffffu << (8 * loA))) | (zeroCodes >> (32 - 8 * loA));
+                  b0 = -__int_as_float(__builtin_amdgcn_ds_bpermute(static_cast<int>(cw[0] >> (8 * loA)), lutv));
                 }
               } else {
-                // the cells before a row's start add sigma = 0, so that s0 stays zero (the three-state pass skips them instead)
-                if (sharedA && loA != 0) cwA0 = (cw[0] & (0xffffffffu << (8 * loA))) | (zeroCodes >> (32 - 8 * loA));
-                if (sharedB) cwB0 = (cw[0] & (0xffffffffu << (8 * loB))) | (zeroCodes >> (32 - 8 * loB));   // (loB is 1 or 3)
-                // both rows on row a's word: row a + 1 starts at minus sigma of cell a, and is exactly zero behind that cell
-                if (dual) b0 = -__int_as_float(__builtin_amdgcn_ds_bpermute(static_cast<int>(cw[0] >> (8 * loA)), lutv));
+                uint32_t zA = (zz0 | zz1) & validA, zB = (zz0 | zz1) & validB, tA = swA & bitK, tB = swB & bitK;
+                asm volatile("" : "+s"(zA), "+s"(zB), "+s"(tA), "+s"(tB));
+                const bool evA = zA != 0u, evB = zB != 0u, wasA = tA != 0u, wasB = tB != 0u, sharedA = !wasA && !evA, sharedB = !wasB && !evB;
+                fb = (sharedA ? 1u : 0u) | (sharedB ? 2u : 0u) | (evA ? 4u : 0u) | (evB ? 8u : 0u);
+                if (!first) {
+                  a0 = dkA[0];
+                  b0 = dkB[0];
+                  if (!sharedA) {
+                    a1 = a2 = wInA;
+                    if (wasA) { a1 = dkA[static_cast<size_t>(NK) * kWave]; a2 = dkA[static_cast<size_t>(2 * NK) * kWave]; }
+                  }
+                  if (!sharedB) {
+                    b1 = b2 = wInB;
+                    if (wasB) { b1 = dkB[static_cast<size_t>(NK) * kWave]; b2 = dkB[static_cast<size_t>(2 * NK) * kWave]; }
+                  }
+                } else {
+                  // (the three-state pass skips the cells before a row's start instead)
+                  if (sharedA && loA != 0) cwA0 = (cw[0] & (0xffffffffu << (8 * loA))) | (zeroCodes >> (32 - 8 * loA));
+                  if (sharedB) cwB0 = (cw[0] & (0xffffffffu << (8 * loB))) | (zeroCodes >> (32 - 8 * loB));   // (loB is 1 or 3)
+                }
+                if (evA && !wasA) stickyA |= (lane == (k >> 5)) ? bitK : 0u;
+                if (evB && !wasB) stickyB |= (lane == (k >> 5)) ? bitK : 0u;
               }
               float wA = wInA, wB = wInB;   // (a row in the first state only)
+              dp[(k - 1) * heldStride - (kWave - heldStride) + lane] = heldA;
+              dpB[(k - 1) * heldStride - (kWave - heldStride) + lane] = heldB;
               static_for<kGenericTile / 8>([&](auto gc) {
                 constexpr int g = decltype(gc)::value, u0 = 8 * g;
                 if (g == 0 || g < ng) {
@@ -388,8 +412,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GENERIC_W
                         });
                       }
                     };
-                    row(sharedA, evA, validA, cA, oA, wA, a0, a1, a2, m);
-                    row(sharedB, evB, validB, cB, oB, wB, b0, b1, b2, n);
+                    row((fb & 1u) != 0u, (fb & 4u) != 0u, validA, cA, oA, wA, a0, a1, a2, m);
+                    row((fb & 2u) != 0u, (fb & 8u) != 0u, validB, cB, oB, wB, b0, b1, b2, n);
                   }
                   add8(sumA.template at<u0>(), sumA.template at<u0 + 1>(), sumA.template at<u0 + 2>(), sumA.template at<u0 + 3>(),
                        sumA.template at<u0 + 4>(), sumA.template at<u0 + 5>(), sumA.template at<u0 + 6>(), sumA.template at<u0 + 7>(), m[0], m[1],
@@ -399,19 +423,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GENERIC_W
                        n[2], n[3], n[4], n[5], n[6], n[7]);
                 }
               });
-#if defined(RC_GENERIC_EXPERIMENT) && (RC_GENERIC_EXPERIMENT & 2)
-              if (more && k == 1000000) {
-#else
-              if (more) {
-#endif
-                dkA[0] = a0;
-                dkB[0] = b0;
-                if (!sharedA) { dkA[static_cast<size_t>(NK) * kWave] = a1; dkA[static_cast<size_t>(2 * NK) * kWave] = a2; }
-                if (!sharedB) { dkB[static_cast<size_t>(NK) * kWave] = b1; dkB[static_cast<size_t>(2 * NK) * kWave] = b2; }
+              heldA = a0; heldB = b0;   // (stored by the next pass, or behind the loop)
+              if (!dual && more) {
+                if (!(fb & 1u)) { dkA[static_cast<size_t>(NK) * kWave] = a1; dkA[static_cast<size_t>(2 * NK) * kWave] = a2; }
+                if (!(fb & 2u)) { dkB[static_cast<size_t>(NK) * kWave] = b1; dkB[static_cast<size_t>(2 * NK) * kWave] = b2; }
               }
-              if (evA && !wasA) stickyA |= (lane == (k >> 5)) ? 1u << (k & 31) : 0u;
-              if (evB && !wasB) stickyB |= (lane == (k >> 5)) ? 1u << (k & 31) : 0u;
             }
+            if (more) { dp[static_cast<size_t>(NK - 1) * kWave + lane] = heldA; dpB[static_cast<size_t>(NK - 1) * kWave + lane] = heldB; }
             static_for<kGenericTile>([&](auto uc) {
               constexpr int u = decltype(uc)::value;
               if ((validA >> u) & 1u) {   // a <= j0 + u < jendA
