@@ -4,21 +4,25 @@
 // Same decomposition as k_null (lane = null sample, 64 samples of one block per wavefront, work items from per-XCD queues) and
 // the same arithmetic in the same order, but nothing is unrolled over the sequences: the node states of the simulation and the
 // sigma codes live in a per-workgroup scratch in global memory ([...][lane], coalesced), tables are read from the blob.  A DP row
-// is cut into tiles of kGenericTile end codons; within a tile the loop runs sequence by sequence -- the three states of the
-// current sequence in registers (parked in the scratch between tiles), its 64-entry sigma table spread over the lanes and read
-// with ds_bpermute like in k_null -- and adds each sequence's max3 to the tile's sums, which stay in registers, in the reference's
-// order k = 0, 1, ...; the HSS scan then walks the tile.
-// Tried on top of this and dropped (tools/time_wide.py, 1024 blocks of 100 x 300: 1.60 s): unguarded steps with the row's last
-// tile computed in full (35 % more steps at this length: 1.68 s), groups of eight steps skipped past the row end (2.1 s: the
-// branches cost more than the steps), the next sequence's loads issued during the current one's steps (1.7-2.2 s: 13 more live
-// registers, and the pass is issue-bound, not latency-bound), tiles of 16 or 24 end codons, 3 or 5 wavefronts per SIMD.
-// Round 4, measured and taken back: the thirteen operands of a sequence's pass (sigma table entry, eight code words,
-// frame-shift word, three parked states) fetched one sequence AHEAD with the look-ups in two halves of sixteen -- 256 blocks of
-// 100 x 300 at n = 1000: 412 -> 628 ms at four wavefronts per SIMD (51 spilled registers), 565 at three, 580 at two.  The counters say
-// the pass is neither issue-bound (0.33 VALU instructions per ns and SIMD, C3: 0.71) nor short of bandwidth (3.2 TB/s); what it waits
-// for is the round trip of the parked states and code words at four wavefronts per SIMD, and the registers that would hide it are
-// the ones the tile's 32 sums occupy.  The form that would fix it keeps the states of <= 16 sequences resident over a whole row
-// and carries the per-cell k-sum between chunks of sequences (ascending k, as the reference adds): another kernel.
+// is cut into tiles of kGenericTile end codons; within a tile the loop runs sequence by sequence and adds each sequence's max3 to
+// the tile's sums, which stay in registers, in the reference's order k = 0, 1, ...; the HSS scan then walks the tile.
+// Round 4 -- 1024 blocks of 100 x 300 at n = 1000: 1.60 -> 1.03 s, 256 blocks: 412 -> 328 ms:
+//  * a sequence that has met no frame shift since the row's start has s1 == s2 == the row's running sum of omega, the same number
+//    in every lane: its pass keeps s0 only (add / max / add per cell instead of three adds and a max3) and parks s0 only;
+//  * rows go in pairs on one set of look-ups and code words (half the ds_bpermutes, half the code traffic);
+//  * the look-ups and cells of a group of eight are written out (the compiler waited for every look-up behind its issue), the
+//    codes are stored times four so that the code word itself is a ds_bpermute address (tools/mb_bpermute_addr.hip);
+//  * the sums are distinct scalars updated in ONE place per group (an array, or an update per kind of pass, and the register
+//    allocator keeps two sets of sums and copies all of them at both ends of every pass);
+//  * scalar work of the common pass cut to one decision word; the parked s0 stored behind the next pass's loads.
+// What the counters say about the rest (tools/pmc_wide.sh, tools/mb_footprint.hip; timing-only builds without the code words /
+// the parked states / the simulation / the DP): the simulation is a quarter of the kernel and waits for the scalar unit, which the
+// CU's four SIMDs share (5.5e10 SALU + 1.4e10 SMEM instructions per 1024 blocks at 1.3 per ns and CU); the DP without its memory
+// operations runs at 0.50 s of the 1.03, the access pattern alone reaches 6.3 TB/s over a 20 GB footprint, yet more wavefronts
+// per SIMD (5, 6), the next pass's operands fetched ahead into LDS (global_load_lds_dword, 12 dwords per lane: bit-exact, 1.14 ->
+// 1.20 s) and the simulation's table look-ups issued eight sequences ahead (1.08 -> 1.17 s) all measured slower or equal.
+// Tried earlier and dropped (1024 blocks: 1.60 s then): unguarded steps with the row's last tile computed in full, tiles of 16 or
+// 24 end codons, 3 or 5 wavefronts per SIMD, operands fetched one sequence ahead in registers (51 spilled registers).
 // It is the slow, complete path for rare inputs; the division is the plain '/'.
 #pragma once
 #include "rc_null_kernel.h"
@@ -204,11 +208,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GENERIC_W
     // ---- simulate the L reference-residue columns (evolve.c:416-433) and emit sigma codes for both strands
     unsigned int clamped = 0;
     for (int r = 0; r < N; r++) win[r * kWave] = 0;
-#if defined(RC_GENERIC_EXPERIMENT) && (RC_GENERIC_EXPERIMENT & 8)
-    for (int i = 1; i <= 0; i++) {
-#else
     for (int i = 1; i <= L; i++) {
-#endif
       const size_t ubase = static_cast<size_t>(refcol[i]) * A.Spad + sidx;
       const size_t qstride = static_cast<size_t>(cols) * A.Spad;
       uint32_t cur = 0;   // the word of node states being filled (nodes come parents first)
@@ -276,11 +276,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GENERIC_W
     const uint32_t zeroCodes = (static_cast<uint32_t>(db->code_zero) << 2) * 0x01010101u;   // four copies of the code whose sigma is 0
     float *__restrict__ rowbuf = reinterpret_cast<float *>(mine + lay.offRow) + lane;
     float *__restrict__ dpB = dp + static_cast<size_t>(3 * NK + 1) * kWave;
-#if defined(RC_GENERIC_EXPERIMENT) && (RC_GENERIC_EXPERIMENT & 4)
-    for (int s = 0; s < 0; s++)
-#else
     for (int s = 0; s < 2; s++)
-#endif
       for (int f = 0; f < 3; f++) {
         const int sites = (L - f) / 3;
         if (sites <= 0) continue;
@@ -330,10 +326,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GENERIC_W
               // (fetched behind the code words: it is needed first, and a wait for it in front of their issue would be two round trips)
               const uint32_t zhalf = reinterpret_cast<const uint32_t *>(zw)[((static_cast<size_t>(s * L1 + 3 + f) + static_cast<size_t>(3 * jl)) * ZW + (k >> 5)) * 2 + ((k >> 4) & 1)];
               const uint32_t zcl = (zhalf >> (2 * (k & 15))) & 3u;
-#if defined(RC_GENERIC_EXPERIMENT) && (RC_GENERIC_EXPERIMENT & 1)
-#pragma unroll
-              for (int w = 0; w < kGenericTile / 4; w++) cw[w] = (static_cast<uint32_t>(lane * 0x01010101u + k + w) & 0x3f3f3f3fu) << 2;   // timing only: no code traffic
-#endif
               const uint32_t zz0 = static_cast<uint32_t>(__ballot(zcl & 1u)), zz1 = static_cast<uint32_t>(__ballot(zcl & 2u));
               const uint32_t swA = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(stickyA), k >> 5));
               const uint32_t swB = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(stickyB), k >> 5));
