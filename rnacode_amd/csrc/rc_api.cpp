@@ -979,7 +979,9 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
       const rc_ctx::PlainPlan pp = plain_plan(c, p.NK, maxNodes, wantHi);
       if (pp.occ > 0) {
         occ = pp.occ; p.hiOcc = pp.hiOcc; p.plainLds = pp.lds;
-        p.cacheSites = c->suffixCache ? static_cast<int>(pp.lds / (static_cast<size_t>(code_pos_words(p.NK)) * sizeof(uint32_t))) : 0;
+        // (the first NK x 256 bytes of that LDS hold the sigma tables during the DP: the look-ups of these launches read them there)
+        const size_t tables = static_cast<size_t>(p.NK) * kWave * sizeof(float);
+        p.cacheSites = c->suffixCache && pp.lds > tables ? static_cast<int>((pp.lds - tables) / (static_cast<size_t>(code_pos_words(p.NK)) * sizeof(uint32_t))) : 0;
       }
     }
     if (c->gridCapPerCU > 0) occ = std::min(occ, c->gridCapPerCU);

@@ -182,6 +182,8 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
   constexpr int N = NK + 1;
   constexpr int CPW = 5;                  // 6-bit sigma codes per 32-bit word
   constexpr int NCW = (NK + CPW - 1) / CPW;
+  constexpr bool kTableLookups = !LDSC && !EXACT && !DUAL;   // sigma look-ups from tables in LDS (the launches that read their codes from L2)
+  constexpr int kTableWords = kTableLookups ? NK * kWave : 0;
   // The last code word of a site holds CNT = NK - 5 (NCW - 1) codes; with one or two codes it is kept as a byte or a halfword in the
   // staging scratch (a field shifted down by 6t is a look-up address either way: one code is (code << 2) < 256): a site of twelve rows
   // takes 9 bytes per sample instead of 12, one of seven rows 5 instead of 8 -- that much less to write, to re-read from L2, and to hold
@@ -488,6 +490,10 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
           static_for<NK>([&](auto kc) {  // 64-entry sigma table of sequence k spread over the 64 lanes
             constexpr int k = decltype(kc)::value;
             R.template at<k>().lut = __float_as_int(lut[(s * NK + k) * kLutSize + lane]);
+            // codes from L2: the tables go to LDS, [k][64] from byte 0 on -- a look-up is a ds_read_b32 at code x 4 (+ k x 256 in the
+            // instruction's offset) instead of a ds_bpermute_b32: 0.58..0.91 look-ups per ns and CU against 0.34..0.38
+            // (tools/mb_lds_lookup.hip), and the look-ups are what bounds these launches (C5: 0.38 LDS instructions per ns and CU)
+            if constexpr (kTableLookups) lds_codes[k * kWave + lane] = static_cast<uint32_t>(R.template at<k>().lut);
           });
           curS = s;
         }
@@ -516,14 +522,14 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
         } else if constexpr (!EXACT) {
           jc = sites - (A.cacheSites < sites ? A.cacheSites : sites);
           for (int j = jc; j < sites; j++) {
-            uint32_t *dst = lds_codes + (j - jc) * PSW;
+            uint32_t *dst = lds_codes + kTableWords + (j - jc) * PSW;
 #pragma unroll
             for (int x = 0; x < NCW - 1; x++) dst[x * kWave + lane] = word_at(j, x);
             reinterpret_cast<TailT *>(dst + (NCW - 1) * kWave)[lane] = static_cast<TailT>(word_at(j, NCW - 1));
           }
           __builtin_amdgcn_s_waitcnt(0);
         }
-        const uint32_t ldsBase = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_codes));
+        const uint32_t ldsBase = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_codes + kTableWords));   // (the codes: behind the sigma tables, if those are in LDS)
         const uint32_t ldsLane = ldsBase + static_cast<uint32_t>(lane) * 4u;                                  // a lane's dwords
         const uint32_t ldsTail = ldsBase + (NCW - 1) * kWave * 4u + static_cast<uint32_t>(lane) * LB;         // its tail value (suffix cache)
         const uint32_t laneOff = static_cast<uint32_t>(lane) * 4u, laneTail = static_cast<uint32_t>(lane) * LB;
@@ -614,9 +620,15 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
 #ifdef RC_EXP_ONE_LOOKUP
             if constexpr (k > 0) { asm volatile("" : : "v"(addr)); sig[k] = sig[0]; return; }
 #endif
-            const int lutv = R.template at<k>().lut;
             float got;
-            asm volatile("ds_bpermute_b32 %0, %1, %2" : "=v"(got) : "v"(addr), "v"(lutv));
+            if constexpr (kTableLookups) {
+              uint32_t at;
+              asm volatile("v_and_b32 %0, 0xfc, %1" : "=v"(at) : "v"(addr));
+              asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(got) : "v"(at), "n"(k * kWave * 4));
+            } else {
+              const int lutv = R.template at<k>().lut;
+              asm volatile("ds_bpermute_b32 %0, %1, %2" : "=v"(got) : "v"(addr), "v"(lutv));
+            }
             sig[k] = got;
           });
           // one wait for the look-ups; operands of the last code word pin its position.  leave: LDS reads that were issued behind
