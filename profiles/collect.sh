@@ -13,12 +13,12 @@ ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-stream --no-extra $*"
 # one kernel at a time while profiling: by default the native-block kernels run on a second stream beside k_null and
 # their trace intervals then span its whole duration
 export RC_SERIAL_NATIVE=1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$REPO/bench.py" $ARGS > "$OUT/bench_under_trace.json" 2> "$OUT/stats.log"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$REPO/bench.py" $ARGS > /dev/null 2> "$OUT/pmc_fetch.log"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$REPO/bench.py" $ARGS > /dev/null 2> "$OUT/pmc_write.log"
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU \
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$REPO/bench.py" $ARGS > "$OUT/bench_under_trace.json" 2> "$OUT/stats.log"
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$REPO/bench.py" $ARGS > /dev/null 2> "$OUT/pmc_fetch.log"
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$REPO/bench.py" $ARGS > /dev/null 2> "$OUT/pmc_write.log"
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU \
   --output-format csv -d "$OUT/pmc_sq" -- python3 "$REPO/bench.py" $ARGS > /dev/null 2> "$OUT/pmc_sq.log"
-rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM \
+timeout 600 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM \
   --output-format csv -d "$OUT/pmc_sq2" -- python3 "$REPO/bench.py" $ARGS > /dev/null 2> "$OUT/pmc_sq2.log"
 find "$OUT" -name "*.csv" | head -40
 # keep the merged output small: the per-dispatch PMC csvs are summarised by profiles/summarize.py
