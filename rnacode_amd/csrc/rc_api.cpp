@@ -276,6 +276,7 @@ struct rc_ctx {
   int gridCapPerCU = 0;       // RC_GRID_CAP_PER_CU: at most this many k_null workgroups per CU (experiments on cache residency of the code scratch); 0 = what fits
   double splitFactor = 0.5;   // a k_null launch with fewer (block, sample group) items than this fraction of the chip's wavefront slots splits every item into its six strand x frame parts (RC_SPLIT_FACTOR)
   int dualRows = 1;           // RC_DUAL_ROWS=0: never the two-row instantiations of k_null (A/B)
+  int dualFromL2 = 1;         // RC_DUAL_FROM_L2: the two-row k_null reads its codes from L2 behind a suffix cache where staging them would leave <= 12 workgroups per CU (1, default), never (0), wherever the two-row kernel runs (2)
   long long fatStreamMinItems = 16384;   // RC_FAT_STREAM_MIN_ITEMS: a stream's sub-batch of fat classes takes the two-row path from this many (block, 64-sample group) items on: four rounds of the chip's wavefront slots (1024 blocks at n = 1000)
   int nativeFirst = -1;       // RC_NATIVE_FIRST: 1 always queue a batch's native-block kernels in front of its k_null, 0 never (and no two-row k_null for fat classes); -1: for batches that take the fat path (see fat_class)
   int copyResults = 0;        // RC_COPY_RESULTS=1: the small results go back with hipMemcpyAsync instead of k_results_out (A/B)
@@ -533,6 +534,7 @@ int rc_ctx_create(int device, rc_ctx **out) {
   // (rc_api.cpp, fat_class) never touches the native-block stream, a single batch never the second compute stream.
   c->prioLow = prioLow; c->prioHigh = prioHigh;
   trace("ctx: streams", nullptr);
+  if (const char *e = std::getenv("RC_DUAL_FROM_L2")) c->dualFromL2 = std::atoi(e);
   c->serialNative = std::getenv("RC_SERIAL_NATIVE") ? 1 : 0;   // profiling: one kernel at a time, clean per-kernel intervals
   c->stopTwoRoundsMinItems = 4LL * c->numCU * 16;   // the chip filled four times over
   if (const char *e = std::getenv("RC_STOP_MIN_ITEMS")) c->stopTwoRoundsMinItems = std::atoll(e);
@@ -828,7 +830,7 @@ static size_t native_grid(const rc_ctx *c, size_t items, int smax, int mode = 0)
 static bool fat_class(const rc_batch *b, const rc_ctx *c, int NK, int maxL) {
   if (NK < 3 || NK > kDualRowsMaxNK || b->allExact) return false;
   const size_t lds = static_cast<size_t>(maxL / 3) * ((NK + 4) / 5) * kWave * sizeof(uint32_t);
-  return lds <= c->ldsMaxBytes;
+  return lds <= c->ldsMaxBytes;   // (longer blocks: the two-row kernel from L2 gains 3-4 % on the launch and loses it again to the native-block kernels queued in front)
 }
 
 static int launch_native_block(const RunEnv &R) {
@@ -900,12 +902,12 @@ static size_t steal_words(const rc_ctx *c) { return 16 + 4 * steal_slots(c); }  
 // for batches of one row-count class: round 3 measured +1..7 % there and -5 % on a stream of ten classes, whose small kernels ran in the
 // registers those wavefronts take --, how many workgroups per CU, and how much LDS each gets: what phase A needs at least, and with the
 // suffix cache everything the occupancy leaves (160 KB / workgroups per CU), which phase B fills with the most re-read code words.
-static rc_ctx::PlainPlan plain_plan(rc_ctx *c, int NK, int maxNodes, bool wantHi) {
-  const auto key = std::make_tuple(NK, maxNodes, wantHi ? 1 : 0);
+static rc_ctx::PlainPlan plain_plan(rc_ctx *c, int NK, int maxNodes, int wantHi) {   // wantHi: 1 the k_null_occ build, 2 the two-row kernel
+  const auto key = std::make_tuple(NK, maxNodes, wantHi);
   auto it = c->plainPlans.find(key);
   if (it != c->plainPlans.end()) return it->second;
   rc_ctx::PlainPlan pp{0, 0, 0};
-  for (int hi = wantHi ? 1 : 0; hi >= 0 && pp.occ <= 0; hi--) {
+  for (int hi = wantHi; hi >= 0 && pp.occ <= 0; hi = hi == 2 ? 0 : hi - 1) {
     const size_t minLds = hi ? al256(static_cast<size_t>(maxNodes) * 64 + 64 * 64) : static_cast<size_t>(kPhaseALds);
     const int occ = null_occupancy_plain(NK, minLds, hi);
     if (occ <= 0) continue;
@@ -966,7 +968,14 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
     // per-workgroup scratch in global memory.
     p.ldsBytes = static_cast<size_t>(maxLc / 3) * NCW * kWave * sizeof(uint32_t);
     const bool exactOnly = b->allExact || p.NK >= kFastRows;   // wide blocks (N > 32) only have the EXACT instantiation
-    if (p.ldsBytes > c->ldsMaxBytes || exactOnly) p.ldsBytes = 0;
+    // The two-row kernel with its codes staged in LDS runs 160 KB / staged bytes workgroups per CU, and its time goes almost with
+    // the inverse of that number (6 / 8 / 10 / 12 / 16 per CU: 93.5 / 71.6 / 59.6 / 51.6 / 42.5 ms at the headline's shape).  Where
+    // staging leaves twelve or fewer (blocks of more than ~135 columns), the same kernel reading its codes from L2 behind a suffix
+    // cache runs sixteen and is faster: 6 rows x 150 columns 77.3 -> 71.7 ms; at 120 columns (fifteen staged) it is slower, 42.6 -> 47.0.
+    bool dualL2 = false;
+    if (c->dualFromL2 && c->dualRows && !exactOnly && p.NK >= 3 && p.NK <= kDualRowsMaxNK && R.fat && p.ldsBytes <= c->ldsMaxBytes)
+      dualL2 = c->dualFromL2 == 2 || c->ldsPerCU / std::max<size_t>(p.ldsBytes, kPhaseALds) <= 12;
+    if (p.ldsBytes > c->ldsMaxBytes || exactOnly || dualL2) p.ldsBytes = 0;
     else p.ldsBytes = std::max<size_t>(p.ldsBytes, kPhaseALds);   // phase A keeps the tree's threshold table and the pair table there
     const std::pair<int, size_t> key(p.NK, p.ldsBytes);
     if (!c->occ.count(key)) c->occ[key] = null_occupancy(p.NK, p.ldsBytes);
@@ -975,7 +984,7 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
     if (!p.ldsBytes && !exactOnly) {   // codes from L2
       int maxNodes = 0;
       for (int bi : kv.second) maxNodes = std::max(maxNodes, b->db[bi].nnodes);
-      const bool wantHi = c->highOccupancy == 2 || (c->highOccupancy == 1 && b->classes.size() == 1);
+      const int wantHi = dualL2 ? 2 : (c->highOccupancy == 2 || (c->highOccupancy == 1 && b->classes.size() == 1)) ? 1 : 0;
       const rc_ctx::PlainPlan pp = plain_plan(c, p.NK, maxNodes, wantHi);
       if (pp.occ > 0) {
         occ = pp.occ; p.hiOcc = pp.hiOcc; p.plainLds = pp.lds;
@@ -1044,7 +1053,8 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
         else {
           const bool ex = b->allExact || p.NK >= kFastRows;
           const bool dual = !ex && c->dualRows && p.ldsBytes && p.ldsBytes <= 48 * 1024 && p.NK <= kDualRowsMaxNK && (p.NK == 2 || R.fat);
-          if (!ex && !p.ldsBytes && p.hiOcc) b->nullKernel = "rc::k_null_occ<" + std::to_string(p.NK) + ">";
+          if (!ex && !p.ldsBytes && p.hiOcc == 2) b->nullKernel = "rc::k_null<" + std::to_string(p.NK) + ", false, false, true>";
+          else if (!ex && !p.ldsBytes && p.hiOcc) b->nullKernel = "rc::k_null_occ<" + std::to_string(p.NK) + ">";
           else b->nullKernel = "rc::k_null<" + std::to_string(p.NK) + (!ex && p.ldsBytes ? ", true" : ", false") + (ex ? ", true" : ", false") + (dual ? ", true>" : ", false>");
         }
       }

@@ -182,7 +182,7 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
   constexpr int N = NK + 1;
   constexpr int CPW = 5;                  // 6-bit sigma codes per 32-bit word
   constexpr int NCW = (NK + CPW - 1) / CPW;
-  constexpr bool kTableLookups = !LDSC && !EXACT && !DUAL;   // sigma look-ups from tables in LDS (the launches that read their codes from L2)
+  constexpr bool kTableLookups = !LDSC && !EXACT;   // sigma look-ups from tables in LDS (the launches that read their codes from L2)
   constexpr int kTableWords = kTableLookups ? NK * kWave : 0;
   // The last code word of a site holds CNT = NK - 5 (NCW - 1) codes; with one or two codes it is kept as a byte or a halfword in the
   // staging scratch (a field shifted down by 6t is a look-up address either way: one code is (code << 2) < 256): a site of twelve rows
@@ -196,7 +196,7 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
   // DUAL: two rows of S per pass (see "rows a and a + 1 together" below): for instantiations whose codes are staged in LDS and whose
   // register budget has room for a second row's states and a 32-entry row buffer at four wavefronts per SIMD.  The host picks it per
   // launch (NullArgs::dual): up to 127 VGPRs instead of 74, i.e. no other kernel shares a SIMD with four such wavefronts.
-  static_assert(!DUAL || (LDSC && !EXACT && NK <= kDualRowsMaxNK), "two rows per pass: LDS-staged codes, fast division, few sequences");
+  static_assert(!DUAL || (!EXACT && NK <= kDualRowsMaxNK), "two rows per pass: fast division, few sequences");
   static_assert(!(LDSC && EXACT), "the EXACT instantiation uses no LDS");
   // phase A: threshold table of the tree (nnodes x 64 B); phase B with LDSC: [site][NCW][64] sigma codes
   // of the current strand x frame
@@ -1223,7 +1223,10 @@ template <int NK>
 inline int null_occupancy_plain_one(size_t dynLds, int hiOcc) {
   int nb = 0;
   hipError_t e;
-  if (hiOcc) {
+  if (hiOcc == 2) {   // the two-row kernel with its codes from L2
+    if constexpr (NK >= 3 && NK <= kDualRowsMaxNK) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_null<NK, false, false, true>, 64, dynLds);
+    else return 0;
+  } else if (hiOcc) {
     if constexpr (hi_occ_waves(NK) != 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_null_occ<NK>, 64, dynLds);
     else return 0;
   } else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_null<NK, false, false>, 64, dynLds);
@@ -1252,6 +1255,13 @@ inline void launch_null_one(const NullArgs &a, int grid, size_t ldsBytes, bool e
                        a.classBlocks, a.flags, a.U, a.pair, a.scratch, a.maxima);
   } else {
     const size_t dyn = a.plainLds ? static_cast<size_t>(a.plainLds) : phase_a_lds<NK>();
+    if constexpr (NK >= 3 && NK <= kDualRowsMaxNK) {
+      if (a.hiOcc == 2) {
+        hipLaunchKernelGGL((k_null<NK, false, false, true>), dim3(grid), dim3(64), dyn, stream, a, a.blob, a.dblocks,
+                           a.classBlocks, a.flags, a.U, a.pair, a.scratch, a.maxima);
+        return;
+      }
+    }
     if constexpr (hi_occ_waves(NK) != 0) {
       if (a.hiOcc) {
         hipLaunchKernelGGL((k_null_occ<NK>), dim3(grid), dim3(64), dyn, stream, a, a.blob, a.dblocks,
