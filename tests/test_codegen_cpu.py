@@ -105,12 +105,20 @@ def _audit_pending_registers(txt, name):
     audited = fetches = 0
     for h, labs in loops.items():
         ins = [x for lab in labs for x in blocks[lab]["ins"]]
-        if not any(x.startswith("ds_bpermute_b32") for x in ins):
+        # the sigma look-ups of a cell: ds_bpermute_b32, or (codes from L2) ds_read_b32 from the LDS tables at an address masked with 0xfc
+        table_addr = {m.group(1) for x in ins for m in [re.match(r"v_and_b32 (v\d+), 0xfc, v\d+", x)] if m}
+        if not any(x.startswith("ds_bpermute_b32") for x in ins) and not table_addr:
             continue
         regs = set()
-        for x in ins:
+        for at, x in enumerate(ins):
             m = _FETCH.match(x)
             if m:
+                la = re.match(r"ds_read_b32 v\d+, (v\d+)", x)
+                if la and la.group(1) in table_addr:
+                    # the register's last writer decides: masked with 0xfc -> a look-up (its result is waited for inside the cell), not a fetch
+                    writer = next((y for y in reversed(ins[:at]) if re.match(r"\S+ %s\b" % la.group(1), y)), "")
+                    if writer.startswith("v_and_b32") and "0xfc" in writer:
+                        continue
                 regs.add(m.group(1) or m.group(2))
                 fetches += 1
         if not regs:
