@@ -276,6 +276,7 @@ struct rc_ctx {
   int gridCapPerCU = 0;       // RC_GRID_CAP_PER_CU: at most this many k_null workgroups per CU (experiments on cache residency of the code scratch); 0 = what fits
   double splitFactor = 0.5;   // a k_null launch with fewer (block, sample group) items than this fraction of the chip's wavefront slots splits every item into its six strand x frame parts (RC_SPLIT_FACTOR)
   int dualRows = 1;           // RC_DUAL_ROWS=0: never the two-row instantiations of k_null (A/B)
+  int nativeScanLanes = 1;    // RC_NATIVE_SCAN_LANES=0: getHSS of the native block inside k_native_dp, one wavefront per matrix (A/B)
   int dualFromL2 = 1;         // RC_DUAL_FROM_L2: the two-row k_null reads its codes from L2 behind a suffix cache where staging them would leave <= 12 workgroups per CU (1, default), never (0), wherever the two-row kernel runs (2)
   long long fatStreamMinItems = 16384;   // RC_FAT_STREAM_MIN_ITEMS: a stream's sub-batch of fat classes takes the two-row path from this many (block, 64-sample group) items on: four rounds of the chip's wavefront slots (1024 blocks at n = 1000)
   int nativeFirst = -1;       // RC_NATIVE_FIRST: 1 always queue a batch's native-block kernels in front of its k_null, 0 never (and no two-row k_null for fat classes); -1: for batches that take the fat path (see fat_class)
@@ -380,7 +381,7 @@ struct rc_batch {
   size_t oDblocks = 0, oOk = 0, oClass = 0, oPrefix = 0;   // tail arrays inside the host part
   int nModels = 0;
   // device
-  DevBuf dblob, dmaxima, dhss, dhssCount, dhssPacked, dhssOffsets, dfit, dflags, dexact, dcounters, dscratch, dnativeScratch, dnativeTile, dsteal;
+  DevBuf dblob, dmaxima, dhss, dhssCount, dhssPacked, dhssOffsets, dfit, dflags, dexact, dcounters, dscratch, dnativeScratch, dnativeTile, dnativeAll, dsteal;
   float *maxPtr = nullptr;
   bool maximaExternal = false;
   PinBuf hstage, hpacked;
@@ -409,7 +410,7 @@ struct rc_batch {
     ctx = c; device = c->device; retiredKeep = c->retired; poolKeep = c->poolEnabled ? c->bufPool : nullptr;
     Retired *r = retiredKeep.get();
     for (DevBuf *d : {&dblob, &dmaxima, &dhss, &dhssCount, &dhssPacked, &dhssOffsets, &dfit, &dflags, &dexact, &dcounters, &dscratch, &dnativeScratch,
-                      &dnativeTile, &dsteal}) { d->retired = r; d->pool = poolKeep.get(); }
+                      &dnativeTile, &dnativeAll, &dsteal}) { d->retired = r; d->pool = poolKeep.get(); }
     for (PinBuf *h : {&hblob, &hstage, &hpacked}) { h->retired = r; h->pool = poolKeep.get(); }
   }
 };
@@ -535,6 +536,7 @@ int rc_ctx_create(int device, rc_ctx **out) {
   c->prioLow = prioLow; c->prioHigh = prioHigh;
   trace("ctx: streams", nullptr);
   if (const char *e = std::getenv("RC_DUAL_FROM_L2")) c->dualFromL2 = std::atoi(e);
+  if (const char *e = std::getenv("RC_NATIVE_SCAN_LANES")) c->nativeScanLanes = std::atoi(e);
   c->serialNative = std::getenv("RC_SERIAL_NATIVE") ? 1 : 0;   // profiling: one kernel at a time, clean per-kernel intervals
   c->stopTwoRoundsMinItems = 4LL * c->numCU * 16;   // the chip filled four times over
   if (const char *e = std::getenv("RC_STOP_MIN_ITEMS")) c->stopTwoRoundsMinItems = std::atoll(e);
@@ -881,9 +883,17 @@ static int launch_native_block(const RunEnv &R) {
     nc.tileStride = static_cast<size_t>(kWave) * smaxClass;
     const int grid = static_cast<int>(native_grid(c, static_cast<size_t>(nc.nItems), smaxClass, R.nativeMode));
     nc.tile = b->dnativeTile.as<float>();
+    // every matrix of the class kept for a scan with one lane per matrix, where that fits in a sixteenth of the device memory
+    // (headline: 10 000 blocks x 6 x 40 x 40 floats = 384 MB); otherwise DP and scan fused, 64 rows at a time
+    const size_t allFloats = static_cast<size_t>(nc.nItems) * smaxClass * smaxClass;
+    if (c->nativeScanLanes && allFloats * sizeof(float) <= c->totalMem / 16 && nc.nItems >= 6 * 64) {
+      HIP_TRY(b->dnativeAll.ensure(std::max<size_t>(allFloats, 4) * sizeof(float)));
+      nc.sAll = b->dnativeAll.as<float>(); nc.sAllSites = smaxClass;
+    }
     if (!launch_native_dp(kv.first, nc, grid, st))
       return fail(RC_ERR_UNSUPPORTED, "no native DP kernel for this number of rows");
     b->nl[3]++;
+    if (nc.sAll) { launch_native_scan(nc, st); b->nl[3]++; }
   }
   HIP_TRY(hipMemsetAsync(b->dhssOffsets.as<int>() + R.slots, 0, sizeof(int), st));
   launch_hss_pack(b->dhss.as<DevHss>(), b->dhssCount.as<int>(), b->hssCap, R.slots, b->dhssPacked.as<DevHss>(), b->dhssOffsets.as<int>(),

@@ -353,6 +353,7 @@ __global__ __launch_bounds__(64) void k_native_dp(NativeArgs A) {
     const float *sigma = reinterpret_cast<const float *>(A.blob + db->off_sigma);
     const int sites = (L - f) / 3, smax = L / 3;
     float *full = A.fullS ? A.fullS + static_cast<size_t>(combo) * smax * smax : nullptr;
+    float *__restrict__ all = A.sAll ? A.sAll + static_cast<size_t>(item) * A.sAllSites * A.sAllSites : nullptr;
     DevHss *out = A.fullS ? nullptr : A.hss + (static_cast<size_t>(bi) * 6 + combo) * A.hssCap;
     int n = 0;
     ScanState st{0.0f, -1, -1};
@@ -361,31 +362,84 @@ __global__ __launch_bounds__(64) void k_native_dp(NativeArgs A) {
       float s0[NK], s1[NK], s2[NK];
 #pragma unroll
       for (int k = 0; k < NK; k++) s0[k] = s1[k] = s2[k] = 0.0f;
-      for (int j = a0; j < sites; j++) {
-        const int i = 3 * j + 3 + f;
-        constexpr int ZW = (NK + 31) / 32;
-        unsigned long long z[ZW];
+      // sigma and z of 64 end codons at a time, one codon per lane (vector loads, all in flight together), handed to the cell loop
+      // with v_readlane: wave-uniform scalar loads inside that loop were a round trip per end codon, and the kernel is nothing else
+      constexpr int ZP = (NK + 15) / 16;   // z of 16 sequences, 2 bits each, per register
+      for (int jc = a0; jc < sites; jc += kWave) {
+        const int jl = jc + lane < sites ? jc + lane : sites - 1, il = 3 * jl + 3 + f;
+        float sgl[NK];
+        uint32_t zl[ZP];
 #pragma unroll
-        for (int x = 0; x < ZW; x++) z[x] = zw[static_cast<size_t>(s * L1 + i) * ZW + x];
-        if (a <= j && a < sites) {
-          float sum = 0.0f;
+        for (int k = 0; k < NK; k++) sgl[k] = sigma[(s * NK + k) * L1 + il];
 #pragma unroll
-          for (int k = 0; k < NK; k++) {
-            const float sig = sigma[(s * NK + k) * L1 + i];
-            pair_step(static_cast<int>((z[k >> 5] >> (2 * (k & 31))) & 3ull), sig, Delta, Omega, omega, s0[k], s1[k], s2[k]);
-            sum = sum + fmaxf(fmaxf(s0[k], s1[k]), s2[k]);
+        for (int x = 0; x < ZP; x++) zl[x] = reinterpret_cast<const uint32_t *>(zw)[(static_cast<size_t>(s * L1 + il) * ((NK + 31) / 32)) * 2 + x];
+        const int jhi = jc + kWave < sites ? jc + kWave : sites;
+        for (int j = jc; j < jhi; j++) {
+          const int t = j - jc;
+          float sg[NK];
+          uint32_t z[ZP];
+#pragma unroll
+          for (int k = 0; k < NK; k++) sg[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sgl[k]), t));
+#pragma unroll
+          for (int x = 0; x < ZP; x++) z[x] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(zl[x]), t));
+          if (a <= j && a < sites) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int k = 0; k < NK; k++) {
+              pair_step(static_cast<int>((z[k >> 4] >> (2 * (k & 15))) & 3u), sg[k], Delta, Omega, omega, s0[k], s1[k], s2[k]);
+              sum = sum + fmaxf(fmaxf(s0[k], s1[k]), s2[k]);
+            }
+            const float v = fmaxf(sum, Delta) / nkf;
+            if (all) all[static_cast<size_t>(a) * A.sAllSites + j] = v;
+            else tile[static_cast<size_t>(lane) * sites + j] = v;
+            if (full) full[static_cast<size_t>(a) * sites + j] = v;
           }
-          const float v = fmaxf(sum, Delta) / nkf;
-          tile[static_cast<size_t>(lane) * sites + j] = v;
-          if (full) full[static_cast<size_t>(a) * sites + j] = v;
         }
       }
+      if (all) continue;   // getHSS: k_native_scan
       __syncthreads();   // the rows written by the other lanes (one wavefront: a fence, no waiting for anybody)
       native_scan_rows(tile, a0, (a0 + kWave < sites) ? a0 + kWave : sites, sites, s, f, A.tieThr, st, n, out, A.hssCap, lane);
       __syncthreads();   // all read before the next 64 rows (or the next item) overwrite the buffer
     }
-    if (out && lane == 0) A.hssCount[static_cast<size_t>(bi) * 6 + combo] = n;
+    if (out && lane == 0 && !all) A.hssCount[static_cast<size_t>(bi) * 6 + combo] = n;
   }
+}
+
+// getHSS (score.c:864-974) over the matrices k_native_dp left in A.sAll, one LANE per (block, strand x frame): the state machine is serial
+// per matrix -- a wavefront per matrix (native_scan_rows) walked the positive entries one by one with 63 lanes looking on, and was two
+// thirds of the native-block kernels' time at the headline shape (1.39 ms of which 0.94).  Here 64 matrices advance together; the
+// lanes' matrices differ in size, a lane past its own end idles.
+__global__ __launch_bounds__(64) void k_native_scan(NativeArgs A) {
+  const int item = blockIdx.x * kWave + threadIdx.x;
+  if (item >= A.nItems) return;
+  const int bi = A.blocks[item / 6];
+  const int combo = item % 6, s = combo / 3, f = combo % 3;
+  const DevBlock *__restrict__ db = A.dblocks + bi;
+  const int sites = (db->L - f) / 3;
+  const float *__restrict__ S = A.sAll + static_cast<size_t>(item) * A.sAllSites * A.sAllSites;
+  DevHss *out = A.hss + (static_cast<size_t>(bi) * 6 + combo) * A.hssCap;
+  int n = 0;
+  ScanState st{0.0f, -1, -1};
+  for (int a = 0; a < sites; a++) {
+    const float *__restrict__ row = S + static_cast<size_t>(a) * A.sAllSites;
+    for (int j0 = a; j0 < sites; j0 += 8) {   // eight entries fetched at a time: the loads do not depend on the state machine
+      float v8[8];
+#pragma unroll
+      for (int t = 0; t < 8; t++) v8[t] = row[j0 + t < sites ? j0 + t : sites - 1];
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+        const int j = j0 + t;
+        const float v = v8[t];
+        const bool last = (a == sites - 1) && (j == sites - 1);
+        if (j < sites && (v > 0.0f || last))
+          scan_step(st, v, a, j, last, A.tieThr, [&](const ScanState &e) {
+            if (n < A.hssCap) out[n] = DevHss{s, f, e.ss, e.se, e.cm};
+            n++;
+          });
+      }
+    }
+  }
+  A.hssCount[static_cast<size_t>(bi) * 6 + combo] = n;
 }
 
 // One row b of Sk for all k (lane = k-1): out[(k-1)*3 + x][t] for i = b+2+3t <= iMax.
@@ -688,6 +742,10 @@ bool launch_native_dp(int NK, const NativeArgs &a, int grid, hipStream_t stream)
 #undef X
     default: return false;
   }
+}
+
+void launch_native_scan(const NativeArgs &a, hipStream_t stream) {
+  hipLaunchKernelGGL(k_native_scan, dim3((a.nItems + kWave - 1) / kWave), dim3(64), 0, stream, a);
 }
 
 // The HSS records sit in a [block][strand x frame][cap] array of which a few per cent are used: pack the

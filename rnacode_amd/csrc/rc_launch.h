@@ -57,6 +57,8 @@ struct NativeArgs {
   size_t tileStride;          // floats: 64 * (largest L/3 of the launch)
   int nItems;                 // k_native_dp: (block, strand x frame) items of the launch = 6 * blocks
   float *fullS;               // debugging accessor only (one block per launch): the six whole matrices, no records written
+  float *sAll;                // != nullptr: k_native_dp writes every item's matrix, [item][sAllSites][sAllSites] (row a, end codon j), and leaves getHSS to
+  int sAllSites;              //   k_native_scan (one LANE per item: the scan is serial per matrix, and a wavefront per matrix spent two thirds of the kernel on it)
   DevHss *hss;                // [n_blocks][6][kHssCap]
   int *hssCount;              // [n_blocks][6]
   int hssCap;                 // records per (block, strand, frame)
@@ -134,6 +136,7 @@ int null_occupancy_plain(int NK, size_t dynLds, int hiOcc);   // the same for a 
 bool launch_null(int NK, const NullArgs &a, int grid, size_t ldsBytes, bool exact, hipStream_t stream);
 void launch_native_sigma(const NativeArgs &a, int nblocks, hipStream_t stream);
 bool launch_native_dp(int NK, const NativeArgs &a, int grid, hipStream_t stream);   // a.nItems items over `grid` persistent workgroups
+void launch_native_scan(const NativeArgs &a, hipStream_t stream);   // getHSS over a.sAll, one lane per item
 void launch_hss_pack(const DevHss *hss, const int *count, int cap, int slots, DevHss *packed, int *offsets, int *total,
                      hipStream_t stream);
 // k_results_out: up to five word arrays copied from device memory into (mapped) pinned host memory
