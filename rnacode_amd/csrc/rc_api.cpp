@@ -314,6 +314,9 @@ struct rc_ctx {
   int suffixCache = 1;          // RC_SUFFIX_CACHE=0: the launches that read their codes from L2 keep none of them in LDS (A/B)
   int highOccupancy = 1;        // RC_HIGH_OCCUPANCY: 1 k_null_occ (one more wavefront per SIMD) for batches of one row-count class, 0 never, 2 always (A/B)
   size_t ldsMaxBytes = 13312;   // per wavefront: >= 12 wavefronts per CU; measured crossover against reading the codes from L2 (cols 150: 52.0 vs 54.0 ms, cols 180: 41.5 vs 39.3 ms)
+  size_t ldsMaxBytesOneRow = 10752;   // the one-row kernels: staging only where it leaves >= 15 workgroups per CU (6 rows x 120 / 135 / 150 columns: staged 19.6 / 25.8 / 34.0 ms, from L2 with the LDS sigma tables 20.2 / 24.9 / 30.2)
+  bool stageManyRows = false;   // RC_LDS_MAX_BYTES set: classes of six or more other sequences may stage their codes as well (by default they never do: their look-ups
+                                // are ds_bpermute_b32 then, and from L2 with the LDS sigma tables they are 0..30 % faster at every block length measured)
   int debugSkip = 0;
   DevBuf d_cellStats;              // RC_PROFILING builds with RC_CELL_STATS=1: k_null's cell counters, printed when the context goes
   int serialNative = 0;
@@ -563,7 +566,7 @@ int rc_ctx_create(int device, rc_ctx **out) {
   }
   trace("ctx: tables", nullptr);
   c->tieThr = float_threshold_lt(0.0001);
-  if (const char *e = std::getenv("RC_LDS_MAX_BYTES")) c->ldsMaxBytes = static_cast<size_t>(std::atol(e));
+  if (const char *e = std::getenv("RC_LDS_MAX_BYTES")) { c->ldsMaxBytes = c->ldsMaxBytesOneRow = static_cast<size_t>(std::atol(e)); c->stageManyRows = true; }
   if (kProfiling) if (const char *e = std::getenv("RC_DEBUG_SKIP")) c->debugSkip = std::atoi(e);   // RC_PROFILING builds only: results are wrong
   if (kProfiling && std::getenv("RC_CELL_STATS")) {
     HIP_TRY(c->d_cellStats.ensure(6 * sizeof(unsigned long long)));
@@ -985,7 +988,8 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
     bool dualL2 = false;
     if (c->dualFromL2 && c->dualRows && !exactOnly && p.NK >= 3 && p.NK <= kDualRowsMaxNK && R.fat && p.ldsBytes <= c->ldsMaxBytes)
       dualL2 = c->dualFromL2 == 2 || c->ldsPerCU / std::max<size_t>(p.ldsBytes, kPhaseALds) <= 12;
-    if (p.ldsBytes > c->ldsMaxBytes || exactOnly || dualL2) p.ldsBytes = 0;
+    const bool twoRows = c->dualRows && p.NK <= kDualRowsMaxNK && (p.NK == 2 || R.fat);   // (the launch's own test, below)
+    if (p.ldsBytes > (twoRows ? c->ldsMaxBytes : std::min(c->ldsMaxBytes, c->ldsMaxBytesOneRow)) || exactOnly || dualL2 || (p.NK > kDualRowsMaxNK && !c->stageManyRows)) p.ldsBytes = 0;
     else p.ldsBytes = std::max<size_t>(p.ldsBytes, kPhaseALds);   // phase A keeps the tree's threshold table and the pair table there
     const std::pair<int, size_t> key(p.NK, p.ldsBytes);
     if (!c->occ.count(key)) c->occ[key] = null_occupancy(p.NK, p.ldsBytes);
