@@ -259,6 +259,42 @@ def test_stream_plan_sizes(ctx):
     whole.close()
 
 
+def test_native_scan_by_lanes_equals_the_fused_scan_and_the_oracle(monkeypatch):
+    """Batches of >= 64 blocks leave getHSS of the native block to k_native_scan (one lane per strand x frame matrix); smaller ones and
+    RC_NATIVE_SCAN_LANES=0 keep it inside k_native_dp (one wavefront per matrix).  Same HSS tables either way -- coding-like blocks with
+    many positive entries, random ones, different lengths in one class -- and equal to the oracle's on a sample of the blocks."""
+    from oracle import binding as ob
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_block, synth_blocks
+    rng = np.random.RandomState(77)
+    blocks = [b.upper() for b in synth_blocks(150, 5, 90, seed=31)]
+    blocks += [synth_block(rng, 5, int(rng.choice([30, 45, 60, 120, 150])), index=i, gaps=bool(i % 3), mean_branch=float(rng.choice([0.01, 0.05, 0.4]))).upper()
+               for i in range(150)]                                   # short branches: conserved, long positive stretches
+    blocks += [b.upper() for b in synth_blocks(80, 9, 60, seed=32)]    # a second class in the same batch
+    p = api.default_params(sampleN=64, seed_base=3)
+
+    def tables(env):
+        if env is None:
+            monkeypatch.delenv("RC_NATIVE_SCAN_LANES", raising=False)
+        else:
+            monkeypatch.setenv("RC_NATIVE_SCAN_LANES", env)
+        ctx = api.Context(0)
+        batch = api.Batch(ctx, blocks, p).run()
+        out = [[(h["strand"], h["frame"], h["start"], h["end"], np.float32(h["score"])) for h in sorted(batch.scoreAln(i), key=hss_key)] for i in range(len(blocks))]
+        batch.close(); ctx.close()
+        return out
+
+    lanes, fused = tables(None), tables("0")
+    assert lanes == fused
+    assert sum(len(t) for t in lanes) > 5 * len(blocks)
+    op = ob.default_params(64)
+    for i in list(range(0, len(blocks), 23)):
+        b = blocks[i]
+        res = ob.run_block([r.seq for r in b.rows], [r.name for r in b.rows], b.rows[0].start, b.rows[0].length, b.tree, b.kappa, op, 3)
+        want = sorted(res.hss, key=hss_key)
+        assert lanes[i] == [(h["strand"], h["frame"], h["start"], h["end"], np.float32(h["score"])) for h in want], i
+
+
 def test_stop_early_runs_fewer_samples_and_agrees_with_the_oracle(monkeypatch):
     """--stop-early (score.c:992,1036-1042): blocks whose first samples already beat the native score more often
     than the cutoff allows are decided (rc = -1) and get no further samples; all others are sampled in full.
