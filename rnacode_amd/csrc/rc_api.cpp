@@ -277,6 +277,7 @@ struct rc_ctx {
   double splitFactor = 0.5;   // a k_null launch with fewer (block, sample group) items than this fraction of the chip's wavefront slots splits every item into its six strand x frame parts (RC_SPLIT_FACTOR)
   int dualRows = 1;           // RC_DUAL_ROWS=0: never the two-row instantiations of k_null (A/B)
   int nativeScanLanes = 1;    // RC_NATIVE_SCAN_LANES=0: getHSS of the native block inside k_native_dp, one wavefront per matrix (A/B)
+  int genericSplit = 1;       // RC_GENERIC_SPLIT=0: blocks of more than 64 rows simulated and scored by one kernel (A/B)
   int dualFromL2 = 1;         // RC_DUAL_FROM_L2: the two-row k_null reads its codes from L2 behind a suffix cache where staging them would leave <= 12 workgroups per CU (1, default), never (0), wherever the two-row kernel runs (2)
   long long fatStreamMinItems = 16384;   // RC_FAT_STREAM_MIN_ITEMS: a stream's sub-batch of fat classes takes the two-row path from this many (block, 64-sample group) items on: four rounds of the chip's wavefront slots (1024 blocks at n = 1000)
   int nativeFirst = -1;       // RC_NATIVE_FIRST: 1 always queue a batch's native-block kernels in front of its k_null, 0 never (and no two-row k_null for fat classes); -1: for batches that take the fat path (see fat_class)
@@ -539,6 +540,7 @@ int rc_ctx_create(int device, rc_ctx **out) {
   c->prioLow = prioLow; c->prioHigh = prioHigh;
   trace("ctx: streams", nullptr);
   if (const char *e = std::getenv("RC_DUAL_FROM_L2")) c->dualFromL2 = std::atoi(e);
+  if (const char *e = std::getenv("RC_GENERIC_SPLIT")) c->genericSplit = std::atoi(e);
   if (const char *e = std::getenv("RC_NATIVE_SCAN_LANES")) c->nativeScanLanes = std::atoi(e);
   c->serialNative = std::getenv("RC_SERIAL_NATIVE") ? 1 : 0;   // profiling: one kernel at a time, clean per-kernel intervals
   c->stopTwoRoundsMinItems = 4LL * c->numCU * 16;   // the chip filled four times over
@@ -939,7 +941,8 @@ static rc_ctx::PlainPlan plain_plan(rc_ctx *c, int NK, int maxNodes, int wantHi)
 static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t extraSkip, size_t *sizeOnly = nullptr) {
   rc_batch *b = R.b; rc_ctx *c = R.c;
   const int groupsHere = gHi - gLo;
-  struct Plan { int NK, grid, gridExact, comboSplit; size_t stride, ldsBytes, need; double itemCost; int hiOcc, cacheSites; size_t plainLds; };
+  struct Plan { int NK, grid, gridExact, comboSplit; size_t stride, ldsBytes, need; double itemCost; int hiOcc, cacheSites; size_t plainLds;
+                int simGrid, roundBlocks; size_t codesBytes, stateBytes; };   // (the last four: the wide-block class in two launches)
   std::vector<Plan> plans;
   size_t needSum = 0, needMax = 0;
   // Several row-count classes: first planned as launches that run side by side (no strand x frame split: together they fill the chip);
@@ -970,6 +973,25 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
       // every wavefront keeps the sigma codes of its 64 samples (N x L x 2 bytes per sample): the scratch, not the registers, bounds the occupancy
       p.grid = static_cast<int>(std::max<size_t>(1, std::min<size_t>(p.grid, c->genericScratchWords / std::max<size_t>(p.stride, 1))));
       p.need = p.stride * p.grid;
+      if (c->genericSplit && p.comboSplit && static_cast<size_t>(kv.second.size()) * groupsHere * null_generic_codes_bytes(maxN, maxLc, maxNodes) <= c->genericScratchWords * sizeof(uint32_t)) {
+        // Few items (every item split into its six strand x frame parts to fill the chip): two launches -- k_generic_sim leaves the
+        // codes of every (block, sample group) item in the scratch, k_generic_dp's six parts of an item read them there, instead of
+        // each part simulating the item again (16 blocks of 100 x 300: 67.7 -> 53.1 ms).  Not for large batches: the simulation's
+        // LDS (node states, codon windows) allows no more wavefronts per CU than the DP's registers do, so nothing is gained, and the
+        // codes of all items at once (5 MB each) would have to go through the scratch in rounds (1024 blocks: 1.03 -> 1.33 s).
+        p.codesBytes = null_generic_codes_bytes(maxN, maxLc, maxNodes);
+        p.stateBytes = null_generic_state_bytes(maxN, maxLc, maxNodes);
+        const int occD = std::max(1, generic_dp_occupancy(p.ldsBytes)), occS = std::max(1, generic_sim_occupancy(p.ldsBytes));
+        long long itemsB = static_cast<long long>(kv.second.size()) * groupsHere;
+        const size_t budget = c->genericScratchWords * sizeof(uint32_t);
+        const size_t slots = std::max<size_t>(static_cast<size_t>(groupsHere), budget / p.codesBytes);
+        p.roundBlocks = static_cast<int>(std::max<size_t>(1, std::min<size_t>(kv.second.size(), slots / static_cast<size_t>(groupsHere))));
+        const long long roundItems = static_cast<long long>(p.roundBlocks) * groupsHere;
+        (void)itemsB;   // (comboSplit stays as planned above: it is what brought us here)
+        p.grid = static_cast<int>(std::min<long long>(roundItems * (p.comboSplit ? 6 : 1), static_cast<long long>(c->numCU) * occD));
+        p.simGrid = static_cast<int>(std::min<long long>(roundItems, static_cast<long long>(c->numCU) * occS));
+        p.need = (static_cast<size_t>(roundItems) * p.codesBytes + static_cast<size_t>(p.grid) * p.stateBytes + 3) / 4 + 64;
+      }
       needSum += p.need; needMax = std::max(needMax, p.need);
       plans.push_back(p);
       continue;
@@ -1077,6 +1099,28 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
       a.skipMask = extraSkip;
       a.scratchStride = p.stride * sizeof(uint32_t);   // bytes for this kernel
       a.workCounter = work + p.NK * 8;
+      if (p.codesBytes) {
+        uint8_t *base = reinterpret_cast<uint8_t *>(a.scratch);
+        const size_t codesAllBytes = (static_cast<size_t>(p.roundBlocks) * groupsHere * p.codesBytes + 255) & ~static_cast<size_t>(255);
+        a.codesAll = base; a.codesStride = p.codesBytes;
+        a.scratchStride = p.stateBytes;
+        unsigned int *simWork = work + kClassSlots * 8 + p.NK * 8;   // (the class's unused "exact" queue counters)
+        const int *list = a.classBlocks;
+        for (size_t at = 0; at < members.size(); at += static_cast<size_t>(p.roundBlocks)) {
+          if (at) {   // the queues of the round before are spent
+            HIP_TRY(hipMemsetAsync(a.workCounter, 0, 8 * sizeof(unsigned int), st));
+            HIP_TRY(hipMemsetAsync(simWork, 0, 8 * sizeof(unsigned int), st));
+          }
+          NullArgs r = a;
+          r.classBlocks = list + at;
+          r.nClassBlocks = static_cast<int>(std::min<size_t>(static_cast<size_t>(p.roundBlocks), members.size() - at));
+          NullArgs sim = r;
+          sim.workCounter = simWork;
+          launch_generic_sim(sim, p.simGrid, p.ldsBytes, st);
+          launch_generic_dp(r, p.grid, p.ldsBytes, base + codesAllBytes, st);
+          b->nl[2]++;
+        }
+      } else
       launch_null_generic(a, p.grid, p.ldsBytes, reinterpret_cast<uint8_t *>(a.scratch), st);
       b->nl[2]++;
     } else if (b->allExact || p.NK >= kFastRows) {

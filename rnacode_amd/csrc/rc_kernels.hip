@@ -801,6 +801,25 @@ int null_generic_occupancy(size_t ldsBytes) {
   return nb;
 }
 
+size_t null_generic_codes_bytes(int N, int L, int nnodes) { return generic_codes_bytes(N, L, nnodes); }
+size_t null_generic_state_bytes(int N, int L, int nnodes) { return generic_state_bytes(N, L, nnodes); }
+int generic_sim_occupancy(size_t ldsBytes) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_generic_sim, 64, ldsBytes) != hipSuccess) return 0;
+  return nb;
+}
+int generic_dp_occupancy(size_t ldsBytes) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_generic_dp, 64, ldsBytes) != hipSuccess) return 0;
+  return nb;
+}
+void launch_generic_sim(const NullArgs &a, int grid, size_t ldsBytes, hipStream_t stream) {
+  hipLaunchKernelGGL(k_generic_sim, dim3(grid), dim3(64), ldsBytes, stream, a, a.blob, a.dblocks, a.classBlocks, a.flags, a.U, a.pair, static_cast<uint8_t *>(nullptr), a.maxima);
+}
+void launch_generic_dp(const NullArgs &a, int grid, size_t ldsBytes, uint8_t *scratchBytes, hipStream_t stream) {
+  hipLaunchKernelGGL(k_generic_dp, dim3(grid), dim3(64), ldsBytes, stream, a, a.blob, a.dblocks, a.classBlocks, a.flags, a.U, a.pair, scratchBytes, a.maxima);
+}
+
 void launch_null_generic(const NullArgs &a, int grid, size_t ldsBytes, uint8_t *scratchBytes, hipStream_t stream) {
   hipLaunchKernelGGL(k_null_generic, dim3(grid), dim3(64), ldsBytes, stream, a, a.blob, a.dblocks, a.classBlocks, a.flags, a.U, a.pair, scratchBytes, a.maxima);
 }

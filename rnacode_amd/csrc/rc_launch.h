@@ -38,6 +38,8 @@ struct NullArgs {
   int comboSplit;             // 1: items are (block, group, strand x frame); maxima combined by atomic max
   unsigned int *workCounter;  // [8], zeroed before the launch: next unclaimed work item of each XCD queue
   unsigned int *steal;        // tail sharing (see k_null): 16 + 4 x grid words, zeroed before the launch; null = off
+  uint8_t *codesAll;          // k_generic_sim / k_generic_dp: the codes of every item of the launch pair, item u at u * codesStride
+  size_t codesStride;
   int cacheSites;             // codes from L2: the words of the last cacheSites sites of a strand x frame are kept in LDS (0: none)
   int plainLds;               // host only: dynamic LDS bytes of a launch that reads its codes from L2 (phase A's tables, then the suffix cache); 0: the default
   int hiOcc;                  // host only: 1 = launch k_null_occ (one more wavefront per SIMD), where this N-1 has one
@@ -154,6 +156,13 @@ size_t null_generic_scratch_bytes(int N, int L, int nnodes);
 size_t null_generic_lds_bytes(int N, int nnodes);   // packed node states + codon windows of the widest block of the launch
 int null_generic_occupancy(size_t ldsBytes);
 void launch_null_generic(const NullArgs &a, int grid, size_t ldsBytes, uint8_t *scratchBytes, hipStream_t stream);
+// the same in two launches (simulation with many light wavefronts, then the DP): bytes of an item's codes / of a DP workgroup's states
+size_t null_generic_codes_bytes(int N, int L, int nnodes);
+size_t null_generic_state_bytes(int N, int L, int nnodes);
+int generic_sim_occupancy(size_t ldsBytes);
+int generic_dp_occupancy(size_t ldsBytes);
+void launch_generic_sim(const NullArgs &a, int grid, size_t ldsBytes, hipStream_t stream);
+void launch_generic_dp(const NullArgs &a, int grid, size_t ldsBytes, uint8_t *scratchBytes, hipStream_t stream);
 void launch_native_dp_generic(const NativeArgs &a, int nblocks, float *scratch, size_t scratchStride, hipStream_t stream);
 void launch_stop_mark(const FitArgs &a, int nblocks, hipStream_t stream);
 void launch_evd_fit(const FitArgs &a, int nblocks, bool latency, hipStream_t stream);   // latency: no other batch is in flight

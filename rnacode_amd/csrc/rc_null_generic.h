@@ -47,6 +47,10 @@ struct GenericLayout {
   }
 };
 
+// two launches: bytes of an item's codes, and of a DP workgroup's states + row buffer
+__host__ __device__ inline size_t generic_codes_bytes(int N, int L, int nn) { return GenericLayout(N, L, nn).offState; }
+__host__ __device__ inline size_t generic_state_bytes(int N, int L, int nn) { const GenericLayout l(N, L, nn); return l.total - l.offState; }
+
 constexpr int kGenericTile = 32;
 #ifndef RC_GENERIC_WAVES
 #define RC_GENERIC_WAVES 4   // wavefronts per SIMD of k_null_generic
@@ -159,18 +163,23 @@ __host__ __device__ inline size_t generic_lds_bytes(int N, int nn) {
   return (static_cast<size_t>((nn + 15) >> 4) * sizeof(uint32_t) + static_cast<size_t>(N)) * kWave;
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GENERIC_WAVES, RC_GENERIC_WAVES))) void k_null_generic(NullArgs A, const uint8_t *__restrict__ blob, const DevBlock *__restrict__ dblocks,
-                                                     const int *__restrict__ classBlocks, const uint32_t *__restrict__ flags,
-                                                     const uint32_t *__restrict__ Ustream, const uint8_t *__restrict__ pairTab,
-                                                     uint8_t *__restrict__ scratch, float *__restrict__ maxima) {
-  extern __shared__ uint32_t ldsGeneric[];
+// MODE 0: simulation and DP of an item in one go, the sigma codes in the workgroup's own scratch (small batches).
+// MODE 1 / 2: two launches, for batches of so few items that each is split into its six strand x frame parts: k_generic_sim writes the
+// codes of item u = (block of the class) x groups + (group - gLo) to codesAll + u * codesStride, k_generic_dp's six parts of the item
+// read them there instead of simulating it six times.  (For large batches the two launches gain nothing: the simulation's LDS allows
+// no more wavefronts per CU than the DP's registers, and 5 MB of codes per item would have to go through the scratch in rounds.)
+template <int MODE>
+__device__ __forceinline__ void generic_body(const NullArgs &A, const uint8_t *__restrict__ blob, const DevBlock *__restrict__ dblocks,
+                                             const int *__restrict__ classBlocks, const uint32_t *__restrict__ flags,
+                                             const uint32_t *__restrict__ Ustream, const uint8_t *__restrict__ pairTab,
+                                             uint8_t *__restrict__ scratch, float *__restrict__ maxima, uint32_t *ldsGeneric) {
   const int lane = threadIdx.x;
   uint8_t *__restrict__ mine = scratch + static_cast<size_t>(blockIdx.x) * A.scratchStride;   // scratchStride in bytes here
   unsigned int xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   const int home = static_cast<int>(xcc & 7u);
   const int nBlocks = A.nClassBlocks;
-  const int parts = A.comboSplit ? 6 : 1;   // few items: one strand x frame part each (phase A recomputed, maxima meet in an atomic max), as in k_null
+  const int parts = (A.comboSplit && MODE != 1) ? 6 : 1;   // few items: one strand x frame part each (maxima meet in an atomic max), as in k_null
   for (int qi = 0; qi < 8;) {
     const int q = (home + qi) & 7;
     const int g0 = A.gLo + ((q - A.gLo) & 7);
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GENERIC_W
     if (A.skipMask && (flags[bi] & A.skipMask)) continue;
     const int sub = t % perBlock;
     const int grp = g0 + 8 * (sub / parts);
-    const int onlyCombo = A.comboSplit ? sub % parts : -1;
+    const int onlyCombo = (A.comboSplit && MODE != 1) ? sub % parts : -1;
     const DevBlock *__restrict__ db = dblocks + bi;
     const int N = db->N, NK = db->NK, cols = db->cols, L = db->L, nnodes = db->nnodes, L1 = L + 1;
     const int NCW = (NK + 4) / 5, ZW = db->zw_words;
@@ -199,13 +208,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GENERIC_W
     const uint32_t *__restrict__ maskw = reinterpret_cast<const uint32_t *>(blob + db->off_mask);
     const float *__restrict__ lut = reinterpret_cast<const float *>(blob + db->off_lut);
     const GenericLayout lay(N, L, nnodes);
-    uint8_t *__restrict__ codes = mine + lay.offCodes;
+    uint8_t *__restrict__ codes = MODE == 0 ? mine + lay.offCodes
+                                            : A.codesAll + (static_cast<size_t>(t / perBlock) * (A.gHi - A.gLo) + static_cast<size_t>(grp - A.gLo)) * A.codesStride;
     uint32_t *nodeSt = ldsGeneric + lane;                                                                     // word w: [w * 64]
     uint8_t *win = reinterpret_cast<uint8_t *>(ldsGeneric + static_cast<size_t>((nnodes + 15) >> 4) * kWave) + lane;   // row r: [r * 64]
-    float *__restrict__ dp = reinterpret_cast<float *>(mine + lay.offState) + kWave;   // (the row in front: see the parked s0 below)
+    const size_t stateAt = MODE == 0 ? lay.offState : 0;   // (two launches: the workgroup's scratch holds the states and the row buffer only)
+    float *__restrict__ dp = reinterpret_cast<float *>(mine + stateAt) + kWave;   // (the row in front: see the parked s0 below)
     const int sidx = grp * kWave + lane;
 
     // ---- simulate the L reference-residue columns (evolve.c:416-433) and emit sigma codes for both strands
+    if constexpr (MODE != 2) {
     unsigned int clamped = 0;
     for (int r = 0; r < N; r++) win[r * kWave] = 0;
     for (int i = 1; i <= L; i++) {
@@ -261,6 +273,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GENERIC_W
       }
     }
     if (clamped && sidx < A.sampleN && onlyCombo <= 0) atomicAdd(A.clampCount, static_cast<unsigned long long>(clamped));   // (the six parts of a split item redo the same simulation)
+    }
+    if constexpr (MODE == 1) continue;
 
     // ---- both strands x 3 frames: DP over (start a, end j) + serial HSS scan (score.c:496-535, 830-845, 888-962)
     // A sequence that has met no frame shift since the row's start has s1 == s2 == the row's running sum of omega, the same
@@ -274,7 +288,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GENERIC_W
     const float negTie = -A.tieThr;
     const float *__restrict__ chainW = reinterpret_cast<const float *>(blob + db->off_chain);
     const uint32_t zeroCodes = (static_cast<uint32_t>(db->code_zero) << 2) * 0x01010101u;   // four copies of the code whose sigma is 0
-    float *__restrict__ rowbuf = reinterpret_cast<float *>(mine + lay.offRow) + lane;
+    float *__restrict__ rowbuf = reinterpret_cast<float *>(mine + (lay.offRow - lay.offState) + stateAt) + lane;
     float *__restrict__ dpB = dp + static_cast<size_t>(3 * NK + 1) * kWave;
     for (int s = 0; s < 2; s++)
       for (int f = 0; f < 3; f++) {
@@ -453,6 +467,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GENERIC_W
       else *dst = best;
     }
   }
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GENERIC_WAVES, RC_GENERIC_WAVES))) void k_null_generic(NullArgs A, const uint8_t *__restrict__ blob, const DevBlock *__restrict__ dblocks,
+                                                     const int *__restrict__ classBlocks, const uint32_t *__restrict__ flags,
+                                                     const uint32_t *__restrict__ Ustream, const uint8_t *__restrict__ pairTab,
+                                                     uint8_t *__restrict__ scratch, float *__restrict__ maxima) {
+  extern __shared__ uint32_t ldsGeneric[];
+  generic_body<0>(A, blob, dblocks, classBlocks, flags, Ustream, pairTab, scratch, maxima, ldsGeneric);
+}
+__global__ __launch_bounds__(64) void k_generic_sim(NullArgs A, const uint8_t *__restrict__ blob, const DevBlock *__restrict__ dblocks,
+                                                    const int *__restrict__ classBlocks, const uint32_t *__restrict__ flags,
+                                                    const uint32_t *__restrict__ Ustream, const uint8_t *__restrict__ pairTab,
+                                                    uint8_t *__restrict__ scratch, float *__restrict__ maxima) {
+  extern __shared__ uint32_t ldsGeneric[];
+  generic_body<1>(A, blob, dblocks, classBlocks, flags, Ustream, pairTab, scratch, maxima, ldsGeneric);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GENERIC_WAVES, RC_GENERIC_WAVES))) void k_generic_dp(NullArgs A, const uint8_t *__restrict__ blob, const DevBlock *__restrict__ dblocks,
+                                                   const int *__restrict__ classBlocks, const uint32_t *__restrict__ flags,
+                                                   const uint32_t *__restrict__ Ustream, const uint8_t *__restrict__ pairTab,
+                                                   uint8_t *__restrict__ scratch, float *__restrict__ maxima) {
+  extern __shared__ uint32_t ldsGeneric[];
+  generic_body<2>(A, blob, dblocks, classBlocks, flags, Ustream, pairTab, scratch, maxima, ldsGeneric);
 }
 
 // native block, any number of rows: one wavefront per (block, strand x frame), lane = start codon, the states of the lane's row
