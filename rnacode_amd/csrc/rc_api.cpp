@@ -891,7 +891,7 @@ static int launch_native_block(const RunEnv &R) {
     // every matrix of the class kept for a scan with one lane per matrix, where that fits in a sixteenth of the device memory
     // (headline: 10 000 blocks x 6 x 40 x 40 floats = 384 MB); otherwise DP and scan fused, 64 rows at a time
     const size_t allFloats = static_cast<size_t>(nc.nItems) * smaxClass * smaxClass;
-    if (c->nativeScanLanes && allFloats * sizeof(float) <= c->totalMem / 16 && nc.nItems >= 6 * 64) {
+    if (c->nativeScanLanes && allFloats * sizeof(float) <= c->totalMem / 16 && nc.nItems >= 6 * 64 && (kv.first <= 16 || kv.first > 32)) {   // (17..32: see k_native_dp)
       HIP_TRY(b->dnativeAll.ensure(std::max<size_t>(allFloats, 4) * sizeof(float)));
       nc.sAll = b->dnativeAll.as<float>(); nc.sAllSites = smaxClass;
     }

@@ -353,7 +353,9 @@ __global__ __launch_bounds__(64) void k_native_dp(NativeArgs A) {
     const float *sigma = reinterpret_cast<const float *>(A.blob + db->off_sigma);
     const int sites = (L - f) / 3, smax = L / 3;
     float *full = A.fullS ? A.fullS + static_cast<size_t>(combo) * smax * smax : nullptr;
-    float *__restrict__ all = A.sAll ? A.sAll + static_cast<size_t>(item) * A.sAllSites * A.sAllSites : nullptr;
+    // (17..32 other sequences: this fully unrolled kernel spills already; it stays exactly as it was -- scalar loads, scan inside)
+    constexpr bool kOld = NK > 16 && NK <= 32;
+    float *__restrict__ all = (!kOld && A.sAll) ? A.sAll + static_cast<size_t>(item) * A.sAllSites * A.sAllSites : nullptr;
     DevHss *out = A.fullS ? nullptr : A.hss + (static_cast<size_t>(bi) * 6 + combo) * A.hssCap;
     int n = 0;
     ScanState st{0.0f, -1, -1};
@@ -362,6 +364,9 @@ __global__ __launch_bounds__(64) void k_native_dp(NativeArgs A) {
       float s0[NK], s1[NK], s2[NK];
 #pragma unroll
       for (int k = 0; k < NK; k++) s0[k] = s1[k] = s2[k] = 0.0f;
+      // (17..32 other sequences: the lane-fetched operands are 2 (N-1) registers more than this fully unrolled kernel has -- 21 rows x 90
+      // columns 2.5 -> 4.5 ms with them, spilled; those keep the scalar loads)
+      if constexpr (NK <= 16 || NK > 32) {
       // sigma and z of 64 end codons at a time, one codon per lane (vector loads, all in flight together), handed to the cell loop
       // with v_readlane: wave-uniform scalar loads inside that loop were a round trip per end codon, and the kernel is nothing else
       constexpr int ZP = (NK + 15) / 16;   // z of 16 sequences, 2 bits each, per register
@@ -396,12 +401,33 @@ __global__ __launch_bounds__(64) void k_native_dp(NativeArgs A) {
           }
         }
       }
-      if (all) continue;   // getHSS: k_native_scan
+      } else {
+      for (int j = a0; j < sites; j++) {
+        const int i = 3 * j + 3 + f;
+        constexpr int ZW = (NK + 31) / 32;
+        unsigned long long z[ZW];
+#pragma unroll
+        for (int x = 0; x < ZW; x++) z[x] = zw[static_cast<size_t>(s * L1 + i) * ZW + x];
+        if (a <= j && a < sites) {
+          float sum = 0.0f;
+#pragma unroll
+          for (int k = 0; k < NK; k++) {
+            const float sig = sigma[(s * NK + k) * L1 + i];
+            pair_step(static_cast<int>((z[k >> 5] >> (2 * (k & 31))) & 3ull), sig, Delta, Omega, omega, s0[k], s1[k], s2[k]);
+            sum = sum + fmaxf(fmaxf(s0[k], s1[k]), s2[k]);
+          }
+          const float v = fmaxf(sum, Delta) / nkf;
+          tile[static_cast<size_t>(lane) * sites + j] = v;
+          if (full) full[static_cast<size_t>(a) * sites + j] = v;
+        }
+      }
+      }
+      if constexpr (!kOld) { if (all) continue; }   // getHSS: k_native_scan
       __syncthreads();   // the rows written by the other lanes (one wavefront: a fence, no waiting for anybody)
       native_scan_rows(tile, a0, (a0 + kWave < sites) ? a0 + kWave : sites, sites, s, f, A.tieThr, st, n, out, A.hssCap, lane);
       __syncthreads();   // all read before the next 64 rows (or the next item) overwrite the buffer
     }
-    if (out && lane == 0 && !all) A.hssCount[static_cast<size_t>(bi) * 6 + combo] = n;
+    if (out && lane == 0 && (kOld || !all)) A.hssCount[static_cast<size_t>(bi) * 6 + combo] = n;
   }
 }
 
