@@ -59,7 +59,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 VALU_PEAK_GOPS = 78643.2       # 256 CU x 4 SIMD x 64 lanes / 2 cycles x 2.4 GHz (v_add/v_max wave64 = 2 cyc/SIMD)
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 CONFIGS = {
     # name: (blocks, cols, seqs, samples, description)
@@ -90,7 +90,7 @@ def measured_traffic(config, kernel):
     (MI355X_MICROARCH.md, HBM), so the read side is doubled.  `kernel` is the instantiation this run just timed
     (rc_batch_null_kernel): a profile of another kernel is refused.  (None, reason) if no usable profile is committed."""
     why = "no committed profile"
-    for rnd in (PROFILE_ROUND, "r03", "r02", "r01"):
+    for rnd in (PROFILE_ROUND, "r04", "r03", "r02", "r01"):
         for name in (f"k_null_{config}_pmc.json", "k_null_pmc.json" if config == "c3" else None):
             if not name:
                 continue
@@ -239,7 +239,7 @@ def file_leg(api, ctx, key, min_s=1.0):
     out = {"workload": desc, "blocks": len(blocks), "scored_blocks": len(scored), "samples": n, "units": units, "unit": "alignment-columns*samples/s"}
     for label, fn in (("batch", as_batch), ("per_block_shim_sequence", per_block)):
         fn()
-        dt, k = timed_region(fn, min_s)
+        dt, k = timed_region(fn, min_s, min_steps=200 if label == "batch" else 3)
         sp = spread()
         out[label] = {"ms_per_file": sp["median"], "ms_per_file_spread": sp, "files": k, "value": units / (sp["median"] * 1e-3)}
     out["value"] = out["batch"]["value"]
@@ -276,9 +276,14 @@ def timed_region(step, min_s, min_steps=3):
 
 
 def spread():
-    """min / median / max of the last timed region's steps, ms"""
+    """min / median / p99 / max of the last timed region's steps (ms), and how many took more than ten times the median: a stalled
+    step (round 4: 1.6 s among 5 ms ones, a hardware-queue oversubscription) must be visible, not averaged away"""
     x = sorted(LAST_STEP_MS)
-    return {"min": x[0], "median": x[len(x) // 2], "max": x[-1]} if x else None
+    if not x:
+        return None
+    med = x[len(x) // 2]
+    return {"min": x[0], "median": med, "p99": x[min(len(x) - 1, int(0.99 * len(x)))], "max": x[-1], "steps": len(x),
+            "steps_over_10x_median": sum(1 for v in x if v > 10.0 * med)}
 
 
 def resident_leg(api, ctx, blocks, params, min_s, warmup=2):
@@ -301,6 +306,7 @@ def resident_leg(api, ctx, blocks, params, min_s, warmup=2):
     batch.close()
     resident_leg.spread = spread()
     resident_leg.spread["mean"] = dt / n * 1e3
+    resident_leg.null_interval_ms = acc["null"] / acc["n"]   # the whole sampling interval of a step (several class launches side by side)
     # the MEDIAN step (a stalled step -- before the collector was switched off around the timed regions, single steps took 0.3-2 s
     # now and then -- would shift a three-second mean by tens of per cent; min / median / max / mean are reported)
     return resident_leg.spread["median"], acc["null"] / acc["n"] / acc["launches"], kernel, cs, n, m
@@ -450,6 +456,92 @@ def cpu_baseline_all_cores(blocks, sampleN, seed, per_core_blocks, cores):
         os.rmdir(d)
 
 
+def _sig(x, digits=4):
+    """floats to `digits` significant digits (the compact line), recursively"""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def compact_line(out):
+    """The one line bench.py prints: at most ~1900 characters.  Keys of the bench contract unchanged; `legs` holds the other
+    measurements as numbers only (DESIGN.md section 7 says what each is; the full record is in bench_full.json):
+      stream / cont: ms per pass from host blocks to fitted results, pass by pass / as one continuous stream
+      e2e, e2e100k, e2emix: the native driver as a fresh process, file in -> listing out (units/s; 10 000 blocks, 100 000, 10 000 mixed)
+      c1, c2: the shipped inputs as one batch [median ms, p99 ms, max ms, steps, steps over 10 x median]; c1pb, c2pb: block by block through the shim's call order
+      shard: one of eight ranks' 1250 blocks [resident ms, efficiency vs a perfect eighth, streamed ms, continuous ms, valu frac]
+      mixed: ten row-count classes [streamed ms, continuous ms, resident ms, resident units/s, valu frac]
+      c5: 1000 blocks x 300 x 12 at n = 10 000 [ms, valu frac, traffic TB per launch]
+      cpu16: the reference on every usable core [units/s, cores]"""
+    def g(d, *path, default=None):
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return default
+            d = d[k]
+        return d
+
+    def sp(leg, form):
+        x = g(out, leg, form, "ms_per_file_spread") or {}
+        return [x.get("median"), x.get("p99"), x.get("max"), x.get("steps"), x.get("steps_over_10x_median")]
+
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: out[k] for k in keep if k in out}
+    cfg = out.get("config", {})
+    line["config"] = {"workload": "synthetic MAF %s blocks x %s cols x %s seqs, n=%s (BASELINE configs[2]/[3])" % (
+        g(out, "config", "blocks_per_gpu"), cfg.get("cols"), cfg.get("seqs"), cfg.get("samples")), "exchange": cfg.get("exchange", "none")[:40]}
+    for k in ("rccl_env", "exchange_ab"):
+        if k in cfg:
+            line["config"][k] = cfg[k]
+    r = out.get("roofline") or {}
+    line["roofline"] = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms")}
+    line["roofline"]["hbm_frac"] = g(r, "hbm", "frac")
+    line["roofline"]["traffic_over_algorithmic"] = g(r, "hbm", "traffic_over_algorithmic")
+    c = out.get("cpu_baseline")
+    if c:
+        line["cpu_baseline"] = {"value": c.get("value"), "unit": "units/s", "cores": c.get("cores"), "kind": c.get("kind"),
+                                "sample": "first %s blocks of the workload, %.0f s" % (c.get("blocks"), c.get("seconds") or 0)}
+    legs = {}
+    if "stream" in out:
+        legs["stream"] = g(out, "stream", "ms_per_step"); legs["cont"] = g(out, "stream", "continuous", "ms_per_step")
+    for short, key in (("e2e", "end_to_end"), ("e2e100k", "end_to_end_100k"), ("e2emix", "end_to_end_mixed")):
+        if key in out:
+            legs[short] = g(out, key, "value") if "error" not in out[key] else "error"
+    for key in ("c1", "c2"):
+        if key in out:
+            legs[key] = sp(key, "batch"); legs[key + "pb"] = sp(key, "per_block_shim_sequence")[:3]
+    if "shard" in out:
+        legs["shard"] = [g(out, "shard", "ms_per_step"), g(out, "shard", "efficiency"), g(out, "shard", "stream", "ms_per_step"),
+                         g(out, "shard", "stream", "continuous", "ms_per_step"), g(out, "shard", "roofline", "valu", "frac")]
+    if "mixed" in out:
+        legs["mixed"] = [g(out, "mixed", "ms_per_step"), g(out, "mixed", "continuous", "ms_per_step"), g(out, "mixed", "resident", "ms_per_step"),
+                         g(out, "mixed", "resident", "value"), g(out, "mixed", "resident", "roofline", "valu", "frac")]
+    if "c5" in out:
+        t = g(out, "c5", "roofline", "traffic")
+        legs["c5"] = [g(out, "c5", "ms_per_step"), g(out, "c5", "roofline", "valu", "frac"), None if t is None else t / 1e12]
+    if "cpu_baseline_all_cores" in out:
+        legs["cpu16"] = [g(out, "cpu_baseline_all_cores", "value"), g(out, "cpu_baseline_all_cores", "cores")]
+    for k in ("weak_scaling", "native_driver_multi_gpu"):
+        if k in out:
+            v = out[k]
+            legs[k] = {kk: (g(v, kk, "value") if isinstance(v.get(kk), dict) else v.get(kk)) for kk in v if kk != "note"} if isinstance(v, dict) else v
+    if "n_ranks_seen" in out:
+        line["n_ranks_seen"] = out["n_ranks_seen"]
+        line["distinct_devices"] = g(out, "devices", "distinct_devices")
+    line["legs"] = legs
+    line = _sig(line)
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > 1950:   # never let the tail cut the head: drop the least important entries first
+        for k in ("cpu16", "c1pb", "c2pb", "cont", "native_driver_multi_gpu", "weak_scaling"):
+            line["legs"].pop(k, None)
+            if len(json.dumps(line, separators=(",", ":"))) <= 1950:
+                break
+    return line
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -458,6 +550,7 @@ def free_port():
 
 def parse_args():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--full-json", default=None, help="where the full record goes (default gpurun_out/bench_full.json); the printed line is the compact one")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=5)
@@ -516,6 +609,7 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or without torchrun)")
     dist = None
     torch = None
+    init_error = None
     coll_dev = f"cuda:{local_rank}"
     # test hook: RC_BENCH_FORCE_DIST=1 takes the multi-rank code path with a world of one, so that a box with a
     # single GPU still runs init_process_group("nccl"), the all-gather and the reductions through RCCL
@@ -541,13 +635,47 @@ def main():
             # ring is per-link bound at this size anyway.  An explicit setting in the environment wins.
             os.environ.setdefault("NCCL_MAX_NCHANNELS", "2")
             os.environ.setdefault("NCCL_MIN_NCHANNELS", "1")
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            except Exception as e:   # noqa: BLE001 -- the line must still be printed: every exchange through host memory over gloo instead
+                init_error = "init_process_group(nccl): %s: %s" % (type(e).__name__, str(e)[:300])
+                coll_dev = "cpu"
+                dist.init_process_group("gloo")
 
     import numpy as np
 
     from rnacode_amd import api
     from rnacode_amd import distributed as rd
     from rnacode_amd.synth import synth_blocks
+
+    # If anything on the RCCL path raises -- the warm-up comparison of the two exchange orders, a gather, a reduction -- the run goes on
+    # with every collective through host memory over a gloo group made now (`fb`), says so in config.exchange_ab, and still prints its
+    # line: a first run on an 8-GPU node must not end without a number.  (A failure on ONE rank only can still hang the others inside
+    # the collective until RCCL's own timeout; what this covers is the symmetric kind: unsupported call, allocation, configuration.)
+    fb = {"on": False, "error": init_error, "group": None, "fail_test": os.environ.get("RC_BENCH_TEST_FAIL_EXCHANGE"), "calls": 0}
+    if multi and coll_dev != "cpu":
+        try:
+            fb["group"] = dist.new_group(backend="gloo")
+        except Exception:   # noqa: BLE001 -- no gloo in this build: no fallback either
+            fb["group"] = None
+
+    def cdev():
+        return "cpu" if fb["on"] else coll_dev
+
+    def cgroup():
+        return fb["group"] if fb["on"] else None
+
+    def fall_back(e, where):
+        if fb["on"] or fb["group"] is None:
+            raise e
+        fb["on"] = True
+        fb["error"] = "%s: %s: %s" % (where, type(e).__name__, str(e)[:300])
+
+    def inject(where):   # test hook
+        if fb["fail_test"] == where and not fb["on"]:
+            fb["calls"] += 1
+            if fb["calls"] >= 2:
+                raise RuntimeError("injected failure of the %s path (RC_BENCH_TEST_FAIL_EXCHANGE)" % where)
 
     t0 = time.perf_counter()
     if args.scaling == "weak":   # this rank's own shard: generator seed 1 + rank (generator seed 1)
@@ -603,6 +731,7 @@ def main():
     if extras:
         legs["end_to_end"] = end_to_end_leg(blocks, args.samples, args.seed_base)
         legs["end_to_end_100k"] = end_to_end_leg(blocks, args.samples, args.seed_base, runs=3, repeat=10)
+        legs["end_to_end_mixed"] = end_to_end_leg(mixed, args.samples, args.seed_base, runs=3)   # file in -> listing out on the ten-class workload
 
     ctx = api.Context(local_rank)
     cpus = api.lib().rc_host_cpus()
@@ -644,14 +773,21 @@ def main():
         """The path's one exchange (RCCL over xGMI): results of all blocks on every rank.  Synchronised before it
         returns: the next step overwrites the gathered buffer's source on the library's own streams."""
         nonlocal gathered
-        if args.exchange == "maxima":
-            src = mine if src is None else src
-            gathered = rd.all_gather_maxima(src if coll_dev != "cpu" else src.cpu(), counts)
-        else:
-            fits = torch.from_numpy(fit_rows).to(coll_dev, non_blocking=True)
-            gathered = rd.all_gather_fits(fits, counts)
-        if coll_dev != "cpu":
-            torch.cuda.current_stream().synchronize()
+        for attempt in (0, 1):
+            try:
+                if attempt == 0:
+                    inject("gather")
+                if args.exchange == "maxima":
+                    src = mine if src is None else src
+                    gathered = rd.all_gather_maxima(src if cdev() != "cpu" else src.cpu(), counts, group=cgroup())
+                else:
+                    fits = torch.from_numpy(fit_rows).to(cdev(), non_blocking=True)
+                    gathered = rd.all_gather_fits(fits, counts, group=cgroup())
+                if cdev() != "cpu":
+                    torch.cuda.current_stream().synchronize()
+                return
+            except Exception as e:   # noqa: BLE001
+                fall_back(e, "all-gather")
 
     def resident_step():
         nonlocal step_no
@@ -659,8 +795,14 @@ def main():
             src = overlap.source(step_no)    # (waits for the gather of two steps ago, long done)
             batch.bind_maxima(src.data_ptr())
             batch.run()                      # synchronous: this step's maxima are complete in the tensor
-            if mode["overlap"]:
-                overlap.launch(step_no)      # their all-gather runs while the next step is scored
+            if mode["overlap"] and not fb["on"]:
+                try:
+                    inject("overlap")
+                    overlap.launch(step_no)      # their all-gather runs while the next step is scored
+                except Exception as e:   # noqa: BLE001
+                    fall_back(e, "overlapped all-gather")
+                    mode["overlap"] = False
+                    exchange(None, src)
             else:
                 exchange(None, src)
             step_no += 1
@@ -686,8 +828,13 @@ def main():
             rows.append(sb.fits())       # (evd_rc, mu, lambda, better) per block: what a caller needs for p-values
             sb.close()                   # buffers back to the stream
         if overlap is not None:
-            if mode["overlap"]:
-                overlap.launch(step_no)
+            if mode["overlap"] and not fb["on"]:
+                try:
+                    overlap.launch(step_no)
+                except Exception as e:   # noqa: BLE001
+                    fall_back(e, "overlapped all-gather (stream)")
+                    mode["overlap"] = False
+                    exchange(None, src)
             else:
                 exchange(None, src)
             step_no += 1
@@ -698,27 +845,40 @@ def main():
     def sync():
         nonlocal gathered
         if multi:
-            if overlap is not None:          # every all-gather started so far is complete before the clock is read
-                g = overlap.finish()
-                if g is not None and mode["overlap"]:
-                    gathered = g
+            if overlap is not None and not fb["on"]:          # every all-gather started so far is complete before the clock is read
+                try:
+                    g = overlap.finish()
+                    if g is not None and mode["overlap"]:
+                        gathered = g
+                except Exception as e:   # noqa: BLE001
+                    fall_back(e, "waiting for the overlapped all-gathers")
+                    mode["overlap"] = False
             if coll_dev != "cpu":
                 torch.cuda.synchronize()
-            dist.barrier()
+            try:
+                dist.barrier(group=cgroup())
+            except Exception as e:   # noqa: BLE001
+                fall_back(e, "barrier")
+                dist.barrier(group=cgroup())
             if coll_dev != "cpu":
                 torch.cuda.synchronize()
 
     if multi:   # RCCL's first collective builds its rings: keep that out of the timed steps even with --warmup 0
-        probe = torch.zeros((1, 4), dtype=torch.float32, device=coll_dev)
-        rd.all_gather_rows(probe, [1] * world)
+        try:
+            probe = torch.zeros((1, 4), dtype=torch.float32, device=coll_dev)
+            rd.all_gather_rows(probe, [1] * world)
+        except Exception as e:   # noqa: BLE001
+            fall_back(e, "first collective")
         sync()
 
     # ---- which order of the exchange?  k steps of each between barriers, the slowest rank's time decides (every rank takes the same branch)
     exchange_ab = None
-    if overlap is not None and not args.overlap:
+    if overlap is not None and not args.overlap and not fb["on"]:
         k = args.ab_steps or max(3, args.warmup)
         t_ab = {}
         for name, flag in (("synchronous", False), ("overlapped", True), ("synchronous_again", False)):
+            if fb["on"]:
+                break
             mode["overlap"] = flag
             resident_step()              # one untimed step per order: its first gather may still build something
             sync()
@@ -726,11 +886,15 @@ def main():
             for _ in range(k):
                 resident_step()
             sync()
-            t_ab[name] = rd.max_over_ranks((time.perf_counter() - t0) / k * 1e3, device=coll_dev)
-        t_sync = min(t_ab["synchronous"], t_ab["synchronous_again"])   # the second run of it guards against a warm-up effect in the first
-        mode["overlap"] = bool(t_ab["overlapped"] < t_sync)
-        exchange_ab = {"ms_per_step_synchronous": t_sync, "ms_per_step_overlapped": t_ab["overlapped"], "steps_each": k,
-                       "all_timings_ms": t_ab, "chosen": "overlapped" if mode["overlap"] else "synchronous"}
+            t_ab[name] = rd.max_over_ranks((time.perf_counter() - t0) / k * 1e3, device=cdev(), group=cgroup())
+        if fb["on"]:
+            mode["overlap"] = False
+            exchange_ab = {"all_timings_ms": t_ab}
+        else:
+            t_sync = min(t_ab["synchronous"], t_ab["synchronous_again"])   # the second run of it guards against a warm-up effect in the first
+            mode["overlap"] = bool(t_ab["overlapped"] < t_sync)
+            exchange_ab = {"ms_per_step_synchronous": t_sync, "ms_per_step_overlapped": t_ab["overlapped"], "steps_each": k,
+                           "all_timings_ms": t_ab, "chosen": "overlapped" if mode["overlap"] else "synchronous"}
     elif overlap is not None:
         exchange_ab = {"chosen": "overlapped", "forced": "--overlap"}
     elif multi and args.exchange == "maxima":
@@ -772,7 +936,7 @@ def main():
         elapsed = time.perf_counter() - t0
         gc.enable()
         if multi:
-            elapsed = rd.max_over_ranks(elapsed, device=coll_dev)
+            elapsed = rd.max_over_ranks(elapsed, device=cdev(), group=cgroup())
         return elapsed, tk, nlaunch
 
     elapsed, tk, nlaunch = timed(resident_step, True)
@@ -818,11 +982,16 @@ def main():
 
         def weak_step():
             wbatch.run()
-            if args.exchange == "maxima":
-                rd.all_gather_maxima(wmine if coll_dev != "cpu" else wmine.cpu(), wcounts)
-            else:
-                rd.all_gather_fits(torch.from_numpy(wbatch.fits()).to(coll_dev), wcounts)
-            if coll_dev != "cpu":
+            for attempt in (0, 1):
+                try:
+                    if args.exchange == "maxima":
+                        rd.all_gather_maxima(wmine if cdev() != "cpu" else wmine.cpu(), wcounts, group=cgroup())
+                    else:
+                        rd.all_gather_fits(torch.from_numpy(wbatch.fits()).to(cdev()), wcounts, group=cgroup())
+                    break
+                except Exception as e:   # noqa: BLE001
+                    fall_back(e, "all-gather (weak scaling)")
+            if cdev() != "cpu":
                 torch.cuda.current_stream().synchronize()
 
         w_elapsed, _, _ = timed(weak_step, False)
@@ -864,8 +1033,8 @@ def main():
 
     sa, cs = batch.work()
     if multi:   # units of all ranks (shards may differ by one block under strong scaling)
-        tot = torch.tensor([float(cs), float(sa)], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tot)
+        tot = torch.tensor([float(cs), float(sa)], dtype=torch.float64, device=cdev())
+        dist.all_reduce(tot, group=cgroup())
         cs, sa = int(tot[0].item()), int(tot[1].item())
     total_units = cs * args.steps
     value = total_units / elapsed
@@ -888,6 +1057,7 @@ def main():
         legs["shard"] = {
             "blocks": hi - lo, "of": len(blocks), "ranks": 8, "host_threads": t8, "usable_cpus": cpus,
             "ms_per_step": sh_ms, "ms_per_step_spread": sh_res_spread, "steps": sh_steps, "kernel_ms": sh_null, "ideal_ms": main_ms / 8,
+            "roofline": roofline_object(blocks[lo:hi], args.samples, sh_null, sh_kernel, "shard", True),
             "efficiency": (main_ms / 8) / sh_ms, "value": sh_units / (sh_ms * 1e-3),
             "stream": {"ms_per_step": sh_stream_ms, "ms_per_step_spread": sh_stream_spread, "passes": sh_passes, "frac_of_resident": sh_ms / sh_stream_ms, "sub_batches": sh_sub,
                        "efficiency": (main_ms / 8) / sh_stream_ms,
@@ -904,6 +1074,8 @@ def main():
         # ---- mixed: ten row-count classes, ragged lengths, as a stream from host blocks
         mx_ms, mx_null, mx_kernel, mx_units, mx_steps, mx_m = resident_leg(api, ctx, mixed, params, args.extra_seconds, warmup=2)
         mx_res_spread = resident_leg.spread
+        mx_interval = resident_leg.null_interval_ms
+        mx_roof = roofline_object(mixed, args.samples, mx_interval, "%d class launches side by side (largest: %s)" % (len({b.n for b in mixed}), mx_kernel), "mixed", True)
         classes = len({b.n for b in mixed})
         mx_sub = api.stream_plan(ctx, params, len(mixed), classes)
         # (three warm-up passes: the stream's three batch objects each grow their multi-GB staging areas to the largest sub-batch once)
@@ -917,7 +1089,8 @@ def main():
                          "continuous": {"ms_per_step": mx_cont_ms, "passes": mx_cont_passes, "value": mx_units / (mx_cont_ms * 1e-3),
                                         "sub_batch_later_passes": max(mx_sub),
                                         "note": "the 10 000 blocks pass after pass as ONE stream: the pipeline fills once"},
-                         "resident": {"ms_per_step": mx_ms, "steps": mx_steps, "value": mx_units / (mx_ms * 1e-3), "ms_per_step_spread": mx_res_spread},
+                         "resident": {"ms_per_step": mx_ms, "steps": mx_steps, "value": mx_units / (mx_ms * 1e-3), "ms_per_step_spread": mx_res_spread,
+                                      "sampling_interval_ms": mx_interval, "roofline": mx_roof},
                          "generate_s": genm, "note": "value = the streamed rate (host rc_block arrays -> fitted results on the host), from the median pass"}
         del mx_m, mixed
 
@@ -1003,11 +1176,23 @@ def main():
             out["devices"] = devices_seen
         if multi and coll_dev != "cpu":
             out["config"]["rccl_env"] = {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS")}
+        if fb["error"] is not None:   # the RCCL path raised: what, and that the numbers above went through host memory
+            exchange_ab = dict(exchange_ab or {}, error=fb["error"], chosen="synchronous (host fallback)")
         if exchange_ab is not None:
             out["config"]["exchange_ab"] = exchange_ab
         for k, v in legs.items():
             out[k] = v
-        print(json.dumps(out))
+        # The driver keeps the last 2000 characters of this process's output: the ONE line printed is therefore a compact one -- the
+        # contract's keys, roofline, cpu_baseline and the numbers of every extra leg under short names (KEY below) -- and the full
+        # record with its prose goes to a file (gpurun_out/bench_full.json, or --full-json): what profiles/<round>/bench_default_run.json is.
+        full_path = args.full_json or os.path.join(ROOT, "gpurun_out", "bench_full.json")
+        try:
+            os.makedirs(os.path.dirname(full_path), exist_ok=True)
+            with open(full_path, "w") as fh:
+                json.dump(out, fh)
+        except OSError:
+            pass
+        print(json.dumps(compact_line(out), separators=(",", ":")))
     if stream is not None:
         stream.close()
     batch.close()

@@ -49,6 +49,25 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 
 namespace {
 
+// RC_TRACE=1: host-side time stamps of the pipeline stages on stderr
+bool trace_on() { static const bool on = std::getenv("RC_TRACE") != nullptr; return on; }
+// CLOCK_MONOTONIC in microseconds (what Python's time.monotonic() reads as well: a driver script can put its own stamps on the same axis)
+double trace_now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+void trace(const char *what, const void *obj) {
+  if (!trace_on()) return;
+  std::fprintf(stderr, "[rc %14.1f us] %-14s %p\n", trace_now_us(), what, obj);
+}
+// a runtime call that may block (allocation, release, synchronisation): under RC_TRACE=1 every one that takes longer than 0.5 ms
+// leaves a line with its duration and size -- how the step that took 300 times the median was found (tools/stall_hunt.py)
+template <typename F> auto timed_call(const char *what, size_t bytes, F f) -> decltype(f()) {
+  if (!trace_on()) return f();
+  const double t0 = trace_now_us();
+  auto r = f();
+  const double dt = trace_now_us() - t0;
+  if (dt > 500.0) std::fprintf(stderr, "[rc %14.1f us] slow call     %s: %.3f ms (%zu bytes)\n", trace_now_us(), what, dt * 1e-3, bytes);
+  return r;
+}
+
 // hipEvent created on first use, destroyed with its owner
 struct Event {
   hipEvent_t e = nullptr;
@@ -68,11 +87,12 @@ struct Retired {
   std::mutex m;
   std::vector<std::pair<void *, bool>> list;   // pointer, pinned host memory?
   size_t bytes = 0;
+  std::atomic<bool> ctxGone{false};            // set by rc_ctx_destroy: a batch that outlives its context must not touch it
   void add(void *p, bool host, size_t n) { std::lock_guard<std::mutex> lk(m); list.emplace_back(p, host); bytes += n; }
   void drain() {
     std::vector<std::pair<void *, bool>> take;
     { std::lock_guard<std::mutex> lk(m); take.swap(list); bytes = 0; }
-    for (auto &e : take) { if (e.second) (void)hipHostFree(e.first); else (void)hipFree(e.first); }
+    for (auto &e : take) { if (e.second) (void)timed_call("retired hipHostFree", 0, [&] { return hipHostFree(e.first); }); else (void)timed_call("retired hipFree", 0, [&] { return hipFree(e.first); }); }
   }
   bool empty() { std::lock_guard<std::mutex> lk(m); return list.empty(); }
   size_t held() { std::lock_guard<std::mutex> lk(m); return bytes; }
@@ -87,7 +107,7 @@ template <typename Alloc> hipError_t alloc_with_retry(Retired *ret, Alloc alloc)
   hipError_t r = alloc();
   if (r == hipSuccess || (ret->empty() && g_retired.empty())) return r;
   (void)hipGetLastError();
-  (void)hipDeviceSynchronize();
+  (void)timed_call("alloc retry hipDeviceSynchronize", 0, [&] { return hipDeviceSynchronize(); });
   ret->drain();
   g_retired.drain();
   return alloc();
@@ -130,8 +150,8 @@ struct BufPool {
   void drain(bool close) {
     std::vector<Slot> d, h;
     { std::lock_guard<std::mutex> lk(m); d.swap(dev); h.swap(host); devBytes = hostBytes = 0; closed = closed || close; }
-    for (auto &s : d) (void)hipFree(s.p);
-    for (auto &s : h) (void)hipHostFree(s.p);
+    for (auto &s : d) (void)timed_call("pool hipFree", s.cap, [&] { return hipFree(s.p); });
+    for (auto &s : h) (void)timed_call("pool hipHostFree", s.cap, [&] { return hipHostFree(s.p); });
   }
   ~BufPool() { drain(true); }
 };
@@ -142,14 +162,14 @@ struct DevBuf {
   Retired *retired = &g_retired;
   BufPool *pool = nullptr;
   ~DevBuf() { release(); }
-  void release() { if (p && !(pool && pool->give(false, p, cap))) (void)hipFree(p); p = nullptr; cap = 0; }
+  void release() { if (p && !(pool && pool->give(false, p, cap))) (void)timed_call("hipFree", cap, [&] { return hipFree(p); }); p = nullptr; cap = 0; }
   hipError_t ensure(size_t bytes) {
     if (bytes <= cap && p) return hipSuccess;
     if (p) retired->add(p, false, cap);
     p = nullptr; cap = 0;
     const size_t want = std::max<size_t>(bytes + bytes / 8, 256);
     if (pool && (p = pool->take(false, want, &cap))) return hipSuccess;
-    hipError_t r = alloc_with_retry(retired, [&] { return hipMalloc(&p, want); });
+    hipError_t r = alloc_with_retry(retired, [&] { return timed_call("hipMalloc", want, [&] { return hipMalloc(&p, want); }); });
     if (r != hipSuccess && pool) { pool->drain(false); r = hipMalloc(&p, want); }
     if (r == hipSuccess) cap = want; else p = nullptr;
     return r;
@@ -162,14 +182,14 @@ struct PinBuf {
   Retired *retired = &g_retired;
   BufPool *pool = nullptr;
   ~PinBuf() { release(); }
-  void release() { if (p && !(pool && pool->give(true, p, cap))) (void)hipHostFree(p); p = nullptr; cap = 0; }
+  void release() { if (p && !(pool && pool->give(true, p, cap))) (void)timed_call("hipHostFree", cap, [&] { return hipHostFree(p); }); p = nullptr; cap = 0; }
   hipError_t ensure(size_t bytes) {
     if (bytes <= cap && p) return hipSuccess;
     if (p) retired->add(p, true, cap);
     p = nullptr; cap = 0;
     const size_t want = std::max<size_t>(bytes + bytes / 8, 4096);
     if (pool && (p = pool->take(true, want, &cap))) return hipSuccess;
-    hipError_t r = alloc_with_retry(retired, [&] { return hipHostMalloc(&p, want, hipHostMallocDefault); });
+    hipError_t r = alloc_with_retry(retired, [&] { return timed_call("hipHostMalloc", want, [&] { return hipHostMalloc(&p, want, hipHostMallocDefault); }); });
     if (r != hipSuccess && pool) { pool->drain(false); r = hipHostMalloc(&p, want, hipHostMallocDefault); }
     if (r == hipSuccess) cap = want; else p = nullptr;
     return r;
@@ -254,15 +274,6 @@ class Pool {
 
 size_t al256(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
 
-// RC_TRACE=1: host-side time stamps of the pipeline stages on stderr
-bool trace_on() { static const bool on = std::getenv("RC_TRACE") != nullptr; return on; }
-// CLOCK_MONOTONIC in microseconds (what Python's time.monotonic() reads as well: a driver script can put its own stamps on the same axis)
-double trace_now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-void trace(const char *what, const void *obj) {
-  if (!trace_on()) return;
-  std::fprintf(stderr, "[rc %14.1f us] %-14s %p\n", trace_now_us(), what, obj);
-}
-
 }  // namespace
 
 struct rc_ctx {
@@ -270,7 +281,7 @@ struct rc_ctx {
   int numCU = 0;
   size_t totalMem = 0;             // device memory (bytes)
   size_t togetherWords = static_cast<size_t>(2) << 30;   // uint32 of staging scratch the side-by-side class launches of a batch may take (RC_TOGETHER_MAX_MB)
-  DevBuf treeJobs, treeIn, treeWork, treeOut, treeRes;   // rc_fit_trees_device
+  DevBuf treeJobs, treeIn, treeWork, treeRes;   // rc_fit_trees_device
   PinBuf treeInPin, treeResPin;
   std::mutex treeMutex;
   int gridCapPerCU = 0;       // RC_GRID_CAP_PER_CU: at most this many k_null workgroups per CU (experiments on cache residency of the code scratch); 0 = what fits
@@ -294,6 +305,7 @@ struct rc_ctx {
   hipStream_t aux = nullptr;       // synchronous helpers (second-stage result copies, backtrack rows, stand-alone fits): never behind queued batches
   hipStream_t tree = nullptr;      // rc_fit_trees_device: 25-40 ms kernels of a driver's tree-fit thread, kept off the helper stream
   int prioLow = 0, prioHigh = 0;   // stream priorities (compute streams low, the small latency-bound work high)
+  int classPrio = 0;               // priority of the class streams
   std::mutex streamMutex;          // ctx_stream
   std::vector<hipStream_t> classStreams;   // k_null launches of different row-count classes, when a batch has several
   unsigned seq = 0;
@@ -366,6 +378,10 @@ static TablePtrs table_ptrs(const rc_ctx *c, int blosum) {
 struct rc_stream;
 
 struct rc_batch {
+  // Declared FIRST, hence destroyed LAST: the DevBuf / PinBuf members below hand their memory to the pool (or park it in the list)
+  // from their destructors, and a batch may be destroyed after its context -- these references are then the last ones.
+  std::shared_ptr<Retired> retiredKeep;   // the context's list of outgrown buffers
+  std::shared_ptr<BufPool> poolKeep;      // ... and its pool of buffers of destroyed batches
   rc_ctx *ctx = nullptr;
   int device = 0;
   rc_params par{};
@@ -406,8 +422,6 @@ struct rc_batch {
   std::string nullKernel;   // the k_null instantiation that did most of the last run's sampling, as rocprofv3 prints it
   double nullKernelCost = 0.0;
   rc_stream *owner = nullptr;
-  std::shared_ptr<Retired> retiredKeep;   // the context's list of outgrown buffers (kept alive: a batch may be destroyed after its context)
-  std::shared_ptr<BufPool> poolKeep;      // ... and its pool of buffers of destroyed batches
   // bind the batch to its context: from now on its buffers, when outgrown, are parked in that context's list, and come from and go
   // back to its pool
   void adopt(rc_ctx *c) {
@@ -466,6 +480,7 @@ void rc_ctx_destroy(rc_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
+  c->retired->ctxGone.store(true);
   c->retired->drain();
   g_retired.drain();
   c->bufPool->drain(true);
@@ -509,7 +524,7 @@ int rc_ctx_create(int device, rc_ctx **out) {
   c->retiredCapBytes = prop.totalGlobalMem / 16;
   c->bufPool->devCap = prop.totalGlobalMem / 16;
   if (const char *e = std::getenv("RC_BUFFER_POOL")) c->poolEnabled = std::atoi(e) != 0;
-  for (DevBuf *d : {&c->treeJobs, &c->treeIn, &c->treeWork, &c->treeOut, &c->treeRes, &c->d_tables, &c->d_cellStats}) d->retired = c->retired.get();
+  for (DevBuf *d : {&c->treeJobs, &c->treeIn, &c->treeWork, &c->treeRes, &c->d_tables, &c->d_cellStats}) d->retired = c->retired.get();
   for (PinBuf *h : {&c->treeInPin, &c->treeResPin}) h->retired = c->retired.get();
   c->genericScratchWords = std::max<size_t>(static_cast<size_t>(1) << 30, prop.totalGlobalMem / 12 / sizeof(uint32_t));
   c->togetherWords = std::max<size_t>(static_cast<size_t>(1) << 30, prop.totalGlobalMem / 36 / sizeof(uint32_t));   // 8 GB of 288: allocating more costs a short run more than it gains (tools/cli_mixed_sweep.sh)
@@ -538,6 +553,12 @@ int rc_ctx_create(int device, rc_ctx **out) {
   // six of them were 60 ms of every context -- a fifth of the stand-alone driver's run on a 10 000-block input -- and a run of fat batches
   // (rc_api.cpp, fat_class) never touches the native-block stream, a single batch never the second compute stream.
   c->prioLow = prioLow; c->prioHigh = prioHigh;
+  c->classPrio = 0;
+  if (const char *e = std::getenv("RC_STREAM_PRIO")) {   // experiment: "flat" every stream at the default priority, "classlow" the class streams with the compute streams
+    if (!std::strcmp(e, "flat")) c->prioLow = c->prioHigh = c->classPrio = 0;
+    else if (!std::strcmp(e, "classlow")) c->classPrio = prioLow;
+    else if (!std::strcmp(e, "two")) { c->prioHigh = 0; c->classPrio = prioLow; }   // two levels: compute + class low, the rest default
+  }
   trace("ctx: streams", nullptr);
   if (const char *e = std::getenv("RC_DUAL_FROM_L2")) c->dualFromL2 = std::atoi(e);
   if (const char *e = std::getenv("RC_GENERIC_SPLIT")) c->genericSplit = std::atoi(e);
@@ -592,10 +613,13 @@ int rc_ctx_host_threads(const rc_ctx *c) { return c ? c->hostThreads : 0; }
 
 void rc_batch_destroy(rc_batch *b) {
   if (!b) return;
+  trace("destroy", b);
   (void)hipSetDevice(b->device);
-  if (b->state == rc_batch::RUNNING) { if (b->evDone.e) (void)hipEventSynchronize(b->evDone); if (b->ctx) b->ctx->inflight.fetch_sub(1); }
+  const bool ctxAlive = b->ctx && !(b->retiredKeep && b->retiredKeep->ctxGone.load());
+  if (b->state == rc_batch::RUNNING) { if (b->evDone.e) (void)hipEventSynchronize(b->evDone); if (ctxAlive) b->ctx->inflight.fetch_sub(1); }
   else if (b->state == rc_batch::READY && b->evPrep.e) (void)hipEventSynchronize(b->evPrep);   // the upload reads the pinned blob
   delete b;
+  trace("destroyed", b);
 }
 
 // ------------------------------------------------------------------------------------------ prepare + upload
@@ -761,8 +785,11 @@ int rc_batch_create(rc_ctx *ctx, const rc_block *blocks, int32_t n_blocks, const
   std::unique_ptr<rc_batch, void (*)(rc_batch *)> guard(new rc_batch(), rc_batch_destroy);   // released on success only
   rc_batch *b = guard.get();
   b->adopt(ctx);
+  trace("create", b);
   RC_TRY(batch_prepare(b, blocks, n_blocks, par));
+  trace("prepared", b);
   RC_TRY(batch_upload(b));
+  trace("uploaded", b);
   *out = guard.release();
   return RC_OK;
 }
@@ -1064,7 +1091,7 @@ static int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint
     if (concurrent) {
       while (c->classStreams.size() < std::min<size_t>(plans.size(), 8)) {
         hipStream_t ns = nullptr;
-        HIP_TRY(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, c->classPrio));
         c->classStreams.push_back(ns);
       }
       st = c->classStreams[pi % c->classStreams.size()];
@@ -1309,7 +1336,7 @@ static int batch_wait(rc_batch *b) {
   if (b->state != rc_batch::RUNNING) return fail(RC_ERR_ARG, "batch is not running");
   rc_ctx *c = b->ctx;
   HIP_TRY(hipSetDevice(c->device));
-  hipError_t e = hipEventSynchronize(b->evDone);
+  hipError_t e = timed_call("wait hipEventSynchronize", 0, [&] { return hipEventSynchronize(b->evDone); });
   // nothing in flight: releasing outgrown buffers stalls nobody.  A stream kept full never gets there: once the parked buffers
   // exceed a sixteenth of the device memory they are released anyway (one stall, instead of holding every generation of a growing buffer)
   if (c->inflight.fetch_sub(1) == 1 || c->retired->held() > c->retiredCapBytes) { if (!c->retired->empty()) c->retired->drain(); }
@@ -1368,8 +1395,12 @@ int rc_batch_wait(rc_batch *b) {
 
 int rc_batch_run(rc_batch *b) {
   if (!b) return fail(RC_ERR_ARG, "null batch");
+  trace("run", b);
   RC_TRY(rc_batch_run_async(b));
-  return batch_wait(b);
+  trace("queued", b);
+  const int r = batch_wait(b);
+  trace("done", b);
+  return r;
 }
 
 int rc_batch_bind_maxima(rc_batch *b, void *device_ptr) {
@@ -1902,65 +1933,89 @@ int rc_fit_trees_device(rc_ctx *c, const rc_block *blocks, int32_t n_blocks, cha
     work();
     for (auto &x : th) x.join();
   }
-  std::vector<TreeJob> jobs;
-  std::vector<int> owner;
-  size_t work_doubles = 0, in_bytes = 0, res_doubles = 0;
+  // Jobs, the longest fits first (a launch hands its workgroups out in order, and a fit of 12 rows x 200 patterns takes a hundred
+  // times one of 3 x 60), then grouped into launches by the LDS a fit needs: a block's whole working set -- tree, distance matrices,
+  // masks, conditional-likelihood columns -- lives in its workgroup's LDS (rc_tree_kernel.hip), so the blocks of a launch are the ones
+  // that fit the same number of times into a CU's 160 KB; blocks whose columns would leave fewer than two workgroups per CU keep them
+  // in global memory (RC_TREE_LDS_MAX: the most LDS a fit may take, bytes).
   int hostDone = 0;
-  // the longest fits first: the launch hands workgroups out in order, and a fit of 12 rows x 200 patterns takes a hundred times one of 3 x 60
   std::vector<int> order(n_blocks);
   for (int i = 0; i < n_blocks; i++) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
     const auto cost = [&](int i) { return ok[i] == 1 ? static_cast<double>(ps[i].N) * ps[i].N * ps[i].P : -1.0; };
     return cost(x) > cost(y);
   });
+  size_t ldsMax = std::min<size_t>(static_cast<size_t>(tree_fit_max_lds()), c->ldsPerCU / 2);
+  if (const char *e = std::getenv("RC_TREE_LDS_MAX")) ldsMax = std::min<size_t>(static_cast<size_t>(tree_fit_max_lds()), static_cast<size_t>(std::max(0ll, std::atoll(e))));
+  struct Launch { bool big; int occ; size_t lds; std::vector<int> blocks; };
+  std::vector<Launch> launches;   // [0]: the big blocks; then by workgroups per CU, ascending
+  launches.push_back(Launch{true, 0, 0, {}});
   for (int i : order) {
     if (ok[i] == 2) { hostDone++; continue; }   // fitted on the host above
     newick_out[static_cast<size_t>(i) * cap] = 0; kappa_out[i] = 0.0f;
     if (lnl_out) lnl_out[i] = 0.0;
     if (!ok[i]) continue;
-    TreeJob j{};
-    j.N = ps[i].N; j.P = ps[i].P;
-    j.off_mask = in_bytes;
-    in_bytes = (in_bytes + ps[i].mask.size() + 7) & ~static_cast<size_t>(7);
-    j.off_w = in_bytes;
-    in_bytes += sizeof(double) * ps[i].P;
-    j.off_work = work_doubles;
-    work_doubles += tree_work_doubles(j.N, j.P);
-    j.off_out = res_doubles;
-    res_doubles += tree_result_doubles(j.N);
-    jobs.push_back(j);
-    owner.push_back(i);
+    const size_t need = tree_fit_lds_bytes(ps[i].N, ps[i].P, false);
+    if (need > ldsMax) {
+      launches[0].blocks.push_back(i);
+      launches[0].lds = std::max(launches[0].lds, tree_fit_lds_bytes(ps[i].N, ps[i].P, true));
+      continue;
+    }
+    const int occ = static_cast<int>(std::min<size_t>(32, c->ldsPerCU / std::max<size_t>(need, 1)));
+    size_t at = 1;
+    while (at < launches.size() && launches[at].occ != occ) at++;
+    if (at == launches.size()) launches.push_back(Launch{false, occ, 0, {}});
+    launches[at].blocks.push_back(i);
+    launches[at].lds = std::max(launches[at].lds, need);
   }
-  const int nj = static_cast<int>(jobs.size());
+  std::sort(launches.begin() + 1, launches.end(), [](const Launch &a, const Launch &b) { return a.occ < b.occ; });
+  std::vector<TreeJob> jobs;
+  std::vector<int> owner;
+  size_t work_doubles = 0, in_bytes = 0, res_doubles = 0;
+  for (const Launch &L : launches)
+    for (int i : L.blocks) {
+      TreeJob j{};
+      j.N = ps[i].N; j.P = ps[i].P;
+      j.off_mask = in_bytes;
+      in_bytes = (in_bytes + ps[i].mask.size() + 7) & ~static_cast<size_t>(7);
+      j.off_w = in_bytes;
+      in_bytes += sizeof(double) * ps[i].P;
+      j.off_work = work_doubles;
+      if (L.big) work_doubles += tree_work_doubles(j.N, j.P);
+      j.off_out = res_doubles;
+      res_doubles += tree_result_doubles(j.N);
+      jobs.push_back(j);
+      owner.push_back(i);
+    }
+  const int nj = static_cast<int>(jobs.size()), nBig = static_cast<int>(launches[0].blocks.size());
   if (nj == 0) return hostDone;
-  // the per-block work areas of one launch share a scratch of at most 8 GiB (RC_TREE_SCRATCH_BYTES): long batches
+  if (nBig && launches[0].lds > static_cast<size_t>(tree_fit_max_lds())) return fail(RC_ERR_UNSUPPORTED, "a block's tree does not fit the device's LDS");
+  // the column areas of the big blocks of one launch share a scratch of at most 8 GiB (RC_TREE_SCRATCH_BYTES): long batches
   // go in several launches on the one stream, which re-use it
   size_t capDoubles = (static_cast<size_t>(8) << 30) / sizeof(double);
   if (const char *e = std::getenv("RC_TREE_SCRATCH_BYTES")) capDoubles = std::max<size_t>(1, static_cast<size_t>(std::atoll(e)) / sizeof(double));
   std::vector<int> chunkStart{0};
   size_t maxChunk = 0;
-  int maxJobs = 0;
   {
     size_t base = 0;
-    for (int q = 0; q < nj; q++) {
-      const size_t end = (q + 1 < nj) ? static_cast<size_t>(jobs[q + 1].off_work) : work_doubles;
+    for (int q = 0; q < nBig; q++) {
+      const size_t end = (q + 1 < nBig) ? static_cast<size_t>(jobs[q + 1].off_work) : work_doubles;
       if (end - base > capDoubles && q > chunkStart.back()) { chunkStart.push_back(q); base = static_cast<size_t>(jobs[q].off_work); }
       maxChunk = std::max(maxChunk, end - base);
     }
-    chunkStart.push_back(nj);
+    chunkStart.push_back(nBig);
     for (size_t ch = 0; ch + 1 < chunkStart.size(); ch++) {
+      if (chunkStart[ch] >= nBig) break;
       const size_t b0 = static_cast<size_t>(jobs[chunkStart[ch]].off_work);
       for (int q = chunkStart[ch]; q < chunkStart[ch + 1]; q++) jobs[q].off_work -= b0;
-      maxJobs = std::max(maxJobs, chunkStart[ch + 1] - chunkStart[ch]);
     }
   }
   // device and pinned buffers live in the context: a driver fits its blocks in several calls
   std::lock_guard<std::mutex> treeLock(c->treeMutex);
-  DevBuf &d_jobs = c->treeJobs, &d_in = c->treeIn, &d_work = c->treeWork, &d_out = c->treeOut, &d_res = c->treeRes;
+  DevBuf &d_jobs = c->treeJobs, &d_in = c->treeIn, &d_work = c->treeWork, &d_res = c->treeRes;
   HIP_TRY(d_jobs.ensure(sizeof(TreeJob) * nj));
   HIP_TRY(d_in.ensure(in_bytes));
-  HIP_TRY(d_work.ensure(sizeof(double) * maxChunk));
-  HIP_TRY(d_out.ensure(sizeof(TreeOut) * maxJobs));   // the kernel's working copies: one launch at a time uses them
+  HIP_TRY(d_work.ensure(sizeof(double) * std::max<size_t>(maxChunk, 1)));
   HIP_TRY(d_res.ensure(sizeof(double) * res_doubles));
   HIP_TRY(c->treeInPin.ensure(in_bytes));
   HIP_TRY(c->treeResPin.ensure(sizeof(double) * res_doubles));
@@ -1985,10 +2040,21 @@ int rc_fit_trees_device(rc_ctx *c, const rc_block *blocks, int32_t n_blocks, cha
   RC_STREAM_TRY(ts, stream_tree(c));
   HIP_TRY(hipMemcpyAsync(d_jobs.p, jobs.data(), sizeof(TreeJob) * nj, hipMemcpyHostToDevice, ts));
   HIP_TRY(hipMemcpyAsync(d_in.p, c->treeInPin.p, in_bytes, hipMemcpyHostToDevice, ts));
+  const TreeJob *dj = static_cast<const TreeJob *>(d_jobs.p);
+  const uint8_t *din = static_cast<const uint8_t *>(d_in.p);
   for (size_t ch = 0; ch + 1 < chunkStart.size(); ch++) {
     const int q0 = chunkStart[ch], q1 = chunkStart[ch + 1];
-    launch_tree_fit(static_cast<const TreeJob *>(d_jobs.p) + q0, q1 - q0, static_cast<const uint8_t *>(d_in.p), static_cast<double *>(d_work.p),
-                    static_cast<TreeOut *>(d_out.p), static_cast<double *>(d_res.p), ts);
+    if (q1 > q0 && !launch_tree_fit(dj + q0, q1 - q0, true, launches[0].lds, din, static_cast<double *>(d_work.p), static_cast<double *>(d_res.p), ts))
+      return fail(RC_ERR_DEVICE, "k_tree_fit: the device refused the launch's LDS request");
+  }
+  {
+    int q0 = nBig;
+    for (size_t l = 1; l < launches.size(); l++) {
+      const int cnt = static_cast<int>(launches[l].blocks.size());
+      if (cnt && !launch_tree_fit(dj + q0, cnt, false, launches[l].lds, din, static_cast<double *>(d_work.p), static_cast<double *>(d_res.p), ts))
+        return fail(RC_ERR_DEVICE, "k_tree_fit: the device refused the launch's LDS request");
+      q0 += cnt;
+    }
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(c->treeResPin.p, d_res.p, sizeof(double) * res_doubles, hipMemcpyDeviceToHost, ts));

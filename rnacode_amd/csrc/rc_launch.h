@@ -111,25 +111,51 @@ struct TreeJob {
   int N, P;
   uint64_t off_mask;          // bytes into the input blob: [N][P] state masks
   uint64_t off_w;             // bytes into the input blob (8-aligned): [P] pattern weights
-  uint64_t off_work;          // doubles into the scratch: tree_work_doubles(N, P)
+  uint64_t off_work;          // doubles into the scratch: tree_work_doubles(N, P) -- only jobs of the big-block launches have one
   uint64_t off_out;           // doubles into the result buffer: the job's TreeResult record (tree_result_doubles(N) doubles)
 };
-// the kernel's working copy of the tree (global memory, one per job of a launch)
-struct TreeOut {
-  int root;
-  int parent[127], nchild[127], child[127 * 3], preorder[127];   // 2 kMaxTipsDevice - 1 nodes
-  double len[127];
-  double kappa, lnl;
-};
 // What travels back to the host per job, nn = 2N - 2 nodes: doubles {kappa, lnl, len[nn]} then ints {root, nchild[nn], child[3 nn]}
-// (260 bytes for six rows; the working copy above is 4 KB)
-// a job's work area: D, V [N][N]; down, msg, up [nn][4][P]; bionj's temporaries (N doubles, 2 N + nn ints)
-inline size_t tree_work_doubles(int N, int P) {
-  const size_t n = static_cast<size_t>(N), nn = 2 * n - 2;
-  return 2 * n * n + 3 * nn * 4 * static_cast<size_t>(P) + n + (2 * n + nn + 1) / 2;
-}
+// (260 bytes for six rows)
 inline size_t tree_result_doubles(int N) { const size_t nn = 2 * static_cast<size_t>(N) - 2; return 2 + nn + (1 + 4 * nn + 1) / 2; }
-void launch_tree_fit(const TreeJob *jobs, int njobs, const uint8_t *in, double *scratch, TreeOut *work, double *results, hipStream_t stream);
+// A fit's working set, as offsets (in doubles) into the workgroup's LDS.  Always there: branch lengths, the five transfer constants
+// and three exponentials per branch, BIONJ's D and V and its temporaries, the tree as integer arrays.  With cols: the pattern weights,
+// the conditional-likelihood columns -- dn and up of the N - 3 internal nodes below the root, [4][P] each, and the four Newton
+// constants per pattern -- and the masks; a block whose columns do not fit keeps those three in global memory (big).
+struct TreeLdsLayout { uint32_t len, coef, e3, D, V, tmpD, opt, ints, w, cols, mask, total; };
+constexpr uint32_t kTreeOptDoubles = 40;   // room for treefit::OptState (rc_tree_kernel.hip asserts it)
+__host__ __device__ inline size_t tree_col_doubles(int N, int P) { return (static_cast<size_t>(2) * (N > 3 ? N - 3 : 0) * 4 + 4) * static_cast<size_t>(P); }
+__host__ __device__ inline TreeLdsLayout tree_lds_layout(int N, int P, bool big) {
+  const uint32_t n = static_cast<uint32_t>(N), nn = 2 * n - 2, p = static_cast<uint32_t>(P);
+  TreeLdsLayout l{};
+  uint32_t at = 0;
+  l.len = at; at += nn;
+  l.coef = at; at += 5 * nn;
+  l.e3 = at; at += 3 * nn;
+  l.D = at; at += n * n;
+  l.V = at; at += n * n;
+  l.tmpD = at; at += n;
+  l.opt = at; at += kTreeOptDoubles;
+  l.ints = at; at += (7 * nn + 2 * n + 1) / 2;   // parent, nchild, child[3], preorder, then bionj's 2 N + nn
+  l.w = l.cols = l.mask = at;
+  if (!big) {
+    l.w = at; at += p;
+    l.cols = at; at += static_cast<uint32_t>(tree_col_doubles(N, P));
+    l.mask = at; at += (n * p + 7) / 8;
+  }
+  l.total = at;
+  return l;
+}
+inline size_t tree_fit_lds_bytes(int N, int P, bool big) {   // (64-bit: a block that cannot fit must not wrap round to a small number)
+  const size_t n = static_cast<size_t>(N), nn = 2 * n - 2, p = static_cast<size_t>(P);
+  size_t at = 9 * nn + 2 * n * n + n + kTreeOptDoubles + (7 * nn + 2 * n + 1) / 2;
+  if (!big) at += p + tree_col_doubles(N, P) + (n * p + 7) / 8;
+  return at * sizeof(double);
+}
+// a big-block job's work area in global memory: the columns
+inline size_t tree_work_doubles(int N, int P) { return tree_col_doubles(N, P); }
+int tree_fit_max_lds();   // bytes of LDS one workgroup may ask for on the current device
+// one launch: jobs that share a storage class and an LDS request; false if the device refuses that much LDS
+bool launch_tree_fit(const TreeJob *jobs, int njobs, bool big, size_t ldsBytes, const uint8_t *in, double *scratch, double *results, hipStream_t stream);
 
 void launch_mt_stream(uint32_t seedBase, int Spad, int D, uint32_t *U, hipStream_t stream);
 void launch_prep(const PrepArgs &a, hipStream_t stream);   // k_prep_models, then k_prep_lut

@@ -27,6 +27,8 @@ struct SerialExec {
   int lane() const { return 0; }
   int nlanes() const { return 1; }
   double sum(double x) const { return x; }
+  void sum2(double &, double &) const {}
+  void exp3(double x0, double x1, double x2, double &e0, double &e1, double &e2) const { e0 = std::exp(x0); e1 = std::exp(x1); e2 = std::exp(x2); }
   void sync() const {}
   int broadcast_root(int r) const { return r; }
 };
@@ -35,7 +37,9 @@ struct SerialExec {
 struct Fitter {
   treefit::Work k{};
   std::vector<uint8_t> mask;
-  std::vector<double> w, D, V, len, down, msg, up, tmpD;
+  std::vector<double> w, D, V, len, e3, dnI, upI, kc, tmpD;
+  std::vector<treefit::Coef> coef;
+  treefit::OptState opt{};
   std::vector<int> parent, nchild, child, preorder, tmpI;
 
   void load(const PatternSet &ps) {
@@ -47,11 +51,12 @@ struct Fitter {
     const int N = k.N;
     D.assign(static_cast<size_t>(N) * N, 0.0); V = D;
     len.assign(nn, kBlMin); parent.assign(nn, -1); nchild.assign(nn, 0); child.assign(static_cast<size_t>(nn) * 3, -1); preorder.assign(nn, 0);
-    const size_t sz = static_cast<size_t>(nn) * 4 * k.P;
-    down.assign(sz, 0.0); msg.assign(sz, 0.0); up.assign(sz, 0.0);
+    const size_t sz = static_cast<size_t>(std::max(nn - N, 1)) * 4 * k.P;   // columns of the internal nodes only
+    dnI.assign(sz, 0.0); upI.assign(sz, 0.0); kc.assign(static_cast<size_t>(4) * k.P, 0.0);
+    coef.assign(nn, treefit::Coef{}); e3.assign(static_cast<size_t>(3) * nn, 0.0);
     k.mask = mask.data(); k.w = w.data(); k.D = D.data(); k.V = V.data(); k.len = len.data();
     k.parent = parent.data(); k.nchild = nchild.data(); k.child = child.data(); k.preorder = preorder.data();
-    k.down = down.data(); k.msg = msg.data(); k.up = up.data();
+    k.dnI = dnI.data(); k.upI = upI.data(); k.kc = kc.data(); k.coef = coef.data(); k.e3 = e3.data(); k.opt = &opt;
     tmpD.assign(N, 0.0); tmpI.assign(static_cast<size_t>(2) * N + nn, 0);
     k.tmpD = tmpD.data(); k.tmpI = tmpI.data();
   }
@@ -189,8 +194,8 @@ bool tree_lnl(const std::vector<std::string> &rows, const std::vector<std::strin
     f.len[v] = std::max(t.length[q], kBlMin);
   }
   for (int q = 0, n = 0; q < t.nnodes; q++) f.preorder[n++] = id[q];   // parse order is a pre-order
-  treefit::tip_partials(f.k, ex);
-  treefit::invalidate_all(f.k);
+  // (the parsed tree numbers its internal nodes from N in parse order -- the root is node N, not the last one -- and the columns
+  // are indexed by node - N either way)
   *lnl_out = treefit::total_lnl(f.k, ex);
   return true;
 }

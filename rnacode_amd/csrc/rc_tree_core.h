@@ -45,50 +45,39 @@ RC_HD inline int state_mask(char c) {
   }
 }
 
+// HKY85 with mean rate 1.  States A C G T = 0..3; purines (A, G: class 0) and pyrimidines (C, T: class 1) are the model's two classes:
+// the class of state i is i & 1.  P(t) has three exponentials, e1 = exp(-beta t) and e_g = exp(-beta c_g t) with
+// c_g = 1 + G_g (kappa - 1), G_g the class frequency:
+//   P_ij = pi_j + pi_j (1/G_g - 1) e1 + ((G_g - pi_j) / G_g) e_g      i == j (g the class of both)
+//        = pi_j + pi_j (1/G_g - 1) e1 - (pi_j / G_g) e_g              i != j in one class (transition)
+//        = pi_j (1 - e1)                                              different classes (transversion)
+// so the image of a conditional-likelihood column d across a branch needs no matrix:
+//   (P d)_i = a S + b_g S_g + e_g d_i,   S_g = sum_{j in g} pi_j d_j,  S = S_R + S_Y,  a = 1 - e1,  b_g = (e1 - e_g) / G_g
+// (twelve operations and five branch constants instead of sixteen products of a 4 x 4 matrix), and by reversibility the same map
+// carries a column DOWN a branch (pi_j P_ji / pi_i = P_ij).
 struct Hky {
-  double pi[4], kappa, beta, grp[4];
+  double pi[4], kappa, beta, G[2], c[2];
   RC_HD void set(const double p[4], double k) {
     for (int i = 0; i < 4; i++) pi[i] = p[i];
     kappa = k;
-    const double R = pi[0] + pi[2], Y = pi[1] + pi[3];
-    grp[0] = grp[2] = R; grp[1] = grp[3] = Y;
-    beta = 1.0 / (2.0 * (R * Y + kappa * (pi[0] * pi[2] + pi[1] * pi[3])));   // mean rate 1
-  }
-  RC_HD void probs(double t, double P[4][4]) const {
-    const double e1 = exp(-beta * t);
-    // purines (A, G) share one exponential, pyrimidines (C, T) the other: grp[0] == grp[2], grp[1] == grp[3]
-    const double eR = exp(-beta * t * (1.0 + grp[0] * (kappa - 1.0))), eY = exp(-beta * t * (1.0 + grp[1] * (kappa - 1.0)));
-    for (int i = 0; i < 4; i++) {
-      const double e2 = (i & 1) ? eY : eR;
-      for (int j = 0; j < 4; j++) {
-        if (i == j) P[i][j] = pi[j] + pi[j] * (1.0 / grp[j] - 1.0) * e1 + (grp[j] - pi[j]) / grp[j] * e2;
-        else if (((i ^ j) & 1) == 0) P[i][j] = pi[j] + pi[j] * (1.0 / grp[j] - 1.0) * e1 - pi[j] / grp[j] * e2;
-        else P[i][j] = pi[j] * (1.0 - e1);
-      }
-    }
-  }
-  // P(t) with dP/dt and d2P/dt2 (the same three exponentials: d/dt exp(-beta c t) = -beta c exp(-beta c t))
-  RC_HD void probs_d(double t, double P[4][4], double P1[4][4], double P2[4][4]) const {
-    const double cR = 1.0 + grp[0] * (kappa - 1.0), cY = 1.0 + grp[1] * (kappa - 1.0);
-    const double e1 = exp(-beta * t), eR = exp(-beta * t * cR), eY = exp(-beta * t * cY);
-    const double d1 = -beta * e1, dd1 = beta * beta * e1;
-    for (int i = 0; i < 4; i++) {
-      const double c = (i & 1) ? cY : cR, e2 = (i & 1) ? eY : eR;
-      const double d2 = -beta * c * e2, dd2 = beta * beta * c * c * e2;
-      for (int j = 0; j < 4; j++) {
-        if (i == j) {
-          const double x = pi[j] * (1.0 / grp[j] - 1.0), y = (grp[j] - pi[j]) / grp[j];
-          P[i][j] = pi[j] + x * e1 + y * e2; P1[i][j] = x * d1 + y * d2; P2[i][j] = x * dd1 + y * dd2;
-        } else if (((i ^ j) & 1) == 0) {
-          const double x = pi[j] * (1.0 / grp[j] - 1.0), y = pi[j] / grp[j];
-          P[i][j] = pi[j] + x * e1 - y * e2; P1[i][j] = x * d1 - y * d2; P2[i][j] = x * dd1 - y * dd2;
-        } else {
-          P[i][j] = pi[j] * (1.0 - e1); P1[i][j] = -pi[j] * d1; P2[i][j] = -pi[j] * dd1;
-        }
-      }
-    }
+    G[0] = pi[0] + pi[2]; G[1] = pi[1] + pi[3];
+    beta = 1.0 / (2.0 * (G[0] * G[1] + kappa * (pi[0] * pi[2] + pi[1] * pi[3])));   // mean rate 1
+    c[0] = 1.0 + G[0] * (kappa - 1.0); c[1] = 1.0 + G[1] * (kappa - 1.0);
   }
 };
+struct Coef { double a, bR, bY, eR, eY; };
+RC_HD inline Coef coef_of(const Hky &m, double e1, double eR, double eY) {
+  Coef c;
+  c.a = 1.0 - e1; c.bR = (e1 - eR) / m.G[0]; c.bY = (e1 - eY) / m.G[1]; c.eR = eR; c.eY = eY;
+  return c;
+}
+RC_HD inline void transfer(const Hky &m, const Coef &c, const double d[4], double out[4]) {
+  const double sR = m.pi[0] * d[0] + m.pi[2] * d[2], sY = m.pi[1] * d[1] + m.pi[3] * d[3];
+  const double base = c.a * (sR + sY);
+  const double rR = base + c.bR * sR, rY = base + c.bY * sY;
+  out[0] = rR + c.eR * d[0]; out[2] = rR + c.eR * d[2];
+  out[1] = rY + c.eY * d[1]; out[3] = rY + c.eY * d[3];
+}
 
 // 1-D minimiser on [lo, hi]: golden section with parabolic steps, as a resumable object -- start(), then feed() the value at `u`
 // until it returns false; the minimiser is `x`.  (Written this way so that the code that evaluates the objective exists once: the
@@ -173,7 +162,45 @@ RC_HD double minimise_local(F f, double lo, double hi, double x0, double factor,
   return x;
 }
 
-// everything one fit works on; the arrays are provided by the caller (host vectors / GPU scratch)
+// minimise_local as a resumable object (start(), then feed() the value at `u` until it returns false; the minimiser is `x`): the
+// search for kappa below evaluates its objective -- a pass over the whole tree -- at ONE place in the code.
+struct LocalMin {
+  Brent br;
+  double lo, hi, factor, xtol, a, b, x, u;
+  int itmax, attempt;
+  RC_HD void bracket() {
+    a = x / factor; b = x * factor;
+    if (a < lo) a = lo;
+    if (b > hi) b = hi;
+    br.start(a, b, x, xtol, itmax);
+    u = br.u;
+  }
+  RC_HD void start(double lo_, double hi_, double x0, double factor_, double xtol_, int itmax_) {
+    lo = lo_; hi = hi_; factor = factor_; xtol = xtol_; itmax = itmax_; attempt = 0;
+    x = x0 < lo ? lo : (x0 > hi ? hi : x0);
+    bracket();
+  }
+  RC_HD bool feed(double fu) {
+    if (br.feed(fu)) { u = br.u; return true; }
+    x = br.x;
+    const double tol = 4 * (xtol * fabs(x) + 1e-10);
+    const bool atLow = (x - a) <= tol && a > lo, atHigh = (b - x) <= tol && b < hi;
+    if ((!atLow && !atHigh) || ++attempt >= 8) return false;
+    factor *= 4.0;
+    bracket();
+    return true;
+  }
+};
+
+// the state of optimise() between two evaluations of the likelihood: wave-uniform, and kept in memory (on the GPU: LDS) rather than
+// in forty registers across the tree pass
+struct OptState {
+  LocalMin lm;
+  double prev, kap, h, f0, f1;
+  int what, round, probe;
+};
+
+// everything one fit works on; the arrays are provided by the caller (host vectors / the kernel's LDS and, for long blocks, global scratch)
 struct Work {
   int N, P, nn, root;
   const uint8_t *mask;   // [N][P] allowed-state masks
@@ -188,74 +215,89 @@ struct Work {
   double *len;           // [nn]
   double *D, *V;         // [N][N]
   double *tmpD;          // [N]           bionj's row sums
-  int *tmpI;             // [2 N + nn]    bionj's slot tables and the stack of its pre-order walk (kept out of the kernel's private memory:
-                         //               a kernel with 1.8 KB of scratch per lane gets fewer wavefronts from the runtime than its registers allow)
-  double *down, *msg, *up;   // [nn][4][P]
-  // which of those columns are current (bit v of word v / 64), see refresh_down / refresh_up: a branch-length change makes only
-  // part of them stale, and recomputing exactly the stale ones gives the same numbers as recomputing everything
-  static constexpr int kSetWords = (kMaxNodes + 63) / 64;
-  uint64_t okDn[kSetWords], okMs[kSetWords], okUp[kSetWords];
-  // On the device a set is two words: the word is picked by comparison, not by a run-time index, so that the sets stay in registers
-  // (a run-time index would put them, and with them a scratch allocation per lane, into private memory).
-  RC_HD static bool bit(const uint64_t *m, int v) {
-    if constexpr (kSetWords <= 2) { uint64_t w = m[0]; for (int x = 1; x < kSetWords; x++) if ((v >> 6) == x) w = m[x]; return (w >> (v & 63)) & 1ull; }
-    else return (m[v >> 6] >> (v & 63)) & 1ull;
-  }
-  RC_HD static void set_bit(uint64_t *m, int v) {
-    if constexpr (kSetWords <= 2) { for (int x = 0; x < kSetWords; x++) m[x] |= ((v >> 6) == x) ? (1ull << (v & 63)) : 0ull; }
-    else m[v >> 6] |= 1ull << (v & 63);
-  }
-  RC_HD static void clear_bit(uint64_t *m, int v) {
-    if constexpr (kSetWords <= 2) { for (int x = 0; x < kSetWords; x++) m[x] &= ((v >> 6) == x) ? ~(1ull << (v & 63)) : ~0ull; }
-    else m[v >> 6] &= ~(1ull << (v & 63));
-  }
-  RC_HD double &dn(int v, int s, int p) const { return down[(static_cast<size_t>(v) * 4 + s) * P + p]; }
-  RC_HD double &ms(int v, int s, int p) const { return msg[(static_cast<size_t>(v) * 4 + s) * P + p]; }
-  RC_HD double &upp(int v, int s, int p) const { return up[(static_cast<size_t>(v) * 4 + s) * P + p]; }
+  int *tmpI;             // [2 N + nn]    bionj's slot tables and the stack of its pre-order walk
+  Coef *coef;            // [nn]          what each node's branch does to a column under the current model and length
+  double *e3;            // [3 nn]        the three exponentials of every branch (coef_all)
+  // Conditional-likelihood columns, [4][P] each, of the INTERNAL nodes only (a tip's column is its mask):
+  //   dn(v): the subtree below v;  up(v): the rest of the tree as seen from the top of v's branch (without pi);
+  // kc: the four per-pattern constants of the branch being optimised (see branch_constants)
+  double *dnI, *upI;     // [nn - N][4][P]
+  double *kc;            // [4][P]
+  OptState *opt;         // optimise()'s state
 };
 
 // empirical base frequencies; ambiguous characters are shared out by the current estimate (8 rounds,
-// as phyml/utilities.c:1926-1990)
+// as phyml/utilities.c:1926-1990).  An unambiguous character adds its weight to its state whatever the estimate is, so those are
+// counted once; a block without ambiguity codes or gaps needs no rounds at all.
 template <typename Exec>
 RC_HD void base_freqs(Work &k, Exec &ex) {
+  double base[4] = {0, 0, 0, 0}, amb = 0;
+  for (int p = ex.lane(); p < k.P; p += ex.nlanes())
+    for (int r = 0; r < k.N; r++) {
+      const int m = k.mask[static_cast<size_t>(r) * k.P + p];
+      if ((m & (m - 1)) == 0) { for (int s = 0; s < 4; s++) base[s] += (m >> s & 1) ? k.w[p] : 0.0; }
+      else amb += 1.0;
+    }
+  for (int s = 0; s < 4; s++) base[s] = ex.sum(base[s]);
+  amb = ex.sum(amb);
   double f[4] = {0.25, 0.25, 0.25, 0.25};
   for (int it = 0; it < 8; it++) {
     double cnt[4] = {0, 0, 0, 0};
-    for (int p = ex.lane(); p < k.P; p += ex.nlanes())
-      for (int r = 0; r < k.N; r++) {
-        const int m = k.mask[static_cast<size_t>(r) * k.P + p];
-        double tot = 0;
-        for (int s = 0; s < 4; s++) if (m >> s & 1) tot += f[s];
-        for (int s = 0; s < 4; s++) if (m >> s & 1) cnt[s] += k.w[p] * f[s] / tot;
-      }
-    for (int s = 0; s < 4; s++) cnt[s] = ex.sum(cnt[s]);
+    if (amb > 0) {
+      for (int p = ex.lane(); p < k.P; p += ex.nlanes())
+        for (int r = 0; r < k.N; r++) {
+          const int m = k.mask[static_cast<size_t>(r) * k.P + p];
+          if ((m & (m - 1)) == 0) continue;
+          double tot = 0;
+          for (int s = 0; s < 4; s++) tot += (m >> s & 1) ? f[s] : 0.0;
+          const double q = k.w[p] / tot;
+          for (int s = 0; s < 4; s++) cnt[s] += (m >> s & 1) ? q * f[s] : 0.0;
+        }
+      for (int s = 0; s < 4; s++) cnt[s] = ex.sum(cnt[s]);
+    }
+    for (int s = 0; s < 4; s++) cnt[s] += base[s];
     const double sum = cnt[0] + cnt[1] + cnt[2] + cnt[3];
     for (int s = 0; s < 4; s++) f[s] = cnt[s] / sum;
+    if (!(amb > 0)) break;   // nothing depends on the estimate: the first round's answer is every round's
   }
   for (int s = 0; s < 4; s++) k.pi[s] = f[s];
 }
 
-// ML distance of two rows from the joint frequencies of their unambiguous sites (one lane does a pair)
+// ML distance of two rows from the joint frequencies of their unambiguous sites (one lane does a pair).  The sixteen entries of
+// P(d) are nine distinct functions of d (four identities, four transitions, one transversion factor 1 - e1 times pi_j), so an
+// evaluation of the likelihood costs three exponentials and nine logarithms.
 RC_HD inline double pair_distance(const Work &k, int x, int y) {
-  double F[4][4] = {{0}}, tot = 0;
+  uint32_t cnt[16];
+  for (int c = 0; c < 16; c++) cnt[c] = 0;
   for (int p = 0; p < k.P; p++) {
     const int a = k.mask[static_cast<size_t>(x) * k.P + p], b = k.mask[static_cast<size_t>(y) * k.P + p];
     if ((a & (a - 1)) || (b & (b - 1))) continue;   // ambiguous in either row: hidden
     const int ia = (a == 1) ? 0 : (a == 2) ? 1 : (a == 4) ? 2 : 3, ib = (b == 1) ? 0 : (b == 2) ? 1 : (b == 4) ? 2 : 3;
-    // F[ia][ib] += w with compile-time subscripts (x + 0.0 == x for these sums): a run-time subscript would move F into private memory
-    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) F[i][j] += (i == ia && j == ib) ? k.w[p] : 0.0;
-    tot += k.w[p];
+    const uint32_t wi = static_cast<uint32_t>(k.w[p]);   // a multiplicity: a small integer
+    const int idx = ia * 4 + ib;
+    // compile-time subscripts: a run-time subscript would move the counters into private memory
+    for (int c = 0; c < 16; c++) cnt[c] += (idx == c) ? wi : 0u;
   }
+  double F[4][4], tot = 0, diff = 0;
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { F[i][j] = static_cast<double>(cnt[i * 4 + j]); tot += F[i][j]; if (i != j) diff += F[i][j]; }
   if (tot <= 0) return -1.0;
-  double diff = 0;
-  for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) if (i != j) diff += F[i][j];
   if (diff == 0) return 0.0;
   const Hky &mod = k.mod;
+  // transversions: log P_ij = log pi_j + log(1 - e1); their pi part is a constant of the search
+  double Ftv = 0, Ctv = 0;
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) if (((i ^ j) & 1) && F[i][j] > 0) { Ftv += F[i][j]; Ctv += F[i][j] * log(mod.pi[j]); }
+  auto lg = [](double v) { return log(v > 1e-300 ? v : 1e-300); };
   auto nll = [&](double d) {
-    double Pm[4][4], s = 0;
-    mod.probs(d, Pm);
-    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) if (F[i][j] > 0) s -= F[i][j] * log(Pm[i][j] > 1e-300 ? Pm[i][j] : 1e-300);
-    return s;
+    const double e1 = exp(-mod.beta * d), eg[2] = {exp(-mod.beta * mod.c[0] * d), exp(-mod.beta * mod.c[1] * d)};
+    double s = Ctv;
+    if (Ftv > 0) s += Ftv * lg(1.0 - e1);
+    for (int i = 0; i < 4; i++) {
+      const int g = i & 1, j = i ^ 2;   // j: the other state of i's class
+      const double x1 = mod.pi[i] * (1.0 / mod.G[g] - 1.0);
+      if (F[i][i] > 0) s += F[i][i] * lg(mod.pi[i] + x1 * e1 + (mod.G[g] - mod.pi[i]) / mod.G[g] * eg[g]);
+      if (F[j][i] > 0) s += F[j][i] * lg(mod.pi[i] + x1 * e1 - mod.pi[i] / mod.G[g] * eg[g]);
+    }
+    return -s;
   };
   double x0 = 1.5 * diff / tot + 0.01;
   if (x0 > 1.0) x0 = 1.0;
@@ -324,135 +366,170 @@ RC_HD inline void bionj(Work &k) {
   }
 }
 
-template <typename Exec>
-RC_HD void tip_partials(Work &k, Exec &ex) {
-  for (int t = 0; t < k.N; t++)
-    for (int p = ex.lane(); p < k.P; p += ex.nlanes())
-      for (int s = 0; s < 4; s++) k.dn(t, s, p) = (k.mask[static_cast<size_t>(t) * k.P + p] >> s & 1) ? 1.0 : 0.0;
-}
+// ---- conditional likelihoods.  A lane owns its patterns for the whole fit, so columns need no synchronisation: what a lane reads
+// it has written itself.
 
-// Conditional likelihoods of the subtree below each node (down), their images across the node's branch (msg), and the rest of
-// the tree as seen from the top of each node's branch (up, excluding pi).  What depends on what:
-//   down(v), msg(v): the branches strictly below v (msg(v) also v's own)
-//   up(v):           every branch outside v's subtree except v's own
-// so after branch v changed, msg(v), down/msg of v's ancestors and up of every node that is neither v nor an ancestor of v are
-// stale; after the model changed everything is.
-RC_HD inline void invalidate_all(Work &k) {
-  for (int x = 0; x < Work::kSetWords; x++) k.okDn[x] = k.okMs[x] = k.okUp[x] = 0;
-  for (int t = 0; t < k.N; t++) Work::set_bit(k.okDn, t);   // tip columns are data (tip_partials)
-}
-RC_HD inline void branch_changed(Work &k, int v) {
-  uint64_t keep[Work::kSetWords];
-  for (int x = 0; x < Work::kSetWords; x++) keep[x] = 0;
-  Work::set_bit(keep, v);
-  Work::clear_bit(k.okMs, v);
-  for (int a = k.parent[v];; a = k.parent[a]) {
-    Work::set_bit(keep, a);
-    Work::clear_bit(k.okDn, a);
-    Work::clear_bit(k.okMs, a);
-    if (a == k.root) break;
+// the column below node v at pattern p: a tip's is its mask, an internal node's is stored
+RC_HD inline void load_down(const Work &k, int v, int p, double d[4]) {
+  if (v < k.N) {
+    const int m = k.mask[static_cast<size_t>(v) * k.P + p];
+    for (int s = 0; s < 4; s++) d[s] = (m >> s & 1) ? 1.0 : 0.0;
+  } else {
+    const double *c = k.dnI + static_cast<size_t>(v - k.N) * 4 * k.P + p;
+    for (int s = 0; s < 4; s++) d[s] = c[static_cast<size_t>(s) * k.P];
   }
-  for (int x = 0; x < Work::kSetWords; x++) k.okUp[x] &= keep[x];
 }
 
-// every stale down / msg column, children before parents
+// the three exponentials and the transfer constants of every branch under the current model and lengths: one exponential per
+// lane (on the GPU 3 (nn - 1) of them at once instead of one branch after the other on every lane)
 template <typename Exec>
-RC_HD void refresh_down(Work &k, Exec &ex) {
+RC_HD void coef_all(Work &k, Exec &ex) {
+  for (int q = ex.lane(); q < 3 * k.nn; q += ex.nlanes()) {
+    const int v = q / 3, kind = q - 3 * v;
+    const double rate = kind == 0 ? 1.0 : (kind == 1 ? k.mod.c[0] : k.mod.c[1]);   // (no run-time subscript: the model stays in registers)
+    k.e3[q] = exp(-k.mod.beta * rate * k.len[v]);
+  }
+  ex.sync();
+  for (int v = ex.lane(); v < k.nn; v += ex.nlanes()) k.coef[v] = coef_of(k.mod, k.e3[3 * v], k.e3[3 * v + 1], k.e3[3 * v + 2]);
+  ex.sync();
+}
+
+// out *= the image of node x's column across x's branch, at pattern p
+RC_HD inline void times_image(const Work &k, int x, const Coef &cx, int p, double out[4]) {
+  double d[4], m[4];
+  load_down(k, x, p, d);
+  transfer(k.mod, cx, d, m);
+  for (int s = 0; s < 4; s++) out[s] *= m[s];
+}
+// up to three nodes whose images meet in a product (a node's children; a node's siblings): ids and branch constants as plain
+// members -- an array indexed by a loop counter would live in the lane's private memory, i.e. in global memory
+struct Trio {
+  int x0, x1, x2;        // node ids, -1: slot not used
+  Coef c0, c1, c2;
+  RC_HD void product(const Work &k, int p, double out[4]) const {
+    for (int s = 0; s < 4; s++) out[s] = 1.0;
+    if (x0 >= 0) times_image(k, x0, c0, p, out);
+    if (x1 >= 0) times_image(k, x1, c1, p, out);
+    if (x2 >= 0) times_image(k, x2, c2, p, out);
+  }
+};
+// the children of v except `except`, child c in slot c (a slot chosen at run time would be a pointer chosen at run time, and the
+// structure would live in private memory)
+RC_HD inline Trio children_of(const Work &k, int v, int except) {
+  Trio t;
+  const int nc = k.nchild[v];
+  const int a = k.child[v * 3], b = nc > 1 ? k.child[v * 3 + 1] : -1, c = nc > 2 ? k.child[v * 3 + 2] : -1;
+  t.x0 = (nc > 0 && a != except) ? a : -1;
+  t.x1 = (b >= 0 && b != except) ? b : -1;
+  t.x2 = (c >= 0 && c != except) ? c : -1;
+  const Coef *q = k.coef;
+  const Coef &r0 = q[t.x0 >= 0 ? t.x0 : 0], &r1 = q[t.x1 >= 0 ? t.x1 : 0], &r2 = q[t.x2 >= 0 ? t.x2 : 0];
+  t.c0.a = r0.a; t.c0.bR = r0.bR; t.c0.bY = r0.bY; t.c0.eR = r0.eR; t.c0.eY = r0.eY;
+  t.c1.a = r1.a; t.c1.bR = r1.bR; t.c1.bY = r1.bY; t.c1.eR = r1.eR; t.c1.eY = r1.eY;
+  t.c2.a = r2.a; t.c2.bR = r2.bR; t.c2.bY = r2.bY; t.c2.eR = r2.eR; t.c2.eY = r2.eY;
+  return t;
+}
+
+// dn(v) of one internal node from its children's columns
+template <typename Exec>
+RC_HD void refresh_down_node(Work &k, Exec &ex, int v) {
+  const Trio ch = children_of(k, v, -1);
+  double *dst = k.dnI + static_cast<size_t>(v - k.N) * 4 * k.P;
+  for (int p = ex.lane(); p < k.P; p += ex.nlanes()) {
+    double d[4];
+    ch.product(k, p, d);
+    for (int s = 0; s < 4; s++) dst[static_cast<size_t>(s) * k.P + p] = d[s];
+  }
+}
+
+// every dn column from the tips up, and the log-likelihood read at the root; needs coef_all first
+template <typename Exec>
+RC_HD double full_down(Work &k, Exec &ex) {
+  double lnl = 0;
   for (int o = k.nn - 1; o >= 0; o--) {
     const int v = k.preorder[o];
-    if (v >= k.N && !Work::bit(k.okDn, v)) {
-      for (int p = ex.lane(); p < k.P; p += ex.nlanes())
-        for (int s = 0; s < 4; s++) {
-          double d = 1.0;
-          for (int c = 0; c < k.nchild[v]; c++) d *= k.ms(k.child[v * 3 + c], s, p);
-          k.dn(v, s, p) = d;
-        }
-      Work::set_bit(k.okDn, v);
-    }
-    if (v != k.root && !Work::bit(k.okMs, v)) {
-      double Pm[4][4];
-      k.mod.probs(k.len[v], Pm);
-      for (int p = ex.lane(); p < k.P; p += ex.nlanes()) {
-        const double d0 = k.dn(v, 0, p), d1 = k.dn(v, 1, p), d2 = k.dn(v, 2, p), d3 = k.dn(v, 3, p);
-        for (int i = 0; i < 4; i++) k.ms(v, i, p) = Pm[i][0] * d0 + Pm[i][1] * d1 + Pm[i][2] * d2 + Pm[i][3] * d3;
-      }
-      Work::set_bit(k.okMs, v);
-    }
-  }
-}
-
-// the stale up columns on the path from the root to `target` (parents before children); needs refresh_down first
-template <typename Exec>
-RC_HD void refresh_up(Work &k, Exec &ex, int target) {
-  uint64_t path[Work::kSetWords];
-  for (int x = 0; x < Work::kSetWords; x++) path[x] = 0;
-  for (int a = target; a != k.root; a = k.parent[a]) Work::set_bit(path, a);
-  for (int o = 0; o < k.nn; o++) {
-    const int v = k.preorder[o];
-    if (v == k.root || !Work::bit(path, v) || Work::bit(k.okUp, v)) continue;
-    const int par = k.parent[v];
-    double W[4][4];
-    if (par != k.root) {   // what comes from above the parent, through the parent's own branch
-      double Pm[4][4];
-      k.mod.probs(k.len[par], Pm);
-      for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) W[i][j] = Pm[j][i] * k.mod.pi[j] / k.mod.pi[i];
-    }
+    if (v < k.N) continue;
+    if (v != k.root) { refresh_down_node(k, ex, v); continue; }
+    const Trio ch = children_of(k, v, -1);
     for (int p = ex.lane(); p < k.P; p += ex.nlanes()) {
-      double u[4] = {1.0, 1.0, 1.0, 1.0};
-      for (int c = 0; c < k.nchild[par]; c++) {
-        const int sib = k.child[par * 3 + c];
-        if (sib != v) for (int s = 0; s < 4; s++) u[s] *= k.ms(sib, s, p);
-      }
-      if (par != k.root) {
-        const double a0 = k.upp(par, 0, p), a1 = k.upp(par, 1, p), a2 = k.upp(par, 2, p), a3 = k.upp(par, 3, p);
-        for (int i = 0; i < 4; i++) u[i] *= W[i][0] * a0 + W[i][1] * a1 + W[i][2] * a2 + W[i][3] * a3;
-      }
-      for (int s = 0; s < 4; s++) k.upp(v, s, p) = u[s];
+      double d[4];
+      ch.product(k, p, d);
+      const double s = k.mod.pi[0] * d[0] + k.mod.pi[1] * d[1] + k.mod.pi[2] * d[2] + k.mod.pi[3] * d[3];
+      lnl += k.w[p] * log(s > 1e-300 ? s : 1e-300);
     }
-    Work::set_bit(k.okUp, v);
-  }
-}
-
-template <typename Exec>
-RC_HD double edge_lnl(const Work &k, Exec &ex, int v, double t) {
-  double Pm[4][4], lnl = 0;
-  k.mod.probs(t, Pm);
-  for (int p = ex.lane(); p < k.P; p += ex.nlanes()) {
-    const double d0 = k.dn(v, 0, p), d1 = k.dn(v, 1, p), d2 = k.dn(v, 2, p), d3 = k.dn(v, 3, p);
-    double s = 0;
-    for (int i = 0; i < 4; i++)
-      s += k.mod.pi[i] * k.upp(v, i, p) * (Pm[i][0] * d0 + Pm[i][1] * d1 + Pm[i][2] * d2 + Pm[i][3] * d3);
-    lnl += k.w[p] * log(s > 1e-300 ? s : 1e-300);
   }
   return ex.sum(lnl);
 }
 
-// Maximum-likelihood length of branch v by Newton's method on d lnL / dt (what the columns below and above the branch make it a
-// function of t alone): t <- t - f'/f'' while f'' < 0, a step along the gradient by a factor 4 where the curve is not concave,
-// every step kept within a factor 8 of the current length and inside [kBlMin, kBlMax]; stops when the length moves by less than
-// 1e-5 of itself.  Three or four evaluations where a bracketing search needs ten: near its optimum lnL(t) is very nearly a parabola.
+// log-likelihood of the current tree and model
 template <typename Exec>
-RC_HD double edge_newton(const Work &k, Exec &ex, int v, double t) {
+RC_HD double total_lnl(Work &k, Exec &ex) {
+  coef_all(k, ex);
+  return full_down(k, ex);
+}
+
+// Branch v seen from its two ends: d = dn(v), u = up(v).  Its site likelihood as a function of the branch's length t is
+//   s(t) = sum_i pi_i u_i (P(t) d)_i = k0 + k1 e^{-beta t} + k2 e^{-beta c_R t} + k3 e^{-beta c_Y t}
+// with, U_g = sum_{i in g} pi_i u_i, S_g = sum_{i in g} pi_i d_i, T_g = sum_{i in g} pi_i u_i d_i, q_g = S_g U_g / G_g:
+//   k0 = (S_R + S_Y)(U_R + U_Y),  k1 = q_R + q_Y - k0,  k2 = T_R - q_R,  k3 = T_Y - q_Y
+// -- four numbers per pattern, made once per visit of the branch; Newton's iterations then never touch a column.
+// Also leaves up(v) in its column if v is an internal node (its children will need it).
+template <typename Exec>
+RC_HD void branch_constants(Work &k, Exec &ex, int v) {
+  const int par = k.parent[v];
+  const Trio sib = children_of(k, par, v);
+  const bool above = par != k.root;
+  Coef cp = k.coef[above ? par : v];
+  const double *upPar = above ? k.upI + static_cast<size_t>(par - k.N) * 4 * k.P : nullptr;
+  double *upV = v >= k.N ? k.upI + static_cast<size_t>(v - k.N) * 4 * k.P : nullptr;
+  const Hky &m = k.mod;
+  for (int p = ex.lane(); p < k.P; p += ex.nlanes()) {
+    double u[4];
+    sib.product(k, p, u);
+    if (above) {   // what comes from above the parent, through the parent's own branch
+      double a[4], t[4];
+      for (int s = 0; s < 4; s++) a[s] = upPar[static_cast<size_t>(s) * k.P + p];
+      transfer(m, cp, a, t);
+      for (int s = 0; s < 4; s++) u[s] *= t[s];
+    }
+    if (upV) for (int s = 0; s < 4; s++) upV[static_cast<size_t>(s) * k.P + p] = u[s];
+    double d[4];
+    load_down(k, v, p, d);
+    const double u0 = m.pi[0] * u[0], u1 = m.pi[1] * u[1], u2 = m.pi[2] * u[2], u3 = m.pi[3] * u[3];
+    const double UR = u0 + u2, UY = u1 + u3;
+    const double SR = m.pi[0] * d[0] + m.pi[2] * d[2], SY = m.pi[1] * d[1] + m.pi[3] * d[3];
+    const double TR = u0 * d[0] + u2 * d[2], TY = u1 * d[1] + u3 * d[3];
+    const double k0 = (SR + SY) * (UR + UY), qR = SR * UR / m.G[0], qY = SY * UY / m.G[1];
+    k.kc[p] = k0;
+    k.kc[static_cast<size_t>(k.P) + p] = qR + qY - k0;
+    k.kc[2 * static_cast<size_t>(k.P) + p] = TR - qR;
+    k.kc[3 * static_cast<size_t>(k.P) + p] = TY - qY;
+  }
+}
+
+// Maximum-likelihood length of the branch whose constants are in kc, by Newton's method on d lnL / dt: t <- t - f'/f'' while
+// f'' < 0, a step along the gradient by a factor 4 where the curve is not concave, every step kept within a factor 8 of the current
+// length and inside [kBlMin, kBlMax]; stops when the length moves by less than 1e-5 of itself.  Three or four evaluations where a
+// bracketing search needs ten: near its optimum lnL(t) is very nearly a parabola.
+template <typename Exec>
+RC_HD double edge_newton(const Work &k, Exec &ex, double t) {
+  const double b = k.mod.beta, cR = k.mod.c[0], cY = k.mod.c[1];
+  const double *k0 = k.kc, *k1 = k.kc + k.P, *k2 = k.kc + 2 * static_cast<size_t>(k.P), *k3 = k.kc + 3 * static_cast<size_t>(k.P);
   for (int it = 0; it < 40; it++) {
-    double Pm[4][4], P1[4][4], P2[4][4], g = 0, h = 0;
-    k.mod.probs_d(t, Pm, P1, P2);
+    double e1, eR, eY, g = 0, h = 0;
+    ex.exp3(-b * t, -b * cR * t, -b * cY * t, e1, eR, eY);
     for (int p = ex.lane(); p < k.P; p += ex.nlanes()) {
-      const double d0 = k.dn(v, 0, p), d1 = k.dn(v, 1, p), d2 = k.dn(v, 2, p), d3 = k.dn(v, 3, p);
-      double s0 = 0, s1 = 0, s2 = 0;
-      for (int i = 0; i < 4; i++) {
-        const double u = k.mod.pi[i] * k.upp(v, i, p);
-        s0 += u * (Pm[i][0] * d0 + Pm[i][1] * d1 + Pm[i][2] * d2 + Pm[i][3] * d3);
-        s1 += u * (P1[i][0] * d0 + P1[i][1] * d1 + P1[i][2] * d2 + P1[i][3] * d3);
-        s2 += u * (P2[i][0] * d0 + P2[i][1] * d1 + P2[i][2] * d2 + P2[i][3] * d3);
-      }
+      const double A = k1[p] * e1, B = k2[p] * eR, C = k3[p] * eY;
+      const double s0 = k0[p] + A + B + C;
       if (s0 > 1e-300) {
-        const double r1 = s1 / s0;
+        const double r = 1.0 / s0;
+        const double r1 = -b * (A + cR * B + cY * C) * r;                 // s'/s
+        const double r2 = b * b * (A + cR * cR * B + cY * cY * C) * r;    // s''/s
         g += k.w[p] * r1;
-        h += k.w[p] * (s2 / s0 - r1 * r1);
+        h += k.w[p] * (r2 - r1 * r1);
       }
     }
-    g = ex.sum(g);
-    h = ex.sum(h);
+    ex.sum2(g, h);
     double tn;
     if (h < 0) tn = t - g / h;
     else tn = g > 0 ? t * 4.0 : t * 0.25;
@@ -467,58 +544,71 @@ RC_HD double edge_newton(const Work &k, Exec &ex, int v, double t) {
   return t;
 }
 
-// log-likelihood of the current tree and model, read at the root's first branch (its up column needs no other up column)
+// One pass over the branches in the tree's pre-order (parents before children; what PhyML's own branch optimiser walks too): at
+// node v everything above it has its new lengths already and everything below is untouched, so up(v) is one product of the
+// siblings' images and the parent's up column, and dn(v) is still the column the last bottom-up pass left.  When a subtree is
+// finished (the next node of the order hangs off one of v's ancestors) the dn columns on the way up to that ancestor are rebuilt
+// from their children: three images per branch and round, where recomputing "whatever is stale" cost two per level of the tree.
+// Needs coef_all + full_down first; leaves every dn column current again.
 template <typename Exec>
-RC_HD double total_lnl(Work &k, Exec &ex) {
-  const int v = k.child[k.root * 3];
-  refresh_down(k, ex);
-  refresh_up(k, ex, v);
-  return edge_lnl(k, ex, v, k.len[v]);
+RC_HD void branch_pass(Work &k, Exec &ex) {
+  for (int o = 1; o < k.nn; o++) {
+    const int v = k.preorder[o];
+    branch_constants(k, ex, v);
+    const double t = edge_newton(k, ex, k.len[v]);
+    double e1, eR, eY;
+    ex.exp3(-k.mod.beta * t, -k.mod.beta * k.mod.c[0] * t, -k.mod.beta * k.mod.c[1] * t, e1, eR, eY);
+    k.len[v] = t;                          // (every lane stores the same values)
+    k.coef[v] = coef_of(k.mod, e1, eR, eY);
+    ex.sync();
+    const int stop = o + 1 < k.nn ? k.parent[k.preorder[o + 1]] : k.root;
+    for (int a = v; a != stop; a = k.parent[a]) if (a >= k.N) refresh_down_node(k, ex, a);
+  }
 }
 
 // coordinate-wise ML: every branch, then kappa, until the log-likelihood moves by less than 1e-4
-// (PhyML's Round_Optimize stops at 1e-3, phyml/utilities.c:5207).  Branch lengths by Newton's method (edge_newton); kappa, whose
-// every evaluation is a pass over the whole tree, by the bracketing minimiser on a bracket around the current value
-// (minimise_local: a factor 4 either way in the first round, 2 later).
+// (PhyML's Round_Optimize stops at 1e-3, phyml/utilities.c:5207).  Branch lengths by Newton's method (edge_newton).  kappa, whose
+// every evaluation is a pass over the whole tree: a Newton step from three likelihood values one per cent apart (the round's closing
+// evaluation shows what it achieved, the next round refines it); where the curve is not convex there, or the step would more than
+// double or halve kappa, the bracketing minimiser on a bracket around the current value instead (a factor 4 either way in the first
+// round, 2 later).  Written as one loop around ONE evaluation of the likelihood -- what the value is for is a small state -- so that
+// the code of the tree pass exists once (the kernel's instruction stream has to fit the instruction cache).
 template <typename Exec>
 RC_HD double optimise(Work &k, Exec &ex) {
-  tip_partials(k, ex);
-  invalidate_all(k);
-  double prev = total_lnl(k, ex);
-  for (int round = 0; round < 60; round++) {
-    const double factor = round == 0 ? 4.0 : 2.0;
-    for (int v = 0; v < k.nn; v++) {
-      if (v == k.root) continue;
-      refresh_down(k, ex);
-      refresh_up(k, ex, v);
-      k.len[v] = edge_newton(k, ex, v, k.len[v]);
-      branch_changed(k, v);
+  enum { kClose, kProbe, kSearch };   // the value is: the round's closing likelihood / one of the three probes / an evaluation of the search
+  OptState &st = *k.opt;
+  st.what = kClose; st.round = -1; st.probe = 0;
+  st.prev = 0; st.kap = k.mod.kappa; st.h = 0; st.f0 = 0; st.f1 = 0;
+  for (;;) {
+    ex.sync();
+    const double lnl = total_lnl(k, ex);
+    bool close = false;
+    if (st.what == kClose) {
+      if (st.round >= 0 && fabs(lnl - st.prev) < 1e-4) return lnl;
+      st.prev = lnl;
+      if (++st.round >= 60) return lnl;
+      ex.sync();
+      branch_pass(k, ex);
+      st.kap = k.mod.kappa; st.h = 0.01 * st.kap;
+      st.what = kProbe; st.probe = 0;
+      k.mod.set(k.pi, st.kap - st.h);
+    } else if (st.what == kProbe) {
+      const double f = -lnl;
+      if (st.probe == 0) { st.f0 = f; st.probe = 1; k.mod.set(k.pi, st.kap); }
+      else if (st.probe == 1) { st.f1 = f; st.probe = 2; k.mod.set(k.pi, st.kap + st.h); }
+      else {
+        const double kap = st.kap, h = st.h, f0 = st.f0, f1 = st.f1;
+        const double c = f0 - 2 * f1 + f;
+        const double kn = c > 0 ? kap + 0.5 * h * (f0 - f) / c : 0.0;
+        if (c > 0 && kn > 0.5 * kap && kn < 2.0 * kap && kn > 0.1 && kn < 100.0) { st.kap = kn; close = true; }
+        else { st.lm.start(0.1, 100.0, kap, st.round == 0 ? 4.0 : 2.0, 1e-5, 60); st.what = kSearch; k.mod.set(k.pi, st.lm.u); }
+      }
+    } else {
+      if (st.lm.feed(-lnl)) k.mod.set(k.pi, st.lm.u);
+      else { st.kap = st.lm.x; close = true; }
     }
-    // kappa: every evaluation is a pass over the whole tree.  A Newton step from three values one per cent apart (the round's closing
-    // total_lnl shows what it achieved, the next round refines it); where the curve is not convex there, or the step would more than
-    // double or halve kappa, the bracketing minimiser instead.
-    auto at_kappa = [&](double kk) {
-      k.mod.set(k.pi, kk);
-      invalidate_all(k);
-      return -total_lnl(k, ex);
-    };
-    double kap = k.mod.kappa;
-    {
-      const double h = 0.01 * kap;
-      double fs[3];
-      for (int q = 0; q < 3; q++) fs[q] = at_kappa(kap + (q - 1) * h);   // one call site: the objective's code exists once here
-      const double c = fs[0] - 2 * fs[1] + fs[2];
-      const double kn = c > 0 ? kap + 0.5 * h * (fs[0] - fs[2]) / c : 0.0;
-      if (c > 0 && kn > 0.5 * kap && kn < 2.0 * kap && kn > 0.1 && kn < 100.0) kap = kn;
-      else kap = minimise_local(at_kappa, 0.1, 100.0, kap, factor, 1e-5, 60);
-    }
-    k.mod.set(k.pi, kap);
-    invalidate_all(k);
-    const double cur = total_lnl(k, ex);
-    if (fabs(cur - prev) < 1e-4) { prev = cur; break; }
-    prev = cur;
+    if (close) { k.mod.set(k.pi, st.kap); st.what = kClose; }
   }
-  return prev;
 }
 
 // the whole fit; D must hold no data yet.  Returns the log-likelihood.

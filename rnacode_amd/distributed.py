@@ -23,24 +23,25 @@ def shard_blocks(blocks: Sequence, rank: int, world: int) -> List:
     return list(blocks[lo:hi])
 
 
-def all_gather_rows(local, counts: Sequence[int]):
+def all_gather_rows(local, counts: Sequence[int], group=None):
     """Gather per-rank tensors [n_r, width] (one row per block) into one [sum n_r, width] tensor on
     every rank, in rank order.  Equal shards use a single all_gather_into_tensor (one ring pass);
-    ragged shards are padded to the largest shard first."""
+    ragged shards are padded to the largest shard first.  group: another process group than the default one
+    (bench.py's host fallback: a gloo group beside the RCCL one)."""
     import torch
     import torch.distributed as dist
 
-    world = dist.get_world_size()
+    world = dist.get_world_size(group)
     n_max = max(counts)
     if local.shape[0] != n_max:
         pad = torch.full((n_max - local.shape[0], local.shape[1]), -1.0, dtype=local.dtype, device=local.device)
         local = torch.cat([local, pad], dim=0)
     out = torch.empty((world * n_max, local.shape[1]), dtype=local.dtype, device=local.device)
     try:
-        dist.all_gather_into_tensor(out, local.contiguous())
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
     except (RuntimeError, NotImplementedError):   # backends without the fused form
         parts = [torch.empty_like(local) for _ in range(world)]
-        dist.all_gather(parts, local.contiguous())
+        dist.all_gather(parts, local.contiguous(), group=group)
         out = torch.cat(parts, dim=0)
     if all(c == n_max for c in counts):
         return out
@@ -104,13 +105,13 @@ class OverlappedGather:
 all_gather_fits = all_gather_rows     # [n_r, 4] rows of rc_batch_fit_all
 
 
-def max_over_ranks(seconds: float, device=None) -> float:
+def max_over_ranks(seconds: float, device=None, group=None) -> float:
     """Wall time of the slowest rank (bench contract: MAX over ranks)."""
     import torch
     import torch.distributed as dist
 
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
 
 
