@@ -24,7 +24,7 @@ import numpy as np
 
 from .alnio import AlnBlock
 
-# the library asks the HIP runtime for eight hardware queues (rc_api.cpp, want_hw_queues); in a Python process torch may start the runtime
+# the library asks the HIP runtime for eight hardware queues (rc_context.cpp, want_hw_queues); in a Python process torch may start the runtime
 # first, so the request is made here as well (an explicit setting wins)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 

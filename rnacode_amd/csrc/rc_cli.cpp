@@ -33,6 +33,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <string_view>
 #include <thread>
 #include <vector>
 #include <map>
@@ -45,11 +46,14 @@
 
 namespace {
 
+// A row's name and residues are views into the input's bytes (the reader ends each with a NUL in place: no copy of a 94 MB file, no
+// 1.2 million small allocations); a ClustalW file's rows, concatenated from its pieces, live in g_owned.
 struct Row {
-  std::string name, seq;
+  std::string_view name, seq;
   int start = 0, length = 0;
   char strand = '?';
 };
+std::deque<std::string> g_owned;
 struct Block {
   std::vector<Row> rows;
   std::string tree;     // empty: none
@@ -87,20 +91,20 @@ void check_equal(const Block &b) {
 // Blocks of a MAF stream: 's' lines need exactly 7 fields; 'i', 'e', 'q' and comment lines are skipped; a block ends at the
 // next 'a' line (rnaz_utils.c:132-234).  One pass over the file's bytes, fields cut at white space in place (a 94 MB file of
 // 100 000 blocks: 0.34 s with a string per line and a stream per line's fields, the largest serial stage of the run).
-void read_maf_range(const char *p, const char *end, std::vector<Block> &out) {
+void read_maf_range(char *p, char *end, std::vector<Block> &out) {
   Block cur;
   auto space = [](char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; };
   while (p < end) {
-    const char *eol = static_cast<const char *>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
+    char *eol = static_cast<char *>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
     if (!eol) eol = end;
-    const char *f[8][2];   // up to eight fields: begin, end
+    char *f[8][2];   // up to eight fields: begin, end
     int nf = 0;
-    for (const char *q = p; q < eol;) {
+    for (char *q = p; q < eol;) {
       while (q < eol && space(*q)) q++;
       if (q >= eol) break;
-      const char *b0 = q;
+      char *b0 = q;
       if (nf == 6) {   // the seventh field of an 's' line is the sequence, nearly always the rest of the line: look for white space in bulk
-        const char *e = eol;
+        char *e = eol;
         while (e > b0 && space(e[-1])) e--;
         const size_t len = static_cast<size_t>(e - b0);
         if (!std::memchr(b0, ' ', len) && !std::memchr(b0, '\t', len) && !std::memchr(b0, '\r', len) && !std::memchr(b0, '\v', len) && !std::memchr(b0, '\f', len)) {
@@ -122,14 +126,17 @@ void read_maf_range(const char *p, const char *end, std::vector<Block> &out) {
       if (f[4][0][0] != '+' && f[4][0][0] != '-') die("Invalid MAF format (strand)");
       cur.rows.emplace_back();
       Row &r = cur.rows.back();
-      r.name.assign(f[1][0], f[1][1]); r.seq.assign(f[6][0], f[6][1]);
       r.start = std::atoi(f[2][0]); r.length = std::atoi(f[3][0]);   // (atoi stops at the white space behind the field)
       r.strand = f[4][0][0];
+      // name and residues stay where they are, each ended by a NUL in place of the white space (or line end) behind it -- the buffer
+      // has one spare byte behind its last line
+      r.name = std::string_view(f[1][0], static_cast<size_t>(f[1][1] - f[1][0])); *f[1][1] = 0;
+      r.seq = std::string_view(f[6][0], static_cast<size_t>(f[6][1] - f[6][0])); *f[6][1] = 0;
       continue;
     }
     if (tag == 'a') {
-      if (!cur.rows.empty()) { check_equal(cur); out.push_back(std::move(cur)); }
-      cur = Block();
+      if (!cur.rows.empty()) { check_equal(cur); const size_t k = cur.rows.size(); out.push_back(std::move(cur)); cur = Block(); cur.rows.reserve(k); }
+      else cur = Block();
     }
   }
   if (!cur.rows.empty()) { check_equal(cur); out.push_back(std::move(cur)); }
@@ -137,15 +144,15 @@ void read_maf_range(const char *p, const char *end, std::vector<Block> &out) {
 
 // A large file is cut at lines that start with "a" + white space -- where a block ends for the sequential reader too -- and the
 // pieces are parsed side by side.
-std::vector<Block> read_maf(const std::string &text) {
-  const char *p = text.data(), *end = p + text.size();
-  unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 8u);
-  if (text.size() < (4u << 20)) nt = 1;
-  std::vector<const char *> cut{p};
+std::vector<Block> read_maf(char *p, size_t size) {
+  char *end = p + size;
+  unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+  if (size < (4u << 20)) nt = 1;
+  std::vector<char *> cut{p};
   for (unsigned t = 1; t < nt; t++) {
-    const char *q = p + text.size() / nt * t;
+    char *q = p + size / nt * t;
     while (q + 2 < end) {
-      q = static_cast<const char *>(std::memchr(q, '\n', static_cast<size_t>(end - q)));
+      q = static_cast<char *>(std::memchr(q, '\n', static_cast<size_t>(end - q)));
       if (!q || q + 2 >= end) { q = end; break; }
       if (q[1] == 'a' && (q[2] == ' ' || q[2] == '\t' || q[2] == '\n' || q[2] == '\r')) { q++; break; }
       q++;
@@ -160,6 +167,9 @@ std::vector<Block> read_maf(const std::string &text) {
   read_maf_range(cut[0], cut[1], part[0]);
   for (auto &x : th) x.join();
   std::vector<Block> out = std::move(part[0]);
+  size_t total = out.size();
+  for (size_t t = 1; t < part.size(); t++) total += part[t].size();
+  out.reserve(total);
   for (size_t t = 1; t < part.size(); t++) for (Block &b : part[t]) out.push_back(std::move(b));
   return out;
 }
@@ -189,34 +199,69 @@ std::vector<Block> read_clustal(const std::vector<std::string> &lines) {
   std::vector<Block> out;
   if (!names.empty()) {
     Block b;
-    for (size_t i = 0; i < names.size(); i++) { Row r; r.name = names[i]; r.seq = seqs[i]; b.rows.push_back(r); }
+    for (size_t i = 0; i < names.size(); i++) {
+      Row r;
+      g_owned.push_back(names[i]); r.name = g_owned.back();
+      g_owned.push_back(seqs[i]); r.seq = g_owned.back();
+      b.rows.push_back(r);
+    }
     check_equal(b);
     out.push_back(b);
   }
   return out;
 }
 
+// The whole input in one buffer that lives as long as the process (the rows are views into it): a regular file is read by several
+// threads side by side (pread), anything else as it comes.
 std::vector<Block> read_alignment(FILE *in) {
-  std::string text;
+  char *text = nullptr;
+  size_t size = 0;
   struct stat sp;
-  if (fstat(fileno(in), &sp) == 0 && S_ISREG(sp.st_mode) && sp.st_size > 0) {   // a regular file: one read into a buffer of its size
-    text.resize(static_cast<size_t>(sp.st_size));
-    const size_t got = std::fread(&text[0], 1, text.size(), in);
-    text.resize(got);
+  const int fd = fileno(in);
+  if (fstat(fd, &sp) == 0 && S_ISREG(sp.st_mode) && sp.st_size > 0) {
+    size = static_cast<size_t>(sp.st_size);
+    text = static_cast<char *>(std::malloc(size + 1));
+    if (!text) die("out of memory");
+    const unsigned nt = size < (8u << 20) ? 1u : std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 8u);
+    std::vector<size_t> got(nt, 0);
+    auto piece = [&](unsigned t) {
+      size_t lo = size / nt * t, hi = t + 1 == nt ? size : size / nt * (t + 1), at = lo;
+      while (at < hi) {
+        const ssize_t k = pread(fd, text + at, hi - at, static_cast<off_t>(at));
+        if (k <= 0) break;
+        at += static_cast<size_t>(k);
+      }
+      got[t] = at - lo;
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(piece, t);
+    piece(0);
+    for (auto &x : th) x.join();
+    size_t have = 0;
+    for (unsigned t = 0; t < nt; t++) { const size_t want = (t + 1 == nt ? size : size / nt * (t + 1)) - size / nt * t; have += got[t]; if (got[t] != want) break; }
+    size = have;   // (a file that shrank while it was read: what came in order)
+  } else {
+    size_t cap = 1 << 20;
+    text = static_cast<char *>(std::malloc(cap + 1));
+    if (!text) die("out of memory");
+    for (size_t k; (k = std::fread(text + size, 1, cap - size, in)) > 0;) {
+      size += k;
+      if (size == cap) { cap *= 2; text = static_cast<char *>(std::realloc(text, cap + 1)); if (!text) die("out of memory"); }
+    }
   }
-  char buf[1 << 16];
-  for (size_t k; (k = std::fread(buf, 1, sizeof buf, in)) > 0;) text.append(buf, k);
-  if (std::getenv("RC_CLI_TIMES")) std::fprintf(stderr, "[rnacode_hip] %.1f MB in memory at %.3f s\n", text.size() / 1e6, now() - g_t0);
-  size_t at = text.find_first_not_of(" \t\r\n");
-  if (at != std::string::npos) at = text.rfind('\n', at) == std::string::npos ? 0 : text.rfind('\n', at) + 1;   // start of the first non-blank line
-  if (at != std::string::npos && text.compare(at, 7, "CLUSTAL") == 0) {
+  text[size] = 0;
+  if (std::getenv("RC_CLI_TIMES")) std::fprintf(stderr, "[rnacode_hip] %.1f MB in memory at %.3f s\n", size / 1e6, now() - g_t0);
+  const std::string_view all(text, size);
+  size_t at = all.find_first_not_of(" \t\r\n");
+  if (at != std::string_view::npos) at = all.rfind('\n', at) == std::string_view::npos ? 0 : all.rfind('\n', at) + 1;   // start of the first non-blank line
+  if (at != std::string_view::npos && all.compare(at, 7, "CLUSTAL") == 0) {
     std::vector<std::string> lines;
-    std::istringstream is(text);
+    std::istringstream is(std::string(text, size));
     std::string line;
     while (std::getline(is, line)) lines.push_back(line);
     return read_clustal(lines);
   }
-  return read_maf(text);
+  return read_maf(text, size);
 }
 
 // printResults (misc.c:392-552); the HSS counter runs across blocks and is not advanced after a --best-only break
@@ -382,7 +427,7 @@ void writer_thread(Run &R) {
         std::fprintf(stderr, "Skipping alignment. Failed to build ML tree. (%s)\n", j->why[i].empty() ? "not scored" : j->why[i].c_str());
         continue;
       }
-      R.list.block(std::vector<rc_hss>(j->hss.begin() + j->offs[i], j->hss.begin() + j->offs[i + 1]), blk.rows[0].name,
+      R.list.block(std::vector<rc_hss>(j->hss.begin() + j->offs[i], j->hss.begin() + j->offs[i + 1]), std::string(blk.rows[0].name),
                    j->eps.empty() ? nullptr : &j->eps[i]);
     }
     R.tList += now() - t;
@@ -402,7 +447,7 @@ std::vector<std::string> draw_block(const Run &R, rc_batch *b, int i, const Bloc
   R.list.arrange(res, hide, order);
   std::vector<std::string> texts;
   std::vector<rceps::Row> rows;
-  for (const Row &r : blk.rows) rows.push_back(rceps::Row{r.name, r.seq, r.start});
+  for (const Row &r : blk.rows) rows.push_back(rceps::Row{std::string(r.name), std::string(r.seq), r.start});
   const int cols = static_cast<int>(blk.rows[0].seq.size()), N = static_cast<int>(blk.rows.size());
   for (size_t idx : R.list.listed(res, hide, order)) {
     const rc_hss &h = res[idx];
@@ -731,7 +776,7 @@ int main(int argc, char **argv) {
   for (int i = 0; i < nRead; i++) blocks[i].index = i;
   if (std::getenv("RC_CLI_TIMES")) std::fprintf(stderr, "[rnacode_hip] %d blocks read and parsed in %.3f s\n", nRead, now() - tRead);
   if (list.eps)   // the plots show the rows as main() leaves them: upper-cased (RNAcode.c:121-128; the library upper-cases its own copy)
-    for (Block &b : blocks) for (Row &r : b.rows) for (char &c : r.seq) c = static_cast<char>(std::toupper(static_cast<unsigned char>(c)));
+    for (Block &b : blocks) for (Row &r : b.rows) for (size_t x = 0; x < r.seq.size(); x++) { char &c = const_cast<char &>(r.seq[x]); c = static_cast<char>(std::toupper(static_cast<unsigned char>(c))); }
   if (!limit.empty()) {   // pruneAln (rnaz_utils.c:724-752, RNAcode.c:130-132): rows whose name starts with a listed string stay
     std::vector<std::string> keep;
     std::stringstream ss(limit);
@@ -755,7 +800,7 @@ int main(int argc, char **argv) {
   if (dumpBlocks) {   // reader check (tests): what was parsed, one record per row, no device needed
     for (int i = 0; i < n; i++) {
       std::printf("B %d\n", i);
-      for (const Row &r : blocks[i].rows) std::printf("S %s %d %d %c %s\n", r.name.c_str(), r.start, r.length, r.strand, r.seq.c_str());
+      for (const Row &r : blocks[i].rows) std::printf("S %s %d %d %c %s\n", r.name.data(), r.start, r.length, r.strand, r.seq.data());
       std::printf("E\n");
     }
     return 0;
@@ -794,7 +839,7 @@ int main(int argc, char **argv) {
   std::vector<std::vector<const char *>> rowPtr(n), namePtr(n);
   R.rb.resize(n);
   for (int i = 0; i < n; i++) {
-    for (const Row &r : blocks[i].rows) { rowPtr[i].push_back(r.seq.c_str()); namePtr[i].push_back(r.name.c_str()); }
+    for (const Row &r : blocks[i].rows) { rowPtr[i].push_back(r.seq.data()); namePtr[i].push_back(r.name.data()); }   // (NUL-terminated: see Row)
     rc_block &b = R.rb[i];
     std::memset(&b, 0, sizeof b);
     b.n_rows = static_cast<int>(blocks[i].rows.size());

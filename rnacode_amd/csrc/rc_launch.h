@@ -1,4 +1,4 @@
-// rc_launch.h -- kernel argument blocks and launcher prototypes (rc_kernels.hip <-> rc_api.cpp).
+// rc_launch.h -- kernel argument blocks and launcher prototypes (the .hip units <-> rc_schedule.cpp, rc_batch.cpp, rc_trees_api.cpp).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -44,7 +44,6 @@ struct NullArgs {
   int plainLds;               // host only: dynamic LDS bytes of a launch that reads its codes from L2 (phase A's tables, then the suffix cache); 0: the default
   int hiOcc;                  // host only: 1 = launch k_null_occ (one more wavefront per SIMD), where this N-1 has one
   int dual;                   // 1: the instantiation that walks two rows of S per pass (N-1 <= kDualRowsMaxNK, codes staged in LDS)
-  int stealRelease;           // how a late item's codes are published to helpers: 0 workgroup-scope release (same-XCD helpers read them from the shared L2), 1 agent-scope release (the documented cross-CU form: writes the L2's dirty lines back)
   int stealWait;              // 1: a workgroup without work waits for owners that are still simulating a late item; 0: it leaves at once (a stream: the next sub-batch's workgroups want its place)
   int debugSkip;              // RC_PROFILING builds only: bit0 skip the DP/scan phase, bit1 skip simulation
   unsigned long long *cellStats;   // RC_PROFILING builds only: [0] wavefront-cells, [1] of those with no lane's sum > 0, [2] lanes with sum > 0, [3..5] cells before the row's first event / at events / after its last
@@ -114,15 +113,20 @@ struct TreeJob {
   uint64_t off_work;          // doubles into the scratch: tree_work_doubles(N, P) -- only jobs of the big-block launches have one
   uint64_t off_out;           // doubles into the result buffer: the job's TreeResult record (tree_result_doubles(N) doubles)
 };
+#ifdef RC_TREE_PROFILE
+constexpr int kTreeProfDoubles = 12;   // profiling builds: cycles of phases 0..8 and counters 9..11 behind every record
+#else
+constexpr int kTreeProfDoubles = 0;
+#endif
 // What travels back to the host per job, nn = 2N - 2 nodes: doubles {kappa, lnl, len[nn]} then ints {root, nchild[nn], child[3 nn]}
 // (260 bytes for six rows)
-inline size_t tree_result_doubles(int N) { const size_t nn = 2 * static_cast<size_t>(N) - 2; return 2 + nn + (1 + 4 * nn + 1) / 2; }
+__host__ __device__ inline size_t tree_result_doubles(int N) { const size_t nn = 2 * static_cast<size_t>(N) - 2; return 2 + nn + (1 + 4 * nn + 1) / 2 + kTreeProfDoubles; }
 // A fit's working set, as offsets (in doubles) into the workgroup's LDS.  Always there: branch lengths, the five transfer constants
 // and three exponentials per branch, BIONJ's D and V and its temporaries, the tree as integer arrays.  With cols: the pattern weights,
 // the conditional-likelihood columns -- dn and up of the N - 3 internal nodes below the root, [4][P] each, and the four Newton
 // constants per pattern -- and the masks; a block whose columns do not fit keeps those three in global memory (big).
 struct TreeLdsLayout { uint32_t len, coef, e3, D, V, tmpD, opt, ints, w, cols, mask, total; };
-constexpr uint32_t kTreeOptDoubles = 40;   // room for treefit::OptState (rc_tree_kernel.hip asserts it)
+constexpr uint32_t kTreeOptDoubles = 32 + kTreeProfDoubles;   // room for treefit::OptState (rc_tree_kernel.hip asserts it), profiling builds: and the phase counters
 __host__ __device__ inline size_t tree_col_doubles(int N, int P) { return (static_cast<size_t>(2) * (N > 3 ? N - 3 : 0) * 4 + 4) * static_cast<size_t>(P); }
 __host__ __device__ inline TreeLdsLayout tree_lds_layout(int N, int P, bool big) {
   const uint32_t n = static_cast<uint32_t>(N), nn = 2 * n - 2, p = static_cast<uint32_t>(P);
@@ -154,6 +158,7 @@ inline size_t tree_fit_lds_bytes(int N, int P, bool big) {   // (64-bit: a block
 // a big-block job's work area in global memory: the columns
 inline size_t tree_work_doubles(int N, int P) { return tree_col_doubles(N, P); }
 int tree_fit_max_lds();   // bytes of LDS one workgroup may ask for on the current device
+int tree_fit_register_occupancy();   // workgroups per CU the kernel's registers allow (no LDS asked for)
 // one launch: jobs that share a storage class and an LDS request; false if the device refuses that much LDS
 bool launch_tree_fit(const TreeJob *jobs, int njobs, bool big, size_t ldsBytes, const uint8_t *in, double *scratch, double *results, hipStream_t stream);
 

@@ -444,18 +444,11 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
         __hip_atomic_store(A.steal + kStealHdr + G + 2 * blockIdx.x, static_cast<unsigned int>(bi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(A.steal + kStealHdr + G + 2 * blockIdx.x + 1, static_cast<unsigned int>(grp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      // Publishing the codes: an agent-scope release (A.stealRelease = 1, the default) is the documented hand-off to another CU
-      // (MI355X_MICROARCH.md, inter-workgroup visibility): it writes this XCD's dirty L2 lines back.  The codes only have to reach
-      // this XCD's L2, though -- helpers are taken from the same XCD, and the L1 writes through --, so a workgroup-scope release
-      // (RC_TAIL_RELEASE=workgroup) does in practice on gfx942 / gfx950 what is needed, without the write-back: measured 1-1.5 %
-      // faster on a stream of small sub-batches (1250-block shard 7.8 against 7.9 ms per pass, 313 resident blocks 1.91 against
-      // 1.94 ms), nothing on a 10 000-block batch.  Not worth an undocumented dependency: kept as a switch, and
-      // tests/test_gpu_stream.py::test_tail_sharing_stress_every_item_late holds both forms to bit-identical results.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
-#error "k_null's tail sharing publishes with a workgroup-scope release; that is only known to reach other CUs on gfx942 / gfx950"
-#endif
-      if (A.stealRelease) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      // Publishing the codes: an agent-scope release, the documented hand-off to another CU (MI355X_MICROARCH.md, inter-workgroup
+      // visibility): it writes this XCD's dirty L2 lines back.  (Helpers are taken from the owner's XCD and the L1 writes through, so a
+      // workgroup-scope release did in practice on gfx950 what is needed, 1-1.5 % faster on streams of small sub-batches, nothing on
+      // 10 000 blocks -- profiles/r04/ab_tail_release.txt; not worth an undocumented dependency, and removed in round 5.)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       __builtin_amdgcn_s_waitcnt(0);
       if (lane == 0) {
         atomicExch(A.steal + kStealHdr + blockIdx.x, 1u);
@@ -611,15 +604,6 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
             if constexpr (!LDSC && !EXACT && t == 0) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[k / CPW]) : "n"(NCW - 1 - k / CPW));
             uint32_t addr;
             if constexpr (t == 0) addr = w[k / CPW]; else addr = w[k / CPW] >> (6 * t);   // bits [7:2] select the lane
-            // timing experiments, never in the product build (wrong results; tools/ab_lookup.sh): what the address shifts and the
-            // look-ups themselves cost -- -DRC_EXP_NO_SHIFTS: every look-up uses the unshifted word; -DRC_EXP_ONE_LOOKUP: one
-            // ds_bpermute per cell instead of one per sequence (the shifts stay)
-#ifdef RC_EXP_NO_SHIFTS
-            addr = w[k / CPW];
-#endif
-#ifdef RC_EXP_ONE_LOOKUP
-            if constexpr (k > 0) { asm volatile("" : : "v"(addr)); sig[k] = sig[0]; return; }
-#endif
             float got;
             if constexpr (kTableLookups) {
               uint32_t at;
@@ -1194,7 +1178,7 @@ void k_null(NullArgs A, const uint8_t *__restrict__ blob,
 // registers allow by themselves: 6..8 other sequences (81-85 VGPRs) for six (80 VGPRs, a handful of spills: 24 workgroups per CU
 // instead of 20), 10..12 (101-113 VGPRs) for five (96 VGPRs: 20 instead of 16).  Round 3 measured +1..7 % on uniform batches and
 // -5 % on a stream of ten row-count classes, whose native-block, table and fit kernels ran in the registers these wavefronts take --
-// so the host launches it only for batches of ONE row-count class (rc_api.cpp, high_occupancy_class).
+// so the host launches it only for batches of ONE row-count class (rc_schedule.cpp, plain_plan).
 constexpr int hi_occ_waves(int NK) { return (NK >= 6 && NK <= 8) ? 6 : (NK >= 10 && NK <= 12) ? 5 : 0; }
 template <int NK>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(hi_occ_waves(NK) ? hi_occ_waves(NK) : 1)))

@@ -30,6 +30,8 @@ struct SerialExec {
   void sum2(double &, double &) const {}
   void exp3(double x0, double x1, double x2, double &e0, double &e1, double &e2) const { e0 = std::exp(x0); e1 = std::exp(x1); e2 = std::exp(x2); }
   void sync() const {}
+  void mark(int) const {}
+  void count(int) const {}
   int broadcast_root(int r) const { return r; }
 };
 
@@ -145,11 +147,6 @@ bool fit_tree(const std::vector<std::string> &rows, const std::vector<std::strin
   f.allocate(2 * ps.N - 2);
   SerialExec ex;
   const double l = treefit::fit(f.k, ex);
-  if (std::getenv("RC_TREE_DEBUG")) {   // every bit of the result (A/B runs of the estimator: tools/tree_bits.py)
-    std::fprintf(stderr, "freqs %.17g %.17g %.17g %.17g lnl %.17g kappa %.17g len", f.k.pi[0], f.k.pi[1], f.k.pi[2], f.k.pi[3], l, f.k.mod.kappa);
-    for (int v = 0; v < f.k.nn; v++) std::fprintf(stderr, " %.17g", f.k.len[v]);
-    std::fprintf(stderr, "\n");
-  }
   newick = newick_of(ps.N, f.k.root, f.k.nchild, f.k.child, f.k.len, names);
   kappa = static_cast<float>(f.k.mod.kappa);
   if (lnl_out) *lnl_out = l;

@@ -8,8 +8,9 @@
 // branch lengths and kappa on that topology; ambiguity codes as partial information, gaps as missing.
 //
 // Exec supplies: lane(), nlanes() (site patterns p = lane, lane + nlanes, ... belong to a lane for the
-// whole fit, so per-pattern arrays need no synchronisation), sum(x) (the same total on every lane),
-// sync() (makes lane 0's serial work visible).
+// whole fit, so per-pattern arrays need no synchronisation), sum(x) / sum2(a, b) (the same totals on every lane),
+// exp3 (three exponentials at once), sync() (makes lane 0's serial work visible), mark(phase) / count(counter)
+// (profiling builds of the kernel: cycles per phase, see tools/tree_phases.sh; nothing otherwise).
 #pragma once
 #include <cmath>
 #include <cstdint>
@@ -517,6 +518,7 @@ RC_HD double edge_newton(const Work &k, Exec &ex, double t) {
   const double *k0 = k.kc, *k1 = k.kc + k.P, *k2 = k.kc + 2 * static_cast<size_t>(k.P), *k3 = k.kc + 3 * static_cast<size_t>(k.P);
   for (int it = 0; it < 40; it++) {
     double e1, eR, eY, g = 0, h = 0;
+    ex.count(10);
     ex.exp3(-b * t, -b * cR * t, -b * cY * t, e1, eR, eY);
     for (int p = ex.lane(); p < k.P; p += ex.nlanes()) {
       const double A = k1[p] * e1, B = k2[p] * eR, C = k3[p] * eY;
@@ -554,8 +556,11 @@ template <typename Exec>
 RC_HD void branch_pass(Work &k, Exec &ex) {
   for (int o = 1; o < k.nn; o++) {
     const int v = k.preorder[o];
+    ex.mark(7);
     branch_constants(k, ex, v);
+    ex.mark(5);
     const double t = edge_newton(k, ex, k.len[v]);
+    ex.mark(6);
     double e1, eR, eY;
     ex.exp3(-k.mod.beta * t, -k.mod.beta * k.mod.c[0] * t, -k.mod.beta * k.mod.c[1] * t, e1, eR, eY);
     k.len[v] = t;                          // (every lane stores the same values)
@@ -564,6 +569,7 @@ RC_HD void branch_pass(Work &k, Exec &ex) {
     const int stop = o + 1 < k.nn ? k.parent[k.preorder[o + 1]] : k.root;
     for (int a = v; a != stop; a = k.parent[a]) if (a >= k.N) refresh_down_node(k, ex, a);
   }
+  ex.mark(7);
 }
 
 // coordinate-wise ML: every branch, then kappa, until the log-likelihood moves by less than 1e-4
@@ -581,13 +587,16 @@ RC_HD double optimise(Work &k, Exec &ex) {
   st.prev = 0; st.kap = k.mod.kappa; st.h = 0; st.f0 = 0; st.f1 = 0;
   for (;;) {
     ex.sync();
+    ex.mark(8);
     const double lnl = total_lnl(k, ex);
+    ex.mark(4); ex.count(9);
     bool close = false;
     if (st.what == kClose) {
       if (st.round >= 0 && fabs(lnl - st.prev) < 1e-4) return lnl;
       st.prev = lnl;
       if (++st.round >= 60) return lnl;
       ex.sync();
+      ex.count(11);
       branch_pass(k, ex);
       st.kap = k.mod.kappa; st.h = 0.01 * st.kap;
       st.what = kProbe; st.probe = 0;
@@ -614,7 +623,9 @@ RC_HD double optimise(Work &k, Exec &ex) {
 // the whole fit; D must hold no data yet.  Returns the log-likelihood.
 template <typename Exec>
 RC_HD double fit(Work &k, Exec &ex) {
+  ex.mark(0);
   base_freqs(k, ex);
+  ex.mark(1);
   k.mod.set(k.pi, 4.0);   // treeML.c:75
   const int N = k.N, npairs = N * (N - 1) / 2;
   for (int q = ex.lane(); q < npairs; q += ex.nlanes()) {   // pair q -> (i, j), i < j
@@ -625,6 +636,7 @@ RC_HD double fit(Work &k, Exec &ex) {
     k.D[i * N + j] = k.D[j * N + i] = d;
   }
   ex.sync();
+  ex.mark(2);
   if (ex.lane() == 0) {
     double dmax = 0;
     for (int i = 0; i < N; i++) { k.D[i * N + i] = 0; for (int j = 0; j < N; j++) if (i != j && k.D[i * N + j] > dmax) dmax = k.D[i * N + j]; }
@@ -633,6 +645,7 @@ RC_HD double fit(Work &k, Exec &ex) {
   }
   ex.sync();
   k.root = ex.broadcast_root(k.root);
+  ex.mark(3);
   return optimise(k, ex);
 }
 

@@ -45,7 +45,25 @@ __device__ __forceinline__ double wave_sum(double v) {
   return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 
+// -DRC_TREE_PROFILE (tools/tree_phases.sh builds it into tools/, never the product): cycles per phase of the fit and three counters,
+// appended to every job's result record (kTreeProfDoubles doubles) and summed by rc_fit_trees_device
+#ifdef RC_TREE_PROFILE
+constexpr bool kTreeProfile = true;
+#else
+constexpr bool kTreeProfile = false;
+#endif
+
 struct WaveExec {
+  double *prof = nullptr;          // [kTreeProfDoubles] in LDS
+  long long last = 0;
+  __device__ void mark(int phase) {
+    if constexpr (kTreeProfile) {
+      const long long now = clock64();
+      if (threadIdx.x == 0) prof[phase] += static_cast<double>(now - last);
+      last = now;
+    }
+  }
+  __device__ void count(int c) { if constexpr (kTreeProfile) { if (threadIdx.x == 0) prof[c] += 1.0; } }
   __device__ int lane() const { return static_cast<int>(threadIdx.x); }
   __device__ int nlanes() const { return kWave; }
   __device__ double sum(double x) const { return wave_sum(x); }
@@ -95,7 +113,15 @@ __device__ __forceinline__ void tree_fit_body(const TreeJob *jobs, const uint8_t
     __syncthreads();
   }
   WaveExec ex;
+  if constexpr (kTreeProfile) {
+    ex.prof = d + lay.opt + kTreeOptDoubles - kTreeProfDoubles;   // the tail of the optimiser-state slot
+    static_assert(sizeof(treefit::OptState) <= (kTreeOptDoubles - kTreeProfDoubles) * sizeof(double), "no room for the profile");
+    if (threadIdx.x < kTreeProfDoubles) ex.prof[threadIdx.x] = 0.0;
+    __syncthreads();
+    ex.last = clock64();
+  }
   const double lnl = treefit::fit(k, ex);
+  if constexpr (kTreeProfile) ex.mark(8);
   // the compact result record (rc_launch.h, tree_result_doubles)
   double *rd = results + j.off_out;
   int *ri = reinterpret_cast<int *>(rd + 2 + nn);
@@ -104,6 +130,11 @@ __device__ __forceinline__ void tree_fit_body(const TreeJob *jobs, const uint8_t
     rd[2 + v] = k.len[v];
     ri[1 + v] = k.nchild[v];
     for (int c = 0; c < 3; c++) ri[1 + nn + 3 * v + c] = k.child[3 * v + c];
+  }
+  if constexpr (kTreeProfile) {
+    __syncthreads();
+    double *pd = rd + tree_result_doubles(N) - kTreeProfDoubles;
+    if (threadIdx.x < kTreeProfDoubles) pd[threadIdx.x] = ex.prof[threadIdx.x];
   }
 }
 
@@ -122,6 +153,15 @@ int tree_fit_max_lds() {
     return v;
   }();
   return cap;
+}
+
+int tree_fit_register_occupancy() {
+  static const int occ = [] {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_tree_fit<false>, kWave, 0) != hipSuccess || nb <= 0) { (void)hipGetLastError(); nb = 8; }
+    return nb;
+  }();
+  return occ;
 }
 
 bool launch_tree_fit(const TreeJob *jobs, int njobs, bool big, size_t ldsBytes, const uint8_t *in, double *scratch, double *results, hipStream_t stream) {

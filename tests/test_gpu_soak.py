@@ -43,12 +43,12 @@ def test_soak_slice(monkeypatch, mode, env, blocks):
 
 
 KNOBS = [
-    {"RC_TAIL_SHARING": "0"}, {"RC_TAIL_RELEASE": "workgroup"}, {"RC_DUAL_ROWS": "0"}, {"RC_NATIVE_FIRST": "0"}, {"RC_NATIVE_FIRST": "1"},
-    {"RC_FAT_STREAM_MIN_ITEMS": "0"}, {"RC_COPY_RESULTS": "1"}, {"RC_COMPUTE_STREAMS": "1"}, {"RC_COMPUTE_STREAMS": "3"},
+    {"RC_TAIL_SHARING": "0"}, {"RC_FAT_STREAM_MIN_ITEMS": "0"},
     {"RC_HOST_THREADS": "1", "RC_SPLIT_FACTOR": "0"}, {"RC_SPLIT_FACTOR": "100"}, {"RC_NATIVE_WAVES_PER_CU": "1"},
     {"RC_NATIVE_WAVES_PER_CU": "32"}, {"RC_TOGETHER_MAX_MB": "0"}, {"RC_STOP_ROUNDS": "6", "RC_STOP_MIN_ITEMS": "0"},
     {"RC_GENERIC_MIN_ROWS": "3"}, {"RC_LDS_MAX_BYTES": "0"}, {"RC_LDS_MAX_BYTES": "65536"}, {"RC_GRID_CAP_PER_CU": "2"},
-    {"RC_GENERIC_SCRATCH_MB": "64"}, {"RC_SERIAL_NATIVE": "1"}, {"RC_SUFFIX_CACHE": "0"}, {"RC_HIGH_OCCUPANCY": "0"}, {"RC_HIGH_OCCUPANCY": "2"}, {"RC_BUFFER_POOL": "0"}, {"RC_DUAL_FROM_L2": "0"}, {"RC_DUAL_FROM_L2": "2"}, {"RC_NATIVE_SCAN_LANES": "0"}, {"RC_GENERIC_SPLIT": "0"},
+    {"RC_GENERIC_SCRATCH_MB": "64"}, {"RC_SERIAL_NATIVE": "1"}, {"RC_HIGH_OCCUPANCY": "0"}, {"RC_HIGH_OCCUPANCY": "2"},
+    {"RC_TREE_LDS_MAX": "0"}, {"GPU_MAX_HW_QUEUES": "2"},
 ]
 
 

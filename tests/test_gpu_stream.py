@@ -259,10 +259,11 @@ def test_stream_plan_sizes(ctx):
     whole.close()
 
 
-def test_native_scan_by_lanes_equals_the_fused_scan_and_the_oracle(monkeypatch):
-    """Batches of >= 64 blocks leave getHSS of the native block to k_native_scan (one lane per strand x frame matrix); smaller ones and
-    RC_NATIVE_SCAN_LANES=0 keep it inside k_native_dp (one wavefront per matrix).  Same HSS tables either way -- coding-like blocks with
-    many positive entries, random ones, different lengths in one class -- and equal to the oracle's on a sample of the blocks."""
+def test_native_scan_by_lanes_equals_the_fused_scan_and_the_oracle():
+    """Batches of >= 64 blocks per class leave getHSS of the native block to k_native_scan (one lane per strand x frame matrix); smaller
+    ones keep it inside k_native_dp (one wavefront per matrix).  The same blocks as one large batch and in slices of 40 give the same
+    HSS tables -- coding-like blocks with many positive entries, random ones, different lengths in one class -- equal to the oracle's on
+    a sample of the blocks."""
     from oracle import binding as ob
     from rnacode_amd import api
     from rnacode_amd.synth import synth_block, synth_blocks
@@ -272,19 +273,17 @@ def test_native_scan_by_lanes_equals_the_fused_scan_and_the_oracle(monkeypatch):
                for i in range(150)]                                   # short branches: conserved, long positive stretches
     blocks += [b.upper() for b in synth_blocks(80, 9, 60, seed=32)]    # a second class in the same batch
     p = api.default_params(sampleN=64, seed_base=3)
+    ctx = api.Context(0)
 
-    def tables(env):
-        if env is None:
-            monkeypatch.delenv("RC_NATIVE_SCAN_LANES", raising=False)
-        else:
-            monkeypatch.setenv("RC_NATIVE_SCAN_LANES", env)
-        ctx = api.Context(0)
-        batch = api.Batch(ctx, blocks, p).run()
-        out = [[(h["strand"], h["frame"], h["start"], h["end"], np.float32(h["score"])) for h in sorted(batch.scoreAln(i), key=hss_key)] for i in range(len(blocks))]
-        batch.close(); ctx.close()
+    def tables(sub):
+        batch = api.Batch(ctx, sub, p).run()
+        out = [[(h["strand"], h["frame"], h["start"], h["end"], np.float32(h["score"])) for h in sorted(batch.scoreAln(i), key=hss_key)] for i in range(len(sub))]
+        batch.close()
         return out
 
-    lanes, fused = tables(None), tables("0")
+    lanes = tables(blocks)
+    fused = [t for lo in range(0, len(blocks), 40) for t in tables(blocks[lo:lo + 40])]
+    ctx.close()
     assert lanes == fused
     assert sum(len(t) for t in lanes) > 5 * len(blocks)
     op = ob.default_params(64)
@@ -704,32 +703,34 @@ def test_tail_sharing_on_and_off_give_the_same_results(monkeypatch):
         np.testing.assert_array_equal(got[(name, "1")][0][i][:64], np.float32(want.maxScores))
 
 
-def test_two_rows_per_pass_equal_one_row_per_pass_and_the_oracle(monkeypatch):
+def test_two_rows_per_pass_equal_one_row_per_pass_and_the_oracle():
     """k_null<N-1, true, false, DUAL>: rows a and a + 1 of S share their sigma look-ups, row a + 1's values wait in
     a 32-register buffer.  Batches of ONE row count each (3..6 rows: the classes that take the two-row kernel; a batch of such classes
     only also runs its native-block kernels first), gapped blocks of 30..156 columns -- up to 52 codon sites, so rows longer than the
     buffer (their first cells are made twice), rows whose first site is a frame-shift event (they go alone) and pairs that change
-    their cell kind together all occur.  RC_DUAL_ROWS=0 must give the same maxima, fits and HSS tables bit for bit, and a sample of
-    blocks must equal the CPU oracle."""
+    their cell kind together all occur.  The same blocks in a batch that also holds a class of eight rows are scored by the one-row
+    kernels (the two-row ones run only where nothing shares their SIMDs): same maxima, fits and HSS tables bit for bit, and a sample
+    of blocks must equal the CPU oracle."""
     from oracle import binding as ob
     from rnacode_amd import api
     from rnacode_amd.synth import synth_block
     rng = np.random.RandomState(123)
     cases = {n: [synth_block(rng, n, int(rng.randint(30, 157)), index=i, gaps=True).upper() for i in range(260)] for n in (3, 4, 5, 6)}
+    other = [synth_block(rng, 8, 60, index=i, gaps=True).upper() for i in range(4)]
     kw = dict(sampleN=600, seed_base=17)   # 2600 (block, 64-sample) items: whole items, not their strand x frame parts
     got = {}
-    monkeypatch.delenv("RC_NATIVE_FIRST", raising=False)   # (0 would forbid the two-row kernel for these classes: the name check below wants it)
-    for dual in ("1", "0"):
-        monkeypatch.setenv("RC_DUAL_ROWS", dual)
-        c = api.Context(0)
-        for n, blocks in cases.items():
-            b = api.Batch(c, blocks, api.default_params(**kw)).run()
-            got[(n, dual)] = (b.maxScores_all().copy(), b.fits().copy(), [b.scoreAln(i) for i in range(0, b.n, 11)], b.null_kernel())
+    c = api.Context(0)
+    for n, blocks in cases.items():
+        for dual in ("1", "0"):
+            b = api.Batch(c, blocks + (other if dual == "0" else []), api.default_params(**kw)).run()
+            m = len(blocks)
+            got[(n, dual)] = (b.maxScores_all()[:m].copy(), b.fits()[:m].copy(), [b.scoreAln(i) for i in range(0, m, 11)], b.null_kernel())
             b.close()
-        c.close()
+    c.close()
     for n, blocks in cases.items():
         on, off = got[(n, "1")], got[(n, "0")]
-        assert on[3].endswith(", true>") and off[3].endswith(", false>"), (on[3], off[3])   # the two instantiations really ran
+        # the two instantiations really ran (three rows: two other sequences leave a quarter of the registers free, always two-row)
+        assert on[3].endswith(", true>") and off[3].endswith(", true>" if n == 3 else ", false>"), (on[3], off[3])
         np.testing.assert_array_equal(on[0], off[0], err_msg=f"{n} rows")
         np.testing.assert_array_equal(on[1], off[1], err_msg=f"{n} rows (fits)")
         assert on[2] == off[2]
@@ -741,10 +742,8 @@ def test_two_rows_per_pass_equal_one_row_per_pass_and_the_oracle(monkeypatch):
 
 
 def test_tail_sharing_stress_every_item_late(monkeypatch):
-    """k_null's tail sharing hands an owner's sigma codes to helper workgroups of the same XCD: by default behind an agent-scope
-    release (the documented cross-CU hand-off), with RC_TAIL_RELEASE=workgroup behind a workgroup-scope one (the L1 writes through,
-    owner and helper share an L2: what gfx950 does, not what the memory model promises).  This is the tripwire
-    for both.  One workgroup per CU (RC_GRID_CAP_PER_CU=1) and a little more than one item per workgroup, no strand x frame split:
+    """k_null's tail sharing hands an owner's sigma codes to helper workgroups of the same XCD behind an agent-scope release (the
+    documented cross-CU hand-off).  This is its tripwire.  One workgroup per CU (RC_GRID_CAP_PER_CU=1) and a little more than one item per workgroup, no strand x frame split:
     EVERY item is late, is published, and has its six parts claimed by its owner and by the workgroups that found the queues empty --
     on every launch, hundreds of launches, the staging scratch rewritten with other blocks' codes each time (a stream recycles its
     three batch objects; resident batches are re-run in turn), both code-word paths (LDS-staged and from L2).  Every launch must
@@ -771,8 +770,7 @@ def test_tail_sharing_stress_every_item_late(monkeypatch):
     c0.close()
     monkeypatch.setenv("RC_TAIL_SHARING", "1")
     launches = 0
-    for release in ("workgroup", "agent"):
-        monkeypatch.setenv("RC_TAIL_RELEASE", release)
+    for release in ("agent", "agent, second context"):
         c = api.Context(0)
         st = api.Stream(c, p, 3)
         for rep in range(14):                                             # streamed: helpers leave at once (stealWait = 0)
