@@ -227,14 +227,29 @@ def file_leg(api, ctx, key, min_s=1.0):
                 batch.scoreAln(i)
         batch.close()
 
+    stages = {"create": 0.0, "run": 0.0, "results": 0.0, "close": 0.0, "device_null": 0.0, "device_native": 0.0, "device_fit": 0.0, "files": 0}
+
     def per_block():
+        # (the stage sums: host wall time of create = prepare + upload + table kernels, run = every launch until the results are on the
+        # host, results = HSS list + fit, close; and inside run the device's own intervals of the sampling launch, the native block's
+        # kernels -- which run beside it -- and the fit)
+        pc = time.perf_counter
         for b in scored:
+            t0 = pc()
             batch = api.Batch(ctx, [b], params)      # make_batch (getModels, first call)
             batch.getModels(0)
+            t1 = pc()
             batch.run()                              # scoreAln
+            t2 = pc()
             batch.scoreAln(0)
             batch.getExtremeValuePars(0)             # getExtremeValuePars
+            t3 = pc()
+            tt, _ = batch.timing()
             batch.close()
+            t4 = pc()
+            stages["create"] += t1 - t0; stages["run"] += t2 - t1; stages["results"] += t3 - t2; stages["close"] += t4 - t3
+            stages["device_null"] += tt["null"] * 1e-3; stages["device_native"] += tt["native"] * 1e-3; stages["device_fit"] += tt["evd_fit"] * 1e-3
+        stages["files"] += 1
 
     out = {"workload": desc, "blocks": len(blocks), "scored_blocks": len(scored), "samples": n, "units": units, "unit": "alignment-columns*samples/s"}
     for label, fn in (("batch", as_batch), ("per_block_shim_sequence", per_block)):
@@ -242,6 +257,8 @@ def file_leg(api, ctx, key, min_s=1.0):
         dt, k = timed_region(fn, min_s, min_steps=200 if label == "batch" else 3)
         sp = spread()
         out[label] = {"ms_per_file": sp["median"], "ms_per_file_spread": sp, "files": k, "value": units / (sp["median"] * 1e-3)}
+        if label == "per_block_shim_sequence" and stages["files"]:
+            out[label]["stages_ms_per_file"] = {kk: vv / stages["files"] * 1e3 for kk, vv in stages.items() if kk != "files"}
     out["value"] = out["batch"]["value"]
     out["ms_per_file"] = out["batch"]["ms_per_file"]
     out["note"] = ("latency per file with a warm context, trees and kappa from the fixture (the reference's own PhyML results); value = "

@@ -85,7 +85,10 @@ constexpr int code_tail_bytes(int NK) { return NK - 5 * (code_words(NK) - 1) == 
 constexpr int code_pos_words(int NK) { return (code_words(NK) - 1) * kWave + code_tail_bytes(NK) * (kWave / 4); }   // dwords per (strand, position)
 
 // per-block flag word (device array next to the DevBlocks)
-constexpr int kDualRowsMaxNK = 5;        // k_null walks two rows of S per pass for blocks of up to this many sequences besides the reference (rc_null_kernel.h)
+constexpr int kDualRowsMaxNK = 5;        // k_null walks two rows of S per pass for blocks of up to this many sequences besides the reference (rc_null_kernel.h).
+                                         // (Round 5 instantiated the L2-fed two-row kernel for 6..12 as well: 138..205 VGPRs = 3 or 2 wavefronts per SIMD, and 22..57 % SLOWER
+                                         // than the one-row kernels at 5 or 6 -- 7 / 10 / 13 rows x 150 columns 36.0 / 51.2 / 63.3 -> 44.1 / 65.0 / 85.1 ms, C5 532 -> 832 ms;
+                                         // profiles/r05/ab_dual_l2_wide_slower.txt.  These launches live on occupancy.)
 constexpr uint32_t kFlagExact = 1u;     // score tables outside the range proven for div_by_nk -> scored by the EXACT instantiation
 constexpr uint32_t kFlagStopped = 2u;   // --stop-early: enough samples beat the native score, the remaining ones are not simulated
 

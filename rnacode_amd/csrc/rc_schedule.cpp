@@ -250,7 +250,7 @@ int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t ex
     const auto &members = b->classes[p.NK];
     hipStream_t st = R.cs;
     if (concurrent) {
-      while (c->classStreams.size() < std::min<size_t>(plans.size(), 8)) {
+      while (c->classStreams.size() < std::min<size_t>(plans.size(), 12)) {   // (a stream per class: two classes on one stream run one after the other, and the second then often alone at the end)
         hipStream_t ns = nullptr;
         HIP_TRY(hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, c->classPrio));
         c->classStreams.push_back(ns);

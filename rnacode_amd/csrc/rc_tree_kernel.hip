@@ -138,8 +138,14 @@ __device__ __forceinline__ void tree_fit_body(const TreeJob *jobs, const uint8_t
   }
 }
 
+// RC_TREE_WAVES (a build-time experiment, tools/tree_waves.sh): the register budget as wavefronts per SIMD; unset = what the compiler takes
+#ifdef RC_TREE_WAVES
+#define RC_TREE_BUDGET __attribute__((amdgpu_waves_per_eu(RC_TREE_WAVES, RC_TREE_WAVES)))
+#else
+#define RC_TREE_BUDGET
+#endif
 template <bool BIG>
-__global__ __launch_bounds__(kWave) void k_tree_fit(const TreeJob *jobs, const uint8_t *in, double *scratch, double *results) {
+__global__ __launch_bounds__(kWave) RC_TREE_BUDGET void k_tree_fit(const TreeJob *jobs, const uint8_t *in, double *scratch, double *results) {
   tree_fit_body<BIG>(jobs, in, scratch, results);
 }
 

@@ -217,9 +217,14 @@ int rc_fit_trees_device(rc_ctx *c, const rc_block *blocks, int32_t n_blocks, cha
   const uint8_t *din = static_cast<const uint8_t *>(d_in.p);
   // The launches of the LDS classes alternate between two streams: a launch ends with the tail of its slowest fits, and the next
   // class's workgroups fill the chip meanwhile.  (The big blocks' launches share one scratch and stay in order on the first.)
+  size_t ldsPad = 0;
+#ifdef RC_TREE_PROFILE   // occupancy experiment: a padded LDS request leaves fewer fits per CU (tools/tree_phases.sh)
+  if (const char *e = std::getenv("RC_TREE_LDS_PAD")) ldsPad = static_cast<size_t>(std::atoll(e));
+#endif
   int nSmall = 0;
   for (size_t l = 1; l < launches.size(); l++) nSmall += launches[l].blocks.empty() ? 0 : 1;
-  hipStream_t ts2 = (nSmall + (nBig ? 1 : 0)) > 1 ? stream_tree2(c) : nullptr;
+  // (a second stream costs 10 ms to create: not for a call whose launches are over before that -- a driver's first chunk)
+  hipStream_t ts2 = ((nSmall + (nBig ? 1 : 0)) > 1 && (nj >= 4096 || c->tree2)) ? stream_tree2(c) : nullptr;
   if (ts2) { HIP_TRY(c->treeFork.record(ts)); HIP_TRY(hipStreamWaitEvent(ts2, c->treeFork, 0)); }
   for (size_t ch = 0; ch + 1 < chunkStart.size(); ch++) {
     const int q0 = chunkStart[ch], q1 = chunkStart[ch + 1];
@@ -231,7 +236,7 @@ int rc_fit_trees_device(rc_ctx *c, const rc_block *blocks, int32_t n_blocks, cha
     for (size_t l = 1; l < launches.size(); l++) {
       const int cnt = static_cast<int>(launches[l].blocks.size());
       hipStream_t st = (ts2 && (turn & 1)) ? ts2 : ts;
-      if (cnt && !launch_tree_fit(dj + q0, cnt, false, launches[l].lds, din, static_cast<double *>(d_work.p), static_cast<double *>(d_res.p), st))
+      if (cnt && !launch_tree_fit(dj + q0, cnt, false, launches[l].lds + ldsPad, din, static_cast<double *>(d_work.p), static_cast<double *>(d_res.p), st))
         return fail(RC_ERR_DEVICE, "k_tree_fit: the device refused the launch's LDS request");
       if (cnt) turn++;
       q0 += cnt;
