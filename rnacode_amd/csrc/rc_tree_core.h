@@ -406,12 +406,13 @@ RC_HD inline void times_image(const Work &k, int x, const Coef &cx, int p, doubl
 // members -- an array indexed by a loop counter would live in the lane's private memory, i.e. in global memory
 struct Trio {
   int x0, x1, x2;        // node ids, -1: slot not used
-  Coef c0, c1, c2;
+  // (the branch constants are read where they are used: three sets of five held across the pattern loop were thirty registers, and
+  // the loop runs once for a block of up to 64 patterns)
   RC_HD void product(const Work &k, int p, double out[4]) const {
     for (int s = 0; s < 4; s++) out[s] = 1.0;
-    if (x0 >= 0) times_image(k, x0, c0, p, out);
-    if (x1 >= 0) times_image(k, x1, c1, p, out);
-    if (x2 >= 0) times_image(k, x2, c2, p, out);
+    if (x0 >= 0) times_image(k, x0, k.coef[x0], p, out);
+    if (x1 >= 0) times_image(k, x1, k.coef[x1], p, out);
+    if (x2 >= 0) times_image(k, x2, k.coef[x2], p, out);
   }
 };
 // the children of v except `except`, child c in slot c (a slot chosen at run time would be a pointer chosen at run time, and the
@@ -423,11 +424,6 @@ RC_HD inline Trio children_of(const Work &k, int v, int except) {
   t.x0 = (nc > 0 && a != except) ? a : -1;
   t.x1 = (b >= 0 && b != except) ? b : -1;
   t.x2 = (c >= 0 && c != except) ? c : -1;
-  const Coef *q = k.coef;
-  const Coef &r0 = q[t.x0 >= 0 ? t.x0 : 0], &r1 = q[t.x1 >= 0 ? t.x1 : 0], &r2 = q[t.x2 >= 0 ? t.x2 : 0];
-  t.c0.a = r0.a; t.c0.bR = r0.bR; t.c0.bY = r0.bY; t.c0.eR = r0.eR; t.c0.eY = r0.eY;
-  t.c1.a = r1.a; t.c1.bR = r1.bR; t.c1.bY = r1.bY; t.c1.eR = r1.eR; t.c1.eY = r1.eY;
-  t.c2.a = r2.a; t.c2.bR = r2.bR; t.c2.bY = r2.bY; t.c2.eR = r2.eR; t.c2.eY = r2.eY;
   return t;
 }
 
@@ -480,7 +476,6 @@ RC_HD void branch_constants(Work &k, Exec &ex, int v) {
   const int par = k.parent[v];
   const Trio sib = children_of(k, par, v);
   const bool above = par != k.root;
-  Coef cp = k.coef[above ? par : v];
   const double *upPar = above ? k.upI + static_cast<size_t>(par - k.N) * 4 * k.P : nullptr;
   double *upV = v >= k.N ? k.upI + static_cast<size_t>(v - k.N) * 4 * k.P : nullptr;
   const Hky &m = k.mod;
@@ -490,7 +485,7 @@ RC_HD void branch_constants(Work &k, Exec &ex, int v) {
     if (above) {   // what comes from above the parent, through the parent's own branch
       double a[4], t[4];
       for (int s = 0; s < 4; s++) a[s] = upPar[static_cast<size_t>(s) * k.P + p];
-      transfer(m, cp, a, t);
+      transfer(m, k.coef[par], a, t);
       for (int s = 0; s < 4; s++) u[s] *= t[s];
     }
     if (upV) for (int s = 0; s < 4; s++) upV[static_cast<size_t>(s) * k.P + p] = u[s];
