@@ -287,6 +287,7 @@ int batch_run_async(rc_batch *b, bool streaming) {
     {   // one staging scratch for all rounds
       size_t need = 0, most = 0;
       int r = 0;
+      b->sbufNeed = 0;
       for (int lo = 0, hi = g1; lo < groups; r++) {
         if (r == c->stopRounds - 1) hi = groups;
         RC_TRY(launch_null_groups(R, lo, hi, r, 0, &need));
@@ -294,6 +295,7 @@ int batch_run_async(rc_batch *b, bool streaming) {
         lo = hi; hi = std::min(groups, hi * 2);
       }
       HIP_TRY(b->dscratch.ensure(most * sizeof(uint32_t)));
+      if (b->sbufNeed) HIP_TRY(b->dsbuf.ensure(b->sbufNeed * sizeof(float)));   // rows split over workgroups: the S values between k_null and k_null_rowscan
       if (c->tailSharing) {   // claim words of every (round, class) launch, zeroed: "nothing to take"
         const size_t bytes = static_cast<size_t>(r) * b->classes.size() * steal_words(c) * sizeof(uint32_t);
         HIP_TRY(b->dsteal.ensure(bytes));

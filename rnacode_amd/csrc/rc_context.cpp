@@ -88,6 +88,7 @@ int rc_ctx_create(int device, rc_ctx **out) {
   if (const char *e = std::getenv("RC_SPLIT_FACTOR")) c->splitFactor = std::max(0.0, std::atof(e));
   if (const char *e = std::getenv("RC_NATIVE_WAVES_PER_CU")) c->nativeWavesPerCU = std::max(1, std::min(32, std::atoi(e)));
   if (const char *e = std::getenv("RC_TAIL_SHARING")) c->tailSharing = std::atoi(e) != 0;
+  if (const char *e = std::getenv("RC_ROW_SPLIT")) c->rowSplit = std::atoi(e) != 0;
   if (const char *e = std::getenv("RC_HIGH_OCCUPANCY")) c->highOccupancy = std::max(0, std::min(2, std::atoi(e)));
   if (prop.maxSharedMemoryPerMultiProcessor > 0) c->ldsPerCU = prop.maxSharedMemoryPerMultiProcessor;
   if (const char *e = std::getenv("RC_FAT_STREAM_MIN_ITEMS")) c->fatStreamMinItems = std::max(0ll, std::atoll(e));

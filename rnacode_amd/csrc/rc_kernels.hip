@@ -162,6 +162,84 @@ __global__ __launch_bounds__(64) void k_prep_models(PrepArgs A) {
   }
 }
 
+// The same for a FEW models (a caller that scores block by block; the first sub-batch of a stream): k_prep_models gives a model to a
+// lane, and its 4096-term chain is then the latency of the whole preparation (0.25 ms, a quarter of a one-block batch's run).  Here a
+// WAVEFRONT takes one (model, Hamming class): the terms of its accumulation are made 64 at a time, one per lane, in the order of the
+// reference's loops (the lists below), and only the additions run in sequence, lane by lane through v_readlane -- the same operands into
+// the same chains in the same order, a tenth of the latency at twenty times the instructions (hence only below 2048 models).
+struct PrepLists { uint16_t ab[4096]; int off[6]; };   // (a << 6 | b): pairs with a stop codon, then the pairs of Hamming class 0, 1, 2, 3; a outer, b inner
+constexpr PrepLists make_prep_lists() {
+  PrepLists l{};
+  int n = 0;
+  l.off[0] = 0;
+  for (int a = 0; a < 64; a++) for (int b = 0; b < 64; b++) if (kPepOf(a) == -1 || kPepOf(b) == -1) l.ab[n++] = static_cast<uint16_t>(a << 6 | b);
+  for (int h = 0; h < 4; h++) {
+    l.off[1 + h] = n;
+    for (int a = 0; a < 64; a++) for (int b = 0; b < 64; b++) {
+      if (kPepOf(a) == -1 || kPepOf(b) == -1) continue;
+      const int x = a ^ b;
+      if (((x & 48) != 0) + ((x & 12) != 0) + ((x & 3) != 0) == h) l.ab[n++] = static_cast<uint16_t>(a << 6 | b);
+    }
+  }
+  l.off[5] = n;
+  return l;
+}
+__device__ const PrepLists kPrepLists = make_prep_lists();
+
+__global__ __launch_bounds__(64) void k_prep_models_few(PrepArgs A) {
+  __builtin_amdgcn_s_setprio(3);
+  const int lane = threadIdx.x;
+  const int hq = blockIdx.x & 3, t = blockIdx.x >> 2;   // the grid is 4 x nModels
+  int lo = 0, hi = A.nBlocks;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (A.modelPrefix[mid] <= t) lo = mid; else hi = mid;
+  }
+  const DevBlock *db = A.dblocks + A.blocks[lo];
+  ModelRec *m = reinterpret_cast<ModelRec *>(A.blob + db->off_models) + (t - A.modelPrefix[lo]);
+  const float *__restrict__ P = m->P;
+  const float f0 = m->freqs[0], f1 = m->freqs[1], f2 = m->freqs[2], f3 = m->freqs[3];
+  auto freq = [&](int x) { return x == 0 ? f0 : x == 1 ? f1 : x == 2 ? f2 : f3; };
+  auto term = [&](int ab) {   // P(a -> b) x f(a), the products in calculateBG's order
+    const int a = ab >> 6, b = ab & 63;
+    const int a1 = a >> 4, a2 = (a >> 2) & 3, a3 = a & 3;
+    const float fa = freq(a1) * freq(a2) * freq(a3);
+    float pAB = P[a1 * 4 + (b >> 4)] * P[a2 * 4 + ((b >> 2) & 3)] * P[a3 * 4 + (b & 3)];
+    pAB = pAB * fa;
+    return pAB;
+  };
+  auto add_in_order = [&](float &acc, float v, int cnt) {   // acc += v of lane 0, 1, ..., cnt - 1
+    for (int l = 0; l < cnt; l++) acc = acc + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+  };
+  float probStop = 0.0f;
+  for (int base = kPrepLists.off[0]; base < kPrepLists.off[1]; base += kWave) {
+    const int cnt = kPrepLists.off[1] - base < kWave ? kPrepLists.off[1] - base : kWave;
+    const float v = lane < cnt ? term(kPrepLists.ab[base + lane]) : 0.0f;
+    add_in_order(probStop, v, cnt);
+  }
+  const float keep = 1.0f - probStop;
+  float cq = 0.0f, sq = 0.0f;
+  for (int base = kPrepLists.off[1 + hq]; base < kPrepLists.off[2 + hq]; base += kWave) {
+    const int cnt = kPrepLists.off[2 + hq] - base < kWave ? kPrepLists.off[2 + hq] - base : kWave;
+    float pAB = 0.0f, sp = 0.0f;
+    if (lane < cnt) {
+      const int ab = kPrepLists.ab[base + lane];
+      pAB = term(ab);
+      pAB = pAB / keep;
+      const float sc = static_cast<float>(A.blosum[A.pep[ab >> 6] * 20 + A.pep[ab & 63]]);
+      sp = sc * pAB;
+    }
+    for (int l = 0; l < cnt; l++) {
+      cq = cq + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pAB), l));
+      sq = sq + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sp), l));
+    }
+  }
+  if (lane == 0) {
+    m->scores[hq] = sq / cq;
+    m->probs[hq] = cq;
+  }
+}
+
 // same test as rc_host.cpp in_div_range: 0, or 2^-76 <= |v| < 2^40
 __device__ __forceinline__ bool in_div_range_dev(float v) {
   const float a = fabsf(v);
@@ -291,7 +369,8 @@ __global__ __launch_bounds__(64) void k_prep_gaps(PrepArgs A) {
 void launch_prep(const PrepArgs &a, hipStream_t stream) {
   if (a.nBlocks <= 0) return;
   hipLaunchKernelGGL(k_prep_gaps, dim3(2 * a.nBlocks), dim3(kWave), 0, stream, a);
-  hipLaunchKernelGGL(k_prep_models, dim3(4 * ((a.nModels + kWave - 1) / kWave)), dim3(kWave), 0, stream, a);
+  if (a.nModels <= 2048) hipLaunchKernelGGL(k_prep_models_few, dim3(4 * a.nModels), dim3(kWave), 0, stream, a);
+  else hipLaunchKernelGGL(k_prep_models, dim3(4 * ((a.nModels + kWave - 1) / kWave)), dim3(kWave), 0, stream, a);
   hipLaunchKernelGGL(k_prep_lut, dim3(a.nBlocks), dim3(kWave), 0, stream, a);
 }
 
@@ -717,6 +796,54 @@ __global__ __launch_bounds__(256) void k_evd_fit_f64(const double *x, int n, Fit
   if (threadIdx.x == 0) { out->rc = rc; out->mu = mu; out->lambda = lambda; out->better = 0; }
 }
 
+// getHSS's fold (SampleScan, rc_null_kernel.h) over the S values a ROWS launch of k_null left in its buffers: one wavefront per
+// (block, 64-sample group, strand x frame), lane = sample, entries in the reference's order (row by row), eight loads ahead of the
+// fold.  The maxima meet those of the other five parts in an atomic max on the preset -1.
+__global__ __launch_bounds__(64) void k_null_rowscan(NullArgs A, const DevBlock *__restrict__ dblocks, const int *__restrict__ classBlocks,
+                                                      const uint32_t *__restrict__ flags, float *__restrict__ maxima) {
+  const int lane = threadIdx.x;
+  const int groupsHere = A.gHi - A.gLo;
+  const int part = blockIdx.x % 6, item = blockIdx.x / 6;
+  const int cb = item / groupsHere, grp = A.gLo + item % groupsHere;
+  if (cb >= A.nClassBlocks) return;
+  const int bi = classBlocks[cb];
+  if (A.skipMask && (flags[bi] & A.skipMask)) return;
+  const DevBlock *__restrict__ db = dblocks + bi;
+  const int f = part % 3, sites = (db->L - f) / 3;
+  if (sites <= 0) return;
+  const float *__restrict__ src = A.sbuf + (static_cast<size_t>(item) * 6 + part) * A.sbufStride + lane;
+  const float negTie = -A.tieThr;
+  SampleScan st{0.0f, 0.0f, 0u, 0u};
+  float best = -1.0f;
+  // The entries as one stream of sites (sites + 1) / 2 slots, 64 loads in flight at a time (a wavefront that waits for eight loads
+  // per round trip spends a microsecond per eight entries: 0.4 ms for one block of 10 x 201); the row bookkeeping is scalar.
+  constexpr int kAhead = 64;
+  const int total = sites * (sites + 1) / 2;
+  int a = 0, slotsLeft = sites;
+  float j2f = 1.0f;
+  sample_scan_row_begin(st, best, 0u);
+  for (int base = 0; base < total; base += kAhead) {
+    float v[kAhead];
+#pragma unroll
+    for (int u = 0; u < kAhead; u++) v[u] = (base + u < total) ? src[static_cast<size_t>(base + u) * kWave] : 0.0f;
+#pragma unroll
+    for (int u = 0; u < kAhead; u++) {
+      if (base + u < total) {
+        if (a < sites - 1) { sample_scan_step(st, v[u], j2f, negTie); j2f += 2.0f; }   // (the last row's one slot: the frame's final entry, never computed)
+        if (--slotsLeft == 0) {
+          sample_scan_row_end(st, static_cast<uint32_t>(a));
+          a++;
+          if (a < sites) { sample_scan_row_begin(st, best, static_cast<uint32_t>(a)); slotsLeft = sites - a; j2f = static_cast<float>(2 * a + 1); }
+        }
+      }
+    }
+  }
+  sample_scan_last(st, best);
+  const int sidx = grp * kWave + lane;
+  if (sidx < A.sampleN && best > -1.0f)
+    atomicMax(reinterpret_cast<int *>(maxima + static_cast<size_t>(db->out_index) * A.sampleN + sidx), __float_as_int(best));
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
@@ -756,6 +883,11 @@ bool launch_null(int NK, const NullArgs &a, int grid, size_t ldsBytes, bool exac
   X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) \
   X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40) X(41) \
   X(42) X(43) X(44) X(45) X(46) X(47) X(48) X(49) X(50) X(51) X(52) X(53) X(54) X(55) X(56) X(57) X(58) X(59) X(60) X(61) X(62) X(63)
+
+void launch_null_rowscan(const NullArgs &a, int items, hipStream_t stream) {
+  if (items <= 0) return;
+  hipLaunchKernelGGL(k_null_rowscan, dim3(items * 6), dim3(64), 0, stream, a, a.dblocks, a.classBlocks, a.flags, a.maxima);
+}
 
 void launch_native_sigma(const NativeArgs &a, int nblocks, hipStream_t stream) {
   hipLaunchKernelGGL(k_native_sigma, dim3(nblocks), dim3(256), 0, stream, a);

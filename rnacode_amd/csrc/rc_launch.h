@@ -45,6 +45,11 @@ struct NullArgs {
   int hiOcc;                  // host only: 1 = launch k_null_occ (one more wavefront per SIMD), where this N-1 has one
   int dual;                   // 1: the instantiation that walks two rows of S per pass (N-1 <= kDualRowsMaxNK, codes staged in LDS)
   int stealWait;              // 1: a workgroup without work waits for owners that are still simulating a late item; 0: it leaves at once (a stream: the next sub-batch's workgroups want its place)
+  int simParts, simGrid;      // rows split over workgroups: an item's simulation is cut into simParts site ranges, simGrid workgroups take them (k_null<.., 2>)
+  unsigned int *simCounter;   // ... from queues of their own [8]
+  int rowParts;               // > 1: a strand x frame part's rows are split into this many ranges, each a work item (k_null<.., ROWS>); needs comboSplit
+  float *sbuf;                // ... whose S values go here, [item][6][sbufStride]: getHSS's entry order, [entry][64 lanes]; k_null_rowscan folds them
+  size_t sbufStride;          // floats per (item, strand x frame): 64 x (largest sites (sites + 1) / 2 of the launch)
   int debugSkip;              // RC_PROFILING builds only: bit0 skip the DP/scan phase, bit1 skip simulation
   unsigned long long *cellStats;   // RC_PROFILING builds only: [0] wavefront-cells, [1] of those with no lane's sum > 0, [2] lanes with sum > 0, [3..5] cells before the row's first event / at events / after its last
 };
@@ -167,6 +172,7 @@ void launch_prep(const PrepArgs &a, hipStream_t stream);   // k_prep_models, the
 int null_occupancy(int NK, size_t ldsBytes);   // resident workgroups per CU (0 = cannot launch)
 int null_occupancy_plain(int NK, size_t dynLds, int hiOcc);   // the same for a launch that reads its codes from L2 with dynLds bytes of LDS; hiOcc: k_null_occ (0 if N-1 has none)
 bool launch_null(int NK, const NullArgs &a, int grid, size_t ldsBytes, bool exact, hipStream_t stream);
+void launch_null_rowscan(const NullArgs &a, int items, hipStream_t stream);   // getHSS over the buffers a ROWS launch of k_null left: one wavefront per (item, strand x frame)
 void launch_native_sigma(const NativeArgs &a, int nblocks, hipStream_t stream);
 bool launch_native_dp(int NK, const NativeArgs &a, int grid, hipStream_t stream);   // a.nItems items over `grid` persistent workgroups
 void launch_native_scan(const NativeArgs &a, hipStream_t stream);   // getHSS over a.sAll, one lane per item

@@ -72,7 +72,7 @@ __device__ __forceinline__ void native_scan_rows(const float *rows, int aLo, int
         const int t = __builtin_ctzll(m);
         m &= m - 1ull;
         const int jj = j0 + t;
-        const float vt = __shfl(v, t, kWave);
+        const float vt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), t));   // (t is wave-uniform: a v_readlane, not a ds_bpermute round trip per entry)
         scan_step(st, vt, a, jj, (a == sites - 1) && (jj == sites - 1), tieThr, [&](const ScanState &e) {
           if (out && lane == 0 && n < hssCap) out[n] = DevHss{s, f, e.ss, e.se, e.cm};
           n++;
@@ -174,7 +174,11 @@ __device__ __forceinline__ void sample_scan_last(const SampleScan &st, float &be
 // block tables (z words, tree records, masks) with scalar loads.
 // (The body is a device function so that two kernels can share it: k_null, and k_null_occ, the same code compiled for more
 // wavefronts per SIMD -- see below.)
-template <int NK, bool LDSC, bool EXACT, bool DUAL>
+// MODE 1 and 2 (tiny batches; see "rows split over workgroups" below) cut an item's two phases into pieces that many workgroups take:
+// MODE 2 simulates a RANGE OF SITES of a (block, 64-sample group) and leaves the sigma codes in the item's scratch; MODE 1 then scores
+// one ROW RANGE of one strand x frame part from those codes, its S values going to a buffer instead of through the scan;
+// k_null_rowscan folds them afterwards.  MODE 0: the whole item (or one strand x frame part of it) in one workgroup.
+template <int NK, bool LDSC, bool EXACT, bool DUAL, int MODE = 0>
 __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__restrict__ blob,
                                           const DevBlock *__restrict__ dblocks, const int *__restrict__ classBlocks,
                                           const uint32_t *__restrict__ flags, const uint32_t *__restrict__ Ustream, const uint8_t *__restrict__ pairTab,
@@ -198,6 +202,8 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
   // launch (NullArgs::dual): up to 127 VGPRs instead of 74, i.e. no other kernel shares a SIMD with four such wavefronts.
   static_assert(!DUAL || (!EXACT && NK <= kDualRowsMaxNK), "two rows per pass: fast division, few sequences");
   static_assert(!(LDSC && EXACT), "the EXACT instantiation uses no LDS");
+  constexpr bool ROWS = MODE == 1, SIM = MODE == 2;
+  static_assert(MODE == 0 || (!LDSC && !EXACT && !DUAL), "rows split over workgroups: the one-row kernel that reads its codes from L2");
   // phase A: threshold table of the tree (nnodes x 64 B); phase B with LDSC: [site][NCW][64] sigma codes
   // of the current strand x frame
   extern __shared__ uint32_t lds_codes[];
@@ -213,7 +219,8 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
   unsigned int xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   const int home = static_cast<int>(xcc & 7u);
-  const int parts = A.comboSplit ? 6 : 1;
+  const int rowParts = ROWS ? A.rowParts : 1;
+  const int parts = SIM ? A.simParts : A.comboSplit ? 6 * rowParts : 1;
   const int nBlocks = A.nBlocksPtr ? *A.nBlocksPtr : A.nClassBlocks;
   // The tail of the launch: when the queues have run dry, the workgroups that are still busy hold one item each and the others would
   // idle until the slowest has done its six strand x frame parts.  Instead an item taken near the end of a queue ("late") is
@@ -238,7 +245,7 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
   int helpCursor = 0;   // published items before this one have no part left
   bool helping = false;
   for (int qi = 0;;) {
-    int bi, grp, onlyCombo = -1, firstCombo = 0;
+    int bi, grp, onlyCombo = -1, firstCombo = 0, rowPart = 0, itemIndex = 0;
     bool shared = false;
     int slot = static_cast<int>(blockIdx.x);   // whose staging scratch holds the item's codes
     if (!helping) {
@@ -254,7 +261,7 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
       const int nq = nBlocks * perBlock;
       int t = nq;
       if (nq > 0) {
-        if (lane == 0) t = static_cast<int>(atomicAdd(A.workCounter + q, 1u));
+        if (lane == 0) t = static_cast<int>(atomicAdd((SIM ? A.simCounter : A.workCounter) + q, 1u));
         t = __builtin_amdgcn_readfirstlane(t);
       }
       if (t >= nq) { qi++; continue; }
@@ -264,7 +271,9 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
       if (A.skipMask && (flags[bi] & A.skipMask)) continue;
       const int sub = t % perBlock;
       grp = g0 + 8 * (sub / parts);
-      onlyCombo = A.comboSplit ? sub % parts : -1;
+      onlyCombo = A.comboSplit ? (sub % parts) / rowParts : -1;
+      if constexpr (MODE != 0) { rowPart = SIM ? sub % parts : (sub % parts) % rowParts; itemIndex = (t / perBlock) * (A.gHi - A.gLo) + (grp - A.gLo); }
+      if constexpr (MODE != 0) slot = itemIndex;   // the codes of a split item live in the ITEM's scratch: the simulation's pieces write them, the row ranges read them
       // items per queue that may still be running when the queues run dry (generous: a wrong guess costs six atomics)
       if (stealing && nq - t <= static_cast<int>(gridDim.x >> 3) + 16) {
         shared = true;
@@ -329,7 +338,7 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
     // so that the stream loads and threshold look-ups of independent sites overlap; emit sigma
     // codes for both strands.  Node states of a site are packed 2 bits per node into NODEW
     // registers; the per-branch threshold table sits in LDS (the region phase B reuses for codes).
-    if (!helping && (!kProfiling || !(A.debugSkip & 2))) {
+    if (!ROWS && !helping && (!kProfiling || !(A.debugSkip & 2))) {
       constexpr int SPI = 4;
       constexpr int NODEW = (2 * N - 1 + 15) / 16;   // 16 nodes per 32-bit word
       // The EXACT instantiation uses no LDS at all and reads both tables from global memory (L1/L2): its launches are
@@ -364,7 +373,11 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
         for (int x = 1; x < NODEW; x++) if ((q >> 4) == x) word = ns[x];
         return (word >> (2 * (q & 15))) & 3u;
       };
-      for (int i0 = 1; i0 <= L; i0 += SPI) {
+      // MODE 2: the sites [iLo, iHi] of this piece (sites are independent; a codon needs its three columns, so the window is filled
+      // from two sites earlier and nothing is emitted for those)
+      int iLo = 1, iHi = L;
+      if constexpr (SIM) { iLo = 1 + static_cast<int>(static_cast<long long>(L) * rowPart / parts); iHi = static_cast<int>(static_cast<long long>(L) * (rowPart + 1) / parts); }
+      for (int i0 = (SIM && iLo > 3) ? iLo - 2 : 1; i0 <= iHi; i0 += SPI) {
         size_t ubase[SPI];
         uint32_t ns[SPI][NODEW];
 #pragma unroll
@@ -376,12 +389,9 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
           for (int x = 0; x < NODEW; x++) ns[t][x] = 0;
         }
         const size_t qstride = static_cast<size_t>(cols) * A.Spad;
-        for (int q = 0; q < nnodes; q++) {
+        auto node_step = [&](int q, const uint32_t (&u)[SPI]) {
           const uint32_t bp = nodew[q * 20 + 16];                                // NodeRec as 20 words: scalar loads
           const int pq = static_cast<int>(nodew[q * 20 + 17] & 255u);
-          uint32_t u[SPI];
-#pragma unroll
-          for (int t = 0; t < SPI; t++) u[t] = Ustream[ubase[t] + q * qstride];
           auto evolve = [&](auto withBase) {   // seqgen/evolve.c:416-433 for node q at the pass's sites
 #pragma unroll
             for (int t = 0; t < SPI; t++) {
@@ -389,7 +399,7 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
               const U4 th = thrTab[q * thrStride + ps];
               uint32_t st = (u[t] > th.x) + (u[t] > th.y) + (u[t] > th.z);
               if constexpr (decltype(withBase)::value) st += (bp >> (2 * ps)) & 3u;
-              clamped += (u[t] > th.w);
+              if constexpr (SIM) clamped += (u[t] > th.w) & (i0 + t >= iLo) & (i0 + t <= iHi); else clamped += (u[t] > th.w);
               const uint32_t bits = st << (2 * (q & 15));
 #pragma unroll
               for (int x = 0; x < NODEW; x++) if (NODEW == 1 || (q >> 4) == x) ns[t][x] |= bits;
@@ -397,6 +407,30 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
           };
           // base offsets exist only for degenerate cumulative rows: a real (scalar) branch, not a select
           if (__builtin_expect(bp != 0u, 0)) evolve(std::true_type{}); else evolve(std::false_type{});
+        };
+        if constexpr (SIM) {
+          // Rows split over workgroups is the path of a chip that is nearly empty (one wavefront per SIMD at most): nothing hides the
+          // round trip of a node's draws, and 2N - 2 of them per pass in a chain were 0.55 of the 0.67 ms a one-block launch took.  The draws
+          // of eight nodes are fetched together here (32 loads in flight) -- the form that was slower where sixteen wavefronts share a CU.
+          constexpr int QB = 8;
+          for (int q0 = 0; q0 < nnodes; q0 += QB) {
+            uint32_t ub[QB][SPI];
+#pragma unroll
+            for (int x = 0; x < QB; x++) {
+              const int q = q0 + x < nnodes ? q0 + x : nnodes - 1;
+#pragma unroll
+              for (int t = 0; t < SPI; t++) ub[x][t] = Ustream[ubase[t] + q * qstride];
+            }
+#pragma unroll
+            for (int x = 0; x < QB; x++) if (q0 + x < nnodes) node_step(q0 + x, ub[x]);
+          }
+        } else {
+          for (int q = 0; q < nnodes; q++) {
+            uint32_t u[SPI];
+#pragma unroll
+            for (int t = 0; t < SPI; t++) u[t] = Ustream[ubase[t] + q * qstride];
+            node_step(q, u);
+          }
         }
 #pragma unroll
         for (int t = 0; t < SPI; t++) {
@@ -404,7 +438,7 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
           if (i <= L) {
 #pragma unroll
             for (int r = 0; r < N; r++) win[r] = (win[r] << 2) | get_state(ns[t], static_cast<int>((qtipw[r >> 2] >> (8 * (r & 3))) & 255u));   // low 6 bits = the codon; older sites drift out at the top
-            if (i >= 3) {
+            if (i >= 3 && (!SIM || (i >= iLo && i <= iHi))) {
               const int ip = L + 3 - i;  // reverse-strand position whose codon is these three columns
               const uint32_t aF = win[0] & 63u;
               const uint32_t aR = codon_flip(aF) ^ 63u;
@@ -436,8 +470,9 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
         }
       }
       // padding lanes do not count; with comboSplit the six parts of an item redo the same simulation: the first one reports
-      if (clamped && sidx < A.sampleN && onlyCombo <= 0) atomicAdd(A.clampCount, static_cast<unsigned long long>(clamped));
+      if (clamped && sidx < A.sampleN && (SIM || onlyCombo <= 0)) atomicAdd(A.clampCount, static_cast<unsigned long long>(clamped));
     }
+    if constexpr (SIM) continue;   // the scoring is another launch's (MODE 1)
     if (!helping && shared) {   // a late item: its codes are in the scratch, open it to the workgroups that have run out of work
       const size_t G = gridDim.x;
       if (lane == 0) {
@@ -1069,8 +1104,28 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
             }
           }
         } else {
-          for (int a = 0; a < sites; a++) {
-            sample_scan_row_begin(st, best, static_cast<uint32_t>(a));
+          // ---- Rows split over workgroups (ROWS; batches so small that even their strand x frame parts leave most of the chip idle: a
+          // caller that scores block by block, RNAcode.c:164-216 through the shim).  A part's triangle of cells is cut into rowParts row
+          // ranges of equal cell counts; each range is a work item of its own, its S values go to the item's buffer in getHSS's entry
+          // order (row a's sites - a entries behind those of the rows before it, [entry][64 lanes]) and k_null_rowscan runs the serial
+          // fold over the finished buffer.  Same cells, same fold, same order: bit-identical; the DP's latency is divided by rowParts.
+          int aLo = 0, aHi = sites;
+          float *sdst = nullptr;
+          if constexpr (ROWS) {
+            const long long total = static_cast<long long>(sites) * (sites + 1) / 2;
+            auto row_at = [&](long long cellsBefore) {   // the first row with at least that many entries in front of it
+              int a = 0;
+              long long cum = 0;
+              while (a < sites && cum < cellsBefore) { cum += sites - a; a++; }
+              return a;
+            };
+            aLo = row_at(total * rowPart / rowParts);
+            aHi = rowPart + 1 == rowParts ? sites : row_at(total * (rowPart + 1) / rowParts);
+            const long long before = static_cast<long long>(aLo) * sites - static_cast<long long>(aLo) * (aLo - 1) / 2;
+            sdst = A.sbuf + (static_cast<size_t>(itemIndex) * 6 + c) * A.sbufStride + static_cast<size_t>(before) * kWave + lane;
+          }
+          for (int a = aLo; a < aHi; a++) {
+            if constexpr (!ROWS) sample_scan_row_begin(st, best, static_cast<uint32_t>(a));
             static_for<NK>([&](auto kc) {
               constexpr int k = decltype(kc)::value;
               auto &r = R.template at<k>();
@@ -1091,8 +1146,11 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
               uint32_t wnext[NCW];
               if constexpr (EXACT) load_words(jn, wnext);
               const float v = cell(jn, kind);
-              sample_scan_step(st, v, j2f, negTie);
-              asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
+              if constexpr (ROWS) { *sdst = v; sdst += kWave; }
+              else {
+                sample_scan_step(st, v, j2f, negTie);
+                asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
+              }
               if constexpr (EXACT) {
 #pragma unroll
                 for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
@@ -1142,10 +1200,11 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
                 else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(wcur[x]));
               }
             }
-            sample_scan_row_end(st, static_cast<uint32_t>(a));
+            if constexpr (ROWS) { if (a == sites - 1) sdst += kWave; }   // (the frame's final entry has a slot of its own; it is never computed)
+            else sample_scan_row_end(st, static_cast<uint32_t>(a));
           }
         }
-        sample_scan_last(st, best);   // entry (sites-1, sites-1): its own value can never be reported
+        if constexpr (!ROWS) sample_scan_last(st, best);   // entry (sites-1, sites-1): its own value can never be reported
       }
     }
     if constexpr (kProfiling) {
@@ -1154,7 +1213,7 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
         atomicAdd(A.cellStats + 3, statPristine); atomicAdd(A.cellStats + 4, statEvent); atomicAdd(A.cellStats + 5, statTail);
       }
     }
-    if (sidx < A.sampleN) {
+    if (!ROWS && sidx < A.sampleN) {   // (ROWS: k_null_rowscan writes the maxima)
       float *dst = maxima + static_cast<size_t>(db->out_index) * A.sampleN + sidx;
       // scores are positive floats or the -1 sentinel: integer order == float order on that set
       // (parts of one item scored by several workgroups: the maxima are preset to -1, which no partial maximum needs to replace)
@@ -1164,13 +1223,13 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
   }
 }
 
-template <int NK, bool LDSC, bool EXACT, bool DUAL = false>
+template <int NK, bool LDSC, bool EXACT, bool DUAL = false, int MODE = 0>
 __global__ __launch_bounds__(64)
 void k_null(NullArgs A, const uint8_t *__restrict__ blob,
                                              const DevBlock *__restrict__ dblocks, const int *__restrict__ classBlocks,
                                              const uint32_t *__restrict__ flags, const uint32_t *__restrict__ Ustream, const uint8_t *__restrict__ pairTab,
                                              uint32_t *__restrict__ scratch, float *__restrict__ maxima) {
-  null_body<NK, LDSC, EXACT, DUAL>(A, blob, dblocks, classBlocks, flags, Ustream, pairTab, scratch, maxima);
+  null_body<NK, LDSC, EXACT, DUAL, MODE>(A, blob, dblocks, classBlocks, flags, Ustream, pairTab, scratch, maxima);
 }
 
 // The instantiations that read their code words from L2 live on occupancy (4000 blocks x 150 columns x 9 rows: 49.4 ms at 20
@@ -1239,6 +1298,15 @@ inline void launch_null_one(const NullArgs &a, int grid, size_t ldsBytes, bool e
                        a.classBlocks, a.flags, a.U, a.pair, a.scratch, a.maxima);
   } else {
     const size_t dyn = a.plainLds ? static_cast<size_t>(a.plainLds) : phase_a_lds<NK>();
+    if constexpr (NK < kFastRows) {
+      if (a.rowParts > 1) {   // an item's simulation split by sites (a.simGrid workgroups), then its scoring split by rows; k_null_rowscan (rc_kernels.hip) follows on the same stream
+        hipLaunchKernelGGL((k_null<NK, false, false, false, 2>), dim3(a.simGrid), dim3(64), phase_a_lds<NK>(), stream, a, a.blob, a.dblocks,
+                           a.classBlocks, a.flags, a.U, a.pair, a.scratch, a.maxima);
+        hipLaunchKernelGGL((k_null<NK, false, false, false, 1>), dim3(grid), dim3(64), dyn, stream, a, a.blob, a.dblocks,
+                           a.classBlocks, a.flags, a.U, a.pair, a.scratch, a.maxima);
+        return;
+      }
+    }
     if constexpr (NK >= 3 && NK <= kDualRowsMaxNK) {
       if (a.hiOcc == 2) {
         hipLaunchKernelGGL((k_null<NK, false, false, true>), dim3(grid), dim3(64), dyn, stream, a, a.blob, a.dblocks,

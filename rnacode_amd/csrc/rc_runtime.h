@@ -316,6 +316,7 @@ struct rc_ctx {
   struct PlainPlan { int occ; size_t lds; int hiOcc; };
   std::map<std::tuple<int, int, int>, PlainPlan> plainPlans;   // (N-1, tree nodes, high-occupancy wanted) -> launch shape of a k_null that reads its codes from L2
   size_t ldsPerCU = 160 * 1024;
+  int rowSplit = 1;             // RC_ROW_SPLIT=0: never split a strand x frame part's rows over workgroups (tiny batches; A/B)
   int highOccupancy = 1;        // RC_HIGH_OCCUPANCY: 1 k_null_occ (one more wavefront per SIMD) for batches of one row-count class, 0 never, 2 always (A/B)
   size_t ldsMaxBytes = 13312;   // per wavefront: >= 12 wavefronts per CU; measured crossover against reading the codes from L2 (cols 150: 52.0 vs 54.0 ms, cols 180: 41.5 vs 39.3 ms)
   size_t ldsMaxBytesOneRow = 10752;   // the one-row kernels: staging only where it leaves >= 15 workgroups per CU (6 rows x 120 / 135 / 150 columns: staged 19.6 / 25.8 / 34.0 ms, from L2 with the LDS sigma tables 20.2 / 24.9 / 30.2)
@@ -392,7 +393,8 @@ struct rc_batch {
   size_t oDblocks = 0, oOk = 0, oClass = 0, oPrefix = 0;   // tail arrays inside the host part
   int nModels = 0;
   // device
-  DevBuf dblob, dmaxima, dhss, dhssCount, dhssPacked, dhssOffsets, dfit, dflags, dexact, dcounters, dscratch, dnativeScratch, dnativeTile, dnativeAll, dsteal;
+  DevBuf dblob, dmaxima, dhss, dhssCount, dhssPacked, dhssOffsets, dfit, dflags, dexact, dcounters, dscratch, dnativeScratch, dnativeTile, dnativeAll, dsteal, dsbuf;
+  size_t sbufNeed = 0;      // floats of row buffer the rounds of the current run need (launch_null_groups, sizing pass)
   float *maxPtr = nullptr;
   bool maximaExternal = false;
   PinBuf hstage, hpacked;
@@ -419,7 +421,7 @@ struct rc_batch {
     ctx = c; device = c->device; retiredKeep = c->retired; poolKeep = c->bufPool;
     Retired *r = retiredKeep.get();
     for (DevBuf *d : {&dblob, &dmaxima, &dhss, &dhssCount, &dhssPacked, &dhssOffsets, &dfit, &dflags, &dexact, &dcounters, &dscratch, &dnativeScratch,
-                      &dnativeTile, &dnativeAll, &dsteal}) { d->retired = r; d->pool = poolKeep.get(); }
+                      &dnativeTile, &dnativeAll, &dsteal, &dsbuf}) { d->retired = r; d->pool = poolKeep.get(); }
     for (PinBuf *h : {&hblob, &hstage, &hpacked}) { h->retired = r; h->pool = poolKeep.get(); }
   }
 };
@@ -435,8 +437,8 @@ struct rc_stream {
 // layout of rc_batch::dcounters (uint32 units)
 constexpr size_t kCntExact = 0;                                  // [kClassSlots] int: blocks flagged by k_prep_lut, by class
 constexpr int kMaxRounds = 6;                                    // --stop-early: rounds of sample groups (each doubles the samples simulated so far)
-constexpr size_t kCntWork = kClassSlots + 1;                     // [kMaxRounds][2 fast/exact][kClassSlots][8]
-constexpr size_t kCntClamp = kCntWork + static_cast<size_t>(kMaxRounds) * 2 * kClassSlots * 8;  // one u64 (8-byte aligned: see static_assert)
+constexpr size_t kCntWork = kClassSlots + 1;                     // [kMaxRounds][3: fast / exact / split simulation][kClassSlots][8]
+constexpr size_t kCntClamp = kCntWork + static_cast<size_t>(kMaxRounds) * 3 * kClassSlots * 8;  // one u64 (8-byte aligned: see static_assert)
 constexpr size_t kCntTotal = kCntClamp + 2;
 static_assert((kCntClamp % 2) == 0, "clamp counter alignment");
 

@@ -130,16 +130,17 @@ int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t ex
   rc_batch *b = R.b; rc_ctx *c = R.c;
   const int groupsHere = gHi - gLo;
   struct Plan { int NK, grid, gridExact, comboSplit; size_t stride, ldsBytes, need; double itemCost; int hiOcc, cacheSites; size_t plainLds;
+                int rowParts, simParts, rowSimGrid; size_t sbufStride, sbufFloats;   // rows split over workgroups (k_null<.., ROWS> + k_null_rowscan)
                 int simGrid, roundBlocks; size_t codesBytes, stateBytes; };   // (the last four: the wide-block class in two launches)
   std::vector<Plan> plans;
-  size_t needSum = 0, needMax = 0;
+  size_t needSum = 0, needMax = 0, sbufSum = 0;
   // Several row-count classes: first planned as launches that run side by side (no strand x frame split: together they fill the chip);
   // if their staging areas do not fit side by side, planned again as one launch after the other, each filling the chip by itself.
   bool together = b->classes.size() > 1 && !c->serialNative;
   // ... unless all of them together are too few to fill the chip: then every item is split into its six parts, as for a single small class
   const bool splitAll = static_cast<double>(b->okBlocks.size()) * groupsHere <= c->splitFactor * c->numCU * 16;
  plan_again:
-  plans.clear(); needSum = 0; needMax = 0;
+  plans.clear(); needSum = 0; needMax = 0; sbufSum = 0;
   for (auto &kv : b->classes) {
     Plan p{};
     p.NK = kv.first;
@@ -195,11 +196,27 @@ int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t ex
     // the inverse of that number (6 / 8 / 10 / 12 / 16 per CU: 93.5 / 71.6 / 59.6 / 51.6 / 42.5 ms at the headline's shape).  Where
     // staging leaves twelve or fewer (blocks of more than ~135 columns), the same kernel reading its codes from L2 behind a suffix
     // cache runs sixteen and is faster: 6 rows x 150 columns 77.3 -> 71.7 ms; at 120 columns (fifteen staged) it is slower, 42.6 -> 47.0.
+    // A batch so small that even its strand x frame parts leave most of the chip idle (a caller that scores block by block,
+    // RNAcode.c:164-216 through the shim: one block at n = 1000 is 96 parts on 4096 wavefront slots, and the launch lasts as long as
+    // the DP of one part, ~2300 cells in a chain): every part's rows are split into up to eight ranges of equal cell counts, each a
+    // work item of k_null<.., ROWS>, which leaves the S values in a buffer; k_null_rowscan folds them in getHSS's order afterwards.
+    p.rowParts = 1; p.simParts = 1; p.rowSimGrid = 0; p.sbufStride = 0; p.sbufFloats = 0;
+    if (c->rowSplit && !exactOnly && p.NK < kFastRows && !R.streaming) {
+      const long long slots = static_cast<long long>(c->numCU) * 16;
+      const long long partsAll = static_cast<long long>(together ? b->okBlocks.size() : kv.second.size()) * groupsHere * 6;
+      if ((!together || splitAll) && partsAll * 2 <= slots) {
+        const size_t smax = static_cast<size_t>(maxLc) / 3;
+        p.rowParts = static_cast<int>(std::min<long long>(8, slots / partsAll));
+        p.sbufStride = smax * (smax + 1) / 2 * kWave;
+        p.sbufFloats = p.sbufStride * 6 * kv.second.size() * static_cast<size_t>(groupsHere);
+        if (p.sbufFloats * sizeof(float) > (static_cast<size_t>(256) << 20) || smax < 45) { p.rowParts = 1; p.sbufStride = p.sbufFloats = 0; }   // (under ~1000 cells per part the second kernel and the eightfold simulation cost more than the split saves: 4 x 76: 0.11 -> 0.19 ms)
+      }
+    }
     bool dualL2 = false;
-    if (!exactOnly && p.NK >= 3 && p.NK <= kDualRowsMaxNK && R.fat && p.ldsBytes <= c->ldsMaxBytes)
+    if (p.rowParts == 1 && !exactOnly && p.NK >= 3 && p.NK <= kDualRowsMaxNK && R.fat && p.ldsBytes <= c->ldsMaxBytes)
       dualL2 = c->ldsPerCU / std::max<size_t>(p.ldsBytes, kPhaseALds) <= 12;
     const bool twoRows = p.NK <= kDualRowsMaxNK && (p.NK == 2 || R.fat);   // (the launch's own test, below)
-    if (p.ldsBytes > (twoRows ? c->ldsMaxBytes : std::min(c->ldsMaxBytes, c->ldsMaxBytesOneRow)) || exactOnly || dualL2 || (p.NK > kDualRowsMaxNK && !c->stageManyRows)) p.ldsBytes = 0;
+    if (p.ldsBytes > (twoRows ? c->ldsMaxBytes : std::min(c->ldsMaxBytes, c->ldsMaxBytesOneRow)) || exactOnly || dualL2 || p.rowParts > 1 || (p.NK > kDualRowsMaxNK && !c->stageManyRows)) p.ldsBytes = 0;
     else p.ldsBytes = std::max<size_t>(p.ldsBytes, kPhaseALds);   // phase A keeps the tree's threshold table and the pair table there
     const std::pair<int, size_t> key(p.NK, p.ldsBytes);
     if (!c->occ.count(key)) c->occ[key] = null_occupancy(p.NK, p.ldsBytes);
@@ -220,8 +237,13 @@ int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t ex
     if (c->gridCapPerCU > 0) occ = std::min(occ, c->gridCapPerCU);
     int items = static_cast<int>(kv.second.size()) * groupsHere;
     // small batches: split every item into its six strand x frame parts to fill the chip
-    p.comboSplit = (together ? splitAll : static_cast<double>(items) <= c->splitFactor * c->numCU * occ) ? 1 : 0;
-    if (p.comboSplit) items *= 6;
+    p.comboSplit = (p.rowParts > 1 || (together ? splitAll : static_cast<double>(items) <= c->splitFactor * c->numCU * occ)) ? 1 : 0;
+    if (p.rowParts > 1) {   // the simulation of an item in site ranges of about sixteen sites, as many as fill a quarter of the chip
+      const long long its = static_cast<long long>(kv.second.size()) * groupsHere;
+      p.simParts = static_cast<int>(std::max<long long>(1, std::min<long long>({16, maxLc / 16, static_cast<long long>(c->numCU) * 4 / std::max<long long>(its, 1)})));
+      p.rowSimGrid = static_cast<int>(std::min<long long>(its * p.simParts, static_cast<long long>(c->numCU) * occ));
+    }
+    if (p.comboSplit) items *= 6 * p.rowParts;
     p.grid = std::min(items, c->numCU * occ);
     // very long blocks: bound the sigma-code staging area (4 GiB of uint32) by running fewer workgroups
     p.grid = static_cast<int>(std::max<size_t>(1, std::min<size_t>(p.grid, (static_cast<size_t>(1) << 30) / std::max<size_t>(p.stride, 1))));
@@ -229,7 +251,9 @@ int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t ex
     // number is only known on the device, the launch is a few idle workgroups when there are none
     p.gridExact = exactOnly ? 0 : std::min(p.grid, c->numCU);
     p.need = p.stride * std::max(p.grid, p.gridExact);
+    if (p.rowParts > 1) p.need = p.stride * std::max<size_t>(kv.second.size() * static_cast<size_t>(groupsHere), static_cast<size_t>(p.gridExact));   // one scratch per ITEM
     needSum += p.need; needMax = std::max(needMax, p.need);
+    sbufSum += p.sbufFloats;
     plans.push_back(p);
   }
   // Several row-count classes: their launches are independent (own work queues, own part of the staging
@@ -240,7 +264,8 @@ int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t ex
   if (together && needSum > c->togetherWords) { together = false; goto plan_again; }
   const bool concurrent = together;
   const size_t need = concurrent ? needSum : needMax;
-  if (sizeOnly) { *sizeOnly = need; return RC_OK; }
+  if (sizeOnly) { *sizeOnly = need; b->sbufNeed = std::max(b->sbufNeed, sbufSum); return RC_OK; }
+  size_t sbufOff = 0;
   if (need * sizeof(uint32_t) > b->dscratch.cap) return fail(RC_ERR_ARG, "internal: staging scratch was not sized for this round");
   Event &fork = phase ? b->evMid : b->evS0;
   size_t scratchOff = 0;
@@ -268,7 +293,7 @@ int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t ex
     a.maxima = b->maxPtr; a.clampCount = reinterpret_cast<unsigned long long *>(b->dcounters.as<uint32_t>() + kCntClamp);
     a.tieThr = c->tieThr; a.debugSkip = c->debugSkip; a.comboSplit = p.comboSplit;
     a.cellStats = c->d_cellStats.as<unsigned long long>();
-    unsigned int *work = b->dcounters.as<unsigned int>() + kCntWork + static_cast<size_t>(phase) * 2 * kClassSlots * 8;
+    unsigned int *work = b->dcounters.as<unsigned int>() + kCntWork + static_cast<size_t>(phase) * 3 * kClassSlots * 8;
     {
       const double cost = p.itemCost * static_cast<double>(members.size()) * groupsHere;
       if (cost > b->nullKernelCost) {
@@ -277,9 +302,10 @@ int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t ex
         else {
           const bool ex = b->allExact || p.NK >= kFastRows;
           const bool dual = !ex && p.ldsBytes && p.ldsBytes <= 48 * 1024 && p.NK <= kDualRowsMaxNK && (p.NK == 2 || R.fat);
-          if (!ex && !p.ldsBytes && p.hiOcc == 2) b->nullKernel = "rc::k_null<" + std::to_string(p.NK) + ", false, false, true>";
+          if (!ex && !p.ldsBytes && p.hiOcc == 2) b->nullKernel = "rc::k_null<" + std::to_string(p.NK) + ", false, false, true, false>";
           else if (!ex && !p.ldsBytes && p.hiOcc) b->nullKernel = "rc::k_null_occ<" + std::to_string(p.NK) + ">";
-          else b->nullKernel = "rc::k_null<" + std::to_string(p.NK) + (!ex && p.ldsBytes ? ", true" : ", false") + (ex ? ", true" : ", false") + (dual ? ", true>" : ", false>");
+          else if (p.rowParts > 1) b->nullKernel = "rc::k_null<" + std::to_string(p.NK) + ", false, false, false, true>";
+          else b->nullKernel = "rc::k_null<" + std::to_string(p.NK) + (!ex && p.ldsBytes ? ", true" : ", false") + (ex ? ", true" : ", false") + (dual ? ", true, false>" : ", false, false>");
         }
       }
     }
@@ -321,6 +347,11 @@ int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t ex
       a.workCounter = work + p.NK * 8;
       a.dual = (p.ldsBytes && p.NK <= kDualRowsMaxNK && (p.NK == 2 || R.fat)) ? 1 : 0;
       a.hiOcc = p.hiOcc; a.plainLds = static_cast<int>(p.plainLds); a.cacheSites = p.cacheSites;
+      if (p.rowParts > 1 && b->dsbuf.p && (sbufOff + p.sbufFloats) * sizeof(float) <= b->dsbuf.cap) {
+        a.rowParts = p.rowParts; a.sbuf = b->dsbuf.as<float>() + sbufOff; a.sbufStride = p.sbufStride;
+        a.simParts = p.simParts; a.simGrid = p.rowSimGrid; a.simCounter = work + 2 * kClassSlots * 8 + p.NK * 8;
+        sbufOff += p.sbufFloats;
+      } else if (p.rowParts > 1) return fail(RC_ERR_ARG, "internal: the row buffer was not sized for this round");
       // tail sharing: one slot per workgroup of this launch in the zeroed dsteal area (see batch_run_async)
       if (c->tailSharing && !p.comboSplit && static_cast<size_t>(p.grid) <= steal_slots(c) && b->dsteal.p) {
         const size_t idx = static_cast<size_t>(phase) * b->classes.size() + pi;
@@ -329,6 +360,7 @@ int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t ex
       }
       if (!launch_null(p.NK, a, p.grid, p.ldsBytes, false, st)) return fail(RC_ERR_UNSUPPORTED, "no null kernel for this number of rows");
       b->nl[2]++;
+      if (a.rowParts > 1) launch_null_rowscan(a, static_cast<int>(members.size()) * groupsHere, st);
       NullArgs e = a;
       e.classBlocks = b->dexact.as<int>() + b->classOff[p.NK];
       e.nBlocksPtr = b->dcounters.as<int>() + kCntExact + p.NK;
@@ -336,7 +368,7 @@ int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t ex
       e.skipMask = extraSkip;
       e.comboSplit = 0;
       e.steal = nullptr;
-      e.dual = 0; e.hiOcc = 0; e.plainLds = 0; e.cacheSites = 0;
+      e.dual = 0; e.hiOcc = 0; e.plainLds = 0; e.cacheSites = 0; e.rowParts = 0; e.sbuf = nullptr; e.simParts = 0; e.simGrid = 0; e.simCounter = nullptr;
       e.workCounter = work + kClassSlots * 8 + p.NK * 8;
       if (!launch_null(p.NK, e, p.gridExact, 0, true, st)) return fail(RC_ERR_UNSUPPORTED, "no null kernel for this number of rows");
     }

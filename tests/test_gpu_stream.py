@@ -730,7 +730,7 @@ def test_two_rows_per_pass_equal_one_row_per_pass_and_the_oracle():
     for n, blocks in cases.items():
         on, off = got[(n, "1")], got[(n, "0")]
         # the two instantiations really ran (three rows: two other sequences leave a quarter of the registers free, always two-row)
-        assert on[3].endswith(", true>") and off[3].endswith(", true>" if n == 3 else ", false>"), (on[3], off[3])
+        assert on[3].endswith(", true, false>") and off[3].endswith(", true, false>" if n == 3 else ", false, false>"), (on[3], off[3])
         np.testing.assert_array_equal(on[0], off[0], err_msg=f"{n} rows")
         np.testing.assert_array_equal(on[1], off[1], err_msg=f"{n} rows (fits)")
         assert on[2] == off[2]
@@ -868,3 +868,41 @@ def test_no_step_of_a_small_multi_class_batch_stalls():
     worst = max(times)
     st.close(); resident.close(); ctx.close()
     assert worst <= 10.0 * med, f"a step took {worst:.1f} ms, the median is {med:.2f} ms"
+
+
+def test_rows_split_over_workgroups_equal_the_fused_scan_and_the_oracle(monkeypatch):
+    """Tiny batches (a caller that scores block by block: RNAcode.c:164-216 through the shim) split every strand x frame part's rows
+    over up to eight workgroups (k_null<.., ROWS>: the S values go to a buffer in getHSS's entry order) and fold them afterwards
+    (k_null_rowscan).  One block, two blocks of different row counts, ragged sample counts, gapped blocks with frame-shift events, a
+    block of three codons, --stop-early in rounds: per-sample maxima, fits and HSS tables equal RC_ROW_SPLIT=0's bit for bit, and the
+    oracle's."""
+    from oracle import binding as ob
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_block
+    rng = np.random.RandomState(404)
+    cases = []
+    for rows, cols, n in ((10, 201, 1000), (4, 76, 1000), (8, 342, 1000), (6, 120, 100), (3, 30, 64), (12, 150, 129), (7, 97, 333), (5, 9, 200), (31, 60, 64)):
+        cases.append(([synth_block(rng, rows, cols, index=0, gaps=True).upper()], n, {}))
+    cases.append(([synth_block(rng, 6, 150, index=0, gaps=True).upper(), synth_block(rng, 9, 90, index=1, gaps=True).upper()], 192, {}))
+    cases.append(([synth_block(rng, 8, 120, index=0, gaps=False, mean_branch=0.02).upper()], 1000, dict(stopEarly=1, cutoff=0.05)))
+    got = {}
+    for split in ("1", "0"):
+        monkeypatch.setenv("RC_ROW_SPLIT", split)
+        monkeypatch.setenv("RC_STOP_MIN_ITEMS", "0")     # --stop-early in rounds even for one block
+        c = api.Context(0)
+        for k, (blocks, n, kw) in enumerate(cases):
+            b = api.Batch(c, blocks, api.default_params(sampleN=n, seed_base=23, **kw)).run()
+            got[(k, split)] = (b.maxScores_all().copy(), b.fits().copy(), [b.scoreAln(i) for i in range(b.n)], int(b.clamped()))
+            b.close()
+        c.close()
+    for k, (blocks, n, kw) in enumerate(cases):
+        on, off = got[(k, "1")], got[(k, "0")]
+        np.testing.assert_array_equal(on[0], off[0], err_msg=f"case {k}")
+        np.testing.assert_array_equal(on[1], off[1], err_msg=f"case {k} (fits)")
+        assert on[2] == off[2] and on[3] == off[3]
+        if not kw:
+            blk = blocks[0]
+            m = min(n, 64)
+            want = ob.run_block([r.seq for r in blk.rows], [r.name for r in blk.rows], blk.rows[0].start, blk.rows[0].length, blk.tree, blk.kappa,
+                                ob.default_params(m), 23)
+            np.testing.assert_array_equal(on[0][0][:m], np.float32(want.maxScores), err_msg=f"case {k} against the oracle")

@@ -42,7 +42,8 @@ def soak(budget=60.0, rng_seed=1, mode="", max_blocks=None, log=print):
             pars = dict(blosum=90)
         blocks = []
         fat_n = int(rng.choice([3, 4, 5, 6]))
-        for i in range(int(rng.randint(1, 6 if wide else 25))):
+        most = int(__import__('os').environ.get('RC_SOAK_MAX_BLOCKS_PER_BATCH', 0)) or (5 if wide else 24)   # (tiny batches: the row-split path)
+        for i in range(int(rng.randint(1, most + 1))):
             n = int(rng.choice([3, 3, 4, 5, 6, 6, 7, 8, 10, 12, 17, 32, 33, 40, 64, 65, 90, 130]))
             cols = int(rng.choice([9, 12, 30, 45, 60, 90, 120, 150, 200, 301]))
             if fat:
