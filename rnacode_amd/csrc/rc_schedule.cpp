@@ -302,10 +302,10 @@ int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t ex
         else {
           const bool ex = b->allExact || p.NK >= kFastRows;
           const bool dual = !ex && p.ldsBytes && p.ldsBytes <= 48 * 1024 && p.NK <= kDualRowsMaxNK && (p.NK == 2 || R.fat);
-          if (!ex && !p.ldsBytes && p.hiOcc == 2) b->nullKernel = "rc::k_null<" + std::to_string(p.NK) + ", false, false, true, false>";
+          if (!ex && !p.ldsBytes && p.hiOcc == 2) b->nullKernel = "rc::k_null<" + std::to_string(p.NK) + ", false, false, true, 0>";
           else if (!ex && !p.ldsBytes && p.hiOcc) b->nullKernel = "rc::k_null_occ<" + std::to_string(p.NK) + ">";
-          else if (p.rowParts > 1) b->nullKernel = "rc::k_null<" + std::to_string(p.NK) + ", false, false, false, true>";
-          else b->nullKernel = "rc::k_null<" + std::to_string(p.NK) + (!ex && p.ldsBytes ? ", true" : ", false") + (ex ? ", true" : ", false") + (dual ? ", true, false>" : ", false, false>");
+          else if (p.rowParts > 1) b->nullKernel = "rc::k_null<" + std::to_string(p.NK) + ", false, false, false, 1>";
+          else b->nullKernel = "rc::k_null<" + std::to_string(p.NK) + (!ex && p.ldsBytes ? ", true" : ", false") + (ex ? ", true" : ", false") + (dual ? ", true, 0>" : ", false, 0>");
         }
       }
     }

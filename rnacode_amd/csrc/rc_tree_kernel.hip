@@ -138,7 +138,7 @@ __device__ __forceinline__ void tree_fit_body(const TreeJob *jobs, const uint8_t
   }
 }
 
-// RC_TREE_WAVES (a build-time experiment, tools/tree_waves.sh): the register budget as wavefronts per SIMD; unset = what the compiler takes
+// RC_TREE_WAVES (a build-time experiment: make OBJDIR=… CXXFLAGS+=-DRC_TREE_WAVES=3, profiles/r05/tree_occupancy_and_register_budgets.txt): the register budget as wavefronts per SIMD; unset = what the compiler takes
 #ifdef RC_TREE_WAVES
 #define RC_TREE_BUDGET __attribute__((amdgpu_waves_per_eu(RC_TREE_WAVES, RC_TREE_WAVES)))
 #else

@@ -13,8 +13,8 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ONE_ROW = "_ZN2rc6k_nullILi5ELb1ELb0ELb0ELb0EEEvNS_8NullArgsEPKhPKNS_8DevBlockEPKiPKjSA_S3_PjPf"    # k_null<5, true, false, false>
-TWO_ROWS = "_ZN2rc6k_nullILi5ELb1ELb0ELb1ELb0EEEvNS_8NullArgsEPKhPKNS_8DevBlockEPKiPKjSA_S3_PjPf"   # k_null<5, true, false, true>
+ONE_ROW = "_ZN2rc6k_nullILi5ELb1ELb0ELb0ELi0EEEvNS_8NullArgsEPKhPKNS_8DevBlockEPKiPKjSA_S3_PjPf"    # k_null<5, true, false, false>
+TWO_ROWS = "_ZN2rc6k_nullILi5ELb1ELb0ELb1ELi0EEEvNS_8NullArgsEPKhPKNS_8DevBlockEPKiPKjSA_S3_PjPf"   # k_null<5, true, false, true>
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
@@ -63,7 +63,7 @@ def test_k_null_cell_loops_are_wave_uniform_and_tight(tmp_path):
     assert vgprs <= 128, vgprs       # four wavefronts per SIMD (16 per CU is what the LDS allows)
 
 
-PLAIN = "_ZN2rc6k_nullILi6ELb0ELb0ELb0ELb0EEEvNS_8NullArgsEPKhPKNS_8DevBlockEPKiPKjSA_S3_PjPf"      # k_null<6, false, false, false>
+PLAIN = "_ZN2rc6k_nullILi6ELb0ELb0ELb0ELi0EEEvNS_8NullArgsEPKhPKNS_8DevBlockEPKiPKjSA_S3_PjPf"      # k_null<6, false, false, false>
 OCC6 = "_ZN2rc10k_null_occILi6EEEvNS_8NullArgsEPKhPKNS_8DevBlockEPKiPKjSA_S3_PjPf"             # k_null_occ<6>
 _FETCH = re.compile(r"(?:global_load_(?:dword|ubyte|ushort) (v\d+), v\d+, s\[\d+:\d+\]|ds_read_(?:b32|u8|u16) (v\d+), v\d+)")
 
@@ -177,6 +177,6 @@ def test_no_pending_fetch_register_is_copied_or_spilled_at_twelve_rows(tmp_path)
     latter compiled for 96 registers with some twenty spilled)."""
     txt = _compile_unit(tmp_path, "rc_null_b")
     names = re.findall(r"\.amdhsa_kernel (\S+)", txt)
-    for want in ("k_nullILi11ELb0ELb0ELb0ELb0E", "k_null_occILi11E"):
+    for want in ("k_nullILi11ELb0ELb0ELb0ELi0E", "k_null_occILi11E"):
         audited, fetches = _audit_pending_registers(txt, next(n for n in names if want in n))
         assert audited >= 4 and fetches >= 24, (want, audited, fetches)

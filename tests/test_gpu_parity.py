@@ -984,7 +984,8 @@ def test_native_cli_on_several_gpus_writes_the_single_gpu_listing(tmp_path):
     maf.write_text(to_maf(blocks))
     for fmt in (["-t"], ["-g"], ["-t", "-b"], ["-t", "-r", "-p", "0.5"]):
         one = run([str(maf), "-n", "200", *fmt])
-        for extra in (["--gpus", "2", "--devices", "0,0"], ["--gpus", "3", "--devices", "0,0,0", "--sub-blocks", "37"]):
+        more = [["--gpus", "8", "--devices", "0,0,0,0,0,0,0,0", "--sub-blocks", "41"]] if fmt == ["-t"] else []   # (what an 8-GPU node runs: eight contexts, one writer)
+        for extra in [["--gpus", "2", "--devices", "0,0"], ["--gpus", "3", "--devices", "0,0,0", "--sub-blocks", "37"]] + more:
             got = run([str(maf), "-n", "200", *fmt, *extra])
             assert got.stdout == one.stdout and one.stdout.count("\n") > 100, (fmt, extra)
             assert sorted(got.stderr.splitlines()) == sorted(one.stderr.splitlines())   # the "Skipping alignment" notes

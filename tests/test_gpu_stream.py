@@ -730,7 +730,7 @@ def test_two_rows_per_pass_equal_one_row_per_pass_and_the_oracle():
     for n, blocks in cases.items():
         on, off = got[(n, "1")], got[(n, "0")]
         # the two instantiations really ran (three rows: two other sequences leave a quarter of the registers free, always two-row)
-        assert on[3].endswith(", true, false>") and off[3].endswith(", true, false>" if n == 3 else ", false, false>"), (on[3], off[3])
+        assert on[3].endswith(", true, 0>") and off[3].endswith(", true, 0>" if n == 3 else ", false, 0>"), (on[3], off[3])
         np.testing.assert_array_equal(on[0], off[0], err_msg=f"{n} rows")
         np.testing.assert_array_equal(on[1], off[1], err_msg=f"{n} rows (fits)")
         assert on[2] == off[2]
