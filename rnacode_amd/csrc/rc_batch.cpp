@@ -256,7 +256,7 @@ int batch_run_async(rc_batch *b, bool streaming) {
   }
   bool fat = allFat && (!streaming || static_cast<long long>(b->okBlocks.size()) * groups >= c->fatStreamMinItems);
   if (fat) nativeFirst = true;
-  // k_null_generic's persistent grid takes every register of the chip as well (128 VGPRs, four wavefronts per SIMD): native-block
+  // k_generic_dp's persistent grid takes every register of the chip as well (128 VGPRs, four wavefronts per SIMD): native-block
   // kernels queued beside it either wait for its tail or, worse, get in first and keep part of its workgroups out for their whole run
   if (wide) nativeFirst = true;
   const int nativeMode = c->serialNative ? 0 : nativeFirst ? 1 : 0;

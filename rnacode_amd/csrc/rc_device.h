@@ -13,7 +13,7 @@
 namespace rc {
 
 constexpr int kMaxRows = 500;     // N <= 500 (RC_MAX_ROWS, the reference's MAX_NUM_NAMES, rnaz_utils.h:7)
-constexpr int kTemplRows = 64;    // N <= 64: kernels instantiated per N-1 (k_null<N-1>, k_native_dp<N-1>); above: k_null_generic
+constexpr int kTemplRows = 64;    // N <= 64: kernels instantiated per N-1 (k_null<N-1>, k_native_dp<N-1>); above: k_generic_sim + k_generic_dp
 constexpr int kFastRows = 32;     // N <= 32: register-resident fast instantiations; 33..64 the EXACT instantiation only
 constexpr int kGenericClass = kTemplRows;   // row-count classes are indexed by N-1 (2..63); all wider blocks share this one
 constexpr int kClassSlots = kTemplRows + 1;
@@ -35,8 +35,12 @@ struct alignas(16) NodeRec {
   uint32_t basepack;   // base[p] in bits 2p..2p+1 (non-zero only for degenerate cumulative rows)
   uint16_t parent;     // index of the parent node in this order (root: 0); the instantiated kernels (< 256 nodes) read its low byte
   int16_t tiprow;      // alignment row of this tip, -1 for internal nodes
-  uint8_t pad[8];
+  uint32_t gctrl;      // k_generic_sim: where the parent's state is -- node_ctrl(parent) | bit 31 if the parent is one of this node's group of eight
+  uint8_t pad[4];
 };
+// k_generic_sim keeps the node states of a site 2 bits each, eight nodes per 16-bit word, [word][lane] in LDS: bits 0..3 the position
+// of node q's two bits in its word, bits 7..13 the word's byte offset (q >> 3) * 128
+constexpr uint32_t node_ctrl(uint32_t q) { return (2u * (q & 7u)) | ((q >> 3) << 7); }
 static_assert(sizeof(NodeRec) == 80, "NodeRec layout");
 
 // Background model of one (strand, row) (bgModel, score.h:34-44).  The host fills the HKY85 matrix
@@ -64,7 +68,7 @@ struct DevBlock {
   // offsets (bytes) into the batch blob; host-written part
   uint64_t off_nodes;    // NodeRec[nnodes]
   uint64_t off_qtip;     // u8[N padded to 16] node index of row r's tip (k_null reads words); meaningful for N <= 64 (fewer than 256 nodes)
-  uint64_t off_qtip16;   // u16[N] the same for any N (k_null_generic)
+  uint64_t off_qtip16;   // u16[N] the same for any N (k_generic_sim)
   uint64_t off_chars;    // u8[N][cols] native characters, upper-cased (RNAcode.c:121-128)
   uint64_t off_models;   // ModelRec[2][N]
   // device-only arena
@@ -75,7 +79,7 @@ struct DevBlock {
   uint64_t off_zmask;    // u64[2][3][zm_words] bit j of (strand, frame): some sequence has z != 0 at codon site j (k_prep_gaps)
   uint64_t off_lut;      // f32[2][NK][64] sigma value per code (k_prep_lut)
   uint64_t off_sigma;    // f32[2][NK][L+1] native sigma (k_native_sigma)
-  uint64_t off_chain;    // f32[L/3 + 40] W[3 + t] = omega added t times to 0 (W[0..3] = 0): the gap states of a sequence without a frame shift, t cells into a row (k_prep_lut; k_null_generic)
+  uint64_t off_chain;    // f32[L/3 + 40] W[3 + t] = omega added t times to 0 (W[0..3] = 0): the gap states of a sequence without a frame shift, t cells into a row (k_prep_lut; k_generic_dp)
 };
 
 // k_null's staging scratch: the sigma codes of one (strand, reference position) for the 64 samples of a wavefront -- five 6-bit codes

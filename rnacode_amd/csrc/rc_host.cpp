@@ -520,6 +520,7 @@ int prepare_block(const rc_block &in, const rc_params &par, const PairTable &pt,
     NodeRec &nr = nodes[q];
     std::memset(&nr, 0, sizeof nr);
     nr.parent = static_cast<uint16_t>(t.parent[q]);
+    nr.gctrl = node_ctrl(static_cast<uint32_t>(t.parent[q])) | ((t.parent[q] >> 3) == (q >> 3) ? 0x80000000u : 0u);
     nr.tiprow = -1;
     double M[4][4];
     if (q != 0) hky.cumulative(t.length[q], M);                      // evolve.c:404 (scale 1.0), :292

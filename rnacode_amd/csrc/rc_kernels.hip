@@ -268,7 +268,7 @@ __global__ __launch_bounds__(64) void k_prep_lut(PrepArgs A) {   // one wavefron
     lut[idx] = v;
     mine |= !in_div_range_dev(v);
   }
-  if (N >= A.genericMinRows && threadIdx.x == 0) {   // k_null_generic's running sums of omega, added the way the DP adds them
+  if (N >= A.genericMinRows && threadIdx.x == 0) {   // k_generic_dp's running sums of omega, added the way the DP adds them
     float *W = reinterpret_cast<float *>(A.blob + db->off_chain);
     const int nW = db->L / 3 + 40;
     const float omega = db->omega;
@@ -950,14 +950,7 @@ void launch_sk_row(const uint8_t *blob, const DevBlock *dblocks, int bi, int s, 
   hipLaunchKernelGGL(k_sk_row, dim3(1), dim3(64), 0, stream, blob, dblocks, bi, s, b, iMax, out, stride);
 }
 
-size_t null_generic_scratch_bytes(int N, int L, int nnodes) { return GenericLayout(N, L, nnodes).total; }
 size_t null_generic_lds_bytes(int N, int nnodes) { return generic_lds_bytes(N, nnodes); }
-
-int null_generic_occupancy(size_t ldsBytes) {
-  int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_null_generic, 64, ldsBytes) != hipSuccess) return 0;
-  return nb;
-}
 
 size_t null_generic_codes_bytes(int N, int L, int nnodes) { return generic_codes_bytes(N, L, nnodes); }
 size_t null_generic_state_bytes(int N, int L, int nnodes) { return generic_state_bytes(N, L, nnodes); }
@@ -976,10 +969,6 @@ void launch_generic_sim(const NullArgs &a, int grid, size_t ldsBytes, hipStream_
 }
 void launch_generic_dp(const NullArgs &a, int grid, size_t ldsBytes, uint8_t *scratchBytes, hipStream_t stream) {
   hipLaunchKernelGGL(k_generic_dp, dim3(grid), dim3(64), ldsBytes, stream, a, a.blob, a.dblocks, a.classBlocks, a.flags, a.U, a.pair, scratchBytes, a.maxima);
-}
-
-void launch_null_generic(const NullArgs &a, int grid, size_t ldsBytes, uint8_t *scratchBytes, hipStream_t stream) {
-  hipLaunchKernelGGL(k_null_generic, dim3(grid), dim3(64), ldsBytes, stream, a, a.blob, a.dblocks, a.classBlocks, a.flags, a.U, a.pair, scratchBytes, a.maxima);
 }
 
 void launch_native_dp_generic(const NativeArgs &a, int nblocks, float *scratch, size_t scratchStride, hipStream_t stream) {

@@ -189,10 +189,7 @@ void launch_results_out(const ResultsOutArgs &a, hipStream_t stream);
 void launch_sk_row(const uint8_t *blob, const DevBlock *dblocks, int bi, int s, int b, int iMax, float *out, int stride,
                    hipStream_t stream);
 // wider blocks (N > 64): generic kernels with their states in a global scratch (rc_null_generic.h)
-size_t null_generic_scratch_bytes(int N, int L, int nnodes);
 size_t null_generic_lds_bytes(int N, int nnodes);   // packed node states + codon windows of the widest block of the launch
-int null_generic_occupancy(size_t ldsBytes);
-void launch_null_generic(const NullArgs &a, int grid, size_t ldsBytes, uint8_t *scratchBytes, hipStream_t stream);
 // the same in two launches (simulation with many light wavefronts, then the DP): bytes of an item's codes / of a DP workgroup's states
 size_t null_generic_codes_bytes(int N, int L, int nnodes);
 size_t null_generic_state_bytes(int N, int L, int nnodes);

@@ -15,12 +15,22 @@
 //  * the sums are distinct scalars updated in ONE place per group (an array, or an update per kind of pass, and the register
 //    allocator keeps two sets of sums and copies all of them at both ends of every pass);
 //  * scalar work of the common pass cut to one decision word; the parked s0 stored behind the next pass's loads.
-// What the counters say about the rest (tools/pmc_wide.sh, tools/mb_footprint.hip; timing-only builds without the code words /
-// the parked states / the simulation / the DP): the simulation is a quarter of the kernel and waits for the scalar unit, which the
-// CU's four SIMDs share (5.5e10 SALU + 1.4e10 SMEM instructions per 1024 blocks at 1.3 per ns and CU); the DP without its memory
-// operations runs at 0.50 s of the 1.03, the access pattern alone reaches 6.3 TB/s over a 20 GB footprint, yet more wavefronts
-// per SIMD (5, 6), the next pass's operands fetched ahead into LDS (global_load_lds_dword, 12 dwords per lane: bit-exact, 1.14 ->
-// 1.20 s) and the simulation's table look-ups issued eight sequences ahead (1.08 -> 1.17 s) all measured slower or equal.
+// Round 5 -- 1024 blocks: 1.03 -> 0.93 s, 500 blocks of 200 x 90: 225 -> 189 ms, 16 blocks of 100 x 300: 67 -> 50 ms:
+//  * the simulation rebuilt around what it cost, the CU's one scalar unit and chains of dependent loads (its ISA had ~50 scalar
+//    instructions and nine scalar loads per tree node, the parent's index fetched by a VECTOR load with a full wait behind it, one
+//    table gather round trip per sequence and site): thresholds by ds_bpermute out of one coalesced word per four nodes, control
+//    words ready-made by the host, operands of the next eight nodes and of eight sequences in flight (see the phase below);
+//    alone it takes 117 ms of the 1024-block run, the DP 727 ms;
+//  * the two phases as two launches per round of items for every batch size, not one kernel (see generic_body).
+// What bounds the DP, measured: without its memory operations it runs at 0.50 s; its access pattern alone reaches 6.3 TB/s over a
+// 20 GB footprint (tools/mb_footprint.hip) and a pass moves 3 KB for 64 cell pairs (eight code words, two parked states in, two
+// out): ~3.1 TB per 1024 blocks, every byte from HBM (5 MB of codes per wavefront x 4096 wavefronts); more wavefronts per SIMD
+// (5, 6), the next pass's operands fetched ahead into LDS (global_load_lds_dword: bit-exact, 1.14 -> 1.20 s), and this round the
+// next pass's operands fetched ahead into registers by loads the compiler does not see (code words into the registers of the words
+// just used, no wait in the common pass but the counted ones; needs three wavefronts per SIMD, at four the register allocator's
+// spill reloads in the rare passes put a full wait into the common one): 933 ms against 930 -- latency is not what is left; for
+// 16 blocks (a quarter of the chip's wavefront slots) it is, 50 -> 39 ms, not shipped: a register a pending load writes must not
+// be copied before its wait, and the compiler placed such copies (one parity failure in five runs).
 // Tried earlier and dropped (1024 blocks: 1.60 s then): unguarded steps with the row's last tile computed in full, tiles of 16 or
 // 24 end codons, 3 or 5 wavefronts per SIMD, operands fetched one sequence ahead in registers (51 spilled registers).
 // It is the slow, complete path for rare inputs; the division is the plain '/'.
@@ -29,7 +39,7 @@
 
 namespace rc {
 
-// scratch layout of one workgroup (bytes), for a class whose largest block has N rows, L reference residues, nn tree nodes
+// layout of an item's codes, and behind them of a DP workgroup's scratch (bytes), for a class whose largest block has N rows, L reference residues, nn tree nodes
 struct GenericLayout {
   size_t offCodes;   // u32 [6][NK][nW][64]    sigma codes x 4 per strand x frame and sequence, four consecutive codons per word (byte j & 3)
   size_t offState;   // f32 [2][1 + 3 NK][64]  DP states of every sequence at the last tile boundary, for the two rows of a pass (row 0 of each: spare)
@@ -53,7 +63,7 @@ __host__ __device__ inline size_t generic_state_bytes(int N, int L, int nn) { co
 
 constexpr int kGenericTile = 32;
 #ifndef RC_GENERIC_WAVES
-#define RC_GENERIC_WAVES 4   // wavefronts per SIMD of k_null_generic
+#define RC_GENERIC_WAVES 4   // wavefronts per SIMD of k_generic_dp
 #endif
 
 // The cell sums of a tile as distinct scalar members, not an array: an array becomes one 32-register tuple, and every join of the
@@ -157,18 +167,18 @@ __device__ __forceinline__ void add8(float &c0, float &c1, float &c2, float &c3,
                : "v"(m0), "v"(m1), "v"(m2), "v"(m3), "v"(m4), "v"(m5), "v"(m6), "v"(m7));
 }
 
-// LDS of one workgroup: the node states of the site being simulated, 2 bits each, 16 nodes per word [ceil(nn/16)][64], then the
-// last three states of every row, 6 bits in a byte [N][64]
+// LDS of one workgroup: the node states of the site being simulated, 2 bits each, eight nodes per 16-bit word [ceil(nn/8)][64] (rc_device.h,
+// node_ctrl), then the last three states of every row, 6 bits in a byte [N][64]
 __host__ __device__ inline size_t generic_lds_bytes(int N, int nn) {
   return (static_cast<size_t>((nn + 15) >> 4) * sizeof(uint32_t) + static_cast<size_t>(N)) * kWave;
 }
 
-// MODE 0: simulation and DP of an item in one go, the sigma codes in the workgroup's own scratch (small batches).
-// MODE 1 / 2: two launches, for batches of so few items that each is split into its six strand x frame parts: k_generic_sim writes the
-// codes of item u = (block of the class) x groups + (group - gLo) to codesAll + u * codesStride, k_generic_dp's six parts of the item
-// read them there instead of simulating it six times.  (For large batches the two launches gain nothing: the simulation's LDS allows
-// no more wavefronts per CU than the DP's registers, and 5 MB of codes per item would have to go through the scratch in rounds.)
-template <int MODE>
+// Two launches per round of items: k_generic_sim (SIM) writes the sigma codes of item u = (block of the round) x groups + (group - gLo) to
+// codesAll + u * codesStride, k_generic_dp reads them there -- an item whole, or, in a batch of so few items that each is split into its six
+// strand x frame parts to fill the chip, one part per workgroup.  (Until round 5 large batches ran both phases in one kernel: wavefronts
+// in the simulation and in the DP side by side on a CU cost more than the two in turn -- 1024 blocks of 100 x 300: 972 ms against 117 ms
+// + 727 ms alone, 928 ms as two launches per round of 4096 items; 500 blocks of 200 x 90: 225 -> 189 ms; 40 blocks of 500 x 60: 63.5 -> 45.1.)
+template <bool SIM>
 __device__ __forceinline__ void generic_body(const NullArgs &A, const uint8_t *__restrict__ blob, const DevBlock *__restrict__ dblocks,
                                              const int *__restrict__ classBlocks, const uint32_t *__restrict__ flags,
                                              const uint32_t *__restrict__ Ustream, const uint8_t *__restrict__ pairTab,
@@ -179,7 +189,7 @@ __device__ __forceinline__ void generic_body(const NullArgs &A, const uint8_t *_
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   const int home = static_cast<int>(xcc & 7u);
   const int nBlocks = A.nClassBlocks;
-  const int parts = (A.comboSplit && MODE != 1) ? 6 : 1;   // few items: one strand x frame part each (maxima meet in an atomic max), as in k_null
+  const int parts = (A.comboSplit && !SIM) ? 6 : 1;   // few items: one strand x frame part each (maxima meet in an atomic max), as in k_null
   for (int qi = 0; qi < 8;) {
     const int q = (home + qi) & 7;
     const int g0 = A.gLo + ((q - A.gLo) & 7);
@@ -196,7 +206,7 @@ __device__ __forceinline__ void generic_body(const NullArgs &A, const uint8_t *_
     if (A.skipMask && (flags[bi] & A.skipMask)) continue;
     const int sub = t % perBlock;
     const int grp = g0 + 8 * (sub / parts);
-    const int onlyCombo = (A.comboSplit && MODE != 1) ? sub % parts : -1;
+    const int onlyCombo = (A.comboSplit && !SIM) ? sub % parts : -1;
     const DevBlock *__restrict__ db = dblocks + bi;
     const int N = db->N, NK = db->NK, cols = db->cols, L = db->L, nnodes = db->nnodes, L1 = L + 1;
     const int NCW = (NK + 4) / 5, ZW = db->zw_words;
@@ -208,73 +218,145 @@ __device__ __forceinline__ void generic_body(const NullArgs &A, const uint8_t *_
     const uint32_t *__restrict__ maskw = reinterpret_cast<const uint32_t *>(blob + db->off_mask);
     const float *__restrict__ lut = reinterpret_cast<const float *>(blob + db->off_lut);
     const GenericLayout lay(N, L, nnodes);
-    uint8_t *__restrict__ codes = MODE == 0 ? mine + lay.offCodes
-                                            : A.codesAll + (static_cast<size_t>(t / perBlock) * (A.gHi - A.gLo) + static_cast<size_t>(grp - A.gLo)) * A.codesStride;
-    uint32_t *nodeSt = ldsGeneric + lane;                                                                     // word w: [w * 64]
+    uint8_t *__restrict__ codes = A.codesAll + (static_cast<size_t>(t / perBlock) * (A.gHi - A.gLo) + static_cast<size_t>(grp - A.gLo)) * A.codesStride;
     uint8_t *win = reinterpret_cast<uint8_t *>(ldsGeneric + static_cast<size_t>((nnodes + 15) >> 4) * kWave) + lane;   // row r: [r * 64]
-    const size_t stateAt = MODE == 0 ? lay.offState : 0;   // (two launches: the workgroup's scratch holds the states and the row buffer only)
-    float *__restrict__ dp = reinterpret_cast<float *>(mine + stateAt) + kWave;   // (the row in front: see the parked s0 below)
+    float *__restrict__ dp = reinterpret_cast<float *>(mine) + kWave;   // (the DP's scratch: the states and the row buffer; the row in front: see the parked s0 below)
     const int sidx = grp * kWave + lane;
 
     // ---- simulate the L reference-residue columns (evolve.c:416-433) and emit sigma codes for both strands
-    if constexpr (MODE != 2) {
+    // The CU's one scalar unit and the latency of dependent loads are what this phase costs, so nothing here is derived per node or per
+    // row by scalar arithmetic: a node's sixteen thresholds come as ONE coalesced word per lane for four nodes (lane = node x parent
+    // state x threshold) and reach the lane through four ds_bpermutes addressed by the parent's state; where the parent's state is
+    // comes ready-made from the host (NodeRec::gctrl); the draws and thresholds of the next eight nodes are fetched while these eight
+    // are worked; a row's tip position and its two codon masks are computed by the lane of that row and read with v_readlane.
+    if constexpr (SIM) {
     unsigned int clamped = 0;
+    const uint32_t *__restrict__ nodew = reinterpret_cast<const uint32_t *>(nodes);   // a NodeRec as 20 words
+    const uint32_t *__restrict__ refw = reinterpret_cast<const uint32_t *>(refcol);
+    uint8_t *ldsBytes = reinterpret_cast<uint8_t *>(ldsGeneric);
+    const uint32_t laneSt = static_cast<uint32_t>(lane) * 2u;   // node states: 16-bit word g of lane l at g * 128 + 2 l
+    const int thrLane = lane & 15, thrNode = lane >> 4;
+    const size_t qstride = static_cast<size_t>(cols) * A.Spad;
+    const int lastNode = nnodes - 1;
     for (int r = 0; r < N; r++) win[r * kWave] = 0;
     for (int i = 1; i <= L; i++) {
-      const size_t ubase = static_cast<size_t>(refcol[i]) * A.Spad + sidx;
-      const size_t qstride = static_cast<size_t>(cols) * A.Spad;
-      uint32_t cur = 0;   // the word of node states being filled (nodes come parents first)
-      for (int q0 = 0; q0 < nnodes; q0 += 8) {
-        uint32_t uu[8];   // the draws of eight nodes in flight: their latency, not the arithmetic, is the cost of a node
+      const uint32_t col = (refw[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+      const uint32_t *__restrict__ up = Ustream + (static_cast<size_t>(col) * A.Spad + sidx);
+      uint32_t uu[8], thrA, thrB, ctlV;
+      auto fetch = [&](int q0, uint32_t (&u)[8], uint32_t &ta, uint32_t &tb, uint32_t &cv) {
+        if (q0 + 8 <= nnodes) {
 #pragma unroll
-        for (int t = 0; t < 8; t++) uu[t] = Ustream[ubase + static_cast<size_t>(q0 + t < nnodes ? q0 + t : nnodes - 1) * qstride];
+          for (int t = 0; t < 8; t++) { u[t] = *up; up += qstride; }
+        } else {
 #pragma unroll
-        for (int t = 0; t < 8; t++) {
-          const int qn = q0 + t;
-          if (qn < nnodes) {
-            const NodeRec &nr = nodes[qn];
-            const int par = nr.parent;
-            uint32_t ps = 0u;
-            if (qn != 0) {
-              const uint32_t pw = (par >> 4) == (qn >> 4) ? cur : nodeSt[(par >> 4) * kWave];
-              ps = (pw >> (2 * (par & 15))) & 3u;
-            }
-            // the four threshold rows are wave-uniform (scalar loads); the parent's state picks one per lane
-            const U4 t0 = nr.thr[0], t1 = nr.thr[1], t2 = nr.thr[2], t3 = nr.thr[3];
-            const bool p1 = ps == 1u, p2 = ps == 2u, p3 = ps == 3u;
-            const uint32_t thx = p3 ? t3.x : p2 ? t2.x : p1 ? t1.x : t0.x, thy = p3 ? t3.y : p2 ? t2.y : p1 ? t1.y : t0.y,
-                           thz = p3 ? t3.z : p2 ? t2.z : p1 ? t1.z : t0.z, thw = p3 ? t3.w : p2 ? t2.w : p1 ? t1.w : t0.w;
-            const uint32_t u = uu[t];
-            const uint32_t st = (u > thx) + (u > thy) + (u > thz) + ((nr.basepack >> (2 * ps)) & 3u);
-            clamped += (u > thw);
-            cur |= (st & 3u) << (2 * (qn & 15));
-            if ((qn & 15) == 15 || qn == nnodes - 1) { nodeSt[(qn >> 4) * kWave] = cur; cur = 0u; }
+          for (int t = 0; t < 8; t++) {
+            u[t] = 0u;
+            if (q0 + t < nnodes) { u[t] = *up; up += qstride; }
           }
         }
-      }
-      for (int r = 0; r < N; r++) {
-        const int tip = qtip[r];
-        const uint32_t stt = (nodeSt[(tip >> 4) * kWave] >> (2 * (tip & 15))) & 3u;
-        win[r * kWave] = static_cast<uint8_t>(((static_cast<uint32_t>(win[r * kWave]) << 2) | stt) & 63u);
-      }
-      if (i >= 3) {
-        const int ip = L + 3 - i;  // reverse-strand position whose codon is these three columns
-        const uint32_t aF = win[0];
-        const uint32_t aR = codon_flip(aF) ^ 63u;
-        for (int k = 0; k < NK; k++) {
-          const uint32_t mF = (maskw[(0 * L1 + i) * NCW + k / 5] >> (6 * (k % 5))) & 63u;
-          const uint32_t mR = (maskw[(1 * L1 + ip) * NCW + k / 5] >> (6 * (k % 5))) & 63u;
-          const uint32_t b = win[(k + 1) * kWave];
-          const uint32_t bF = b & mF, bR = (codon_flip(b) ^ 63u) & mR;
-          // column i closes codon j = i/3 - 1 of frame i % 3 (i = 3j + 3 + f)
-          codes[(((static_cast<size_t>(0 + i % 3) * NK + k) * lay.nW + ((i / 3 - 1) >> 2)) * kWave + lane) * 4 + ((i / 3 - 1) & 3)] = static_cast<uint8_t>(pairTab[aF * 64 + bF] << 2);
-          codes[(((static_cast<size_t>(3 + ip % 3) * NK + k) * lay.nW + ((ip / 3 - 1) >> 2)) * kWave + lane) * 4 + ((ip / 3 - 1) & 3)] = static_cast<uint8_t>(pairTab[aR * 64 + bR] << 2);
+        const int qa = q0 + thrNode < lastNode ? q0 + thrNode : lastNode, qb = q0 + 4 + thrNode < lastNode ? q0 + 4 + thrNode : lastNode;
+        ta = nodew[qa * 20 + thrLane];
+        tb = nodew[qb * 20 + thrLane];
+        const int qc = q0 + (lane & 7) < lastNode ? q0 + (lane & 7) : lastNode;
+        cv = nodew[qc * 20 + 16 + ((lane >> 3) & 3)];   // lane t: node q0 + t's basepack, lane 16 + t: its gctrl (scalar loads share the counter of the LDS look-ups)
+      };
+      fetch(0, uu, thrA, thrB, ctlV);
+      for (int q0 = 0; q0 < nnodes; q0 += 8) {
+        uint32_t un[8], tnA = 0u, tnB = 0u, cnV = 0u;
+        if (q0 + 8 < nnodes) fetch(q0 + 8, un, tnA, tnB, cnV);
+        const bool full = q0 + 8 <= nnodes;
+        uint32_t cur = 0u;   // the states of this group of eight
+        auto node = [&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          const uint32_t bp = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ctlV), t));
+          const uint32_t ctl = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ctlV), 16 + t));
+          uint32_t pw = cur;
+          if (static_cast<int>(ctl) >= 0) pw = *reinterpret_cast<const uint16_t *>(ldsBytes + ((ctl & 0x7f80u) | laneSt));
+          const uint32_t ps = (pw >> (ctl & 31u)) & 3u;   // (bit 4 of a control word is zero)   // (the root: its own group, nothing set yet: 0, and its four rows are the same)
+          const int at = static_cast<int>(ps << 4) + (t & 3) * 64;
+          const int tv = static_cast<int>(t < 4 ? thrA : thrB);
+          const uint32_t thx = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(at, tv)), thy = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(at + 4, tv)),
+                         thz = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(at + 8, tv)), thw = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(at + 12, tv));
+          const uint32_t u = uu[t];
+          const uint32_t st = (u > thx) + (u > thy) + (u > thz) + ((bp >> (2 * ps)) & 3u);
+          clamped += (u > thw);
+          cur |= (st & 3u) << (2 * t);
+        };
+        if (full) {
+          static_for<8>(node);
+        } else {
+          static_for<8>([&](auto tc) { if (q0 + decltype(tc)::value < nnodes) node(tc); });
         }
+        *reinterpret_cast<uint16_t *>(ldsBytes + (static_cast<uint32_t>(q0 >> 3) * 128u + laneSt)) = static_cast<uint16_t>(cur);
+#pragma unroll
+        for (int t = 0; t < 8; t++) uu[t] = un[t];
+        thrA = tnA; thrB = tnB; ctlV = cnV;
+      }
+      // the rows: the codon window of each takes in the new state; from the third column on a window is a codon, and with the
+      // reference row's it gives the sigma code of this column's codon on either strand
+      const int ip = L + 3 - i;  // reverse-strand position whose codon is these three columns
+      const int jF = i / 3 - 1, jR = ip / 3 - 1;   // column i closes codon j = i/3 - 1 of frame i % 3 (i = 3j + 3 + f)
+      const uint32_t offF = (static_cast<uint32_t>(0 + i % 3) * NK * lay.nW + static_cast<uint32_t>(jF >> 2)) * (kWave * 4) + lane * 4 + (jF & 3);
+      const uint32_t offR = (static_cast<uint32_t>(3 + ip % 3) * NK * lay.nW + static_cast<uint32_t>(jR >> 2)) * (kWave * 4) + lane * 4 + (jR & 3);
+      const uint32_t *__restrict__ mrowF = maskw + static_cast<size_t>(0 * L1 + i) * NCW, *__restrict__ mrowR = maskw + static_cast<size_t>(1 * L1 + (i >= 3 ? ip : L)) * NCW;
+      const bool emit = i >= 3;
+      uint32_t aF, aR;
+      {
+        const uint32_t c = node_ctrl(qtip[0]);
+        const uint32_t wv = *reinterpret_cast<const uint16_t *>(ldsBytes + ((c & 0x7f80u) | laneSt));
+        aF = ((static_cast<uint32_t>(win[0]) << 2) | ((wv >> (c & 31u)) & 3u)) & 63u;
+        win[0] = static_cast<uint8_t>(aF);
+        aR = codon_flip(aF) ^ 63u;
+      }
+      const uint32_t aF64 = aF * 64u, aR64 = aR * 64u;
+      uint8_t *__restrict__ kp = codes;   // sequence k's words of strand x frame 0, word 0
+      const size_t kstep = static_cast<size_t>(lay.nW) * (kWave * 4);
+      for (int k0 = 0; k0 < NK; k0 += kWave) {
+        // lane l works out what sequence k0 + l needs: the word and the bits of its tip's state, its two masks
+        const int kl = k0 + lane < NK ? k0 + lane : NK - 1;
+        const uint32_t tctl = node_ctrl(qtip[kl + 1]);
+        const uint32_t k5 = static_cast<uint32_t>(kl) / 5u, sh = 6u * (static_cast<uint32_t>(kl) - 5u * k5);
+        const uint32_t mFv = (mrowF[k5] >> sh) & 63u, mRv = (mrowR[k5] >> sh) & 63u;
+        const int nk = NK - k0 < kWave ? NK - k0 : kWave;
+        auto rows = [&](auto cnt, int kk) {   // sequences k0 + kk .. + CNT - 1
+          constexpr int CNT = decltype(cnt)::value;
+          uint32_t bb[CNT], pf[CNT], pr[CNT];
+          uint8_t *wrow = win + (k0 + kk + 1) * kWave;
+          uint32_t cc[CNT], wv[CNT];
+#pragma unroll
+          for (int t = 0; t < CNT; t++) {   // (all the reads in front of the writes: the compiler cannot tell the two LDS arrays apart)
+            cc[t] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(tctl), kk + t));
+            wv[t] = *reinterpret_cast<const uint16_t *>(ldsBytes + ((cc[t] & 0x7f80u) | laneSt));
+            bb[t] = wrow[t * kWave];
+          }
+#pragma unroll
+          for (int t = 0; t < CNT; t++) bb[t] = ((bb[t] << 2) | ((wv[t] >> (cc[t] & 31u)) & 3u)) & 63u;
+#pragma unroll
+          for (int t = 0; t < CNT; t++) wrow[t * kWave] = static_cast<uint8_t>(bb[t]);
+          if (emit) {
+#pragma unroll
+            for (int t = 0; t < CNT; t++) {
+              const uint32_t mF = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mFv), kk + t));
+              const uint32_t mR = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mRv), kk + t));
+              pf[t] = pairTab[aF64 + (bb[t] & mF)];
+              pr[t] = pairTab[aR64 + ((codon_flip(bb[t]) ^ 63u) & mR)];
+            }
+#pragma unroll
+            for (int t = 0; t < CNT; t++) {
+              kp[offF] = static_cast<uint8_t>(pf[t] << 2);
+              kp[offR] = static_cast<uint8_t>(pr[t] << 2);
+              kp += kstep;
+            }
+          }
+        };
+        int kk = 0;
+        for (; kk + 8 <= nk; kk += 8) rows(std::integral_constant<int, 8>{}, kk);
+        for (; kk < nk; kk++) rows(std::integral_constant<int, 1>{}, kk);
       }
     }
-    if (clamped && sidx < A.sampleN && onlyCombo <= 0) atomicAdd(A.clampCount, static_cast<unsigned long long>(clamped));   // (the six parts of a split item redo the same simulation)
+    if (clamped && sidx < A.sampleN) atomicAdd(A.clampCount, static_cast<unsigned long long>(clamped));
     }
-    if constexpr (MODE == 1) continue;
+    if constexpr (SIM) continue;
 
     // ---- both strands x 3 frames: DP over (start a, end j) + serial HSS scan (score.c:496-535, 830-845, 888-962)
     // A sequence that has met no frame shift since the row's start has s1 == s2 == the row's running sum of omega, the same
@@ -288,7 +370,7 @@ __device__ __forceinline__ void generic_body(const NullArgs &A, const uint8_t *_
     const float negTie = -A.tieThr;
     const float *__restrict__ chainW = reinterpret_cast<const float *>(blob + db->off_chain);
     const uint32_t zeroCodes = (static_cast<uint32_t>(db->code_zero) << 2) * 0x01010101u;   // four copies of the code whose sigma is 0
-    float *__restrict__ rowbuf = reinterpret_cast<float *>(mine + (lay.offRow - lay.offState) + stateAt) + lane;
+    float *__restrict__ rowbuf = reinterpret_cast<float *>(mine + (lay.offRow - lay.offState)) + lane;
     float *__restrict__ dpB = dp + static_cast<size_t>(3 * NK + 1) * kWave;
     for (int s = 0; s < 2; s++)
       for (int f = 0; f < 3; f++) {
@@ -469,26 +551,19 @@ __device__ __forceinline__ void generic_body(const NullArgs &A, const uint8_t *_
   }
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GENERIC_WAVES, RC_GENERIC_WAVES))) void k_null_generic(NullArgs A, const uint8_t *__restrict__ blob, const DevBlock *__restrict__ dblocks,
-                                                     const int *__restrict__ classBlocks, const uint32_t *__restrict__ flags,
-                                                     const uint32_t *__restrict__ Ustream, const uint8_t *__restrict__ pairTab,
-                                                     uint8_t *__restrict__ scratch, float *__restrict__ maxima) {
-  extern __shared__ uint32_t ldsGeneric[];
-  generic_body<0>(A, blob, dblocks, classBlocks, flags, Ustream, pairTab, scratch, maxima, ldsGeneric);
-}
 __global__ __launch_bounds__(64) void k_generic_sim(NullArgs A, const uint8_t *__restrict__ blob, const DevBlock *__restrict__ dblocks,
                                                     const int *__restrict__ classBlocks, const uint32_t *__restrict__ flags,
                                                     const uint32_t *__restrict__ Ustream, const uint8_t *__restrict__ pairTab,
                                                     uint8_t *__restrict__ scratch, float *__restrict__ maxima) {
   extern __shared__ uint32_t ldsGeneric[];
-  generic_body<1>(A, blob, dblocks, classBlocks, flags, Ustream, pairTab, scratch, maxima, ldsGeneric);
+  generic_body<true>(A, blob, dblocks, classBlocks, flags, Ustream, pairTab, scratch, maxima, ldsGeneric);
 }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GENERIC_WAVES, RC_GENERIC_WAVES))) void k_generic_dp(NullArgs A, const uint8_t *__restrict__ blob, const DevBlock *__restrict__ dblocks,
                                                    const int *__restrict__ classBlocks, const uint32_t *__restrict__ flags,
                                                    const uint32_t *__restrict__ Ustream, const uint8_t *__restrict__ pairTab,
                                                    uint8_t *__restrict__ scratch, float *__restrict__ maxima) {
   extern __shared__ uint32_t ldsGeneric[];
-  generic_body<2>(A, blob, dblocks, classBlocks, flags, Ustream, pairTab, scratch, maxima, ldsGeneric);
+  generic_body<false>(A, blob, dblocks, classBlocks, flags, Ustream, pairTab, scratch, maxima, ldsGeneric);
 }
 
 // native block, any number of rows: one wavefront per (block, strand x frame), lane = start codon, the states of the lane's row

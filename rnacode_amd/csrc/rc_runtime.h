@@ -286,7 +286,7 @@ struct rc_ctx {
   long long fatStreamMinItems = 16384;   // RC_FAT_STREAM_MIN_ITEMS: a stream's sub-batch of fat classes takes the two-row path from this many (block, 64-sample group) items on: four rounds of the chip's wavefront slots (1024 blocks at n = 1000)
   int tailSharing = 1;        // k_null: items taken near the end of the queues are shared part by part with workgroups that have run out of work (RC_TAIL_SHARING=0: off)
   int nativeWavesPerCU = 8;   // persistent wavefronts of k_native_dp per CU (RC_NATIVE_WAVES_PER_CU): it runs beside k_null and should not crowd it out
-  size_t genericScratchWords = static_cast<size_t>(1) << 30;   // uint32 of staging scratch one k_null_generic launch may take: a twelfth of the device memory (24 GB of 288)
+  size_t genericScratchWords = static_cast<size_t>(1) << 30;   // uint32 of staging scratch the wide-block kernels (k_generic_sim / k_generic_dp) may take per round of items: a twelfth of the device memory (24 GB of 288)
   static constexpr int kComputeStreams = 3;
   hipStream_t compute[kComputeStreams] = {nullptr, nullptr, nullptr};   // null sampling + fit; consecutive batches take them in turn, so the tail of one overlaps the head of the next
   static constexpr int computeStreams = 2;       // consecutive batches alternate between two (a third was measured: the chip is busy with the second batch by then, 1250-block shard streamed 7.85 ms either way)

@@ -147,40 +147,29 @@ int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t ex
     int maxLc = 0, maxNKc = 0;
     for (int bi : kv.second) { maxLc = std::max(maxLc, b->meta[bi].L); maxNKc = std::max(maxNKc, b->meta[bi].NK); }
     p.itemCost = static_cast<double>(maxNKc) * maxLc * maxLc;   // (cell, sequence) steps of the class's longest item, up to a factor
-    if (kv.first == kGenericClass) {   // k_null_generic: one launch for every block of more than 64 rows, whatever its N
+    if (kv.first == kGenericClass) {   // one class for every block of more than 64 rows, whatever its N: k_generic_sim, then k_generic_dp
       int maxN = 0, maxNodes = 0;
       for (int bi : kv.second) { maxN = std::max(maxN, b->meta[bi].N); maxNodes = std::max(maxNodes, b->db[bi].nnodes); }
-      p.stride = (null_generic_scratch_bytes(maxN, maxLc, maxNodes) + 3) / 4;   // in uint32 like the others
       p.ldsBytes = null_generic_lds_bytes(maxN, maxNodes);
-      const std::pair<int, size_t> key(kGenericClass, p.ldsBytes);
-      if (!c->occ.count(key)) c->occ[key] = null_generic_occupancy(p.ldsBytes);
-      const int occ = std::max(1, c->occ[key]);
-      long long items = static_cast<long long>(kv.second.size()) * groupsHere;
-      p.comboSplit = (together ? splitAll : static_cast<double>(items) <= c->splitFactor * c->numCU * occ) ? 1 : 0;
-      if (p.comboSplit) items *= 6;
-      p.grid = static_cast<int>(std::min<long long>(items, static_cast<long long>(c->numCU) * occ));
-      // every wavefront keeps the sigma codes of its 64 samples (N x L x 2 bytes per sample): the scratch, not the registers, bounds the occupancy
-      p.grid = static_cast<int>(std::max<size_t>(1, std::min<size_t>(p.grid, c->genericScratchWords / std::max<size_t>(p.stride, 1))));
-      p.need = p.stride * p.grid;
-      if (p.comboSplit && static_cast<size_t>(kv.second.size()) * groupsHere * null_generic_codes_bytes(maxN, maxLc, maxNodes) <= c->genericScratchWords * sizeof(uint32_t)) {
-        // Few items (every item split into its six strand x frame parts to fill the chip): two launches -- k_generic_sim leaves the
-        // codes of every (block, sample group) item in the scratch, k_generic_dp's six parts of an item read them there, instead of
-        // each part simulating the item again (16 blocks of 100 x 300: 67.7 -> 53.1 ms).  Not for large batches: the simulation's
-        // LDS (node states, codon windows) allows no more wavefronts per CU than the DP's registers do, so nothing is gained, and the
-        // codes of all items at once (5 MB each) would have to go through the scratch in rounds (1024 blocks: 1.03 -> 1.33 s).
-        p.codesBytes = null_generic_codes_bytes(maxN, maxLc, maxNodes);
-        p.stateBytes = null_generic_state_bytes(maxN, maxLc, maxNodes);
-        const int occD = std::max(1, generic_dp_occupancy(p.ldsBytes)), occS = std::max(1, generic_sim_occupancy(p.ldsBytes));
-        long long itemsB = static_cast<long long>(kv.second.size()) * groupsHere;
-        const size_t budget = c->genericScratchWords * sizeof(uint32_t);
-        const size_t slots = std::max<size_t>(static_cast<size_t>(groupsHere), budget / p.codesBytes);
-        p.roundBlocks = static_cast<int>(std::max<size_t>(1, std::min<size_t>(kv.second.size(), slots / static_cast<size_t>(groupsHere))));
-        const long long roundItems = static_cast<long long>(p.roundBlocks) * groupsHere;
-        (void)itemsB;   // (comboSplit stays as planned above: it is what brought us here)
-        p.grid = static_cast<int>(std::min<long long>(roundItems * (p.comboSplit ? 6 : 1), static_cast<long long>(c->numCU) * occD));
-        p.simGrid = static_cast<int>(std::min<long long>(roundItems, static_cast<long long>(c->numCU) * occS));
-        p.need = (static_cast<size_t>(roundItems) * p.codesBytes + static_cast<size_t>(p.grid) * p.stateBytes + 3) / 4 + 64;
-      }
+      p.codesBytes = null_generic_codes_bytes(maxN, maxLc, maxNodes);
+      p.stateBytes = null_generic_state_bytes(maxN, maxLc, maxNodes);
+      const std::pair<int, size_t> keyD(kGenericClass, p.ldsBytes), keyS(kGenericClass + 1, p.ldsBytes);
+      if (!c->occ.count(keyD)) { c->occ[keyD] = generic_dp_occupancy(p.ldsBytes); c->occ[keyS] = generic_sim_occupancy(p.ldsBytes); }
+      const int occD = std::max(1, c->occ[keyD]), occS = std::max(1, c->occ[keyS]);
+      const long long slotsD = static_cast<long long>(c->numCU) * occD;
+      const long long items = static_cast<long long>(kv.second.size()) * groupsHere;
+      // few items: every item's DP is split into its six strand x frame parts to fill the chip (maxima meet in an atomic max)
+      p.comboSplit = (together ? splitAll : static_cast<double>(items) <= c->splitFactor * c->numCU * occD) ? 1 : 0;
+      // The sigma codes of every item of a round lie in the scratch at once (N x L x 2 bytes per sample; 5 MB per item at 100 x 300):
+      // rounds of as many items as the scratch budget holds -- a whole number of the DP's wavefront slots when it holds more than
+      // one (items of a class cost about the same: 4600 items on 4096 slots take as long as 8192).
+      long long roundItems = std::max<long long>(groupsHere, static_cast<long long>(c->genericScratchWords * sizeof(uint32_t) / p.codesBytes));
+      if (roundItems > slotsD) roundItems -= roundItems % slotsD;
+      p.roundBlocks = static_cast<int>(std::max<long long>(1, std::min<long long>(static_cast<long long>(kv.second.size()), roundItems / groupsHere)));
+      roundItems = static_cast<long long>(p.roundBlocks) * groupsHere;
+      p.grid = static_cast<int>(std::min<long long>(roundItems * (p.comboSplit ? 6 : 1), slotsD));
+      p.simGrid = static_cast<int>(std::min<long long>(roundItems, static_cast<long long>(c->numCU) * occS));
+      p.need = (static_cast<size_t>(roundItems) * p.codesBytes + static_cast<size_t>(p.grid) * p.stateBytes + 3) / 4 + 64;
       needSum += p.need; needMax = std::max(needMax, p.need);
       plans.push_back(p);
       continue;
@@ -298,7 +287,7 @@ int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t ex
       const double cost = p.itemCost * static_cast<double>(members.size()) * groupsHere;
       if (cost > b->nullKernelCost) {
         b->nullKernelCost = cost;
-        if (p.NK == kGenericClass) b->nullKernel = "rc::k_null_generic";
+        if (p.NK == kGenericClass) b->nullKernel = "rc::k_generic_dp";
         else {
           const bool ex = b->allExact || p.NK >= kFastRows;
           const bool dual = !ex && p.ldsBytes && p.ldsBytes <= 48 * 1024 && p.NK <= kDualRowsMaxNK && (p.NK == 2 || R.fat);
@@ -311,32 +300,27 @@ int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t ex
     }
     if (p.NK == kGenericClass) {
       a.skipMask = extraSkip;
-      a.scratchStride = p.stride * sizeof(uint32_t);   // bytes for this kernel
       a.workCounter = work + p.NK * 8;
-      if (p.codesBytes) {
-        uint8_t *base = reinterpret_cast<uint8_t *>(a.scratch);
-        const size_t codesAllBytes = (static_cast<size_t>(p.roundBlocks) * groupsHere * p.codesBytes + 255) & ~static_cast<size_t>(255);
-        a.codesAll = base; a.codesStride = p.codesBytes;
-        a.scratchStride = p.stateBytes;
-        unsigned int *simWork = work + kClassSlots * 8 + p.NK * 8;   // (the class's unused "exact" queue counters)
-        const int *list = a.classBlocks;
-        for (size_t at = 0; at < members.size(); at += static_cast<size_t>(p.roundBlocks)) {
-          if (at) {   // the queues of the round before are spent
-            HIP_TRY(hipMemsetAsync(a.workCounter, 0, 8 * sizeof(unsigned int), st));
-            HIP_TRY(hipMemsetAsync(simWork, 0, 8 * sizeof(unsigned int), st));
-          }
-          NullArgs r = a;
-          r.classBlocks = list + at;
-          r.nClassBlocks = static_cast<int>(std::min<size_t>(static_cast<size_t>(p.roundBlocks), members.size() - at));
-          NullArgs sim = r;
-          sim.workCounter = simWork;
-          launch_generic_sim(sim, p.simGrid, p.ldsBytes, st);
-          launch_generic_dp(r, p.grid, p.ldsBytes, base + codesAllBytes, st);
-          b->nl[2]++;
+      uint8_t *base = reinterpret_cast<uint8_t *>(a.scratch);
+      const size_t codesAllBytes = (static_cast<size_t>(p.roundBlocks) * groupsHere * p.codesBytes + 255) & ~static_cast<size_t>(255);
+      a.codesAll = base; a.codesStride = p.codesBytes;
+      a.scratchStride = p.stateBytes;   // bytes for these kernels
+      unsigned int *simWork = work + kClassSlots * 8 + p.NK * 8;   // (the class's unused "exact" queue counters)
+      const int *list = a.classBlocks;
+      for (size_t at = 0; at < members.size(); at += static_cast<size_t>(p.roundBlocks)) {
+        if (at) {   // the queues of the round before are spent
+          HIP_TRY(hipMemsetAsync(a.workCounter, 0, 8 * sizeof(unsigned int), st));
+          HIP_TRY(hipMemsetAsync(simWork, 0, 8 * sizeof(unsigned int), st));
         }
-      } else
-      launch_null_generic(a, p.grid, p.ldsBytes, reinterpret_cast<uint8_t *>(a.scratch), st);
-      b->nl[2]++;
+        NullArgs r = a;
+        r.classBlocks = list + at;
+        r.nClassBlocks = static_cast<int>(std::min<size_t>(static_cast<size_t>(p.roundBlocks), members.size() - at));
+        NullArgs sim = r;
+        sim.workCounter = simWork;
+        launch_generic_sim(sim, p.simGrid, p.ldsBytes, st);
+        launch_generic_dp(r, p.grid, p.ldsBytes, base + codesAllBytes, st);
+        b->nl[2] += 2;
+      }
     } else if (b->allExact || p.NK >= kFastRows) {
       a.skipMask = extraSkip;
       a.workCounter = work + kClassSlots * 8 + p.NK * 8;

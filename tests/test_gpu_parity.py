@@ -434,7 +434,7 @@ def test_wide_blocks_against_oracle(ctx):
 
 
 def test_blocks_beyond_64_rows_against_oracle(ctx):
-    """65..500 rows (the reference's own limit, rnaz_utils.h:7; 100-way genome alignments): k_null_generic and
+    """65..500 rows (the reference's own limit, rnaz_utils.h:7; 100-way genome alignments): k_generic_sim / k_generic_dp and
     k_native_dp_generic keep the per-sequence states in global memory instead of registers.  Same seeds through the HIP
     path and the oracle, blocks of different widths in ONE launch (they share the generic class), mixed with narrow ones,
     as one batch, as a stream and with --stop-early; backtrack of a wide block."""

@@ -1,5 +1,5 @@
 // mb_bpermute_addr.hip -- does ds_bpermute_b32 ignore the address bits above the lane index (addr[7:2]) on gfx950?
-// k_null_generic keeps its sigma codes pre-multiplied by four, one per byte, and uses the code WORD (byte 0) or the word shifted
+// k_generic_dp keeps its sigma codes pre-multiplied by four, one per byte, and uses the code WORD (byte 0) or the word shifted
 // right by 8, 16, 24 as the address: the bytes above the selected one must not matter.
 //   hipcc --offload-arch=gfx950 -O2 -o tools/mb_bpermute_addr tools/mb_bpermute_addr.hip && tools/mb_bpermute_addr
 #include <hip/hip_runtime.h>

@@ -1,4 +1,4 @@
-// mb_footprint.hip -- read bandwidth of k_null_generic's access pattern against the footprint: every wavefront owns a region of R bytes
+// mb_footprint.hip -- read bandwidth of k_generic_dp's access pattern against the footprint: every wavefront owns a region of R bytes
 // and reads 2 KB runs (eight 256-byte rows, one dword per lane) at pseudo-random places in it, eight runs in flight.  Is the
 // 3.4 TB/s the DP of the wide blocks gets a property of the pattern (then R does not matter) or of the address translation
 // (then it falls as 4096 x R outgrows the TLBs)?

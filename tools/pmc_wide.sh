@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of k_null_generic for one library build: tools/pmc_wide.sh [lib.so] [time_wide args]  (every profiler run under its own timeout)
+# SQ counters of the wide-block kernels (k_generic_sim, k_generic_dp) for one library build: tools/pmc_wide.sh [lib.so] [time_wide args]  (every profiler run under its own timeout)
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 LIB=${1:-}; shift
 ARGS="${*:-100 300 256 1000}"
@@ -19,8 +19,9 @@ out=os.environ.get('GRAFT_REPO_ROOT','/root/repo')+'/gpurun_out/pmc_wide'
 for f in sorted(glob.glob(out+'/p*/**/*counter_collection.csv', recursive=True)):
     acc=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if 'k_null_generic' in r['Kernel_Name']:
-            acc[r['Counter_Name']].append(float(r['Counter_Value']))
-    for k,v in acc.items(): print(f"{k:28s} mean={sum(v)/len(v):.6g} n={len(v)}")
+        for kn in ('k_generic_sim', 'k_generic_dp'):
+            if kn in r['Kernel_Name']:
+                acc[(kn, r['Counter_Name'])].append(float(r['Counter_Value']))
+    for (kn, k), v in sorted(acc.items()): print(f"{kn:14s} {k:28s} sum={sum(v):.6g} launches={len(v)}")
 PY
 find "$OUT" -name "*agent_info*" -delete
