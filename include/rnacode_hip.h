@@ -101,6 +101,11 @@ int rc_device_count(void);
  * rc_last_error() is per thread. */
 int rc_ctx_create(int device, rc_ctx **out);
 void rc_ctx_destroy(rc_ctx *ctx);   /* destroy the context's batches and streams first */
+/* A context keeps the device and pinned buffers of its destroyed batches and streams for the next ones (hipFree / hipHostFree wait
+ * for the whole device): up to 1/16 of the device's memory and 1 GB of pinned memory, until rc_ctx_destroy.  rc_ctx_trim gives them
+ * back now (between phases of a job that shares the GPU).  An allocation that fails first gives back what the pools of every
+ * context of this process on that device keep, then tries again. */
+void rc_ctx_trim(rc_ctx *ctx);
 
 /* Host threads used to prepare blocks (default: the CPUs this process may use -- affinity mask and
  * cgroup quota, rc_host_cpus() -- capped at 32; RC_HOST_THREADS overrides).  With several ranks per

@@ -99,6 +99,8 @@ def lib():
         l.rc_last_error.restype = C.c_char_p
         l.rc_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         l.rc_ctx_destroy.argtypes = [C.c_void_p]
+        l.rc_ctx_trim.argtypes = [C.c_void_p]
+        l.rc_ctx_trim.restype = None
         l.rc_batch_create.argtypes = [C.c_void_p, C.POINTER(RcBlock), C.c_int32, C.POINTER(RcParams), C.POINTER(C.c_void_p)]
         l.rc_batch_destroy.argtypes = [C.c_void_p]
         l.rc_batch_run.argtypes = [C.c_void_p]
@@ -154,7 +156,7 @@ def lib():
 
 
 EXPORTED_SYMBOLS = [
-    "rc_default_params", "rc_last_error", "rc_device_count", "rc_ctx_create", "rc_ctx_destroy", "rc_batch_create",
+    "rc_default_params", "rc_last_error", "rc_device_count", "rc_ctx_create", "rc_ctx_destroy", "rc_ctx_trim", "rc_batch_create",
     "rc_batch_destroy", "rc_batch_bind_maxima", "rc_batch_run", "rc_batch_run_async", "rc_batch_wait", "rc_batch_size", "rc_batch_block_error",
     "rc_batch_prep_timing", "rc_host_cpus", "rc_ctx_set_host_threads", "rc_ctx_host_threads", "rc_stream_create", "rc_stream_submit", "rc_stream_submit_bound",
     "rc_stream_next", "rc_stream_recycle", "rc_stream_pending", "rc_stream_plan", "rc_stream_destroy", "rc_set_stream_cache", "rc_batch_work", "rc_batch_timing", "rc_batch_null_kernel", "rc_batch_status",
@@ -282,6 +284,10 @@ class Context:
         self._h = C.c_void_p()
         _check(lib().rc_ctx_create(device, C.byref(self._h)))
         self.device = device
+
+    def trim(self):
+        """Give back the buffers of destroyed batches and streams the context keeps for the next ones (rc_ctx_trim)."""
+        lib().rc_ctx_trim(self._h)
 
     def close(self):
         if self._h:

@@ -31,6 +31,13 @@ int rc_device_count(void) {
 
 int rc_host_cpus(void) { return effective_cpus(); }
 
+void rc_ctx_trim(rc_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  c->retired->drain();
+  c->bufPool->drain(false);
+}
+
 void rc_ctx_destroy(rc_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
@@ -79,6 +86,7 @@ int rc_ctx_create(int device, rc_ctx **out) {
   c->totalMem = prop.totalGlobalMem;
   c->retiredCapBytes = prop.totalGlobalMem / 16;
   c->bufPool->devCap = prop.totalGlobalMem / 16;
+  c->bufPool->device = device;
   for (DevBuf *d : {&c->treeJobs, &c->treeIn, &c->treeWork, &c->treeRes, &c->d_tables, &c->d_cellStats}) d->retired = c->retired.get();
   for (PinBuf *h : {&c->treeInPin, &c->treeResPin}) h->retired = c->retired.get();
   c->genericScratchWords = std::max<size_t>(static_cast<size_t>(1) << 30, prop.totalGlobalMem / 12 / sizeof(uint32_t));

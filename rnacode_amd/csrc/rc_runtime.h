@@ -117,12 +117,26 @@ template <typename Alloc> hipError_t alloc_with_retry(Retired *ret, Alloc alloc)
 // genomic-preprocessed.maf.  A buffer is handed out again for requests between a quarter of its size and its size.  Bounded
 // (a sixteenth of the device memory, 1 GB of pinned memory, 256 buffers); what does not fit is freed as before.  The pool outlives
 // its context while batches still point at it (a batch may be destroyed after its context).
+// Every live pool of the process: an allocation that fails on a device gives back what the pools of the OTHER contexts on that device keep,
+// too, before it gives up (several contexts on one GPU: rnacode_hip --gpus N --devices 0,0,..., the tests).
+struct BufPool;
+struct PoolRegistry {
+  std::mutex m;
+  std::vector<BufPool *> pools;
+  void add(BufPool *p) { std::lock_guard<std::mutex> lk(m); pools.push_back(p); }
+  void remove(BufPool *p) { std::lock_guard<std::mutex> lk(m); pools.erase(std::remove(pools.begin(), pools.end(), p), pools.end()); }
+  inline void drain_device(int device);
+};
+inline PoolRegistry g_pools;
+
 struct BufPool {
   struct Slot { void *p; size_t cap; };
   std::mutex m;
   std::vector<Slot> dev, host;
   size_t devBytes = 0, hostBytes = 0, devCap = static_cast<size_t>(1) << 30, hostCap = static_cast<size_t>(1) << 30;
   bool closed = false;   // the context is gone: nothing is kept any more
+  int device = -1;
+  BufPool() { g_pools.add(this); }
   void *take(bool pinned, size_t want, size_t *got) {
     std::lock_guard<std::mutex> lk(m);
     std::vector<Slot> &v = pinned ? host : dev;
@@ -151,8 +165,12 @@ struct BufPool {
     for (auto &s : d) (void)timed_call("pool hipFree", s.cap, [&] { return hipFree(s.p); });
     for (auto &s : h) (void)timed_call("pool hipHostFree", s.cap, [&] { return hipHostFree(s.p); });
   }
-  ~BufPool() { drain(true); }
+  ~BufPool() { g_pools.remove(this); drain(true); }
 };
+inline void PoolRegistry::drain_device(int device) {
+  std::lock_guard<std::mutex> lk(m);   // (a pool cannot go away while it is being drained: its destructor takes this lock first)
+  for (BufPool *p : pools) if (p->device == device) p->drain(false);
+}
 
 struct DevBuf {
   void *p = nullptr;
@@ -169,6 +187,7 @@ struct DevBuf {
     if (pool && (p = pool->take(false, want, &cap))) return hipSuccess;
     hipError_t r = alloc_with_retry(retired, [&] { return timed_call("hipMalloc", want, [&] { return hipMalloc(&p, want); }); });
     if (r != hipSuccess && pool) { pool->drain(false); r = hipMalloc(&p, want); }
+    if (r != hipSuccess && pool) { g_pools.drain_device(pool->device); r = hipMalloc(&p, want); }
     if (r == hipSuccess) cap = want; else p = nullptr;
     return r;
   }

@@ -830,6 +830,32 @@ def test_a_batch_may_be_destroyed_after_its_context():
         c2.close()
 
 
+def test_a_context_gives_its_kept_buffers_back_when_asked():
+    """rc_ctx_trim (a context keeps up to a sixteenth of the device's memory of destroyed batches' buffers until it is
+    destroyed): after a batch is destroyed its device buffers stay with the context, after trim the device has them back, and the next
+    batch on the trimmed context gives the same numbers."""
+    import torch
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_blocks
+    blocks = [b.upper() for b in synth_blocks(400, 6, 120, seed=12)]
+    p = api.default_params(sampleN=256, seed_base=5)
+    c = api.Context(0)
+    b = api.Batch(c, blocks, p).run()
+    want = b.maxScores_all().copy()
+    torch.cuda.synchronize()
+    used = torch.cuda.mem_get_info(0)[0]
+    b.close()
+    kept = torch.cuda.mem_get_info(0)[0]
+    c.trim()
+    freed = torch.cuda.mem_get_info(0)[0]
+    assert kept - used < (8 << 20), (used, kept)          # the batch's buffers went to the pool, not back to the device
+    assert freed - kept > (32 << 20), (kept, freed)       # ... and trim gives them back
+    again = api.Batch(c, blocks, p).run()
+    np.testing.assert_array_equal(again.maxScores_all(), want)
+    again.close()
+    c.close()
+
+
 def test_no_step_of_a_small_multi_class_batch_stalls():
     """BASELINE configs[1] as one batch, 200 times over in a process that has used every stream of the library before (a resident
     batch, a stream of sub-batches, tree fits): no warm step may take more than ten times the median.  Round 4's bench line had a
