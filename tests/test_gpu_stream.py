@@ -834,20 +834,25 @@ def test_a_context_gives_its_kept_buffers_back_when_asked():
     """rc_ctx_trim (a context keeps up to a sixteenth of the device's memory of destroyed batches' buffers until it is
     destroyed): after a batch is destroyed its device buffers stay with the context, after trim the device has them back, and the next
     batch on the trimmed context gives the same numbers."""
-    import torch
+    import ctypes
     from rnacode_amd import api
     from rnacode_amd.synth import synth_blocks
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        free, total = ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.hipDeviceSynchronize() == 0 and hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
     blocks = [b.upper() for b in synth_blocks(400, 6, 120, seed=12)]
     p = api.default_params(sampleN=256, seed_base=5)
     c = api.Context(0)
     b = api.Batch(c, blocks, p).run()
     want = b.maxScores_all().copy()
-    torch.cuda.synchronize()
-    used = torch.cuda.mem_get_info(0)[0]
+    used = free_bytes()
     b.close()
-    kept = torch.cuda.mem_get_info(0)[0]
+    kept = free_bytes()
     c.trim()
-    freed = torch.cuda.mem_get_info(0)[0]
+    freed = free_bytes()
     assert kept - used < (8 << 20), (used, kept)          # the batch's buffers went to the pool, not back to the device
     assert freed - kept > (32 << 20), (kept, freed)       # ... and trim gives them back
     again = api.Batch(c, blocks, p).run()
