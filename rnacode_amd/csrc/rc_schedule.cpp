@@ -133,6 +133,7 @@ int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t ex
                 int rowParts, simParts, rowSimGrid; size_t sbufStride, sbufFloats;   // rows split over workgroups (k_null<.., ROWS> + k_null_rowscan)
                 int simGrid, roundBlocks; size_t codesBytes, stateBytes; };   // (the last four: the wide-block class in two launches)
   std::vector<Plan> plans;
+  trace("null: plan", b);
   size_t needSum = 0, needMax = 0, sbufSum = 0;
   // Several row-count classes: first planned as launches that run side by side (no strand x frame split: together they fill the chip);
   // if their staging areas do not fit side by side, planned again as one launch after the other, each filling the chip by itself.
@@ -259,6 +260,7 @@ int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t ex
   Event &fork = phase ? b->evMid : b->evS0;
   size_t scratchOff = 0;
   if (concurrent) while (b->classDone.size() < static_cast<size_t>(kMaxRounds) * plans.size()) b->classDone.emplace_back(new Event());
+  trace("null: planned", b);
   for (size_t pi = 0; pi < plans.size(); pi++) {
     const Plan &p = plans[pi];
     const auto &members = b->classes[p.NK];
@@ -270,6 +272,7 @@ int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t ex
         c->classStreams.push_back(ns);
       }
       st = c->classStreams[pi % c->classStreams.size()];
+      if (pi == 0) trace("null: streams", b);
       HIP_TRY(hipStreamWaitEvent(st, fork, 0));   // the memsets / the stop marks
     }
     NullArgs a{};
@@ -356,6 +359,7 @@ int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t ex
       e.workCounter = work + kClassSlots * 8 + p.NK * 8;
       if (!launch_null(p.NK, e, p.gridExact, 0, true, st)) return fail(RC_ERR_UNSUPPORTED, "no null kernel for this number of rows");
     }
+    if (pi == 0) trace("null: first class", b);
     if (concurrent) {
       scratchOff += p.need;
       Event &done = *b->classDone[static_cast<size_t>(phase) * plans.size() + pi];
