@@ -266,7 +266,10 @@ int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t ex
     const auto &members = b->classes[p.NK];
     hipStream_t st = R.cs;
     if (concurrent) {
-      while (c->classStreams.size() < std::min<size_t>(plans.size(), 12)) {   // (a stream per class: two classes on one stream run one after the other, and the second then often alone at the end)
+      // Four streams for the classes' launches, whatever their number: the ten-class workload takes 85..87 ms on 2, 3, 4, 5, 6 or 12 of them
+      // (the launches are persistent grids that share the chip by their sizes, not by their queues), a stream costs 10 ms to create -- ten
+      // were 95 ms inside a fresh process's first submit -- and every one is a hardware queue more for the device to schedule.
+      while (c->classStreams.size() < std::min<size_t>(plans.size(), 4)) {
         hipStream_t ns = nullptr;
         HIP_TRY(hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, c->classPrio));
         c->classStreams.push_back(ns);
