@@ -468,10 +468,35 @@ __global__ __launch_bounds__(64) void k_native_dp(NativeArgs A) {
           for (int x = 0; x < ZP; x++) z[x] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(zl[x]), t));
           if (a <= j && a < sites) {
             float sum = 0.0f;
+            uint32_t zany = 0u;
 #pragma unroll
-            for (int k = 0; k < NK; k++) {
-              pair_step(static_cast<int>((z[k >> 4] >> (2 * (k & 15))) & 3u), sg[k], Delta, Omega, omega, s0[k], s1[k], s2[k]);
-              sum = sum + fmaxf(fmaxf(s0[k], s1[k]), s2[k]);
+            for (int x = 0; x < ZP; x++) zany |= z[x];
+            if (zany == 0u) {   // no sequence has a frame shift at this codon (almost every codon): straight-line code, no case per sequence
+#pragma unroll
+              for (int k = 0; k < NK; k++) {
+                s0[k] = s0[k] + sg[k];
+                s1[k] = s1[k] + omega;
+                s2[k] = s2[k] + omega;
+                sum = sum + fmaxf(fmaxf(s0[k], s1[k]), s2[k]);
+              }
+            } else {
+              // Some sequence is out of frame here -- and stays so until its next gap: in real alignments these are long stretches.  No
+              // case per sequence (a wavefront alone on its SIMD waits for the instruction fetch behind every taken branch, and the
+              // compiler copied all 3 (N-1) states at every join): the three cases of score.c:506-533 computed side by side, the
+              // wave-uniform z selects.  z = +-1: s_x' = max(s_x + Delta, s_y + Omega), y the state before x (z = +1) or behind it (-1).
+#pragma unroll
+              for (int k = 0; k < NK; k++) {
+                const uint32_t zc = (z[k >> 4] >> (2 * (k & 15))) & 3u;
+                const bool zero = zc == 0u, one = zc == 1u;
+                const float d0 = s0[k] + Delta, d1 = s1[k] + Delta, d2 = s2[k] + Delta;
+                const float o0 = s0[k] + Omega, o1 = s1[k] + Omega, o2 = s2[k] + Omega;
+                const float n0 = fmaxf(d0, one ? o2 : o1), n1 = fmaxf(d1, one ? o0 : o2), n2 = fmaxf(d2, one ? o1 : o0);
+                const float p0 = s0[k] + sg[k], p1 = s1[k] + omega, p2 = s2[k] + omega;
+                s0[k] = zero ? p0 : n0;
+                s1[k] = zero ? p1 : n1;
+                s2[k] = zero ? p2 : n2;
+                sum = sum + fmaxf(fmaxf(s0[k], s1[k]), s2[k]);
+              }
             }
             const float v = fmaxf(sum, Delta) / nkf;
             if (all) all[static_cast<size_t>(a) * A.sAllSites + j] = v;
