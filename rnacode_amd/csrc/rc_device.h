@@ -94,6 +94,7 @@ constexpr int kDualRowsMaxNK = 5;        // k_null walks two rows of S per pass 
                                          // than the one-row kernels at 5 or 6 -- 7 / 10 / 13 rows x 150 columns 36.0 / 51.2 / 63.3 -> 44.1 / 65.0 / 85.1 ms, C5 532 -> 832 ms;
                                          // profiles/r05/ab_dual_l2_wide_slower.txt.  These launches live on occupancy.)
 constexpr uint32_t kFlagExact = 1u;     // score tables outside the range proven for div_by_nk -> scored by the EXACT instantiation
+constexpr uint32_t kFlagNan = 4u;       // NaN among the block's score tables (always with kFlagExact): the reference's NaN-order-dependent MAX macro applies (rc_null_kernel.h, ref_max)
 constexpr uint32_t kFlagStopped = 2u;   // --stop-early: enough samples beat the native score, the remaining ones are not simulated
 
 // what a sigma code means (PairTable, shared by all blocks of a context): kind 0 unused, 1 score code

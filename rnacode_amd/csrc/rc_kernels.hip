@@ -257,7 +257,7 @@ __global__ __launch_bounds__(64) void k_prep_lut(PrepArgs A) {   // one wavefron
   const ModelRec *models = reinterpret_cast<const ModelRec *>(A.blob + db->off_models);
   float *lut = reinterpret_cast<float *>(A.blob + db->off_lut);
   const int total = 2 * NK * kLutSize;
-  bool mine = false;
+  bool mine = false, nan = false;
   for (int idx = threadIdx.x; idx < total; idx += kWave) {
     const int code = idx % kLutSize, k = (idx / kLutSize) % NK, s = idx / (kLutSize * NK);
     const CodeInfo ci = A.codeInfo[code];
@@ -267,6 +267,7 @@ __global__ __launch_bounds__(64) void k_prep_lut(PrepArgs A) {   // one wavefron
     else if (ci.kind == 4) v = db->stopk;
     lut[idx] = v;
     mine |= !in_div_range_dev(v);
+    nan |= v != v;
   }
   if (N >= A.genericMinRows && threadIdx.x == 0) {   // k_generic_dp's running sums of omega, added the way the DP adds them
     float *W = reinterpret_cast<float *>(A.blob + db->off_chain);
@@ -278,9 +279,9 @@ __global__ __launch_bounds__(64) void k_prep_lut(PrepArgs A) {   // one wavefron
       W[i] = c;
     }
   }
-  const bool bad = __ballot(mine) != 0ull;
+  const bool bad = __ballot(mine) != 0ull, anyNan = __ballot(nan) != 0ull;
   if (threadIdx.x == 0 && bad) {
-    A.flags[bi] |= kFlagExact;
+    A.flags[bi] |= kFlagExact | (anyNan ? kFlagNan : 0u);
     const int cls = A.genericMinRows > N ? NK : kGenericClass;
     const int at = atomicAdd(A.exactCount + cls, 1);
     A.exactList[A.classOff[cls] + at] = bi;
@@ -438,6 +439,7 @@ __global__ __launch_bounds__(64) void k_native_dp(NativeArgs A) {
     DevHss *out = A.fullS ? nullptr : A.hss + (static_cast<size_t>(bi) * 6 + combo) * A.hssCap;
     int n = 0;
     ScanState st{0.0f, -1, -1};
+    const bool nanSem = A.flags && (A.flags[bi] & kFlagNan);   // NaN score tables: the reference's MAX macro, operand order and all (ref_max)
     for (int a0 = 0; a0 < sites; a0 += kWave) {
       const int a = a0 + lane;
       float s0[NK], s1[NK], s2[NK];
@@ -471,7 +473,13 @@ __global__ __launch_bounds__(64) void k_native_dp(NativeArgs A) {
             uint32_t zany = 0u;
 #pragma unroll
             for (int x = 0; x < ZP; x++) zany |= z[x];
-            if (zany == 0u) {   // no sequence has a frame shift at this codon (almost every codon): straight-line code, no case per sequence
+            if (__builtin_expect(nanSem, 0)) {
+#pragma unroll
+              for (int k = 0; k < NK; k++) {
+                pair_step<true>(static_cast<int>((z[k >> 4] >> (2 * (k & 15))) & 3u), sg[k], Delta, Omega, omega, s0[k], s1[k], s2[k]);
+                sum = sum + ref_max3<true>(s0[k], s1[k], s2[k]);
+              }
+            } else if (zany == 0u) {   // no sequence has a frame shift at this codon (almost every codon): straight-line code, no case per sequence
 #pragma unroll
               for (int k = 0; k < NK; k++) {
                 s0[k] = s0[k] + sg[k];
@@ -517,8 +525,13 @@ __global__ __launch_bounds__(64) void k_native_dp(NativeArgs A) {
 #pragma unroll
           for (int k = 0; k < NK; k++) {
             const float sig = sigma[(s * NK + k) * L1 + i];
-            pair_step(static_cast<int>((z[k >> 5] >> (2 * (k & 31))) & 3ull), sig, Delta, Omega, omega, s0[k], s1[k], s2[k]);
-            sum = sum + fmaxf(fmaxf(s0[k], s1[k]), s2[k]);
+            if (__builtin_expect(nanSem, 0)) {
+              pair_step<true>(static_cast<int>((z[k >> 5] >> (2 * (k & 31))) & 3ull), sig, Delta, Omega, omega, s0[k], s1[k], s2[k]);
+              sum = sum + ref_max3<true>(s0[k], s1[k], s2[k]);
+            } else {
+              pair_step(static_cast<int>((z[k >> 5] >> (2 * (k & 31))) & 3ull), sig, Delta, Omega, omega, s0[k], s1[k], s2[k]);
+              sum = sum + fmaxf(fmaxf(s0[k], s1[k]), s2[k]);
+            }
           }
           const float v = fmaxf(sum, Delta) / nkf;
           tile[static_cast<size_t>(lane) * sites + j] = v;
@@ -573,9 +586,10 @@ __global__ __launch_bounds__(64) void k_native_scan(NativeArgs A) {
 }
 
 // One row b of Sk for all k (lane = k-1): out[(k-1)*3 + x][t] for i = b+2+3t <= iMax.
-__global__ __launch_bounds__(64) void k_sk_row(const uint8_t *blob, const DevBlock *dblocks, int bi, int s, int b, int iMax,
+__global__ __launch_bounds__(64) void k_sk_row(const uint8_t *blob, const DevBlock *dblocks, const uint32_t *flags, int bi, int s, int b, int iMax,
                                                float *out, int stride) {
   const DevBlock *db = dblocks + bi;
+  const bool nanSem = flags && (flags[bi] & kFlagNan);
   const int L1 = db->L + 1;
   const unsigned long long *zw = reinterpret_cast<const unsigned long long *>(blob + db->off_zw);
   const float *sigma = reinterpret_cast<const float *>(blob + db->off_sigma);
@@ -585,7 +599,8 @@ __global__ __launch_bounds__(64) void k_sk_row(const uint8_t *blob, const DevBlo
     for (int i = b + 2; i <= iMax; i += 3, t++) {
       const int zc = static_cast<int>((zw[static_cast<size_t>(s * L1 + i) * db->zw_words + (k >> 5)] >> (2 * (k & 31))) & 3ull);
       // lanes follow different k: the branch may diverge here, which is fine for this helper
-      pair_step(zc, sigma[(static_cast<size_t>(s) * db->NK + k) * L1 + i], db->Delta, db->Omega, db->omega, s0, s1, s2);
+      if (nanSem) pair_step<true>(zc, sigma[(static_cast<size_t>(s) * db->NK + k) * L1 + i], db->Delta, db->Omega, db->omega, s0, s1, s2);
+      else pair_step(zc, sigma[(static_cast<size_t>(s) * db->NK + k) * L1 + i], db->Delta, db->Omega, db->omega, s0, s1, s2);
       out[(static_cast<size_t>(k) * 3 + 0) * stride + t] = s0;
       out[(static_cast<size_t>(k) * 3 + 1) * stride + t] = s1;
       out[(static_cast<size_t>(k) * 3 + 2) * stride + t] = s2;
@@ -970,9 +985,9 @@ void launch_results_out(const ResultsOutArgs &a, hipStream_t stream) {
   hipLaunchKernelGGL(k_results_out, dim3(grid), dim3(64), 0, stream, a);
 }
 
-void launch_sk_row(const uint8_t *blob, const DevBlock *dblocks, int bi, int s, int b, int iMax, float *out, int stride,
+void launch_sk_row(const uint8_t *blob, const DevBlock *dblocks, const uint32_t *flags, int bi, int s, int b, int iMax, float *out, int stride,
                    hipStream_t stream) {
-  hipLaunchKernelGGL(k_sk_row, dim3(1), dim3(64), 0, stream, blob, dblocks, bi, s, b, iMax, out, stride);
+  hipLaunchKernelGGL(k_sk_row, dim3(1), dim3(64), 0, stream, blob, dblocks, flags, bi, s, b, iMax, out, stride);
 }
 
 size_t null_generic_lds_bytes(int N, int nnodes) { return generic_lds_bytes(N, nnodes); }

@@ -69,6 +69,7 @@ struct NativeArgs {
   int *hssCount;              // [n_blocks][6]
   int hssCap;                 // records per (block, strand, frame)
   float tieThr;
+  const uint32_t *flags;      // per batch index: kFlagNan picks the reference's NaN-order-dependent maxima (ref_max)
 };
 
 // block-constant tables derived on the device (k_prep_models, k_prep_lut)
@@ -186,7 +187,7 @@ struct ResultsOutArgs {
   size_t words[kParts];
 };
 void launch_results_out(const ResultsOutArgs &a, hipStream_t stream);
-void launch_sk_row(const uint8_t *blob, const DevBlock *dblocks, int bi, int s, int b, int iMax, float *out, int stride,
+void launch_sk_row(const uint8_t *blob, const DevBlock *dblocks, const uint32_t *flags, int bi, int s, int b, int iMax, float *out, int stride,
                    hipStream_t stream);
 // wider blocks (N > 64): generic kernels with their states in a global scratch (rc_null_generic.h)
 size_t null_generic_lds_bytes(int N, int nnodes);   // packed node states + codon windows of the widest block of the launch

@@ -585,6 +585,7 @@ __global__ __launch_bounds__(64) void k_native_dp_generic(NativeArgs A, float *_
   DevHss *out = A.fullS ? nullptr : A.hss + (static_cast<size_t>(bi) * 6 + combo) * A.hssCap;
   int n = 0;
   ScanState st{0.0f, -1, -1};
+  const bool nanSem = A.flags && (A.flags[bi] & kFlagNan);   // NaN score tables: the reference's MAX macro (rc_null_kernel.h, ref_max)
   for (int a0 = 0; a0 < sites; a0 += kWave) {
     const int a = a0 + lane;
     for (int k = 0; k < 3 * NK; k++) dp[static_cast<size_t>(k) * kWave + lane] = 0.0f;
@@ -596,11 +597,12 @@ __global__ __launch_bounds__(64) void k_native_dp_generic(NativeArgs A, float *_
         for (int k = 0; k < NK; k++) {
           float s0 = dp[(0 * static_cast<size_t>(NK) + k) * kWave + lane], s1 = dp[(1 * static_cast<size_t>(NK) + k) * kWave + lane],
                 s2 = dp[(2 * static_cast<size_t>(NK) + k) * kWave + lane];
-          pair_step(static_cast<int>((z[k >> 5] >> (2 * (k & 31))) & 3ull), sigma[(static_cast<size_t>(s) * NK + k) * L1 + i], Delta, Omega, omega, s0, s1, s2);
+          if (nanSem) pair_step<true>(static_cast<int>((z[k >> 5] >> (2 * (k & 31))) & 3ull), sigma[(static_cast<size_t>(s) * NK + k) * L1 + i], Delta, Omega, omega, s0, s1, s2);
+          else pair_step(static_cast<int>((z[k >> 5] >> (2 * (k & 31))) & 3ull), sigma[(static_cast<size_t>(s) * NK + k) * L1 + i], Delta, Omega, omega, s0, s1, s2);
           dp[(0 * static_cast<size_t>(NK) + k) * kWave + lane] = s0;
           dp[(1 * static_cast<size_t>(NK) + k) * kWave + lane] = s1;
           dp[(2 * static_cast<size_t>(NK) + k) * kWave + lane] = s2;
-          sum = sum + fmaxf(fmaxf(s0, s1), s2);
+          sum = sum + (nanSem ? ref_max3<true>(s0, s1, s2) : fmaxf(fmaxf(s0, s1), s2));
         }
         const float v = fmaxf(sum, Delta) / nkf;
         tile[static_cast<size_t>(lane) * sites + j] = v;

@@ -16,8 +16,21 @@ namespace rc {
 // shared device pieces
 // ------------------------------------------------------------------------------------------
 
+// The reference's MAX and MAX3 (score.h:28-29) are "x > y ? x : y": with a NaN operand they return y -- a NaN in y goes through, a NaN
+// in x is dropped --, where v_max_f32 / fmaxf return the operand that is a number.  NaNs only exist in blocks whose background models
+// are NaN (an alignment without one of the four nucleotides: HKY85 with a zero frequency, score.c:204-244): k_prep_lut flags those
+// kFlagNan, and the kernels give them the reference's order of operands and its macro, a compare and a select per maximum, in a path
+// of their own (SEM = true); every other block keeps the one-instruction maximum (found by tools/soak_parity.py, round 5:
+// tests/data/soak_hss_positive_delta.json).
+template <bool SEM> __device__ __forceinline__ float ref_max(float x, float y) {
+  if constexpr (SEM) return x > y ? x : y;
+  else return fmaxf(x, y);
+}
+template <bool SEM> __device__ __forceinline__ float ref_max3(float x, float y, float z) { return ref_max<SEM>(ref_max<SEM>(x, y), z); }
+
 // One step of the 3-state max-plus recurrence for one sequence k (score.c:506-533).
 // zc: 0 -> z = 0, 1 -> z = +1, 2 -> z = -1 (wave-uniform).
+template <bool SEM = false>
 __device__ __forceinline__ void pair_step(int zc, float sig, float Delta, float Omega, float omega,
                                           float &s0, float &s1, float &s2) {
   if (zc == 0) {
@@ -25,14 +38,14 @@ __device__ __forceinline__ void pair_step(int zc, float sig, float Delta, float 
     s1 = s1 + omega;
     s2 = s2 + omega;
   } else if (zc == 1) {
-    const float n0 = fmaxf(s0 + Delta, s2 + Omega);
-    const float n1 = fmaxf(s0 + Omega, s1 + Delta);
-    const float n2 = fmaxf(s1 + Omega, s2 + Delta);
+    const float n0 = ref_max<SEM>(s0 + Delta, s2 + Omega);
+    const float n1 = ref_max<SEM>(s0 + Omega, s1 + Delta);
+    const float n2 = ref_max<SEM>(s1 + Omega, s2 + Delta);
     s0 = n0; s1 = n1; s2 = n2;
   } else {
-    const float n0 = fmaxf(s0 + Delta, s1 + Omega);
-    const float n1 = fmaxf(s1 + Delta, s2 + Omega);
-    const float n2 = fmaxf(s2 + Delta, s0 + Omega);
+    const float n0 = ref_max<SEM>(s0 + Delta, s1 + Omega);
+    const float n1 = ref_max<SEM>(s1 + Delta, s2 + Omega);
+    const float n2 = ref_max<SEM>(s2 + Delta, s0 + Omega);
     s0 = n0; s1 = n1; s2 = n2;
   }
 }
@@ -321,6 +334,7 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
     }
     uint32_t *__restrict__ cod = scratch + static_cast<size_t>(slot) * A.scratchStride;
     const DevBlock *__restrict__ db = dblocks + bi;
+    const bool nanSem = EXACT && (flags[bi] & kFlagNan) != 0u;   // NaN score tables (only ever in the EXACT launches): see ref_max
     const int cols = db->cols, L = db->L, nnodes = db->nnodes;
     const float Delta = db->Delta, Omega = db->Omega, omega = db->omega, nkf = db->nkf;
     const NodeRec *__restrict__ nodes = reinterpret_cast<const NodeRec *>(blob + db->off_nodes);
@@ -788,6 +802,23 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
           });
           return finish(sum);
         };
+        // every codon of a block with NaN score tables: the recurrence as the reference writes it, its MAX macro and operand order (ref_max)
+        auto nan_cell = [&](uint32_t (&w)[NCW], int j, int jn, auto kind) -> float {
+          float sig[NK];
+          lookup(w, sig, jn, std::true_type{}, kind);
+          unsigned long long z[ZW];
+#pragma unroll
+          for (int x = 0; x < ZW; x++) z[x] = zbase[static_cast<size_t>(3 * j) * ZW + x];
+          float sum = 0.0f;
+          static_for<NK>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            auto &r = R.template at<k>();
+            pair_step<true>(static_cast<int>((z[k >> 5] >> (2 * (k & 31))) & 3ull), sig[k], Delta, Omega, omega, r.s0, r.s1, r.s2);
+            const float m = ref_max3<true>(r.s0, r.s1, r.s2);
+            sum = (k == 0) ? m : sum + m;
+          });
+          return finish(sum);
+        };
         // first site >= j (and < end) with an event, or end
         auto next_event = [&](int j, int end) -> int {
           while (j < end) {
@@ -1156,6 +1187,13 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
                 for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
               }
             };
+            if constexpr (EXACT) {
+              if (nanSem)   // (the whole row: none of the shortcuts below holds with NaN states)
+                for (; j < jend; j++) {
+                  const int jj = j;
+                  one(std::true_type{}, [&](int jn, auto kd) { return nan_cell(wcur, jj, jn, kd); });
+                }
+            }
             {   // pristine segment: up to the row's first event
               const int e = next_event(j, jend);
               float wv = 0.0f;

@@ -223,6 +223,7 @@ int rc_batch_native_S(const rc_batch *b, int32_t blk, int32_t strand, int32_t fr
     na.blob = b->dblob.as<uint8_t>(); na.dblocks = reinterpret_cast<const DevBlock *>(blob + b->oDblocks); na.blocks = idx.as<int>();
     na.hssCap = b->hssCap; na.tieThr = c->tieThr; na.tile = tile.as<float>(); na.tileStride = tileStride; na.nItems = 6;
     na.fullS = full.as<float>();
+    na.flags = b->dflags.as<uint32_t>();
     if (generic) launch_native_dp_generic(na, 1, tile.as<float>(), tileStride, nullptr);
     else if (!launch_native_dp(h.NK, na, 6, nullptr)) return fail(RC_ERR_UNSUPPORTED, "no native DP kernel for this number of rows");
     HIP_TRY(hipDeviceSynchronize());
@@ -259,7 +260,7 @@ int rc_batch_backtrack(const rc_batch *b, int32_t blk, int32_t strand, int32_t o
   DevBuf d_out;
   HIP_TRY(d_out.ensure(sizeof(float) * NK * 3 * steps));
   RC_STREAM_TRY(st, stream_aux(c));
-  launch_sk_row(b->dblob.as<uint8_t>(), reinterpret_cast<const DevBlock *>(b->dblob.as<uint8_t>() + b->oDblocks), blk, strand, opt_b, opt_i,
+  launch_sk_row(b->dblob.as<uint8_t>(), reinterpret_cast<const DevBlock *>(b->dblob.as<uint8_t>() + b->oDblocks), b->dflags.as<uint32_t>(), blk, strand, opt_b, opt_i,
                 d_out.as<float>(), steps, st);
   std::vector<float> sk(static_cast<size_t>(NK) * 3 * steps);
   hipError_t e = hipStreamSynchronize(st);   // the streams are non-blocking: a default-stream copy would not wait

@@ -39,6 +39,7 @@ int launch_native_block(const RunEnv &R) {
   NativeArgs na{};
   na.blob = b->dblob.as<uint8_t>(); na.dblocks = R.dblocks; na.blocks = R.okList; na.pair = R.tp.pair;
   na.hss = b->dhss.as<DevHss>(); na.hssCount = b->dhssCount.as<int>(); na.hssCap = b->hssCap; na.tieThr = c->tieThr;
+  na.flags = b->dflags.as<uint32_t>();
   HIP_TRY(hipMemsetAsync(b->dhssCount.p, 0, static_cast<size_t>(R.n) * 6 * sizeof(int), st));
   launch_native_sigma(na, static_cast<int>(b->okBlocks.size()), st); b->nl[3]++;
   {   // one 64-row buffer per persistent workgroup, shared by the class launches (same stream)

@@ -371,6 +371,43 @@ def test_extreme_shapes_against_oracle(ctx):
     batch.close()
 
 
+def test_block_without_two_of_the_nucleotides_takes_the_references_nan_semantics(ctx):
+    """A block of C and T only (found by tools/soak_parity.py, 1 of 1.2 million random blocks): HKY85 with two zero frequencies makes
+    every background model NaN (score.c:204-244), every sigma NaN, and the reference's results then depend on how its MAX macro
+    (score.h:28: x > y ? x : y) treats a NaN -- a NaN in y goes through, one in x is dropped -- where v_max_f32 returns the operand
+    that is a number.  k_prep_lut flags such blocks (kFlagNan), the native-block kernels and the EXACT k_null instantiations then
+    use the macro and the reference's operand order (ref_max): per-sample maxima, the HSS table and the fit's verdict equal the
+    oracle's, in the batch the soak had the block in, alone, and with positive and default gap parameters."""
+    import json
+    import os
+    from oracle import binding as ob
+    from rnacode_amd import api
+    from rnacode_amd.alnio import AlnBlock, AlnRow
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "data", "soak_hss_positive_delta.json")))
+
+    def block(e):
+        rows = [AlnRow(n, s) for n, s in zip(e["names"], e["rows"])]
+        rows[0].start, rows[0].length = e["start"], e["length"]
+        return AlnBlock(rows, "r", e["tree"], e["kappa"])
+
+    at = next(i for i, e in enumerate(d["batch"]) if e["rows"] == d["rows"] and e["tree"] == d["tree"])
+    for pars in ({"Delta": d["pars"]["Delta"]}, {}):
+        hp = api.default_params(sampleN=130, seed_base=d["seed"], **pars)
+        p = ob.default_params(130)
+        for k, v in pars.items():
+            setattr(p, k, v)
+        res = ob.run_block(d["rows"], d["names"], d["start"], d["length"], d["tree"], d["kappa"], p, d["seed"])
+        assert not np.isfinite(res.models[1]["scores"][0])            # the premise: NaN models
+        for blocks, i in (([block(e) for e in d["batch"]], at), ([block(d)], 0)):
+            b = api.Batch(ctx, blocks, hp).run()
+            np.testing.assert_array_equal(b.maxScores(i), np.float32(res.maxScores))
+            got, want = sorted(b.scoreAln(i), key=hss_key), sorted(res.hss, key=hss_key)
+            assert [(h["strand"], h["frame"], h["start"], h["end"], np.float32(h["score"])) for h in got] == \
+                   [(h["strand"], h["frame"], h["start"], h["end"], np.float32(h["score"])) for h in want]
+            assert b.getExtremeValuePars(i)[0] == res.evd_rc
+            b.close()
+
+
 def test_wide_blocks_against_oracle(ctx):
     """More than 32 rows (46-/100-way MAFs; the reference takes up to 500, rnaz_utils.h:7): N = 33, 48 and 64 run the
     wide instantiations (second z word, node states in more words, 13 code words per site).  Same seeds through the HIP

@@ -97,12 +97,21 @@ def soak(budget=60.0, rng_seed=1, mode="", max_blocks=None, log=print):
             res = ob.run_block([x.seq for x in b.rows], [x.name for x in b.rows], b.rows[0].start, b.rows[0].length, b.tree, b.kappa, p, seed)
             rc0 = batch.getExtremeValuePars(i)[0]
             # --stop-early: a decided block (rc -1) may have fewer samples simulated here than the reference had when it left its loop
+            why = []
             ok = np.array_equal(batch.maxScores(i), np.float32(res.maxScores)) or (stop and rc0 == -1 and res.evd_rc == -1)
+            if not ok:
+                why.append("maxima")
             got, want = sorted(batch.scoreAln(i), key=key), sorted(res.hss, key=key)
-            ok = ok and [(g["strand"], g["frame"], g["start"], g["end"], np.float32(g["score"])) for g in got] == \
+            same = [(g["strand"], g["frame"], g["start"], g["end"], np.float32(g["score"])) for g in got] == \
                 [(w["strand"], w["frame"], w["start"], w["end"], np.float32(w["score"])) for w in want]
+            if not same:
+                why.append("hss")
+            ok = ok and same
             rc, mu, lam = batch.getExtremeValuePars(i)
-            ok = ok and rc == res.evd_rc and (rc != 1 or (abs(mu - res.mu) <= 1e-6 * max(1, abs(res.mu)) and abs(lam - res.lam) <= 1e-6 * max(1, abs(res.lam))))
+            same = rc == res.evd_rc and (rc != 1 or (abs(mu - res.mu) <= 1e-6 * max(1, abs(res.mu)) and abs(lam - res.lam) <= 1e-6 * max(1, abs(res.lam))))
+            if not same:
+                why.append(f"fit rc {rc} / {res.evd_rc}, mu {mu!r} / {res.mu!r}, lambda {lam!r} / {res.lam!r}")
+            ok = ok and same
             if ok and got and rng.rand() < 0.15:   # state path of the best HSS: rc_batch_backtrack against the oracle's backtrack
                 h = got[0]
                 strand = 0 if h["strand"] == "+" else 1
@@ -121,7 +130,15 @@ def soak(budget=60.0, rng_seed=1, mode="", max_blocks=None, log=print):
             blocks_done += 1
             if not ok:
                 bad += 1
-                log(f"MISMATCH round {rounds} block {i}: {b.n} x {b.cols}, n={n_samples}, seed={seed}, pars={pars}")
+                log(f"MISMATCH round {rounds} block {i}: {b.n} x {b.cols}, n={n_samples}, seed={seed}, pars={pars}: {'; '.join(why) or 'backtrack path'}"
+                    f" (batch of {len(blocks)}, {'stream' if len(parts) > 1 or parts[0].n != len(blocks) else 'one batch'})")
+                import json, os   # the block, to replay it: tools/soak_replay.py
+                os.makedirs("gpurun_out/soak_fail", exist_ok=True)
+                with open(f"gpurun_out/soak_fail/{mode or 'any'}_{rng_seed}_{rounds}_{i}.json", "w") as fh:
+                    json.dump(dict(rows=[x.seq for x in b.rows], names=[x.name for x in b.rows], start=b.rows[0].start, length=b.rows[0].length, tree=b.tree,
+                                   kappa=b.kappa, n_samples=n_samples, seed=seed, pars=pars, why=why,
+                                   batch=[dict(rows=[x.seq for x in bb.rows], names=[x.name for x in bb.rows], start=bb.rows[0].start, length=bb.rows[0].length,
+                                               tree=bb.tree, kappa=bb.kappa) for bb in blocks]), fh)
         for pb in parts:
             pb.close()
     ctx.close()
