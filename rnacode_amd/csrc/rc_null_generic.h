@@ -208,6 +208,7 @@ __device__ __forceinline__ void generic_body(const NullArgs &A, const uint8_t *_
     const int grp = g0 + 8 * (sub / parts);
     const int onlyCombo = (A.comboSplit && !SIM) ? sub % parts : -1;
     const DevBlock *__restrict__ db = dblocks + bi;
+    const bool nanSem = !SIM && (flags[bi] & kFlagNan) != 0u;   // NaN score tables: every cell through the written-out recurrence with the reference's MAX macro (rc_null_kernel.h, ref_max)
     const int N = db->N, NK = db->NK, cols = db->cols, L = db->L, nnodes = db->nnodes, L1 = L + 1;
     const int NCW = (NK + 4) / 5, ZW = db->zw_words;
     const float Delta = db->Delta, Omega = db->Omega, omega = db->omega, nkf = db->nkf;
@@ -383,7 +384,9 @@ __device__ __forceinline__ void generic_body(const NullArgs &A, const uint8_t *_
           sample_scan_row_begin(st, best, static_cast<uint32_t>(a));
           const int jendA = (a == sites - 1) ? sites - 1 : sites;   // the frame's final entry is never reported (score.c:892-900)
           const int jendB = (b >= sites - 1) ? sites - 1 : sites;   // (b == sites: no cell passes b <= j < sites - 1)
-          uint32_t stickyA = 0u, stickyB = 0u;   // bit k & 31 of lane k >> 5: sequence k has met a frame shift in this row
+          // bit k & 31 of lane k >> 5: sequence k has met a frame shift in this row (a block with NaN tables: every sequence, from the start -- no pass
+          // of it is ever the common one, at no cost to the common pass's decision)
+          uint32_t stickyA = nanSem ? 0xffffffffu : 0u, stickyB = stickyA;
           // tiles start at multiples of four codons (the code words hold four), so a row's first tile may begin before a
           for (int j0 = a & ~3; j0 < jendA; j0 += kGenericTile) {
             const bool first = j0 <= a, more = j0 + kGenericTile < jendA;
@@ -446,7 +449,7 @@ __device__ __forceinline__ void generic_body(const NullArgs &A, const uint8_t *_
               } else {
                 uint32_t zA = (zz0 | zz1) & validA, zB = (zz0 | zz1) & validB, tA = swA & bitK, tB = swB & bitK;
                 asm volatile("" : "+s"(zA), "+s"(zB), "+s"(tA), "+s"(tB));
-                const bool evA = zA != 0u, evB = zB != 0u, wasA = tA != 0u, wasB = tB != 0u, sharedA = !wasA && !evA, sharedB = !wasB && !evB;
+                const bool evA = zA != 0u || nanSem, evB = zB != 0u || nanSem, wasA = tA != 0u, wasB = tB != 0u, sharedA = !wasA && !evA, sharedB = !wasB && !evB;
                 fb = (sharedA ? 1u : 0u) | (sharedB ? 2u : 0u) | (evA ? 4u : 0u) | (evB ? 8u : 0u);
                 if (!first) {
                   a0 = dkA[0];
@@ -494,8 +497,10 @@ __device__ __forceinline__ void generic_body(const NullArgs &A, const uint8_t *_
                           const float sg = mm[v];
                           mm[v] = 0.0f;   // a cell outside the row adds zero to a sum that is never read
                           if ((valid >> u) & 1u) {
-                            pair_step(static_cast<int>(((zz0 >> u) & 1u) | (((zz1 >> u) & 1u) << 1)), sg, Delta, Omega, omega, s0, s1, s2);
-                            mm[v] = fmaxf(fmaxf(s0, s1), s2);
+                            // (the reference's MAX macro for every block that comes here: equal to v_max_f32 where no operand is a NaN, and what a block
+                            // with NaN tables needs -- rc_null_kernel.h, ref_max; two instructions per maximum in these few cells)
+                            pair_step<true>(static_cast<int>(((zz0 >> u) & 1u) | (((zz1 >> u) & 1u) << 1)), sg, Delta, Omega, omega, s0, s1, s2);
+                            mm[v] = ref_max3<true>(s0, s1, s2);
                           }
                         });
                       }

@@ -406,6 +406,23 @@ def test_block_without_two_of_the_nucleotides_takes_the_references_nan_semantics
                    [(h["strand"], h["frame"], h["start"], h["end"], np.float32(h["score"])) for h in want]
             assert b.getExtremeValuePars(i)[0] == res.evd_rc
             b.close()
+    # the same with more than 64 rows (k_generic_dp: every cell through the written-out recurrence) and with 40 (EXACT only)
+    from rnacode_amd.synth import synth_block
+    for n_rows, cols in ((66, 30), (40, 33)):
+        blk = synth_block(np.random.RandomState(77), n_rows, cols, index=0, gaps=True).upper()
+        for r in blk.rows:
+            r.seq = r.seq.replace("A", "C").replace("G", "T")
+        rows, names = [r.seq for r in blk.rows], [r.name for r in blk.rows]
+        p = ob.default_params(70)
+        res = ob.run_block(rows, names, blk.rows[0].start, blk.rows[0].length, blk.tree, blk.kappa, p, 9)
+        assert not np.isfinite(res.models[1]["scores"][0])
+        b = api.Batch(ctx, [blk], api.default_params(sampleN=70, seed_base=9)).run()
+        np.testing.assert_array_equal(b.maxScores(0), np.float32(res.maxScores))
+        got, want = sorted(b.scoreAln(0), key=hss_key), sorted(res.hss, key=hss_key)
+        assert [(h["strand"], h["frame"], h["start"], h["end"], np.float32(h["score"])) for h in got] == \
+               [(h["strand"], h["frame"], h["start"], h["end"], np.float32(h["score"])) for h in want]
+        assert b.getExtremeValuePars(0)[0] == res.evd_rc
+        b.close()
 
 
 def test_wide_blocks_against_oracle(ctx):
