@@ -576,13 +576,30 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
         const uint32_t ldsTail = ldsBase + (NCW - 1) * kWave * 4u + static_cast<uint32_t>(lane) * LB;         // its tail value (suffix cache)
         const uint32_t laneOff = static_cast<uint32_t>(lane) * 4u, laneTail = static_cast<uint32_t>(lane) * LB;
         // asm fetches of a site's code words: the compiler does not know them as memory operations and places no waits of its own
+        // (RC_PLAIN_FETCH, a build for cross-checks -- tools/ab_plain_fetch.sh: the same fetches as plain loads, which the compiler sees and
+        // waits for itself: slower, and free of the hazard the asm form carries -- a register it does not know to be pending must not be
+        // copied or spilled in front of its wait, tests/test_codegen_cpu.py.  Results must not differ.)
+        [[maybe_unused]] const uint8_t *ldsBytesAll = reinterpret_cast<const uint8_t *>(lds_codes + kTableWords) - ldsBase;   // (so that the asm form's byte addresses index it)
         auto fetch_staged = [&](uint32_t (&w)[NCW], int j) {        // LDSC: [site][NCW][64] dwords
           const uint32_t at = ldsLane + static_cast<uint32_t>(j) * (NCW * kWave * 4u);
 #pragma unroll
-          for (int x = 0; x < NCW; x++) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(w[x]) : "v"(at), "n"(x * kWave * 4));
+          for (int x = 0; x < NCW; x++) {
+#ifdef RC_PLAIN_FETCH
+            w[x] = *reinterpret_cast<const uint32_t *>(ldsBytesAll + at + x * kWave * 4);
+#else
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(w[x]) : "v"(at), "n"(x * kWave * 4));
+#endif
+          }
         };
         auto fetch_cached = [&](uint32_t (&w)[NCW], int j) {        // suffix cache: site j >= jc, the scratch's layout
           const uint32_t off = static_cast<uint32_t>(j - jc) * kCacheSiteBytes;
+#ifdef RC_PLAIN_FETCH
+          if constexpr (NCW > 1) {
+#pragma unroll
+            for (int x = 0; x < NCW - 1; x++) w[x] = *reinterpret_cast<const uint32_t *>(ldsBytesAll + ldsLane + off + x * kWave * 4);
+          }
+          w[NCW - 1] = static_cast<uint32_t>(*reinterpret_cast<const TailT *>(ldsBytesAll + ldsTail + off));
+#else
           if constexpr (NCW > 1) {
             const uint32_t at = ldsLane + off;
 #pragma unroll
@@ -592,9 +609,17 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
           if constexpr (LB == 1) asm volatile("ds_read_u8 %0, %1" : "=v"(w[NCW - 1]) : "v"(att));
           else if constexpr (LB == 2) asm volatile("ds_read_u16 %0, %1" : "=v"(w[NCW - 1]) : "v"(att));
           else asm volatile("ds_read_b32 %0, %1" : "=v"(w[NCW - 1]) : "v"(att));
+#endif
         };
         auto fetch_global = [&](uint32_t (&w)[NCW], const uint32_t *p) {   // p: wave-uniform, settled in scalar registers five wait states ago
           const uint32_t lo = laneOff + 0u, lt = laneTail + 0u;   // (copies: an asm operand alone does not make a generic lambda capture the variable)
+#ifdef RC_PLAIN_FETCH
+          const uint8_t *pb = reinterpret_cast<const uint8_t *>(p);
+#pragma unroll
+          for (int x = 0; x < NCW - 1; x++) w[x] = *reinterpret_cast<const uint32_t *>(pb + lo + x * kWave * 4);
+          w[NCW - 1] = static_cast<uint32_t>(*reinterpret_cast<const TailT *>(pb + lt + (NCW - 1) * kWave * 4));
+          return;
+#endif
 #pragma unroll
           for (int x = 0; x < NCW - 1; x++) asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(w[x]) : "v"(lo), "s"(p), "n"(x * kWave * 4));
           if constexpr (LB == 1) asm volatile("global_load_ubyte %0, %1, %2 offset:%3" : "=v"(w[NCW - 1]) : "v"(lt), "s"(p), "n"((NCW - 1) * kWave * 4));
