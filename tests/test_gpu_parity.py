@@ -487,6 +487,34 @@ def test_wide_blocks_against_oracle(ctx):
     assert hs is not None
 
 
+def test_wide_blocks_in_several_rounds_equal_one_round(ctx):
+    """k_generic_sim leaves the codes of a ROUND of items in the scratch for k_generic_dp (rc_schedule.cpp): with a scratch of 24 GB
+    a batch of a few wide blocks is one round, with 8 MB (RC_GENERIC_SCRATCH_MB, read when a context is created) every block's
+    sample groups are a round of their own -- queues reset between rounds, the last round short.  Same maxima, HSS and fits."""
+    import os
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_blocks
+    blocks = [b.upper() for b in synth_blocks(5, 70, 60, seed=61) + synth_blocks(2, 130, 45, seed=62) + synth_blocks(3, 6, 60, seed=63)]
+    p = api.default_params(sampleN=200, seed_base=5)
+    one = api.Batch(ctx, blocks, p).run()
+    want = (one.maxScores_all().copy(), one.fits().copy(), one.scoreAln_all())
+    launches_one = one.timing()[1]["null"]
+    one.close()
+    os.environ["RC_GENERIC_SCRATCH_MB"] = "8"
+    try:
+        small = api.Context(0)
+    finally:
+        del os.environ["RC_GENERIC_SCRATCH_MB"]
+    b = api.Batch(small, blocks, p).run()
+    assert b.timing()[1]["null"] > launches_one          # more rounds = more launches
+    np.testing.assert_array_equal(b.maxScores_all(), want[0])
+    np.testing.assert_array_equal(b.fits()[:, 0], want[1][:, 0])
+    np.testing.assert_allclose(b.fits()[:, 1:3], want[1][:, 1:3], rtol=1e-6)
+    assert [[hss_key(h) for h in x] for x in b.scoreAln_all()] == [[hss_key(h) for h in x] for x in want[2]]
+    b.close()
+    small.close()
+
+
 def test_blocks_beyond_64_rows_against_oracle(ctx):
     """65..500 rows (the reference's own limit, rnaz_utils.h:7; 100-way genome alignments): k_generic_sim / k_generic_dp and
     k_native_dp_generic keep the per-sequence states in global memory instead of registers.  Same seeds through the HIP
