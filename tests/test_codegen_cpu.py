@@ -180,3 +180,35 @@ def test_no_pending_fetch_register_is_copied_or_spilled_at_twelve_rows(tmp_path)
     for want in ("k_nullILi11ELb0ELb0ELb0ELi0E", "k_null_occILi11E"):
         audited, fetches = _audit_pending_registers(txt, next(n for n in names if want in n))
         assert audited >= 4 and fetches >= 24, (want, audited, fetches)
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_wide_simulation_and_native_dp_stay_lean(tmp_path):
+    """Round 5 rebuilt two kernels around what their ISA showed.  k_generic_sim (blocks of more than 64 rows) had ~50 scalar
+    instructions and nine scalar loads per tree node -- 215 s_load in the kernel, a vector load of the parent's index with a full
+    wait behind it -- and is now fed by coalesced lane loads, ds_bpermute and v_readlane: a handful of scalar loads in all.
+    k_native_dp<N-1> branched per sequence on z and copied all 3 (N-1) states at every join (1598 lines of ISA at ten rows, 20 v_mov
+    per sequence and codon): a codon where no sequence is out of frame must be ONE straight-line block of 3 adds and a max3 per
+    sequence, and the out-of-frame codons a second one that selects with the wave-uniform z."""
+    txt = _compile_unit(tmp_path, "rc_kernels")
+    sim = txt[txt.index("_ZN2rc13k_generic_simE"):]
+    sim = sim[sim.index(":\n"):sim.index(".Lfunc_end")]
+    assert sim.count("s_load_") <= 40, sim.count("s_load_")
+    assert sim.count("ds_bpermute_b32") >= 32 and sim.count("v_readlane_b32") >= 16      # thresholds and control words of eight nodes
+    assert "scratch_" not in sim
+    name = "_ZN2rc11k_native_dpILi9EEEvNS_10NativeArgsE"
+    body = txt[txt.index(name + ":"):]
+    body = body[:body.index(".Lfunc_end")]
+    blocks, cur = [], None
+    for ln in body.split("\n"):
+        if re.match(r"^\.LBB\d+_\d+:", ln):
+            cur = []
+            blocks.append(cur)
+        elif cur is not None and ln.startswith("\t") and not ln.startswith(("\t.", "\t;")):
+            cur.append(ln.strip())
+    # (the compiler hoists the in-frame sums in front of the test of z: the in-frame block is what remains, nine max3 and the running sum)
+    fast = [b for b in blocks if sum(x.startswith("v_max3_f32") for x in b) == 9 and len(b) <= 60 and not any(x.startswith("v_cndmask") for x in b)]
+    assert fast, "no short straight-line block for a codon where every sequence is in frame"
+    assert not any(x.startswith("s_cbranch") for x in fast[0][:-2])
+    select = [b for b in blocks if sum(x.startswith("v_cndmask_b32") for x in b) >= 9 * 6]
+    assert select and sum(x.startswith("s_cbranch") for x in select[0]) <= 4, "the out-of-frame codons branch per sequence again"
