@@ -275,7 +275,7 @@ int batch_run_async(rc_batch *b, bool streaming) {
     FitArgs fa{};
     fa.dblocks = R.dblocks; fa.blocks = R.okList; fa.maxima = b->maxPtr; fa.hss = b->dhss.as<DevHss>();
     fa.hssCount = b->dhssCount.as<int>(); fa.hssCap = b->hssCap; fa.out = b->dfit.as<FitOut>(); fa.flags = b->dflags.as<uint32_t>();
-    fa.sampleN = sampleN; fa.stopEarly = b->par.stopEarly;
+    fa.sampleN = sampleN; fa.stopEarly = b->par.stopEarly; fa.expMode = c->expMode;
     fa.stopCutoff = static_cast<int>(b->par.cutoff * b->par.sampleN);   // score.c:992
     // --stop-early: a first round of sample groups for every block, then -- doubling the samples each round -- only the blocks
     // that are still undecided (k_stop_mark between the rounds)

@@ -87,6 +87,8 @@ int rc_ctx_create(int device, rc_ctx **out) {
   c->retiredCapBytes = prop.totalGlobalMem / 16;
   c->bufPool->devCap = prop.totalGlobalMem / 16;
   c->bufPool->device = device;
+  static const int hostExp = exp_mode_of_host();   // (once per process: 20 000 exp calls, 2 ms)
+  c->expMode = hostExp;
   for (DevBuf *d : {&c->treeJobs, &c->treeIn, &c->treeWork, &c->treeRes, &c->d_tables, &c->d_cellStats}) d->retired = c->retired.get();
   for (PinBuf *h : {&c->treeInPin, &c->treeResPin}) h->retired = c->retired.get();
   c->genericScratchWords = std::max<size_t>(static_cast<size_t>(1) << 30, prop.totalGlobalMem / 12 / sizeof(uint32_t));

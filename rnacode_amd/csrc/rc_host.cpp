@@ -12,6 +12,7 @@
 // Float/double promotions follow the reference's C expressions exactly;
 // f32()/f64() below make every rounding step explicit.
 #include "rc_host.h"
+#include "rc_refexp.h"
 
 #include <algorithm>
 #include <cmath>
@@ -540,6 +541,19 @@ int prepare_block(const rc_block &in, const rc_params &par, const PairTable &pt,
     nodes[q].tiprow = static_cast<int16_t>(r);
   }
   return done(RC_OK);
+}
+
+int exp_mode_of_host() {
+  bool fused = true, generic = true;
+  uint64_t s = 88172645463325252ull;
+  for (int i = 0; i < 20000 && (fused || generic); i++) {
+    s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+    const double x = -745.2 * (static_cast<double>(s >> 11) * (1.0 / 9007199254740992.0));   // where the fit's exp(-lambda x) lives
+    const uint64_t want = exp_bits(std::exp(x));
+    if (fused && exp_bits(ref_exp(x, true)) != want) fused = false;
+    if (generic && exp_bits(ref_exp(x, false)) != want) generic = false;
+  }
+  return fused ? 2 : generic ? 1 : 0;
 }
 
 float pvalue_of(float score, float parMu, float parLambda) {   // RNAcode.c:182

@@ -18,6 +18,7 @@
 // order; compile with -ffp-contract=off; float division is hipcc's correctly rounded default.
 #include "rc_null_kernel.h"
 #include "rc_null_generic.h"
+#include "rc_refexp.h"
 
 namespace rc {
 
@@ -664,12 +665,15 @@ __device__ __forceinline__ void fit_sum4(double &a, double &b, double &c, double
   }
 }
 
+// exp as the reference's C library computes it (rc_refexp.h): the Newton iteration's stopping test is decided by its last bit
+__device__ __forceinline__ double fit_exp(int mode, double a) { return mode == 2 ? ref_exp(a, true) : mode == 1 ? ref_exp(a, false) : exp(a); }
+
 template <int THREADS>
-__device__ void lawless416(const float *x, int n, double lambda, double *sh, double *f, double *df) {
+__device__ void lawless416(int mode, const float *x, int n, double lambda, double *sh, double *f, double *df) {
   double e = 0, xe = 0, xxe = 0, xs = 0;
   for (int i = threadIdx.x; i < n; i += THREADS) {
     const double xi = static_cast<double>(x[i]);
-    const double ex = exp(-1. * lambda * xi);
+    const double ex = fit_exp(mode, -1. * lambda * xi);
     xs += xi; xe += xi * ex; xxe += xi * xi * ex; e += ex;
   }
   fit_sum4<THREADS>(e, xe, xxe, xs, sh);
@@ -679,12 +683,12 @@ __device__ void lawless416(const float *x, int n, double lambda, double *sh, dou
 }
 
 template <int THREADS>
-__device__ int evd_fit_block(const float *x, int n, double *sh, double *mu_out, double *lambda_out) {
+__device__ int evd_fit_block(int mode, const float *x, int n, double *sh, double *mu_out, double *lambda_out) {
   double lambda = 0.2, fx, dfx;
   const double tol = 1e-5;
   int it;
   for (it = 0; it < 100; it++) {
-    lawless416<THREADS>(x, n, lambda, sh, &fx, &dfx);
+    lawless416<THREADS>(mode, x, n, lambda, sh, &fx, &dfx);
     if (fabs(fx) < tol) break;
     lambda = lambda - fx / dfx;
     if (lambda <= 0.) lambda = 0.001;
@@ -692,23 +696,23 @@ __device__ int evd_fit_block(const float *x, int n, double *sh, double *mu_out, 
   if (it == 100) {  // bisection fallback (extreme_fit.c:193-236)
     double left = 0.2, right = 0.2, mid = 0.2;
     lambda = 0.2;
-    lawless416<THREADS>(x, n, lambda, sh, &fx, &dfx);
+    lawless416<THREADS>(mode, x, n, lambda, sh, &fx, &dfx);
     if (fx < 0.) {
       do {
         left -= 0.1;
         if (left < 0.) return 0;
-        lawless416<THREADS>(x, n, left, sh, &fx, &dfx);
+        lawless416<THREADS>(mode, x, n, left, sh, &fx, &dfx);
       } while (fx < 0.);
     } else {
       do {
         right += 0.1;
-        lawless416<THREADS>(x, n, right, sh, &fx, &dfx);
+        lawless416<THREADS>(mode, x, n, right, sh, &fx, &dfx);
         if (right > 100.) return 0;
       } while (fx > 0.);
     }
     for (it = 0; it < 100; it++) {
       mid = (left + right) / 2.;
-      lawless416<THREADS>(x, n, mid, sh, &fx, &dfx);
+      lawless416<THREADS>(mode, x, n, mid, sh, &fx, &dfx);
       if (fabs(fx) < tol) break;
       if (fx > 0.) left = mid; else right = mid;
     }
@@ -716,7 +720,7 @@ __device__ int evd_fit_block(const float *x, int n, double *sh, double *mu_out, 
     lambda = mid;
   }
   double e = 0, z0 = 0, z1 = 0, z2 = 0;
-  for (int i = threadIdx.x; i < n; i += THREADS) e += exp(-1 * lambda * static_cast<double>(x[i]));
+  for (int i = threadIdx.x; i < n; i += THREADS) e += fit_exp(mode, -1 * lambda * static_cast<double>(x[i]));
   fit_sum4<THREADS>(e, z0, z1, z2, sh);
   *mu_out = -1. * log(e / static_cast<double>(n)) / lambda;
   *lambda_out = lambda;
@@ -777,14 +781,14 @@ __global__ __launch_bounds__(THREADS) void k_evd_fit(FitArgs A) {
   const bool nothingScored = scored == 0.0;
   if (!stopped && !nothingScored) {
     double mu, lambda;
-    if (evd_fit_block<THREADS>(x, A.sampleN, sh, &mu, &lambda) == 1) { o.rc = 1; o.mu = mu; o.lambda = lambda; }
+    if (evd_fit_block<THREADS>(A.expMode, x, A.sampleN, sh, &mu, &lambda) == 1) { o.rc = 1; o.mu = mu; o.lambda = lambda; }
   }
   if (threadIdx.x == 0) A.out[db->out_index] = o;
 }
 
 // EVDMaxLikelyFit on caller-supplied doubles (rc_evd_fit): same code path with float inputs would
 // lose bits, so this variant reads doubles.
-__global__ __launch_bounds__(256) void k_evd_fit_f64(const double *x, int n, FitOut *out) {
+__global__ __launch_bounds__(256) void k_evd_fit_f64(const double *x, int n, FitOut *out, int mode) {
   __shared__ double sh[8];
   // reuse the float path by templating would duplicate code; the sums are written out here
   double lambda = 0.2, fx = 0, dfx = 0;
@@ -793,7 +797,7 @@ __global__ __launch_bounds__(256) void k_evd_fit_f64(const double *x, int n, Fit
     double e = 0, xe = 0, xxe = 0, xs = 0;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
       const double xi = x[i];
-      const double ex = exp(-1. * lam * xi);
+      const double ex = fit_exp(mode, -1. * lam * xi);
       xs += xi; xe += xi * ex; xxe += xi * xi * ex; e += ex;
     }
     e = block_sum(e, sh); xe = block_sum(xe, sh); xxe = block_sum(xxe, sh); xs = block_sum(xs, sh);
@@ -829,7 +833,7 @@ __global__ __launch_bounds__(256) void k_evd_fit_f64(const double *x, int n, Fit
   double mu = 0;
   if (rc) {
     double e = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) e += exp(-1 * lambda * x[i]);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) e += fit_exp(mode, -1 * lambda * x[i]);
     e = block_sum(e, sh);
     mu = -1. * log(e / static_cast<double>(n)) / lambda;
   }
@@ -1027,8 +1031,8 @@ void launch_evd_fit(const FitArgs &a, int nblocks, bool latency, hipStream_t str
   else hipLaunchKernelGGL(k_evd_fit<64>, dim3(nblocks), dim3(64), 0, stream, a);
 }
 
-void launch_evd_fit_f64(const double *x, int n, FitOut *out, hipStream_t stream) {
-  hipLaunchKernelGGL(k_evd_fit_f64, dim3(1), dim3(256), 0, stream, x, n, out);
+void launch_evd_fit_f64(const double *x, int n, FitOut *out, int expMode, hipStream_t stream) {
+  hipLaunchKernelGGL(k_evd_fit_f64, dim3(1), dim3(256), 0, stream, x, n, out, expMode);
 }
 
 }  // namespace rc

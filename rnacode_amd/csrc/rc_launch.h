@@ -109,6 +109,7 @@ struct FitArgs {
   int firstN;                 // k_stop_mark: number of samples simulated so far
   int stopEarly;
   int stopCutoff;
+  int expMode;                // which exp the fit uses: 0 the device library's, 1 / 2 the host C library's algorithm, generic / fused (rc_refexp.h)
 };
 
 // tree estimator (rc_tree_kernel.hip): one job = one alignment block
@@ -201,6 +202,6 @@ void launch_generic_dp(const NullArgs &a, int grid, size_t ldsBytes, uint8_t *sc
 void launch_native_dp_generic(const NativeArgs &a, int nblocks, float *scratch, size_t scratchStride, hipStream_t stream);
 void launch_stop_mark(const FitArgs &a, int nblocks, hipStream_t stream);
 void launch_evd_fit(const FitArgs &a, int nblocks, bool latency, hipStream_t stream);   // latency: no other batch is in flight
-void launch_evd_fit_f64(const double *x, int n, FitOut *out, hipStream_t stream);
+void launch_evd_fit_f64(const double *x, int n, FitOut *out, int expMode, hipStream_t stream);
 
 }  // namespace rc

@@ -317,6 +317,7 @@ struct rc_ctx {
   hipStream_t tree = nullptr;      // rc_fit_trees_device: 25-40 ms kernels of a driver's tree-fit thread, kept off the helper stream
   int prioLow = 0, prioHigh = 0;   // stream priorities (compute streams low, the small latency-bound work high)
   int classPrio = 0;               // priority of the class streams
+  int expMode = 0;                 // the EVD fit's exp: the host C library's algorithm and variant, if it is one the library knows (rc_refexp.h)
   std::mutex streamMutex;          // ctx_stream
   std::vector<hipStream_t> classStreams;   // k_null launches of different row-count classes, when a batch has several
   unsigned seq = 0;

@@ -315,7 +315,7 @@ int rc_evd_fit(rc_ctx *c, const double *x, int32_t n, double *mu, double *lambda
   HIP_TRY(hipMalloc(&d_x, sizeof(double) * n));
   HIP_TRY(hipMalloc(&d_o, sizeof(FitOut)));
   HIP_TRY(hipMemcpy(d_x, x, sizeof(double) * n, hipMemcpyHostToDevice));
-  launch_evd_fit_f64(d_x, n, d_o, aux);
+  launch_evd_fit_f64(d_x, n, d_o, c->expMode, aux);
   FitOut o;
   hipError_t e = hipStreamSynchronize(aux);
   if (e == hipSuccess) e = hipMemcpy(&o, d_o, sizeof o, hipMemcpyDeviceToHost);

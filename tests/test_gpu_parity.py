@@ -487,6 +487,35 @@ def test_wide_blocks_against_oracle(ctx):
     assert hs is not None
 
 
+def test_fits_at_the_noise_floor_of_exp_follow_the_reference(ctx):
+    """Two fits tools/soak_parity.py could not match (3 of 1.4 million blocks): one or two samples, maxima nearly equal, the root of
+    Lawless 4.1.6 at lambda = 140 and 53 124 -- where exp(-lambda x) is subnormal, f is known to about its tolerance and which Newton
+    iterate passes |f| < 1e-5 (or none before the 100th: then the fit fails, extreme_fit.c:205-211) hangs on the last bit of exp().
+    The fit kernels compute exp by the host C library's algorithm and variant (rc_refexp.h: checked bit for bit against this image's
+    glibc on 32 million arguments per variant): verdict, mu and lambda as the reference's floats."""
+    import json
+    import os
+    from oracle import binding as ob
+    from rnacode_amd import api
+    from rnacode_amd.alnio import AlnBlock, AlnRow
+    for name in ("soak_fit_two_samples.json", "soak_fit_one_sample.json"):
+        d = json.load(open(os.path.join(os.path.dirname(__file__), "data", name)))
+        rows = [AlnRow(n, s) for n, s in zip(d["names"], d["rows"])]
+        rows[0].start, rows[0].length = d["start"], d["length"]
+        blk = AlnBlock(rows, "r", d["tree"], d["kappa"])
+        pars = dict(d["pars"])
+        p = ob.default_params(d["n_samples"])
+        for k, v in pars.items():
+            setattr(p, k, v)
+        res = ob.run_block(d["rows"], d["names"], d["start"], d["length"], d["tree"], d["kappa"], p, d["seed"])
+        b = api.Batch(ctx, [blk], api.default_params(sampleN=d["n_samples"], seed_base=d["seed"], **pars)).run()
+        np.testing.assert_array_equal(b.maxScores(0), np.float32(res.maxScores))
+        rc, mu, lam = b.getExtremeValuePars(0)
+        assert rc == res.evd_rc == 1
+        assert np.float32(lam) == np.float32(res.lam) and np.float32(mu) == np.float32(res.mu), (mu, res.mu, lam, res.lam)
+        b.close()
+
+
 def test_wide_blocks_in_several_rounds_equal_one_round(ctx):
     """k_generic_sim leaves the codes of a ROUND of items in the scratch for k_generic_dp (rc_schedule.cpp): with a scratch of 24 GB
     a batch of a few wide blocks is one round, with 8 MB (RC_GENERIC_SCRATCH_MB, read when a context is created) every block's
