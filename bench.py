@@ -1204,11 +1204,12 @@ def main():
         # record with its prose goes to a file (gpurun_out/bench_full.json, or --full-json): what profiles/<round>/bench_default_run.json is.
         full_path = args.full_json or os.path.join(ROOT, "gpurun_out", "bench_full.json")
         try:
-            os.makedirs(os.path.dirname(full_path), exist_ok=True)
+            if os.path.dirname(full_path):   # (a bare file name has none: makedirs('') raises)
+                os.makedirs(os.path.dirname(full_path), exist_ok=True)
             with open(full_path, "w") as fh:
                 json.dump(out, fh)
-        except OSError:
-            pass
+        except OSError as e:
+            print(f"bench.py: the full record could not be written to {full_path}: {e}", file=sys.stderr)
         print(json.dumps(compact_line(out), separators=(",", ":")))
     if stream is not None:
         stream.close()

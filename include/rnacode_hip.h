@@ -114,6 +114,14 @@ int rc_host_cpus(void);
 int rc_ctx_set_host_threads(rc_ctx *ctx, int32_t threads);
 int rc_ctx_host_threads(const rc_ctx *ctx);
 
+/* Which exp() the EVD fit (EVDMaxLikelyFit, extreme_fit.c:157-251) computes with.  The reference's Newton iteration stops on |f| < 1e-5, and on
+ * near-degenerate maxima (one or two samples, all maxima equal) the last bit of exp decides which iterate passes or whether the fit fails; the
+ * reference follows ITS host's C library.  The library reproduces glibc >= 2.28's exp bit for bit in both x86-64 variants and picks the one the
+ * host's exp() agrees with when a context is created: 1 = generic, 2 = compiled with fused multiply-adds; 0 = the host's exp is neither (musl,
+ * aarch64, another glibc): the device library's exp (<= 1 ulp), and such fits may then differ from a reference run on this host.
+ * RC_FIT_EXP=generic|fused|device overrides the probe (to reproduce a listing made on another machine). */
+int rc_ctx_fit_exp_mode(const rc_ctx *ctx);
+
 /* getModels x2 (RNAcode.c:164-165) + everything block-constant the kernels need.  The host (threads)
  * parses the tree, takes base frequencies, tip distances, the HKY85 matrices, the gap pattern and the
  * integer thresholds of the branch matrices, and writes them straight into one pinned blob; ONE

@@ -112,6 +112,7 @@ def lib():
         l.rc_batch_prep_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int64)]
         l.rc_ctx_set_host_threads.argtypes = [C.c_void_p, C.c_int32]
         l.rc_ctx_host_threads.argtypes = [C.c_void_p]
+        l.rc_ctx_fit_exp_mode.argtypes = [C.c_void_p]
         l.rc_stream_create.argtypes = [C.c_void_p, C.POINTER(RcParams), C.c_int32, C.POINTER(C.c_void_p)]
         l.rc_stream_submit.argtypes = [C.c_void_p, C.POINTER(RcBlock), C.c_int32]
         l.rc_stream_submit_bound.argtypes = [C.c_void_p, C.POINTER(RcBlock), C.c_int32, C.c_void_p]
@@ -158,7 +159,7 @@ def lib():
 EXPORTED_SYMBOLS = [
     "rc_default_params", "rc_last_error", "rc_device_count", "rc_ctx_create", "rc_ctx_destroy", "rc_ctx_trim", "rc_batch_create",
     "rc_batch_destroy", "rc_batch_bind_maxima", "rc_batch_run", "rc_batch_run_async", "rc_batch_wait", "rc_batch_size", "rc_batch_block_error",
-    "rc_batch_prep_timing", "rc_host_cpus", "rc_ctx_set_host_threads", "rc_ctx_host_threads", "rc_stream_create", "rc_stream_submit", "rc_stream_submit_bound",
+    "rc_batch_prep_timing", "rc_host_cpus", "rc_ctx_set_host_threads", "rc_ctx_host_threads", "rc_ctx_fit_exp_mode", "rc_stream_create", "rc_stream_submit", "rc_stream_submit_bound",
     "rc_stream_next", "rc_stream_recycle", "rc_stream_pending", "rc_stream_plan", "rc_stream_destroy", "rc_set_stream_cache", "rc_batch_work", "rc_batch_timing", "rc_batch_null_kernel", "rc_batch_status",
     "rc_batch_models", "rc_batch_maxima", "rc_batch_maxima_all", "rc_batch_fit", "rc_batch_fit_all", "rc_batch_hss", "rc_batch_hss_all", "rc_batch_clamped",
     "rc_batch_native_S", "rc_batch_backtrack", "rc_fit_tree", "rc_fit_trees", "rc_fit_trees_device", "rc_tree_lnl", "rc_evd_fit", "rc_pvalue", "rc_mt_stream", "rc_code_tables",
@@ -308,6 +309,11 @@ class Context:
     @property
     def host_threads(self) -> int:
         return lib().rc_ctx_host_threads(self._h)
+
+    @property
+    def fit_exp_mode(self) -> str:
+        """Which exp() the EVD fit uses (rc_ctx_fit_exp_mode): the host glibc's generic or fused variant, or the device library's."""
+        return {0: "device", 1: "generic", 2: "fused"}[_check(lib().rc_ctx_fit_exp_mode(self._h))]
 
     def evd_fit(self, x) -> Tuple[int, float, float]:
         """EVDMaxLikelyFit (extreme_fit.c:157-251) on the device."""

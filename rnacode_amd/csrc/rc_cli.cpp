@@ -146,7 +146,7 @@ void read_maf_range(char *p, char *end, std::vector<Block> &out) {
 // pieces are parsed side by side.
 std::vector<Block> read_maf(char *p, size_t size) {
   char *end = p + size;
-  unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+  unsigned nt = std::min<unsigned>(static_cast<unsigned>(std::max(1, rc_host_cpus())), 16u);   // (the CPUs this process may use, not the machine's)
   if (size < (4u << 20)) nt = 1;
   std::vector<char *> cut{p};
   for (unsigned t = 1; t < nt; t++) {
@@ -218,16 +218,19 @@ std::vector<Block> read_alignment(FILE *in) {
   size_t size = 0;
   struct stat sp;
   const int fd = fileno(in);
-  if (fstat(fd, &sp) == 0 && S_ISREG(sp.st_mode) && sp.st_size > 0) {
-    size = static_cast<size_t>(sp.st_size);
+  // (a regular file is read from where its descriptor stands -- a stdin redirected from a file that something has read the head of --, not from offset 0)
+  const off_t from = lseek(fd, 0, SEEK_CUR);
+  if (fstat(fd, &sp) == 0 && S_ISREG(sp.st_mode) && from >= 0 && sp.st_size > from) {
+    size = static_cast<size_t>(sp.st_size - from);
     text = static_cast<char *>(std::malloc(size + 1));
     if (!text) die("out of memory");
-    const unsigned nt = size < (8u << 20) ? 1u : std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 8u);
+    // threads: the CPUs this process may use (affinity mask and cgroup quota: rc_host_cpus), not the machine's
+    const unsigned nt = size < (8u << 20) ? 1u : std::min<unsigned>(static_cast<unsigned>(std::max(1, rc_host_cpus())), 8u);
     std::vector<size_t> got(nt, 0);
     auto piece = [&](unsigned t) {
       size_t lo = size / nt * t, hi = t + 1 == nt ? size : size / nt * (t + 1), at = lo;
       while (at < hi) {
-        const ssize_t k = pread(fd, text + at, hi - at, static_cast<off_t>(at));
+        const ssize_t k = pread(fd, text + at, hi - at, from + static_cast<off_t>(at));
         if (k <= 0) break;
         at += static_cast<size_t>(k);
       }

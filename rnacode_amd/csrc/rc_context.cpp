@@ -34,6 +34,9 @@ int rc_host_cpus(void) { return effective_cpus(); }
 void rc_ctx_trim(rc_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  // the retired list holds outgrown buffers that queued kernels and copies may still use: wait for the device first (alloc_with_retry does the same
+  // before it drains).  To be called between batches, like rc_ctx_set_host_threads: nothing here is guarded against another thread using the context.
+  (void)hipDeviceSynchronize();
   c->retired->drain();
   c->bufPool->drain(false);
 }
@@ -89,6 +92,15 @@ int rc_ctx_create(int device, rc_ctx **out) {
   c->bufPool->device = device;
   static const int hostExp = exp_mode_of_host();   // (once per process: 20 000 exp calls, 2 ms)
   c->expMode = hostExp;
+  // RC_FIT_EXP: which exp the EVD fit computes with, whatever this host's C library does -- to reproduce listings made on another machine
+  // (the reference's fit follows ITS host's exp), and for the tests that run both glibc variants.  rc_ctx_fit_exp_mode() reports what is in use.
+  if (const char *e = std::getenv("RC_FIT_EXP")) {
+    const std::string v(e);
+    if (v == "generic" || v == "1") c->expMode = 1;
+    else if (v == "fused" || v == "fma" || v == "2") c->expMode = 2;
+    else if (v == "device" || v == "0") c->expMode = 0;
+    else return fail(RC_ERR_ARG, "RC_FIT_EXP must be generic, fused or device");
+  }
   for (DevBuf *d : {&c->treeJobs, &c->treeIn, &c->treeWork, &c->treeRes, &c->d_tables, &c->d_cellStats}) d->retired = c->retired.get();
   for (PinBuf *h : {&c->treeInPin, &c->treeResPin}) h->retired = c->retired.get();
   c->genericScratchWords = std::max<size_t>(static_cast<size_t>(1) << 30, prop.totalGlobalMem / 12 / sizeof(uint32_t));
@@ -170,5 +182,7 @@ int rc_ctx_set_host_threads(rc_ctx *c, int32_t threads) {
 }
 
 int rc_ctx_host_threads(const rc_ctx *c) { return c ? c->hostThreads : 0; }
+
+int rc_ctx_fit_exp_mode(const rc_ctx *c) { return c ? c->expMode : RC_ERR_ARG; }
 
 }  // extern "C"

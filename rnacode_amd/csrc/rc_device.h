@@ -15,6 +15,7 @@ namespace rc {
 constexpr int kMaxRows = 500;     // N <= 500 (RC_MAX_ROWS, the reference's MAX_NUM_NAMES, rnaz_utils.h:7)
 constexpr int kTemplRows = 64;    // N <= 64: kernels instantiated per N-1 (k_null<N-1>, k_native_dp<N-1>); above: k_generic_sim + k_generic_dp
 constexpr int kFastRows = 32;     // N <= 32: register-resident fast instantiations; 33..64 the EXACT instantiation only
+constexpr int kGenericDefaultMinRows = 37;   // rc_ctx::genericMinRows: from this many rows on the generic kernels are the faster ones (RC_GENERIC_MIN_ROWS overrides, 65 = never below 65)
 constexpr int kGenericClass = kTemplRows;   // row-count classes are indexed by N-1 (2..63); all wider blocks share this one
 constexpr int kClassSlots = kTemplRows + 1;
 constexpr int kMaxNodes = 2 * kMaxRows;

@@ -548,7 +548,9 @@ int exp_mode_of_host() {
   uint64_t s = 88172645463325252ull;
   for (int i = 0; i < 20000 && (fused || generic); i++) {
     s ^= s << 13; s ^= s >> 7; s ^= s << 17;
-    const double x = -745.2 * (static_cast<double>(s >> 11) * (1.0 / 9007199254740992.0));   // where the fit's exp(-lambda x) lives
+    const double u = static_cast<double>(s >> 11) * (1.0 / 9007199254740992.0);
+    // where the fit's exp(-lambda x) lives: x > 0 for a sample with a segment, x = -1 for one without (score.c:1028) -- every fourth probe positive
+    const double x = (i & 3) == 3 ? 709.7 * u : -745.2 * u;
     const uint64_t want = exp_bits(std::exp(x));
     if (fused && exp_bits(ref_exp(x, true)) != want) fused = false;
     if (generic && exp_bits(ref_exp(x, false)) != want) generic = false;

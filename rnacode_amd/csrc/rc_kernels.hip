@@ -612,19 +612,6 @@ __global__ __launch_bounds__(64) void k_sk_row(const uint8_t *blob, const DevBlo
 // ------------------------------------------------------------------------------------------
 // EVD fit (extreme_fit.c:157-251), one workgroup per block, sums reduced across 256 threads
 // ------------------------------------------------------------------------------------------
-struct Sums4 { double e, xe, xxe, x; };
-
-__device__ __forceinline__ double block_sum(double v, double *sh) {
-  const int tid = threadIdx.x;
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  __syncthreads();
-  if ((tid & 63) == 0) sh[tid >> 6] = v;
-  __syncthreads();
-  double r = 0.0;
-  for (int w = 0; w < static_cast<int>(blockDim.x >> 6); w++) r += sh[w];
-  return r;
-}
-
 // The per-block fit comes in two shapes.  THREADS = 64: ONE wavefront without LDS -- in a large batch it is queued behind k_null,
 // whose workgroups hold all of a CU's LDS, beside the next batch's k_null, and must not wait for LDS.  THREADS = 256: four
 // wavefronts that meet through 128 bytes of LDS -- for small batches, where nothing competes for LDS and the latency of the
@@ -668,8 +655,51 @@ __device__ __forceinline__ void fit_sum4(double &a, double &b, double &c, double
 // exp as the reference's C library computes it (rc_refexp.h): the Newton iteration's stopping test is decided by its last bit
 __device__ __forceinline__ double fit_exp(int mode, double a) { return mode == 2 ? ref_exp(a, true) : mode == 1 ? ref_exp(a, false) : exp(a); }
 
-template <int THREADS>
-__device__ void lawless416(int mode, const float *x, int n, double lambda, double *sh, double *f, double *df) {
+// The four sums of Lawless 4.1.6 in the REFERENCE'S order, i = 0 .. n-1 (extreme_fit.c:50-58): every wavefront goes over all n elements
+// sixty-four at a time, lane l makes element base + l's terms, and the sums take them in one by one through v_readlane -- the same
+// additions in the same order as the reference's loop, hence (with rc_refexp.h's exp) the same bits, on every lane of every wavefront, without
+// LDS or barriers.  A sum over n terms in another order differs by ~n 2^-53 relative, which cannot matter to a fit -- except in the
+// comparisons that steer it (|f| < 1e-5, the signs in the bisection), on maxima so degenerate that f is only known to its tolerance (the
+// class of tests/data/soak_fit_*.json).  So the fast evaluation (lawless416: strided partial sums, a tree over lanes) is what runs, and
+// this one decides wherever a difference in the last bits could: fits on few samples, every evaluation from the twelfth Newton step on
+// (a fit that converges takes < 10), the bisection fallback, and any evaluation whose |f| lands within 1e-8 of the tolerance.
+template <typename T>
+__device__ void lawless416_serial(int mode, const T *x, int n, double lambda, double *f, double *df) {
+  const int lane = threadIdx.x & (kWave - 1);
+  double e = 0, xe = 0, xxe = 0, xs = 0;
+  for (int base = 0; base < n; base += kWave) {
+    const int i = base + lane;
+    const double xi = i < n ? static_cast<double>(x[i]) : 0.0;
+    const double ex = i < n ? fit_exp(mode, -1. * lambda * xi) : 0.0;
+    const double t1 = xi * ex, t2 = xi * xi * ex;
+    const int cnt = n - base < kWave ? n - base : kWave;
+    if (cnt == kWave) {
+#pragma unroll
+      for (int l = 0; l < kWave; l++) { xs += row_value(xi, l); xe += row_value(t1, l); xxe += row_value(t2, l); e += row_value(ex, l); }
+    } else {
+      for (int l = 0; l < cnt; l++) { xs += row_value(xi, l); xe += row_value(t1, l); xxe += row_value(t2, l); e += row_value(ex, l); }
+    }
+  }
+  const double total = static_cast<double>(n);
+  *f = 1. / lambda - xs / total + xe / e;
+  *df = ((xe / e) * (xe / e)) - (xxe / e) - (1. / (lambda * lambda));
+}
+// sum of exp(-lambda x_i) in the reference's order (extreme_fit.c:238-245)
+template <typename T>
+__device__ double esum_serial(int mode, const T *x, int n, double lambda) {
+  const int lane = threadIdx.x & (kWave - 1);
+  double e = 0;
+  for (int base = 0; base < n; base += kWave) {
+    const int i = base + lane;
+    const double ex = i < n ? fit_exp(mode, -1 * lambda * static_cast<double>(x[i])) : 0.0;
+    const int cnt = n - base < kWave ? n - base : kWave;
+    for (int l = 0; l < cnt; l++) e += row_value(ex, l);
+  }
+  return e;
+}
+
+template <int THREADS, typename T>
+__device__ void lawless416(int mode, const T *x, int n, double lambda, double *sh, double *f, double *df) {
   double e = 0, xe = 0, xxe = 0, xs = 0;
   for (int i = threadIdx.x; i < n; i += THREADS) {
     const double xi = static_cast<double>(x[i]);
@@ -682,13 +712,23 @@ __device__ void lawless416(int mode, const float *x, int n, double lambda, doubl
   *df = ((xe / e) * (xe / e)) - (xxe / e) - (1. / (lambda * lambda));
 }
 
-template <int THREADS>
-__device__ int evd_fit_block(int mode, const float *x, int n, double *sh, double *mu_out, double *lambda_out) {
+constexpr int kFitSerialMaxN = 128;    // fits on at most this many samples: every evaluation in the reference's order
+constexpr int kFitSerialFromStep = 12; // Newton steps from this one on: the same
+
+template <int THREADS, typename T>
+__device__ int evd_fit_block(int mode, const T *x, int n, double *sh, double *mu_out, double *lambda_out) {
   double lambda = 0.2, fx, dfx;
   const double tol = 1e-5;
+  const bool small = n <= kFitSerialMaxN;
+  // one evaluation: the fast sums, and the reference-ordered ones where the outcome of a comparison could hang on the order (see lawless416_serial)
+  auto eval = [&](double lam, bool careful) {
+    if (careful) { lawless416_serial<T>(mode, x, n, lam, &fx, &dfx); return; }
+    lawless416<THREADS, T>(mode, x, n, lam, sh, &fx, &dfx);
+    if (fabs(fabs(fx) - tol) < 1e-8) lawless416_serial<T>(mode, x, n, lam, &fx, &dfx);
+  };
   int it;
   for (it = 0; it < 100; it++) {
-    lawless416<THREADS>(mode, x, n, lambda, sh, &fx, &dfx);
+    eval(lambda, small || it >= kFitSerialFromStep);
     if (fabs(fx) < tol) break;
     lambda = lambda - fx / dfx;
     if (lambda <= 0.) lambda = 0.001;
@@ -696,23 +736,23 @@ __device__ int evd_fit_block(int mode, const float *x, int n, double *sh, double
   if (it == 100) {  // bisection fallback (extreme_fit.c:193-236)
     double left = 0.2, right = 0.2, mid = 0.2;
     lambda = 0.2;
-    lawless416<THREADS>(mode, x, n, lambda, sh, &fx, &dfx);
+    eval(lambda, true);
     if (fx < 0.) {
       do {
         left -= 0.1;
         if (left < 0.) return 0;
-        lawless416<THREADS>(mode, x, n, left, sh, &fx, &dfx);
+        eval(left, true);
       } while (fx < 0.);
     } else {
       do {
         right += 0.1;
-        lawless416<THREADS>(mode, x, n, right, sh, &fx, &dfx);
+        eval(right, true);
         if (right > 100.) return 0;
       } while (fx > 0.);
     }
     for (it = 0; it < 100; it++) {
       mid = (left + right) / 2.;
-      lawless416<THREADS>(mode, x, n, mid, sh, &fx, &dfx);
+      eval(mid, true);
       if (fabs(fx) < tol) break;
       if (fx > 0.) left = mid; else right = mid;
     }
@@ -720,8 +760,11 @@ __device__ int evd_fit_block(int mode, const float *x, int n, double *sh, double
     lambda = mid;
   }
   double e = 0, z0 = 0, z1 = 0, z2 = 0;
-  for (int i = threadIdx.x; i < n; i += THREADS) e += fit_exp(mode, -1 * lambda * static_cast<double>(x[i]));
-  fit_sum4<THREADS>(e, z0, z1, z2, sh);
+  if (small) e = esum_serial<T>(mode, x, n, lambda);
+  else {
+    for (int i = threadIdx.x; i < n; i += THREADS) e += fit_exp(mode, -1 * lambda * static_cast<double>(x[i]));
+    fit_sum4<THREADS>(e, z0, z1, z2, sh);
+  }
   *mu_out = -1. * log(e / static_cast<double>(n)) / lambda;
   *lambda_out = lambda;
   return 1;
@@ -781,63 +824,17 @@ __global__ __launch_bounds__(THREADS) void k_evd_fit(FitArgs A) {
   const bool nothingScored = scored == 0.0;
   if (!stopped && !nothingScored) {
     double mu, lambda;
-    if (evd_fit_block<THREADS>(A.expMode, x, A.sampleN, sh, &mu, &lambda) == 1) { o.rc = 1; o.mu = mu; o.lambda = lambda; }
+    if (evd_fit_block<THREADS, float>(A.expMode, x, A.sampleN, sh, &mu, &lambda) == 1) { o.rc = 1; o.mu = mu; o.lambda = lambda; }
   }
   if (threadIdx.x == 0) A.out[db->out_index] = o;
 }
 
-// EVDMaxLikelyFit on caller-supplied doubles (rc_evd_fit): same code path with float inputs would
-// lose bits, so this variant reads doubles.
+// EVDMaxLikelyFit on caller-supplied doubles (rc_evd_fit): the same fit instantiated for binary64 inputs.
 __global__ __launch_bounds__(256) void k_evd_fit_f64(const double *x, int n, FitOut *out, int mode) {
-  __shared__ double sh[8];
-  // reuse the float path by templating would duplicate code; the sums are written out here
-  double lambda = 0.2, fx = 0, dfx = 0;
-  const double tol = 1e-5;
-  auto law = [&](double lam, double *f, double *df) {
-    double e = 0, xe = 0, xxe = 0, xs = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      const double xi = x[i];
-      const double ex = fit_exp(mode, -1. * lam * xi);
-      xs += xi; xe += xi * ex; xxe += xi * xi * ex; e += ex;
-    }
-    e = block_sum(e, sh); xe = block_sum(xe, sh); xxe = block_sum(xxe, sh); xs = block_sum(xs, sh);
-    *f = 1. / lam - xs / static_cast<double>(n) + xe / e;
-    *df = ((xe / e) * (xe / e)) - (xxe / e) - (1. / (lam * lam));
-  };
-  int it, rc = 1;
-  for (it = 0; it < 100; it++) {
-    law(lambda, &fx, &dfx);
-    if (fabs(fx) < tol) break;
-    lambda = lambda - fx / dfx;
-    if (lambda <= 0.) lambda = 0.001;
-  }
-  if (it == 100) {
-    double left = 0.2, right = 0.2, mid = 0.2;
-    law(0.2, &fx, &dfx);
-    if (fx < 0.) {
-      do { left -= 0.1; if (left < 0.) { rc = 0; break; } law(left, &fx, &dfx); } while (fx < 0.);
-    } else {
-      do { right += 0.1; law(right, &fx, &dfx); if (right > 100.) { rc = 0; break; } } while (fx > 0.);
-    }
-    if (rc) {
-      for (it = 0; it < 100; it++) {
-        mid = (left + right) / 2.;
-        law(mid, &fx, &dfx);
-        if (fabs(fx) < tol) break;
-        if (fx > 0.) left = mid; else right = mid;
-      }
-      if (it == 100) rc = 0;
-      lambda = mid;
-    }
-  }
-  double mu = 0;
-  if (rc) {
-    double e = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) e += fit_exp(mode, -1 * lambda * x[i]);
-    e = block_sum(e, sh);
-    mu = -1. * log(e / static_cast<double>(n)) / lambda;
-  }
-  if (threadIdx.x == 0) { out->rc = rc; out->mu = mu; out->lambda = lambda; out->better = 0; }
+  __shared__ double sh[(256 / kWave) * 4];
+  double mu = 0, lambda = 0;
+  const int rc = evd_fit_block<256, double>(mode, x, n, sh, &mu, &lambda);
+  if (threadIdx.x == 0) { out->rc = rc; out->mu = rc ? mu : 0; out->lambda = lambda; out->better = 0; }
 }
 
 // getHSS's fold (SampleScan, rc_null_kernel.h) over the S values a ROWS launch of k_null left in its buffers: one wavefront per

@@ -13,6 +13,24 @@
 // uses twice).  Both checked against the C library of this image on 32 million arguments each (the generic one with
 // GLIBC_TUNABLES=glibc.cpu.hwcaps=-FMA,-AVX2_Usable): no difference.  The context asks the host's exp which one it is (exp_mode_of_host) and
 // tells the fit kernels; a host whose exp is neither gets the device's own exp, as before.
+//
+// Provenance and licence.  The METHOD restated here -- the reduction with N = 128, the (value, residual) table layout, the polynomial and its
+// coefficients C2..C5, the constants InvLn2N / NegLn2hiN / NegLn2loN / Shift and the treatment of results near the subnormal range -- is that of
+// math/exp.c of ARM Optimized Routines (https://github.com/ARM-software/optimized-routines), Copyright (c) 2018, Arm Limited, which glibc adopted
+// in 2.28 (sysdeps/ieee754/dbl-64/e_exp.c).  ARM Optimized Routines is dual-licensed MIT OR Apache-2.0 WITH LLVM-exception; this file uses it
+// under the MIT licence, whose notice follows.  No source text of that file or of glibc is reproduced: the code below was written from the
+// published algorithm and the table is recomputed from its definition.
+//
+//   Permission is hereby granted, free of charge, to any person obtaining a copy of this software and associated documentation files (the
+//   "Software"), to deal in the Software without restriction, including without limitation the rights to use, copy, modify, merge, publish,
+//   distribute, sublicense, and/or sell copies of the Software, and to permit persons to whom the Software is furnished to do so, subject to the
+//   following conditions: The above copyright notice and this permission notice shall be included in all copies or substantial portions of the
+//   Software.  THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND, EXPRESS OR IMPLIED, INCLUDING BUT NOT LIMITED TO THE WARRANTIES OF
+//   MERCHANTABILITY, FITNESS FOR A PARTICULAR PURPOSE AND NONINFRINGEMENT.  IN NO EVENT SHALL THE AUTHORS OR COPYRIGHT HOLDERS BE LIABLE FOR ANY
+//   CLAIM, DAMAGES OR OTHER LIABILITY, WHETHER IN AN ACTION OF CONTRACT, TORT OR OTHERWISE, ARISING FROM, OUT OF OR IN CONNECTION WITH THE SOFTWARE
+//   OR THE USE OR OTHER DEALINGS IN THE SOFTWARE.
+//
+// Which variant a context uses is visible and overridable: rc_ctx_fit_exp_mode(), RC_FIT_EXP=generic|fused|device (include/rnacode_hip.h).
 #pragma once
 #include <cstdint>
 #include <cstring>

@@ -345,7 +345,10 @@ struct rc_ctx {
   int debugSkip = 0;
   DevBuf d_cellStats;              // RC_PROFILING builds with RC_CELL_STATS=1: k_null's cell counters, printed when the context goes
   int serialNative = 0;
-  int genericMinRows = kTemplRows + 1;   // blocks with at least this many rows take the generic kernels (RC_GENERIC_MIN_ROWS: tests run everything through them)
+  // blocks with at least this many rows take the generic kernels (RC_GENERIC_MIN_ROWS: tests run everything through them).  Where the crossover lies is
+  // measured (tools/rows_sweep.py, profiles/r06/rows_sweep_*.txt): k_null<N-1> holds 3 (N-1) states in registers -- 2 wavefronts per SIMD up to 36 rows,
+  // ONE from 37 on (0.11..0.18 of the issue roof at 40..64 rows), where k_generic_dp (states parked in memory, any N) runs at 0.19..0.24
+  int genericMinRows = kGenericDefaultMinRows;
   int stopRounds = 6;                    // at most this many rounds (RC_STOP_ROUNDS; <= kMaxRounds)
   long long stopTwoRoundsMinItems = 0;   // --stop-early runs two rounds of sample groups only for batches with at least this many (block, group) items
   int hostThreads = 0;

@@ -7,7 +7,7 @@ order and a different libm than the host)."""
 import numpy as np
 import pytest
 
-from conftest import golden_names, hss_key, load_golden
+from conftest import ROOT, golden_names, hss_key, load_golden
 from helpers import block_from_golden, close_p, param_kwargs
 
 pytestmark = pytest.mark.gpu
@@ -514,6 +514,95 @@ def test_fits_at_the_noise_floor_of_exp_follow_the_reference(ctx):
         assert rc == res.evd_rc == 1
         assert np.float32(lam) == np.float32(res.lam) and np.float32(mu) == np.float32(res.mu), (mu, res.mu, lam, res.lam)
         b.close()
+
+
+_ORACLE_FIT_CHILD = r"""
+import ctypes, json, math, os, sys
+sys.path.insert(0, sys.argv[1])
+from oracle import binding as ob
+out = []
+for name in sys.argv[2:]:
+    d = json.load(open(os.path.join(sys.argv[1], "tests", "data", name)))
+    p = ob.default_params(d["n_samples"])
+    for k, v in d["pars"].items():
+        setattr(p, k, v)
+    r = ob.run_block(d["rows"], d["names"], d["start"], d["length"], d["tree"], d["kappa"], p, d["seed"])
+    out.append(dict(rc=r.evd_rc, mu=r.mu, lam=r.lam, maxScores=[float(x) for x in r.maxScores]))
+libm = ctypes.CDLL("libm.so.6"); libm.exp.restype = ctypes.c_double; libm.exp.argtypes = [ctypes.c_double]
+print(json.dumps(dict(results=out, probe=[libm.exp(-x).hex() for x in (700.123, 300.7, 0.3331, 17.25, 123.456, 531.9)])))
+"""
+
+
+@pytest.mark.parametrize("variant", ["generic", "fused"])
+def test_fits_at_the_noise_floor_follow_the_reference_under_either_exp_variant(variant, monkeypatch):
+    """The reference's fit follows ITS host's exp(), and glibc's x86-64 build has two (rc_refexp.h): the oracle runs in a child process whose C
+    library is held to the generic variant by GLIBC_TUNABLES, or left to pick the fused one; the library is told which by RC_FIT_EXP and says so
+    (rc_ctx_fit_exp_mode).  On the two soak blocks whose fit hangs on the last bit of exp: the oracle's verdict, mu and lambda as floats.
+    (Where the two variants differ the oracle's own results differ between the two runs; where this CPU has no FMA the fused run is the generic one
+    again and is compared as such.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    from rnacode_amd import api
+    from rnacode_amd.alnio import AlnBlock, AlnRow
+    names = ["soak_fit_two_samples.json", "soak_fit_one_sample.json"]
+    env = dict(os.environ)
+    env.pop("GLIBC_TUNABLES", None)
+    if variant == "generic":
+        env["GLIBC_TUNABLES"] = "glibc.cpu.hwcaps=-FMA,-FMA4,-AVX2_Usable,-AVX2"
+    doc = json.loads(subprocess.check_output([sys.executable, "-c", _ORACLE_FIT_CHILD, ROOT] + names, env=env, text=True))
+    # which variant did the child's exp turn out to be?  (six probes where the two differ or agree: compared against the same probes in this process
+    # only to report it; the device side is forced to `variant` either way and must then agree with a child that really ran it)
+    monkeypatch.setenv("RC_FIT_EXP", variant)
+    ctx = api.Context(0)
+    assert ctx.fit_exp_mode == variant
+    for name, want in zip(names, doc["results"]):
+        d = json.load(open(os.path.join(os.path.dirname(__file__), "data", name)))
+        rows = [AlnRow(n, s) for n, s in zip(d["names"], d["rows"])]
+        rows[0].start, rows[0].length = d["start"], d["length"]
+        blk = AlnBlock(rows, "r", d["tree"], d["kappa"])
+        b = api.Batch(ctx, [blk], api.default_params(sampleN=d["n_samples"], seed_base=d["seed"], **d["pars"])).run()
+        np.testing.assert_array_equal(b.maxScores(0), np.float32(want["maxScores"]))
+        rc, mu, lam = b.getExtremeValuePars(0)
+        assert rc == want["rc"], (name, variant, rc, want["rc"])
+        if rc == 1:
+            assert np.float32(lam) == np.float32(want["lam"]) and np.float32(mu) == np.float32(want["mu"]), (name, variant, mu, want["mu"], lam, want["lam"])
+        b.close()
+    ctx.close()
+
+
+def test_the_fit_exp_mode_is_reported_and_a_bad_override_is_refused(monkeypatch):
+    from rnacode_amd import api
+    c = api.Context(0)
+    assert c.fit_exp_mode in ("generic", "fused", "device")
+    c.close()
+    monkeypatch.setenv("RC_FIT_EXP", "device")
+    c = api.Context(0)
+    assert c.fit_exp_mode == "device"
+    c.close()
+    monkeypatch.setenv("RC_FIT_EXP", "glibc")
+    with pytest.raises(api.RnacodeError):
+        api.Context(0)
+
+
+def test_fits_on_few_samples_sum_in_the_references_order(ctx):
+    """Fits on <= 128 samples evaluate Lawless 4.1.6 with the four sums taken in the reference's order, i = 0 .. n-1 (rc_kernels.hip,
+    lawless416_serial; extreme_fit.c:50-58): rc_evd_fit on doubles against the oracle's EVDMaxLikelyFit, lambda to the last bit of a
+    binary64 (mu to an ulp: the device's log) on near-degenerate and ordinary samples alike (the library's exp being this host's, rc_refexp.h)."""
+    from oracle import binding as ob
+    from rnacode_amd import api
+    if ctx.fit_exp_mode == "device":
+        pytest.skip("this host's exp() is not one rc_refexp.h reproduces")
+    rng = np.random.RandomState(77)
+    for n in (1, 2, 3, 17, 64, 65, 100, 128):
+        for spread in (1e-4, 0.02, 3.0):
+            x = 5.0 + spread * rng.rand(n)
+            rc, mu, lam = ctx.evd_fit(x)
+            wrc, wmu, wlam = ob.evd_fit(x)
+            assert rc == wrc, (n, spread, rc, wrc)
+            if rc == 1:
+                assert lam == wlam and abs(mu - wmu) <= 1e-15 * max(1.0, abs(wmu)), (n, spread, mu, wmu, lam, wlam)   # (mu goes through the device's log: one ulp)
 
 
 def test_wide_blocks_in_several_rounds_equal_one_round(ctx):

@@ -28,10 +28,11 @@ SOAK = [
     ("wide", {}, 60),
     ("", {"RC_LDS_MAX_BYTES": "0"}, 300),
     ("", {"RC_GENERIC_MIN_ROWS": "3"}, 240),
+    ("", {"RC_GENERIC_MIN_ROWS": "65"}, 240),   # the k_null<36..63> instantiations: by default blocks of 37 rows and more take the generic kernels (rc_device.h)
 ]
 
 
-@pytest.mark.parametrize("mode,env,blocks", SOAK, ids=["default", "fat", "wide", "codes-from-L2", "all-generic"])
+@pytest.mark.parametrize("mode,env,blocks", SOAK, ids=["default", "fat", "wide", "codes-from-L2", "all-generic", "templated-to-64-rows"])
 def test_soak_slice(monkeypatch, mode, env, blocks):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -46,7 +47,7 @@ KNOBS = [
     {"RC_TAIL_SHARING": "0"}, {"RC_FAT_STREAM_MIN_ITEMS": "0"},
     {"RC_HOST_THREADS": "1", "RC_SPLIT_FACTOR": "0"}, {"RC_SPLIT_FACTOR": "100"}, {"RC_NATIVE_WAVES_PER_CU": "1"},
     {"RC_NATIVE_WAVES_PER_CU": "32"}, {"RC_TOGETHER_MAX_MB": "0"}, {"RC_STOP_ROUNDS": "6", "RC_STOP_MIN_ITEMS": "0"},
-    {"RC_GENERIC_MIN_ROWS": "3"}, {"RC_LDS_MAX_BYTES": "0"}, {"RC_LDS_MAX_BYTES": "65536"}, {"RC_GRID_CAP_PER_CU": "2"},
+    {"RC_GENERIC_MIN_ROWS": "3"}, {"RC_GENERIC_MIN_ROWS": "65"}, {"RC_FIT_EXP": "generic"}, {"RC_FIT_EXP": "fused"}, {"RC_LDS_MAX_BYTES": "0"}, {"RC_LDS_MAX_BYTES": "65536"}, {"RC_GRID_CAP_PER_CU": "2"},
     {"RC_GENERIC_SCRATCH_MB": "64"}, {"RC_SERIAL_NATIVE": "1"}, {"RC_HIGH_OCCUPANCY": "0"}, {"RC_HIGH_OCCUPANCY": "2"},
     {"RC_TREE_LDS_MAX": "0"}, {"GPU_MAX_HW_QUEUES": "2"},
 ]
@@ -65,7 +66,7 @@ def test_parity_subset_under_every_switch(monkeypatch, env):
         monkeypatch.setenv(k, v)
     ctx = api.Context(0)
     # reference-scored goldens: maxima, HSS tables and fit verdicts
-    for name in ("coding_aln_n100", "synth_6x120_n200", "edge_cases_n50", "synth_12x300_n40", "synth_5x60_stopearly_n100", "synth_wide_70x120_n20"):
+    for name in ("coding_aln_n100", "synth_6x120_n200", "edge_cases_n50", "synth_12x300_n40", "synth_5x60_stopearly_n100", "synth_wide_70x120_n20", "synth_wide_40x90_n30"):
         doc = load_golden(name)
         blocks = [block_from_golden(e) for e in doc["blocks"]]
         batch = api.Batch(ctx, blocks, api.default_params(seed_base=doc["seed_base"], **param_kwargs(doc))).run()

@@ -10,6 +10,7 @@ template <int MODE>
 __global__ void probe(float *out, int iters, float a, float b) {
   float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
   int p0 = threadIdx.x * 4;
+  const double ones = __hiloint2double(0x3f800000, 0x3f800000);   // (1.0f, 1.0f)
   for (int i = 0; i < iters; i++) {
     if (MODE == 0) {  // 8 independent v_add_f32 chains
       asm volatile("v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n"
@@ -40,6 +41,31 @@ __global__ void probe(float *out, int iters, float a, float b) {
       asm volatile("v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n"
                    "v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n"
                    : "+v"(x0) : "v"(a));
+    } else if (MODE == 7) {  // v_pk_fma_f32 with multiplier (1.0, 1.0): fma(x, 1, y) = RN(x + y), two adds per instruction
+      asm volatile("v_pk_fma_f32 %0, %0, %5, %4\n v_pk_fma_f32 %1, %1, %5, %4\n v_pk_fma_f32 %2, %2, %5, %4\n v_pk_fma_f32 %3, %3, %5, %4\n"
+                   "v_pk_fma_f32 %0, %0, %5, %4\n v_pk_fma_f32 %1, %1, %5, %4\n v_pk_fma_f32 %2, %2, %5, %4\n v_pk_fma_f32 %3, %3, %5, %4\n"
+                   : "+v"(*(double *)&x0), "+v"(*(double *)&x2), "+v"(*(double *)&x4), "+v"(*(double *)&x6) : "v"(*(double *)&a), "v"(ones));
+    } else if (MODE == 8) {  // v_pk_mul_f32
+      asm volatile("v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4\n"
+                   "v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4\n"
+                   : "+v"(*(double *)&x0), "+v"(*(double *)&x2), "+v"(*(double *)&x4), "+v"(*(double *)&x6) : "v"(ones));
+    } else if (MODE == 9) {  // v_pk_add_f32 with op_sel broadcasting the low half of the second operand (one omega register for both halves)
+      asm volatile("v_pk_add_f32 %0, %0, %4 op_sel_hi:[1,0]\n v_pk_add_f32 %1, %1, %4 op_sel_hi:[1,0]\n v_pk_add_f32 %2, %2, %4 op_sel_hi:[1,0]\n v_pk_add_f32 %3, %3, %4 op_sel_hi:[1,0]\n"
+                   "v_pk_add_f32 %0, %0, %4 op_sel_hi:[1,0]\n v_pk_add_f32 %1, %1, %4 op_sel_hi:[1,0]\n v_pk_add_f32 %2, %2, %4 op_sel_hi:[1,0]\n v_pk_add_f32 %3, %3, %4 op_sel_hi:[1,0]\n"
+                   : "+v"(*(double *)&x0), "+v"(*(double *)&x2), "+v"(*(double *)&x4), "+v"(*(double *)&x6) : "v"(*(double *)&a));
+    } else if (MODE == 10) {  // v_max_f32 with both operands distinct VGPRs, result to a third (no read-write operand)
+      asm volatile("v_max_f32 %0, %1, %8\n v_max_f32 %1, %2, %8\n v_max_f32 %2, %3, %8\n v_max_f32 %3, %4, %8\n"
+                   "v_max_f32 %4, %5, %8\n v_max_f32 %5, %6, %8\n v_max_f32 %6, %7, %8\n v_max_f32 %7, %0, %8\n"
+                   : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a));
+    } else if (MODE == 11) {  // v_pk_max_f32? (not in the gfx950 ISA: kept out) -- v_max_f32 e64 encoding (VOP3)
+      asm volatile("v_max_f32_e64 %0, %0, %8\n v_max_f32_e64 %1, %1, %8\n v_max_f32_e64 %2, %2, %8\n v_max_f32_e64 %3, %3, %8\n"
+                   "v_max_f32_e64 %4, %4, %8\n v_max_f32_e64 %5, %5, %8\n v_max_f32_e64 %6, %6, %8\n v_max_f32_e64 %7, %7, %8\n"
+                   : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a));
+    } else if (MODE == 12) {  // the common arm of a cheaper scan step: one v_cmp to an SGPR pair + two v_cndmask, against the full step's 4 + 2
+      asm volatile("v_cmp_gt_f32 s[20:21], %0, %1\n v_cndmask_b32 %1, %1, %0, s[20:21]\n v_cndmask_b32 %2, %2, %8, s[20:21]\n"
+                   "v_cmp_gt_f32 s[22:23], %3, %4\n v_cndmask_b32 %4, %4, %3, s[22:23]\n v_cndmask_b32 %5, %5, %8, s[22:23]\n"
+                   "v_add_f32 %0, %0, %8\n v_add_f32 %3, %3, %8\n"
+                   : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a) : "s20", "s21", "s22", "s23");
     } else if (MODE == 6) {  // mixed: 8 v_add + 8 s_add (SALU co-issue)
       int s = i;
       asm volatile("v_add_f32 %0, %0, %9\n s_add_u32 %8, %8, 1\n v_add_f32 %1, %1, %9\n s_add_u32 %8, %8, 1\n v_add_f32 %2, %2, %9\n s_add_u32 %8, %8, 1\n v_add_f32 %3, %3, %9\n s_add_u32 %8, %8, 1\n"
@@ -164,7 +190,59 @@ int run2(const char *name, int opsPerIter) {
   return 0;
 }
 
+// The shader clock while every SIMD issues VALU work: s_memtime (shader cycles) against s_memrealtime (100 MHz) over a window in the
+// middle of a long launch of MODE (0: v_add chains, 2: v_max).
+template <int MODE>
+__global__ void clock_probe(float *out, unsigned *cyc, int iters, float a) {
+  float x[8];
+  for (int k = 0; k < 8; k++) x[k] = threadIdx.x + k;
+  unsigned long long c0 = 0, c1 = 0, w0 = 0, w1 = 0;
+  for (int rep = 0; rep < 40; rep++) {
+    if (rep == 20) { c0 = clock64(); w0 = wall_clock64(); }   // s_memtime: shader cycles (MI355X_MICROARCH.md); s_memrealtime: 100 MHz
+    if (rep == 21) { c1 = clock64(); w1 = wall_clock64(); }
+    for (int i = 0; i < iters; i++) {
+      if (MODE == 0) {
+#define OP(k) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[k]) : "v"(a));
+        REP8(OP)
+#undef OP
+      } else {
+#define OP(k) asm volatile("v_max_f32 %0, %0, %1" : "+v"(x[k]) : "v"(a));
+        REP8(OP)
+#undef OP
+      }
+    }
+  }
+  float r = 0;
+  for (int k = 0; k < 8; k++) r += x[k];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+  if (threadIdx.x == 0 && blockIdx.x == 0) { cyc[0] = static_cast<unsigned>(c1 - c0); cyc[1] = static_cast<unsigned>(w1 - w0); }
+}
+template <int MODE>
+int run_clock(const char *name) {
+  hipDeviceProp_t prop;
+  CHECK(hipGetDeviceProperties(&prop, 0));
+  const int cus = prop.multiProcessorCount;
+  float *out;
+  unsigned *cyc, h[2];
+  CHECK(hipMalloc(&out, sizeof(float) * cus * 32 * 64 * 2));
+  CHECK(hipMalloc(&cyc, 8));
+  for (int wavesPerSimd : {1, 4, 8}) {
+    const int blocks = cus * 4 * wavesPerSimd;
+    const int iters = 8000 / wavesPerSimd;
+    hipLaunchKernelGGL(clock_probe<MODE>, dim3(blocks), dim3(64), 0, 0, out, cyc, iters, 1.0f);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipMemcpy(h, cyc, 8, hipMemcpyDeviceToHost));
+    const double instr = double(iters) * 8 * wavesPerSimd;   // wave-instructions the SIMD issued inside the window (all its wavefronts)
+    printf("%-28s waves/SIMD=%d  window %u shader cycles in %u ticks of 10 ns = %.3f GHz; %.2f shader cycles per wave-instruction and SIMD\n", name, wavesPerSimd,
+           h[0], h[1], h[0] / (h[1] * 10.0), h[0] / instr);
+  }
+  CHECK(hipFree(out)); CHECK(hipFree(cyc));
+  return 0;
+}
+
 int main() {
+  run_clock<0>("clock under v_add_f32");
+  run_clock<2>("clock under v_max_f32");
   run<0>("v_add_f32 x8 indep", 8);
   run<1>("v_max3_f32 x8 indep", 8);
   run<2>("ds_bpermute_b32 x8", 8);
@@ -172,6 +250,12 @@ int main() {
   run<4>("v_cmp + 7 v_cndmask", 8);
   run<5>("v_add_f32 dependent x8", 8);
   run<6>("8 v_add + 8 s_add", 16);
+  run<7>("v_pk_fma_f32 x1.0 x8 (16 adds)", 8);
+  run<8>("v_pk_mul_f32 x8 (16 muls)", 8);
+  run<9>("v_pk_add_f32 op_sel_hi x8", 8);
+  run<10>("v_max_f32 3 distinct regs", 8);
+  run<11>("v_max_f32_e64", 8);
+  run<12>("2x(cmp+2cndmask)+2 add", 8);
   run2<0>("v_cndmask (sgpr mask)", 8);
   run2<1>("v_cmp_gt_f32 -> vcc", 8);
   run2<2>("v_max_f32 vop2", 8);

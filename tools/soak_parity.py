@@ -26,6 +26,7 @@ def soak(budget=60.0, rng_seed=1, mode="", max_blocks=None, log=print):
     wide = mode == "wide"
     fat = mode == "fat"
     ctx = api.Context(0)
+    log(f"soak{' ' + mode if mode else ''}: seed {rng_seed}, the EVD fit's exp: {ctx.fit_exp_mode} (rc_ctx_fit_exp_mode; the oracle's is this process's C library)")
     t0 = time.time()
     rounds = blocks_done = bad = paths = 0
     while time.time() - t0 < budget and (max_blocks is None or blocks_done < max_blocks):
