@@ -59,7 +59,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 VALU_PEAK_GOPS = 78643.2       # 256 CU x 4 SIMD x 64 lanes / 2 cycles x 2.4 GHz (v_add/v_max wave64 = 2 cyc/SIMD)
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 CONFIGS = {
     # name: (blocks, cols, seqs, samples, description)
@@ -90,7 +90,7 @@ def measured_traffic(config, kernel):
     (MI355X_MICROARCH.md, HBM), so the read side is doubled.  `kernel` is the instantiation this run just timed
     (rc_batch_null_kernel): a profile of another kernel is refused.  (None, reason) if no usable profile is committed."""
     why = "no committed profile"
-    for rnd in (PROFILE_ROUND, "r04", "r03", "r02", "r01"):
+    for rnd in (PROFILE_ROUND, "r05", "r04", "r03", "r02", "r01"):
         for name in (f"k_null_{config}_pmc.json", "k_null_pmc.json" if config == "c3" else None):
             if not name:
                 continue
@@ -329,6 +329,38 @@ def resident_leg(api, ctx, blocks, params, min_s, warmup=2):
     return resident_leg.spread["median"], acc["null"] / acc["n"] / acc["launches"], kernel, cs, n, m
 
 
+ROWS_LEG = (4, 8, 13, 17, 24, 30, 46, 64, 100)
+
+
+def rows_leg(api, ctx, sampleN, seed, cols=150, target_ms=40.0):
+    """Uniform resident batches of N rows x `cols` columns for N in ROWS_LEG, blocks enough for ~target_ms of sampling each: units/s, the
+    sampling kernel that ran and its FP32 issue fraction by the algorithmic flops."""
+    from rnacode_amd.synth import synth_blocks
+    shapes = []
+    p = api.default_params(sampleN=sampleN, seed_base=seed)
+    for n in ROWS_LEG:
+        base = [b.upper() for b in synth_blocks(32, n, cols, seed=7 + n)]
+        _, fl = algorithmic_work(base, sampleN)
+        want = max(256, min(8000, int(target_ms * 1e-3 * 0.3 * VALU_PEAK_GOPS * 1e9 / (fl / len(base)))))
+        blocks = [base[i % len(base)] for i in range(want)]
+        batch = api.Batch(ctx, blocks, p)
+        batch.run()
+        ts, nulls = [], []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            batch.run()
+            ts.append((time.perf_counter() - t0) * 1e3)
+            nulls.append(batch.timing()[0]["null"])
+        _, fl = algorithmic_work(blocks, sampleN)
+        ms, null_ms = sorted(ts)[1], sorted(nulls)[1]
+        shapes.append({"rows": n, "cols": cols, "blocks": len(blocks), "ms_per_step": ms, "sampling_ms": null_ms, "value": len(blocks) * cols * sampleN / (ms * 1e-3),
+                       "issue_frac": fl / (null_ms * 1e-3) / (VALU_PEAK_GOPS * 1e9), "kernel": batch.null_kernel()})
+        batch.close()
+    return {"shapes": shapes, "unit": "alignment-columns*samples/s", "samples": sampleN,
+            "note": "issue_frac = algorithmic flops of the batch / the sampling launches' interval / 78.6 T lane-ops/s; the full sweep (3..100 rows, 150 and "
+                    "300 columns, registers and occupancy of every kernel) is tools/rows_sweep.py -> profiles/r06/"}
+
+
 def stream_leg(api, ctx, m, params, sub_blocks, min_s, depth=3, warmup=2):
     """Streamed passes over the Marshalled blocks `m` for about min_s seconds: (ms per pass, passes).  sub_blocks: a list of sizes."""
     st = api.Stream(ctx, params, depth)
@@ -488,7 +520,9 @@ def compact_line(out):
     """The one line bench.py prints: at most ~1900 characters.  Keys of the bench contract unchanged; `legs` holds the other
     measurements as numbers only (DESIGN.md section 7 says what each is; the full record is in bench_full.json):
       stream / cont: ms per pass from host blocks to fitted results, pass by pass / as one continuous stream
-      e2e, e2e100k, e2emix: the native driver as a fresh process, file in -> listing out (units/s; 10 000 blocks, 100 000, 10 000 mixed)
+      e2e, e2e100k, e2emix, e2emix100k, e2e_c5: the native driver as a fresh process, file in -> listing out (units/s; 10 000 blocks, 100 000, 10 000 mixed,
+        100 000 mixed, 1000 blocks of 12 x 300 at n = 10 000)
+      rows: uniform batches of N rows x 150 columns [N, fraction of the issue roof] (tools/rows_sweep.py is the whole axis)
       c1, c2: the shipped inputs as one batch [median ms, p99 ms, max ms, steps, steps over 10 x median]; c1pb, c2pb: block by block through the shim's call order
       shard: one of eight ranks' 1250 blocks [resident ms, efficiency vs a perfect eighth, streamed ms, continuous ms, valu frac]
       mixed: ten row-count classes [streamed ms, continuous ms, resident ms, resident units/s, valu frac]
@@ -510,7 +544,7 @@ def compact_line(out):
     cfg = out.get("config", {})
     line["config"] = {"workload": "synthetic MAF %s blocks x %s cols x %s seqs, n=%s (BASELINE configs[2]/[3])" % (
         g(out, "config", "blocks_per_gpu"), cfg.get("cols"), cfg.get("seqs"), cfg.get("samples")), "exchange": cfg.get("exchange", "none")[:40]}
-    for k in ("rccl_env", "exchange_ab"):
+    for k in ("rccl_env", "exchange_ab", "fit_exp_mode"):
         if k in cfg:
             line["config"][k] = cfg[k]
     r = out.get("roofline") or {}
@@ -524,7 +558,8 @@ def compact_line(out):
     legs = {}
     if "stream" in out:
         legs["stream"] = g(out, "stream", "ms_per_step"); legs["cont"] = g(out, "stream", "continuous", "ms_per_step")
-    for short, key in (("e2e", "end_to_end"), ("e2e100k", "end_to_end_100k"), ("e2emix", "end_to_end_mixed")):
+    for short, key in (("e2e", "end_to_end"), ("e2e100k", "end_to_end_100k"), ("e2emix", "end_to_end_mixed"), ("e2emix100k", "end_to_end_mixed_100k"),
+                       ("e2e_c5", "end_to_end_c5")):
         if key in out:
             legs[short] = g(out, key, "value") if "error" not in out[key] else "error"
     for key in ("c1", "c2"):
@@ -536,6 +571,8 @@ def compact_line(out):
     if "mixed" in out:
         legs["mixed"] = [g(out, "mixed", "ms_per_step"), g(out, "mixed", "continuous", "ms_per_step"), g(out, "mixed", "resident", "ms_per_step"),
                          g(out, "mixed", "resident", "value"), g(out, "mixed", "resident", "roofline", "valu", "frac")]
+    if "rows" in out:   # uniform batches by row count at 150 columns: [rows, fraction of the issue roof]
+        legs["rows"] = [[r["rows"], r["issue_frac"]] for r in g(out, "rows", "shapes", default=[])]
     if "c5" in out:
         t = g(out, "c5", "roofline", "traffic")
         legs["c5"] = [g(out, "c5", "ms_per_step"), g(out, "c5", "roofline", "valu", "frac"), None if t is None else t / 1e12]
@@ -552,7 +589,7 @@ def compact_line(out):
     line = _sig(line)
     text = json.dumps(line, separators=(",", ":"))
     if len(text) > 1950:   # never let the tail cut the head: drop the least important entries first
-        for k in ("cpu16", "c1pb", "c2pb", "cont", "native_driver_multi_gpu", "weak_scaling"):
+        for k in ("cpu16", "c1pb", "c2pb", "cont", "native_driver_multi_gpu", "weak_scaling", "e2e"):
             line["legs"].pop(k, None)
             if len(json.dumps(line, separators=(",", ":"))) <= 1950:
                 break
@@ -583,10 +620,12 @@ def parse_args():
                     help="stream mode: equal sub-batches per rank and pass (0: the library's schedule, rc_stream_plan)")
     ap.add_argument("--depth", type=int, default=3, help="stream mode: batches in flight")
     ap.add_argument("--host-threads", type=int, default=0, help="block preparation threads per rank (0: this rank's share of the usable CPUs)")
-    ap.add_argument("--exchange", choices=("maxima", "fits"), default="maxima",
+    ap.add_argument("--exchange", choices=("auto", "maxima", "fits"), default="auto",
                     help="what the ranks all-gather per step: the per-sample maxima (north_star's exchange; 4 B x samples per "
                          "block, written by the kernel straight into the gathered tensor) or only the per-block fit results "
-                         "(16 B per block: enough for p-values, since every rank fits its own blocks on the device)")
+                         "(16 B per block: enough for p-values, since every rank fits its own blocks on the device).  auto (default): the maxima, "
+                         "unless a rank's share of them exceeds 64 MB per step (configs[4] whole: 12 500 blocks x 10 000 samples = 500 MB per rank) -- "
+                         "then the fits (SURVEY.md section 8e)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: wait for every step's all-gather before the next step starts")
     ap.add_argument("--overlap", action="store_true",
@@ -703,6 +742,9 @@ def main():
         blocks = [b.upper() for b in synth_blocks(args.blocks, args.seqs, args.cols, seed=1)[lo:hi]]
         counts = [rd.shard_range(args.blocks, r, world)[1] - rd.shard_range(args.blocks, r, world)[0] for r in range(world)]
     t_gen = time.perf_counter() - t0
+    exchange_auto = args.exchange == "auto"
+    if exchange_auto:   # every rank decides alike: the largest shard's payload
+        args.exchange = "fits" if max(counts) * args.samples * 4 > (64 << 20) else "maxima"
 
     # one GPU, the default workload: the legs that start child processes run first, before this process touches a GPU
     single = world == 1 and not multi
@@ -749,6 +791,8 @@ def main():
         legs["end_to_end"] = end_to_end_leg(blocks, args.samples, args.seed_base)
         legs["end_to_end_100k"] = end_to_end_leg(blocks, args.samples, args.seed_base, runs=3, repeat=10)
         legs["end_to_end_mixed"] = end_to_end_leg(mixed, args.samples, args.seed_base, runs=3)   # file in -> listing out on the ten-class workload
+        legs["end_to_end_mixed_100k"] = end_to_end_leg(mixed, args.samples, args.seed_base, runs=3, repeat=10)   # ... at steady state: the same ten times over
+        legs["end_to_end_c5"] = end_to_end_leg(blocks5, CONFIGS["c5"][3], args.seed_base, runs=3)   # a 1000-block 12 x 300 file at n = 10 000 (configs[4]'s shape)
 
     ctx = api.Context(local_rank)
     cpus = api.lib().rc_host_cpus()
@@ -964,7 +1008,43 @@ def main():
     c_elapsed = None
     if stream is not None:
         s_elapsed, _, _ = timed(stream_step, False)
-        if not multi:
+        if multi:
+            # N > 1: the shard's passes as ONE stream per rank as well (round 5: a shard streamed pass by pass took 8.0 ms against 5.9 as a continuous
+            # stream -- a strong-scaled run that restarts its pipeline every pass caps an 8-GPU curve near 5.9 x before the exchange).  Every pass still
+            # ends with the path's one exchange, of THAT pass's results: the maxima of pass p go to buffer p mod (depth + 1), so that the sub-batches of
+            # the passes queued behind it (at most `depth`) never write what a gather is still reading.
+            nbuf = args.depth + 1
+            srcs = [torch.empty((len(blocks), args.samples), dtype=torch.float32, device=f"cuda:{local_rank}") for _ in range(nbuf)] if args.exchange == "maxima" else None
+            big = max(sub_sizes)
+            one = [(lo, min(len(blocks), lo + big)) for lo in range(0, len(blocks), big)]
+            firstp = [(0, sub_sizes[0])] + ([(sub_sizes[0], one[0][1])] if one[0][1] > sub_sizes[0] else []) + one[1:]
+            slices = [(0, lo, hi, k == len(firstp) - 1) for k, (lo, hi) in enumerate(firstp)]
+            for ps in range(1, args.steps):
+                slices += [(ps, lo, hi, k == len(one) - 1) for k, (lo, hi) in enumerate(one)]
+            sync()
+            gc.collect()
+            gc.disable()
+            sent = done = 0
+            rows = []
+            t0 = time.perf_counter()
+            while done < len(slices):
+                while sent < len(slices) and stream.pending < stream.depth:
+                    ps, lo, hi, _ = slices[sent]
+                    stream.submit(marshalled, lo, hi, (srcs[ps % nbuf].data_ptr() + 4 * lo * args.samples) if srcs else 0)
+                    sent += 1
+                sb = stream.next()
+                rows.append(sb.fits())
+                sb.close()
+                ps, _, _, endp = slices[done]
+                done += 1
+                if endp:
+                    exchange(np.concatenate(rows) if args.exchange == "fits" else None, srcs[ps % nbuf] if srcs else None)
+                    rows = []
+            sync()
+            c_elapsed = rd.max_over_ranks(time.perf_counter() - t0, device=cdev(), group=cgroup())
+            gc.enable()
+            del srcs
+        else:
             # the same sub-batches as ONE stream over all the passes: the pipeline is filled once, not once per pass (what a long input sees)
             big = max(sub_sizes)   # after the fill every sub-batch can be a large one
             slices = [(lo, min(len(blocks), lo + big)) for lo in range(0, len(blocks), big)] * args.steps
@@ -1111,6 +1191,9 @@ def main():
                          "generate_s": genm, "note": "value = the streamed rate (host rc_block arrays -> fitted results on the host), from the median pass"}
         del mx_m, mixed
 
+        # ---- rows: the row-count axis (real multiz MAFs are 17-, 30-, 46-way): uniform resident batches at 150 columns, the kernel
+        # that ran and its fraction of the issue roof by the algorithmic flops (tools/rows_sweep.py is the full sweep, profiles/r06/rows_sweep_*.txt)
+        legs["rows"] = rows_leg(api, ctx, args.samples, args.seed_base)
         # ---- c5: the long-block slice of configs[4] (last: 0.6 s launches at the HBM roof; the legs after it ran a few per cent slower)
         params5 = api.default_params(sampleN=n5, seed_base=args.seed_base)
         c5_ms, c5_null, c5_kernel, c5_units, c5_steps, c5_m = resident_leg(api, ctx, blocks5, params5, args.extra_seconds, warmup=1)
@@ -1139,8 +1222,8 @@ def main():
                                    f"--num-samples {args.samples}, " + ("per GPU" if args.scaling == "weak" else "in total, split across the GPUs")
                                    + f" ({desc})",
                        "blocks_per_gpu": len(blocks), "cols": args.cols, "seqs": args.seqs, "samples": args.samples,
-                       "seed_base": args.seed_base, "sharding": f"blocks x{world}",
-                       "exchange": (("all-gather of " + args.exchange + (", step i's gather overlapped with the scoring of step i + 1 (all complete "
+                       "seed_base": args.seed_base, "sharding": f"blocks x{world}", "fit_exp_mode": ctx.fit_exp_mode,
+                       "exchange": (("all-gather of " + args.exchange + (" (auto)" if exchange_auto else "") + (", step i's gather overlapped with the scoring of step i + 1 (all complete "
                                      "inside the timed region)" if (overlap is not None and mode["overlap"]) else ", every step waits for its gather")) if multi else "none")},
             "value_definition": "resident: inputs in HBM when the timed region starts (bench contract); the host-inclusive pipeline is stream.value",
             "roofline": roofline_object(blocks, args.samples, null_ms, kernel_name, args.config, default_workload and world == 1),

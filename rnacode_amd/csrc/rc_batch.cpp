@@ -87,7 +87,7 @@ int batch_prepare(rc_batch *b, const rc_block *blocks, int32_t n_blocks, const r
       continue;
     }
     b->okBlocks.push_back(i);
-    auto &cls = b->classes[m.N < ctx->genericMinRows ? m.NK : kGenericClass];
+    auto &cls = b->classes[block_class(m.N, m.L, b->db[i].omega, ctx->genericMinRows, ctx->tiledMinRows, ctx->tiledMaxL)];
     if (!cls.empty() && b->meta[cls.front()].L != m.L) sameL = false;
     cls.push_back(i);
     b->maxL = std::max(b->maxL, m.L);
@@ -170,7 +170,7 @@ int batch_upload(rc_batch *b) {
     pa.exactList = b->dexact.as<int>();
     pa.exactCount = b->dcounters.as<int>() + kCntExact;
     std::memcpy(pa.classOff, b->classOff, sizeof pa.classOff);
-    pa.genericMinRows = c->genericMinRows;
+    pa.genericMinRows = c->genericMinRows; pa.tiledMinRows = c->tiledMinRows; pa.tiledMaxL = c->tiledMaxL;
     launch_prep(pa, ps);
   }
   HIP_TRY(b->evPrep.record(ps));
@@ -251,8 +251,8 @@ int batch_run_async(rc_batch *b, bool streaming) {
   for (auto &kv : b->classes) {
     int maxLc = 0;
     for (int bi : kv.second) maxLc = std::max(maxLc, b->meta[bi].L);
-    allFat = allFat && kv.first != kGenericClass && fat_class(b, c, kv.first, maxLc);
-    wide = wide || kv.first == kGenericClass;
+    allFat = allFat && kv.first < kGenericClass && fat_class(b, c, kv.first, maxLc);
+    wide = wide || kv.first >= kGenericClass;   // (the generic class and the tiled ones: persistent grids that take every register of the chip)
   }
   bool fat = allFat && (!streaming || static_cast<long long>(b->okBlocks.size()) * groups >= c->fatStreamMinItems);
   if (fat) nativeFirst = true;

@@ -270,7 +270,8 @@ __global__ __launch_bounds__(64) void k_prep_lut(PrepArgs A) {   // one wavefron
     mine |= !in_div_range_dev(v);
     nan |= v != v;
   }
-  if (N >= A.genericMinRows && threadIdx.x == 0) {   // k_generic_dp's running sums of omega, added the way the DP adds them
+  const int cls = block_class(N, db->L, db->omega, A.genericMinRows, A.tiledMinRows, A.tiledMaxL);
+  if (cls == kGenericClass && threadIdx.x == 0) {   // k_generic_dp's running sums of omega, added the way the DP adds them
     float *W = reinterpret_cast<float *>(A.blob + db->off_chain);
     const int nW = db->L / 3 + 40;
     const float omega = db->omega;
@@ -283,7 +284,6 @@ __global__ __launch_bounds__(64) void k_prep_lut(PrepArgs A) {   // one wavefron
   const bool bad = __ballot(mine) != 0ull, anyNan = __ballot(nan) != 0ull;
   if (threadIdx.x == 0 && bad) {
     A.flags[bi] |= kFlagExact | (anyNan ? kFlagNan : 0u);
-    const int cls = A.genericMinRows > N ? NK : kGenericClass;
     const int at = atomicAdd(A.exactCount + cls, 1);
     A.exactList[A.classOff[cls] + at] = bi;
   }
@@ -997,7 +997,7 @@ size_t null_generic_codes_bytes(int N, int L, int nnodes) { return generic_codes
 size_t null_generic_state_bytes(int N, int L, int nnodes) { return generic_state_bytes(N, L, nnodes); }
 int generic_sim_occupancy(size_t ldsBytes) {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_generic_sim, 64, ldsBytes) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_generic_sim<false>, 64, ldsBytes) != hipSuccess) return 0;
   return nb;
 }
 int generic_dp_occupancy(size_t ldsBytes) {
@@ -1005,8 +1005,12 @@ int generic_dp_occupancy(size_t ldsBytes) {
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_generic_dp, 64, ldsBytes) != hipSuccess) return 0;
   return nb;
 }
-void launch_generic_sim(const NullArgs &a, int grid, size_t ldsBytes, hipStream_t stream) {
-  hipLaunchKernelGGL(k_generic_sim, dim3(grid), dim3(64), ldsBytes, stream, a, a.blob, a.dblocks, a.classBlocks, a.flags, a.U, a.pair, static_cast<uint8_t *>(nullptr), a.maxima);
+void launch_generic_sim(const NullArgs &a, int grid, size_t ldsBytes, hipStream_t stream, bool tiled) {
+  if (tiled) {
+    hipLaunchKernelGGL(k_generic_sim<true>, dim3(grid), dim3(64), ldsBytes, stream, a, a.blob, a.dblocks, a.classBlocks, a.flags, a.U, a.pair, static_cast<uint8_t *>(nullptr), a.maxima);
+    return;
+  }
+  hipLaunchKernelGGL(k_generic_sim<false>, dim3(grid), dim3(64), ldsBytes, stream, a, a.blob, a.dblocks, a.classBlocks, a.flags, a.U, a.pair, static_cast<uint8_t *>(nullptr), a.maxima);
 }
 void launch_generic_dp(const NullArgs &a, int grid, size_t ldsBytes, uint8_t *scratchBytes, hipStream_t stream) {
   hipLaunchKernelGGL(k_generic_dp, dim3(grid), dim3(64), ldsBytes, stream, a, a.blob, a.dblocks, a.classBlocks, a.flags, a.U, a.pair, scratchBytes, a.maxima);

@@ -25,6 +25,8 @@ struct NullArgs {
   const int *nBlocksPtr;      // if set: the number of blocks is read from device memory (list built by k_prep_lut)
   const uint32_t *flags;      // per batch index: kFlagExact, kFlagStopped
   uint32_t skipMask;          // blocks with (flags & skipMask) != 0 are left out
+  uint32_t onlyMask;          // k_tiled_dp: if set, only blocks with (flags & onlyMask) != 0 are taken (the launch for blocks with NaN score tables)
+  int tiledKT;                // k_generic_sim<true> / k_tiled_dp: the tile size of the launch's class
   int gLo, gHi;               // sample groups [gLo, gHi) of 64 samples each
   int sampleN;
   int Spad;                   // ceil(sampleN / 64) * 64: row pitch of U
@@ -88,6 +90,7 @@ struct PrepArgs {
   int *exactCount;            // [kClassSlots] by class
   int classOff[kClassSlots];  // by class (N-1 for the instantiated kernels, kGenericClass for wider blocks)
   int genericMinRows;         // blocks with at least this many rows are in the generic class
+  int tiledMinRows, tiledMaxL;   // ... and those from this many up to 64 rows, of at most this many reference residues, in the tiled classes (rc_device.h, block_class)
 };
 
 struct FitOut {
@@ -197,7 +200,12 @@ size_t null_generic_codes_bytes(int N, int L, int nnodes);
 size_t null_generic_state_bytes(int N, int L, int nnodes);
 int generic_sim_occupancy(size_t ldsBytes);
 int generic_dp_occupancy(size_t ldsBytes);
-void launch_generic_sim(const NullArgs &a, int grid, size_t ldsBytes, hipStream_t stream);
+void launch_generic_sim(const NullArgs &a, int grid, size_t ldsBytes, hipStream_t stream, bool tiled = false);   // tiled: the codes in k_tiled_dp's layout
+// blocks of 28..64 rows in tiles of KT sequences (rc_null_tiled.h): bytes of an item's codes / of a DP workgroup's row buffer, occupancy, launch
+size_t null_tiled_codes_bytes(int NK, int KT, int L);
+size_t null_tiled_state_bytes(int L);
+int tiled_dp_occupancy(int KT, size_t ldsBytes);
+bool launch_tiled_dp(int KT, bool nanSem, const NullArgs &a, int grid, size_t ldsBytes, uint8_t *scratchBytes, hipStream_t stream);
 void launch_generic_dp(const NullArgs &a, int grid, size_t ldsBytes, uint8_t *scratchBytes, hipStream_t stream);
 void launch_native_dp_generic(const NativeArgs &a, int nblocks, float *scratch, size_t scratchStride, hipStream_t stream);
 void launch_stop_mark(const FitArgs &a, int nblocks, hipStream_t stream);

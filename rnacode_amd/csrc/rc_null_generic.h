@@ -36,6 +36,7 @@
 // It is the slow, complete path for rare inputs; the division is the plain '/'.
 #pragma once
 #include "rc_null_kernel.h"
+#include "rc_null_tiled.h"
 
 namespace rc {
 
@@ -178,7 +179,8 @@ __host__ __device__ inline size_t generic_lds_bytes(int N, int nn) {
 // strand x frame parts to fill the chip, one part per workgroup.  (Until round 5 large batches ran both phases in one kernel: wavefronts
 // in the simulation and in the DP side by side on a CU cost more than the two in turn -- 1024 blocks of 100 x 300: 972 ms against 117 ms
 // + 727 ms alone, 928 ms as two launches per round of 4096 items; 500 blocks of 200 x 90: 225 -> 189 ms; 40 blocks of 500 x 60: 63.5 -> 45.1.)
-template <bool SIM>
+// TILED (with SIM): the codes in k_tiled_dp's layout (rc_null_tiled.h) instead, for blocks of up to 64 rows.
+template <bool SIM, bool TILED = false>
 __device__ __forceinline__ void generic_body(const NullArgs &A, const uint8_t *__restrict__ blob, const DevBlock *__restrict__ dblocks,
                                              const int *__restrict__ classBlocks, const uint32_t *__restrict__ flags,
                                              const uint32_t *__restrict__ Ustream, const uint8_t *__restrict__ pairTab,
@@ -319,6 +321,54 @@ __device__ __forceinline__ void generic_body(const NullArgs &A, const uint8_t *_
         const uint32_t k5 = static_cast<uint32_t>(kl) / 5u, sh = 6u * (static_cast<uint32_t>(kl) - 5u * k5);
         const uint32_t mFv = (mrowF[k5] >> sh) & 63u, mRv = (mrowR[k5] >> sh) & 63u;
         const int nk = NK - k0 < kWave ? NK - k0 : kWave;
+        if constexpr (TILED) {
+          // (at most 63 sequences: k0 == 0.)  A word of the tiled layout holds up to five sequences of one tile: window update as below, then
+          // the codes of the word's sequences packed, field c at bits [6c + 7 : 6c + 2], one dword per strand
+          const TiledLayout tl(NK, A.tiledKT);
+          uint32_t *__restrict__ cwp = reinterpret_cast<uint32_t *>(codes) + lane;
+          const size_t posF = static_cast<size_t>(0 * L1 + i) * tl.WT * kWave, posR = static_cast<size_t>(1 * L1 + (emit ? ip : L)) * tl.WT * kWave;
+          auto rowsT = [&](auto cnt, int kk, int widx) {   // sequences kk .. kk + CNT - 1 = the fields of word widx
+            constexpr int CNT = decltype(cnt)::value;
+            uint32_t bb[CNT], cc[CNT], wv[CNT];
+            uint8_t *wrow = win + (kk + 1) * kWave;
+#pragma unroll
+            for (int t = 0; t < CNT; t++) {
+              cc[t] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(tctl), kk + t));
+              wv[t] = *reinterpret_cast<const uint16_t *>(ldsBytes + ((cc[t] & 0x7f80u) | laneSt));
+              bb[t] = wrow[t * kWave];
+            }
+#pragma unroll
+            for (int t = 0; t < CNT; t++) bb[t] = ((bb[t] << 2) | ((wv[t] >> (cc[t] & 31u)) & 3u)) & 63u;
+#pragma unroll
+            for (int t = 0; t < CNT; t++) wrow[t * kWave] = static_cast<uint8_t>(bb[t]);
+            if (emit) {
+              uint32_t wf = 0u, wr = 0u;
+#pragma unroll
+              for (int t = 0; t < CNT; t++) {
+                const uint32_t mF = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mFv), kk + t));
+                const uint32_t mR = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mRv), kk + t));
+                wf |= static_cast<uint32_t>(pairTab[aF64 + (bb[t] & mF)]) << (6 * t + 2);
+                wr |= static_cast<uint32_t>(pairTab[aR64 + ((codon_flip(bb[t]) ^ 63u) & mR)]) << (6 * t + 2);
+              }
+              cwp[posF + static_cast<size_t>(widx) * kWave] = wf;
+              cwp[posR + static_cast<size_t>(widx) * kWave] = wr;
+            }
+          };
+          for (int t = 0; t < tl.T; t++)
+            for (int x = 0; x < tl.WPT; x++) {
+              const int kk = t * tl.KT + 5 * x;
+              int cnt = tl.KT - 5 * x;
+              cnt = cnt > 5 ? 5 : cnt;
+              cnt = cnt > NK - kk ? NK - kk : cnt;
+              const int widx = t * tl.WPT + x;
+              if (cnt >= 5) rowsT(std::integral_constant<int, 5>{}, kk, widx);
+              else if (cnt == 4) rowsT(std::integral_constant<int, 4>{}, kk, widx);
+              else if (cnt == 3) rowsT(std::integral_constant<int, 3>{}, kk, widx);
+              else if (cnt == 2) rowsT(std::integral_constant<int, 2>{}, kk, widx);
+              else if (cnt == 1) rowsT(std::integral_constant<int, 1>{}, kk, widx);
+            }
+          continue;
+        }
         auto rows = [&](auto cnt, int kk) {   // sequences k0 + kk .. + CNT - 1
           constexpr int CNT = decltype(cnt)::value;
           uint32_t bb[CNT], pf[CNT], pr[CNT];
@@ -562,12 +612,13 @@ __device__ __forceinline__ void generic_body(const NullArgs &A, const uint8_t *_
   }
 }
 
+template <bool TILED>
 __global__ __launch_bounds__(64) void k_generic_sim(NullArgs A, const uint8_t *__restrict__ blob, const DevBlock *__restrict__ dblocks,
                                                     const int *__restrict__ classBlocks, const uint32_t *__restrict__ flags,
                                                     const uint32_t *__restrict__ Ustream, const uint8_t *__restrict__ pairTab,
                                                     uint8_t *__restrict__ scratch, float *__restrict__ maxima) {
   extern __shared__ uint32_t ldsGeneric[];
-  generic_body<true>(A, blob, dblocks, classBlocks, flags, Ustream, pairTab, scratch, maxima, ldsGeneric);
+  generic_body<true, TILED>(A, blob, dblocks, classBlocks, flags, Ustream, pairTab, scratch, maxima, ldsGeneric);
 }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RC_GENERIC_WAVES, RC_GENERIC_WAVES))) void k_generic_dp(NullArgs A, const uint8_t *__restrict__ blob, const DevBlock *__restrict__ dblocks,
                                                    const int *__restrict__ classBlocks, const uint32_t *__restrict__ flags,

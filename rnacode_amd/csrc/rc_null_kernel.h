@@ -164,6 +164,10 @@ __device__ __forceinline__ void sample_scan_row_begin(SampleScan &st, float &bes
 }
 // every entry except the frame's final one; j2 = 2j + 1, wave-uniform but held in a VGPR as a float: the
 // caller advances it with a double-rate v_add_f32 instead of copying a scalar counter per entry
+// (Round 6 built the step with a rare-arm branch -- v > currMax and the band test fl(v - currMax) > -thr as two compares into scalar lane masks,
+// the tie rule's other two compares only where some lane sits in the band (score.c:953-954), the two selects written out: same decisions, two
+// v_cmp fewer in the common arm, a scalar and-not, compare and branch more.  Product builds A/B on the headline: 42.68 against 42.80 ms per launch --
+// nothing, and two registers more in the one-row kernels (a wavefront per SIMD lost at 11, 23 and 24 rows).  Taken back; profiles/r06/ab_scan_tie_branch.txt.)
 __device__ __forceinline__ void sample_scan_step(SampleScan &st, float v, float j2, float negTieThr) {
   const float d = v - st.cm;
   const bool upd = (v > st.cm) | ((v > 0.0f) & (d > negTieThr) & (st.Q <= j2));   // score.c:953-954

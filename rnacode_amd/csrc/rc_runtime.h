@@ -349,6 +349,8 @@ struct rc_ctx {
   // measured (tools/rows_sweep.py, profiles/r06/rows_sweep_*.txt): k_null<N-1> holds 3 (N-1) states in registers -- 2 wavefronts per SIMD up to 36 rows,
   // ONE from 37 on (0.11..0.18 of the issue roof at 40..64 rows), where k_generic_dp (states parked in memory, any N) runs at 0.19..0.24
   int genericMinRows = kGenericDefaultMinRows;
+  int tiledMaxL = kTiledDefaultMaxL;
+  int tiledMinRows = kTiledDefaultMinRows;   // blocks of this many rows up to 64 (omega <= 0) take k_tiled_dp (rc_null_tiled.h; RC_TILED_MIN_ROWS, 65 = never)
   int stopRounds = 6;                    // at most this many rounds (RC_STOP_ROUNDS; <= kMaxRounds)
   long long stopTwoRoundsMinItems = 0;   // --stop-early runs two rounds of sample groups only for batches with at least this many (block, group) items
   int hostThreads = 0;

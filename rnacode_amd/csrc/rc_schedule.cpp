@@ -45,7 +45,7 @@ int launch_native_block(const RunEnv &R) {
   {   // one 64-row buffer per persistent workgroup, shared by the class launches (same stream)
     size_t need = 0;
     for (auto &kv : b->classes) {
-      if (kv.first == kGenericClass) continue;
+      if (kv.first >= kGenericClass) continue;
       int smaxClass = 1;
       for (int bi : kv.second) smaxClass = std::max(smaxClass, b->meta[bi].L / 3);
       const size_t grid = native_grid(c, kv.second.size() * 6, smaxClass, R.nativeMode);
@@ -56,7 +56,7 @@ int launch_native_block(const RunEnv &R) {
   for (auto &kv : b->classes) {
     NativeArgs nc = na;
     nc.blocks = R.classList + b->classOff[kv.first];
-    if (kv.first == kGenericClass) {   // more than 64 rows: states in a scratch, at most 256 blocks per launch share it
+    if (kv.first >= kGenericClass) {   // more than 64 rows, or a tiled class (row counts mixed): states in a scratch, at most 256 blocks per launch share it
       int maxNK = 0, smaxG = 1;
       for (int bi : kv.second) { maxNK = std::max(maxNK, b->meta[bi].NK); smaxG = std::max(smaxG, b->meta[bi].L / 3); }
       const size_t stride = static_cast<size_t>(3) * maxNK * kWave + static_cast<size_t>(kWave) * smaxG;   // states, then 64 rows of S
@@ -132,7 +132,8 @@ int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t ex
   const int groupsHere = gHi - gLo;
   struct Plan { int NK, grid, gridExact, comboSplit; size_t stride, ldsBytes, need; double itemCost; int hiOcc, cacheSites; size_t plainLds;
                 int rowParts, simParts, rowSimGrid; size_t sbufStride, sbufFloats;   // rows split over workgroups (k_null<.., ROWS> + k_null_rowscan)
-                int simGrid, roundBlocks; size_t codesBytes, stateBytes; };   // (the last four: the wide-block class in two launches)
+                int simGrid, roundBlocks; size_t codesBytes, stateBytes;   // (the last four: the wide-block class in two launches)
+                int tiledKT; size_t ldsDp; };   // a tiled class (k_generic_sim<true> + k_tiled_dp<KT>): its tile size, the DP's LDS (sigma tables)
   std::vector<Plan> plans;
   trace("null: plan", b);
   size_t needSum = 0, needMax = 0, sbufSum = 0;
@@ -149,19 +150,38 @@ int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t ex
     int maxLc = 0, maxNKc = 0;
     for (int bi : kv.second) { maxLc = std::max(maxLc, b->meta[bi].L); maxNKc = std::max(maxNKc, b->meta[bi].NK); }
     p.itemCost = static_cast<double>(maxNKc) * maxLc * maxLc;   // (cell, sequence) steps of the class's longest item, up to a factor
-    if (kv.first == kGenericClass) {   // one class for every block of more than 64 rows, whatever its N: k_generic_sim, then k_generic_dp
+    if (kv.first >= kGenericClass) {   // one class for every block of more than 64 rows, whatever its N: k_generic_sim, then k_generic_dp;
+                                       // one per tile size for the blocks of 28..64 rows: k_generic_sim<true>, then k_tiled_dp<KT> (rc_null_tiled.h)
       int maxN = 0, maxNodes = 0;
       for (int bi : kv.second) { maxN = std::max(maxN, b->meta[bi].N); maxNodes = std::max(maxNodes, b->db[bi].nnodes); }
       p.ldsBytes = null_generic_lds_bytes(maxN, maxNodes);
-      p.codesBytes = null_generic_codes_bytes(maxN, maxLc, maxNodes);
-      p.stateBytes = null_generic_state_bytes(maxN, maxLc, maxNodes);
-      const std::pair<int, size_t> keyD(kGenericClass, p.ldsBytes), keyS(kGenericClass + 1, p.ldsBytes);
-      if (!c->occ.count(keyD)) { c->occ[keyD] = generic_dp_occupancy(p.ldsBytes); c->occ[keyS] = generic_sim_occupancy(p.ldsBytes); }
-      const int occD = std::max(1, c->occ[keyD]), occS = std::max(1, c->occ[keyS]);
+      int occD = 1, occS = 1;
+      if (kv.first == kGenericClass) {
+        p.codesBytes = null_generic_codes_bytes(maxN, maxLc, maxNodes);
+        p.stateBytes = null_generic_state_bytes(maxN, maxLc, maxNodes);
+        p.ldsDp = p.ldsBytes;
+        const std::pair<int, size_t> keyD(kGenericClass, p.ldsBytes), keyS(-1, p.ldsBytes);
+        if (!c->occ.count(keyD)) { c->occ[keyD] = generic_dp_occupancy(p.ldsBytes); c->occ[keyS] = generic_sim_occupancy(p.ldsBytes); }
+        occD = std::max(1, c->occ[keyD]); occS = std::max(1, c->occ[keyS]);
+      } else {
+        p.tiledKT = kTiledMinKT + (kv.first - kTiledClass0);
+        for (int bi : kv.second) {
+          p.codesBytes = std::max(p.codesBytes, null_tiled_codes_bytes(b->meta[bi].NK, p.tiledKT, b->meta[bi].L));
+        }
+        p.stateBytes = null_tiled_state_bytes(maxLc);
+        p.ldsDp = 0;   // (the kernel's LDS is static: the current tile's sigma tables and the tail of the row buffer, 10 KB -- sixteen workgroups per CU)
+        const std::pair<int, size_t> keyD(kv.first, p.ldsDp), keyS(-1, p.ldsBytes);
+        if (!c->occ.count(keyD)) c->occ[keyD] = tiled_dp_occupancy(p.tiledKT, p.ldsDp);
+        if (!c->occ.count(keyS)) c->occ[keyS] = generic_sim_occupancy(p.ldsBytes);
+        occD = std::max(1, c->occ[keyD]); occS = std::max(1, c->occ[keyS]);
+      }
       const long long slotsD = static_cast<long long>(c->numCU) * occD;
       const long long items = static_cast<long long>(kv.second.size()) * groupsHere;
       // few items: every item's DP is split into its six strand x frame parts to fill the chip (maxima meet in an atomic max)
-      p.comboSplit = (together ? splitAll : static_cast<double>(items) <= c->splitFactor * c->numCU * occD) ? 1 : 0;
+      // ... and so is every item of a batch that fills the chip only a few times over: the simulation is a launch of its own here, the parts redo
+      // nothing, and items of minutes-long cost otherwise quantise badly -- 257 blocks of 64 x 300 are 4112 items on 4096 wavefront slots and took as
+      // long as 8192 (334 ms against 168 for 294 blocks of 56 x 300: tools/rows_sweep.py)
+      p.comboSplit = ((together ? splitAll : static_cast<double>(items) <= c->splitFactor * c->numCU * occD) || items < 8 * slotsD) ? 1 : 0;
       // The sigma codes of every item of a round lie in the scratch at once (N x L x 2 bytes per sample; 5 MB per item at 100 x 300):
       // rounds of as many items as the scratch budget holds -- a whole number of the DP's wavefront slots when it holds more than
       // one (items of a class cost about the same: 4600 items on 4096 slots take as long as 8192).
@@ -295,6 +315,7 @@ int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t ex
       if (cost > b->nullKernelCost) {
         b->nullKernelCost = cost;
         if (p.NK == kGenericClass) b->nullKernel = "rc::k_generic_dp";
+        else if (p.NK > kGenericClass) b->nullKernel = "rc::k_tiled_dp<" + std::to_string(p.tiledKT) + ", false>";
         else {
           const bool ex = b->allExact || p.NK >= kFastRows;
           const bool dual = !ex && p.ldsBytes && p.ldsBytes <= 48 * 1024 && p.NK <= kDualRowsMaxNK && (p.NK == 2 || R.fat);
@@ -305,28 +326,47 @@ int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t ex
         }
       }
     }
-    if (p.NK == kGenericClass) {
+    if (p.NK >= kGenericClass) {
+      const bool tiled = p.NK > kGenericClass;
       a.skipMask = extraSkip;
+      a.tiledKT = p.tiledKT; a.plainLds = static_cast<int>(p.ldsDp);
       a.workCounter = work + p.NK * 8;
       uint8_t *base = reinterpret_cast<uint8_t *>(a.scratch);
       const size_t codesAllBytes = (static_cast<size_t>(p.roundBlocks) * groupsHere * p.codesBytes + 255) & ~static_cast<size_t>(255);
       a.codesAll = base; a.codesStride = p.codesBytes;
       a.scratchStride = p.stateBytes;   // bytes for these kernels
       unsigned int *simWork = work + kClassSlots * 8 + p.NK * 8;   // (the class's unused "exact" queue counters)
+      unsigned int *nanWork = work + 2 * kClassSlots * 8 + p.NK * 8;   // (... and its unused "split simulation" ones: the tiled classes' launch for blocks with NaN tables)
       const int *list = a.classBlocks;
       for (size_t at = 0; at < members.size(); at += static_cast<size_t>(p.roundBlocks)) {
         if (at) {   // the queues of the round before are spent
           HIP_TRY(hipMemsetAsync(a.workCounter, 0, 8 * sizeof(unsigned int), st));
           HIP_TRY(hipMemsetAsync(simWork, 0, 8 * sizeof(unsigned int), st));
+          if (tiled) HIP_TRY(hipMemsetAsync(nanWork, 0, 8 * sizeof(unsigned int), st));
         }
         NullArgs r = a;
         r.classBlocks = list + at;
         r.nClassBlocks = static_cast<int>(std::min<size_t>(static_cast<size_t>(p.roundBlocks), members.size() - at));
         NullArgs sim = r;
         sim.workCounter = simWork;
-        launch_generic_sim(sim, p.simGrid, p.ldsBytes, st);
-        launch_generic_dp(r, p.grid, p.ldsBytes, base + codesAllBytes, st);
-        b->nl[2] += 2;
+        launch_generic_sim(sim, p.simGrid, p.ldsBytes, st, tiled);
+        if (tiled) {
+          // blocks with NaN score tables (flagged on the device by k_prep_lut, none as a rule) are left to a second launch of the instantiation with
+          // the reference's NaN-order-dependent maxima: a few workgroups that look at every item's flag
+          // (gap parameters outside the fast kernels' range -- Delta >= 0: the maximum with Delta counts -- : that instantiation for every block)
+          r.skipMask = extraSkip | (b->allExact ? 0u : kFlagNan);
+          if (!launch_tiled_dp(p.tiledKT, b->allExact, r, p.grid, p.ldsDp, base + codesAllBytes, st)) return fail(RC_ERR_UNSUPPORTED, "no tiled kernel for this tile size");
+          b->nl[2] += 2;
+          if (!b->allExact) {
+            NullArgs e = r;
+            e.skipMask = extraSkip; e.onlyMask = kFlagNan; e.workCounter = nanWork;
+            (void)launch_tiled_dp(p.tiledKT, true, e, std::min(p.grid, c->numCU), p.ldsDp, base + codesAllBytes, st);
+            b->nl[2]++;
+          }
+        } else {
+          launch_generic_dp(r, p.grid, p.ldsBytes, base + codesAllBytes, st);
+          b->nl[2] += 2;
+        }
       }
     } else if (b->allExact || p.NK >= kFastRows) {
       a.skipMask = extraSkip;

@@ -191,11 +191,12 @@ def test_wide_simulation_and_native_dp_stay_lean(tmp_path):
     per sequence and codon): a codon where no sequence is out of frame must be ONE straight-line block of 3 adds and a max3 per
     sequence, and the out-of-frame codons a second one that selects with the wave-uniform z."""
     txt = _compile_unit(tmp_path, "rc_kernels")
-    sim = txt[txt.index("_ZN2rc13k_generic_simE"):]
-    sim = sim[sim.index(":\n"):sim.index(".Lfunc_end")]
-    assert sim.count("s_load_") <= 40, sim.count("s_load_")
-    assert sim.count("ds_bpermute_b32") >= 32 and sim.count("v_readlane_b32") >= 16      # thresholds and control words of eight nodes
-    assert "scratch_" not in sim
+    for variant in ("ILb0EE", "ILb1EE"):   # the wide-block layout, and the tile-major one for k_tiled_dp (round 6)
+        sim = txt[txt.index("_ZN2rc13k_generic_sim" + variant):]
+        sim = sim[sim.index(":\n"):sim.index(".Lfunc_end")]
+        assert sim.count("s_load_") <= 40, sim.count("s_load_")
+        assert sim.count("ds_bpermute_b32") >= 32 and sim.count("v_readlane_b32") >= 16      # thresholds and control words of eight nodes
+        assert "scratch_" not in sim
     name = "_ZN2rc11k_native_dpILi9EEEvNS_10NativeArgsE"
     body = txt[txt.index(name + ":"):]
     body = body[:body.index(".Lfunc_end")]
@@ -212,3 +213,36 @@ def test_wide_simulation_and_native_dp_stay_lean(tmp_path):
     assert not any(x.startswith("s_cbranch") for x in fast[0][:-2])
     select = [b for b in blocks if sum(x.startswith("v_cndmask_b32") for x in b) >= 9 * 6]
     assert select and sum(x.startswith("s_cbranch") for x in select[0]) <= 4, "the out-of-frame codons branch per sequence again"
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_tiled_kernels_keep_four_wavefronts_per_simd_and_spill_nothing_in_a_cell(tmp_path):
+    """k_tiled_dp<KT> (rc_null_tiled.h, blocks of 34..64 rows) exists because a SIMD needs four wavefronts to issue at its rate: every instantiation
+    must fit 128 VGPRs and 10 KB of LDS (sixteen workgroups per CU), and whatever the register allocator spills to get there must stay out of the
+    cell loops -- the blocks that hold a tile's sigma look-ups (a ds_read_b32 per sequence).  (A ring of two or three register sets for a deeper
+    prefetch failed exactly this: 44..190 registers spilled into the cells.)"""
+    txt = _compile_unit(tmp_path, "rc_null_t")
+    names = re.findall(r"\.amdhsa_kernel (\S+)", txt)
+    seen = 0
+    for kt in (12, 13, 14, 15):
+        for sem in ("Lb0E", "Lb1E"):
+            name = next(n for n in names if "k_tiled_dpILi%dE%s" % (kt, sem) in n)
+            meta = txt[txt.index(".name:           " + name):]
+            assert int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1)) <= 128, name
+            head = txt[txt.rindex(".amdhsa_kernel " + name):]
+            assert int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", head).group(1)) <= 10240, name
+            body = txt[txt.index(name + ":"):]
+            body = body[:body.index(".Lfunc_end")]
+            blocks, cur = [], None
+            for ln in body.split("\n"):
+                if re.match(r"^\.LBB\d+_\d+:", ln):
+                    cur = []
+                    blocks.append(cur)
+                elif cur is not None and ln.startswith("\t") and not ln.startswith(("\t.", "\t;")):
+                    cur.append(ln.strip())
+            cells = [b for b in blocks if sum(x.startswith("ds_read_b32") for x in b) >= kt - 1]
+            assert cells, name
+            for b in cells:
+                assert not any(x.startswith("scratch_") for x in b), name + ": a spill inside a cell\n" + "\n".join(b)
+                seen += 1
+    assert seen >= 16

@@ -605,6 +605,53 @@ def test_fits_on_few_samples_sum_in_the_references_order(ctx):
                 assert lam == wlam and abs(mu - wmu) <= 1e-15 * max(1.0, abs(wmu)), (n, spread, mu, wmu, lam, wlam)   # (mu goes through the device's log: one ulp)
 
 
+def test_tiled_kernels_equal_the_oracle(monkeypatch):
+    """k_tiled_dp<KT> (rc_null_tiled.h; blocks of 34..64 rows and up to 210 reference residues by default, here from 17 rows on and any length):
+    the sequences besides the reference in tiles of 12..15, a cell's sum carried from tile to tile in score.c's order.  Per-sample maxima, HSS
+    tables and fit verdicts against the oracle for every tile size and 2..5 tiles, rows longer than the row buffer's LDS tail (300 columns), 64
+    rows (the second z word, a fifth tile), a batch of one block (strand x frame parts over workgroups), a block without two of the nucleotides
+    (NaN tables: the second launch with the reference's MAX macro), Delta >= 0 (that instantiation for every block), --stop-early, and a block
+    with omega > 0, which must not take these kernels (their padded sequences need a gap state never above 0)."""
+    from oracle import binding as ob
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_block
+    monkeypatch.setenv("RC_TILED_MIN_ROWS", "17")
+    monkeypatch.setenv("RC_TILED_MAX_L", "100000")
+    ctx = api.Context(0)
+    rng = np.random.RandomState(606)
+
+    def check(blocks, n, seed, expect_tiled=True, **pars):
+        hp = api.default_params(sampleN=n, seed_base=seed, **pars)
+        b = api.Batch(ctx, blocks, hp).run()
+        assert ("k_tiled_dp" in b.null_kernel()) == expect_tiled, b.null_kernel()
+        for i, blk in enumerate(blocks):
+            p = ob.default_params(n)
+            for k, v in pars.items():
+                setattr(p, k, v)
+            res = ob.run_block([r.seq for r in blk.rows], [r.name for r in blk.rows], blk.rows[0].start, blk.rows[0].length, blk.tree, blk.kappa, p, seed)
+            if not pars.get("stopEarly") or res.evd_rc == 1:
+                np.testing.assert_array_equal(b.maxScores(i), np.float32(res.maxScores), err_msg=f"block {i}: {blk.n} x {blk.cols}")
+            got, want = sorted(b.scoreAln(i), key=hss_key), sorted(res.hss, key=hss_key)
+            assert [(h["strand"], h["frame"], h["start"], h["end"], np.float32(h["score"])) for h in got] == \
+                   [(h["strand"], h["frame"], h["start"], h["end"], np.float32(h["score"])) for h in want]
+            rc, mu, lam = b.getExtremeValuePars(i)
+            assert rc == res.evd_rc and (rc != 1 or (close_p(mu, res.mu) and close_p(lam, res.lam)))
+        b.close()
+
+    shapes = [(17, 60), (25, 45), (27, 90), (29, 45), (31, 60), (34, 150), (40, 90), (46, 45), (47, 60), (61, 30), (64, 45), (20, 300)]
+    blocks = [synth_block(rng, n, c, index=i, gaps=True).upper() for i, (n, c) in enumerate(shapes)]
+    check(blocks, 130, 77)
+    check(blocks[6:7], 200, 5)                               # one block: its strand x frame parts over workgroups
+    check(blocks[:6], 100, 9, Delta=1.5)                     # Delta >= 0: the maximum with Delta counts
+    check(blocks[2:8], 100, 11, stopEarly=1, cutoff=0.2)
+    check(blocks[4:6], 64, 13, expect_tiled=False, omega=0.5)   # omega > 0: not these kernels
+    nan = synth_block(np.random.RandomState(77), 40, 33, index=0, gaps=True).upper()
+    for r in nan.rows:
+        r.seq = r.seq.replace("A", "C").replace("G", "T")
+    check([blocks[3], nan, blocks[9]], 130, 21)
+    ctx.close()
+
+
 def test_wide_blocks_in_several_rounds_equal_one_round(ctx):
     """k_generic_sim leaves the codes of a ROUND of items in the scratch for k_generic_dp (rc_schedule.cpp): with a scratch of 24 GB
     a batch of a few wide blocks is one round, with 8 MB (RC_GENERIC_SCRATCH_MB, read when a context is created) every block's

@@ -28,11 +28,12 @@ SOAK = [
     ("wide", {}, 60),
     ("", {"RC_LDS_MAX_BYTES": "0"}, 300),
     ("", {"RC_GENERIC_MIN_ROWS": "3"}, 240),
-    ("", {"RC_GENERIC_MIN_ROWS": "65"}, 240),   # the k_null<36..63> instantiations: by default blocks of 37 rows and more take the generic kernels (rc_device.h)
+    ("", {"RC_GENERIC_MIN_ROWS": "65", "RC_TILED_MIN_ROWS": "65"}, 240),   # the k_null<36..63> instantiations: by default blocks of 34 rows and more take the tiled or the generic kernels (rc_device.h)
+    ("", {"RC_TILED_MIN_ROWS": "17", "RC_TILED_MAX_L": "100000"}, 240),   # k_tiled_dp for every block of 17..64 rows
 ]
 
 
-@pytest.mark.parametrize("mode,env,blocks", SOAK, ids=["default", "fat", "wide", "codes-from-L2", "all-generic", "templated-to-64-rows"])
+@pytest.mark.parametrize("mode,env,blocks", SOAK, ids=["default", "fat", "wide", "codes-from-L2", "all-generic", "templated-to-64-rows", "tiled-from-17-rows"])
 def test_soak_slice(monkeypatch, mode, env, blocks):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -47,7 +48,7 @@ KNOBS = [
     {"RC_TAIL_SHARING": "0"}, {"RC_FAT_STREAM_MIN_ITEMS": "0"},
     {"RC_HOST_THREADS": "1", "RC_SPLIT_FACTOR": "0"}, {"RC_SPLIT_FACTOR": "100"}, {"RC_NATIVE_WAVES_PER_CU": "1"},
     {"RC_NATIVE_WAVES_PER_CU": "32"}, {"RC_TOGETHER_MAX_MB": "0"}, {"RC_STOP_ROUNDS": "6", "RC_STOP_MIN_ITEMS": "0"},
-    {"RC_GENERIC_MIN_ROWS": "3"}, {"RC_GENERIC_MIN_ROWS": "65"}, {"RC_FIT_EXP": "generic"}, {"RC_FIT_EXP": "fused"}, {"RC_LDS_MAX_BYTES": "0"}, {"RC_LDS_MAX_BYTES": "65536"}, {"RC_GRID_CAP_PER_CU": "2"},
+    {"RC_GENERIC_MIN_ROWS": "3"}, {"RC_GENERIC_MIN_ROWS": "65", "RC_TILED_MIN_ROWS": "65"}, {"RC_TILED_MIN_ROWS": "17", "RC_TILED_MAX_L": "100000"}, {"RC_FIT_EXP": "generic"}, {"RC_FIT_EXP": "fused"}, {"RC_LDS_MAX_BYTES": "0"}, {"RC_LDS_MAX_BYTES": "65536"}, {"RC_GRID_CAP_PER_CU": "2"},
     {"RC_GENERIC_SCRATCH_MB": "64"}, {"RC_SERIAL_NATIVE": "1"}, {"RC_HIGH_OCCUPANCY": "0"}, {"RC_HIGH_OCCUPANCY": "2"},
     {"RC_TREE_LDS_MAX": "0"}, {"GPU_MAX_HW_QUEUES": "2"},
 ]
