@@ -1290,8 +1290,17 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
   }
 }
 
+// A wavefront issues one vector instruction per ~8 cycles whatever its instruction-level parallelism (tools/microbench.hip, profiles/r06/
+// valu_issue_costs_r06.txt): a SIMD needs four wavefronts to issue at its rate, and every wavefront the registers cost below four costs a quarter of
+// it.  The one-row kernels take 131..168 VGPRs at 17..24 rows (three wavefronts) and 174..229 at 25..32 (two) when the register allocator is left
+// alone.  Held to 128 VGPRs at 17..22 rows and to 168 at 25..30 it spills 3..35 registers and keeps them out of the straight-line cells (one scratch
+// access in one kind of cell at 22 rows, two at 30; tests/test_codegen_cpu.py counts them and audits the registers the asm fetches leave pending):
+// 20 rows x 150 / 300 columns 0.307 / 0.388 -> 0.338 / 0.431 of the issue roof, 28 rows 0.252 / 0.325 -> 0.310 / 0.362.  Not at 23, 24 rows (three
+// scratch accesses per cell: 0.313 / 0.392 -> 0.308 / 0.373) nor at 31, 32 (six: 0.245 / 0.315 -> 0.213 / 0.237, and the audit finds a pending
+// register copied).  profiles/r06/rows_sweep_before.txt, rows_sweep_forced_occupancy.txt, rows_sweep_after.txt.
+constexpr int null_min_waves(int NK, bool EXACT, bool DUAL, int MODE) { return (EXACT || DUAL || MODE != 0) ? 1 : (NK >= 16 && NK <= 21) ? 4 : (NK >= 24 && NK <= 29) ? 3 : 1; }
 template <int NK, bool LDSC, bool EXACT, bool DUAL = false, int MODE = 0>
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(null_min_waves(NK, EXACT, DUAL, MODE))))
 void k_null(NullArgs A, const uint8_t *__restrict__ blob,
                                              const DevBlock *__restrict__ dblocks, const int *__restrict__ classBlocks,
                                              const uint32_t *__restrict__ flags, const uint32_t *__restrict__ Ustream, const uint8_t *__restrict__ pairTab,

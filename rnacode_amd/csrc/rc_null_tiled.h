@@ -123,10 +123,13 @@ __device__ __forceinline__ void tiled_body(const NullArgs &A, const uint8_t *__r
               auto &r = R.template at<decltype(kc)::value>();
               r.s0 = r.s1 = r.s2 = 0.0f;
             });
-            // the words of a cell's site and the sum carried into it are fetched one cell ahead (deeper rings of register sets, two and three cells, were
-            // built: the register allocator, held to the 128 VGPRs that four wavefronts per SIMD take, spilled 44..190 of them into the cell loops)
-            uint32_t wcur[WPT];
-            float pcur;
+            // The words of a cell's site and the sum carried into it are fetched TWO cells ahead, into two register sets used in turn: set A holds the
+            // cell being scored, set B the next one, and a cell refills its own set for the cell after next as soon as its look-ups have read it --
+            // nothing is copied in a loop of cell pairs; a span of odd length ends with one exchange of the two sets.  (One cell of distance left
+            // the memory system at ~3.5 TB/s with the SIMDs waiting; rings of three sets, and cells written for every ring position in ONE loop
+            // over all kinds of cell, cost the register allocator, held to 128 VGPRs, 44..190 spills inside the cells.)
+            uint32_t wA[WPT], wB[WPT];
+            float pA, pB;
             auto fetch = [&](int jj, uint32_t (&w)[WPT], float &pv) {
               const int jc = jj < sites ? jj : sites - 1;
 #pragma unroll
@@ -137,21 +140,20 @@ __device__ __forceinline__ void tiled_body(const NullArgs &A, const uint8_t *__r
                 else pv = partial[static_cast<size_t>(jc) * kWave];
               }
             };
-            fetch(a, wcur, pcur);
+            fetch(a, wA, pA);
+            fetch(a + 1, wB, pB);
             float j2f = static_cast<float>(2 * a + 1);
-            // one cell: the next cell's words and carried sum fetched first, the look-ups, `step` on every sequence, the sum onward
-            auto cell = [&](int j, auto &&step) {
-              uint32_t wnext[WPT];
-              float pnext;
-              fetch(j + 1, wnext, pnext);
+            // one cell on the register set (w, pv): the look-ups, the set refilled for the cell after next, `step` on every sequence, the sum onward
+            auto cell = [&](int j, uint32_t (&w)[WPT], float &pv, auto &&step) {
               float sig[KT];
               static_for<KT>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
                 // (the field shifted down and masked is the byte offset of the sigma in the sequence's table)
-                const uint32_t at = (wcur[k / 5] >> (6 * (k % 5))) & 0xfcu;
+                const uint32_t at = (w[k / 5] >> (6 * (k % 5))) & 0xfcu;
                 sig[k] = *reinterpret_cast<const float *>(reinterpret_cast<const uint8_t *>(tab + k * kWave) + at);
               });
-              float sum = pcur;
+              float sum = pv;
+              fetch(j + 2, w, pv);
               static_for<KT>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
                 sum = sum + step(kc, sig[k], R.template at<k>());
@@ -167,22 +169,31 @@ __device__ __forceinline__ void tiled_body(const NullArgs &A, const uint8_t *__r
               } else {
                 partial[static_cast<size_t>(j) * kWave] = sum;
               }
-#pragma unroll
-              for (int x = 0; x < WPT; x++) wcur[x] = wnext[x];
-              pcur = pnext;
             };
             int j = a;
+            // the cells j .. e - 1 through `step`, in pairs on sets A and B; an odd span's last cell on A, then the sets change places
+            auto span = [&](int e, auto &&step) {
+              for (; j + 2 <= e; j += 2) {
+                cell(j, wA, pA, step);
+                cell(j + 1, wB, pB, step);
+              }
+              if (j < e) {
+                cell(j, wA, pA, step);
+                j++;
+#pragma unroll
+                for (int x = 0; x < WPT; x++) { const uint32_t tw = wA[x]; wA[x] = wB[x]; wB[x] = tw; }
+                const float tp = pA; pA = pB; pB = tp;
+              }
+            };
             {   // up to the row's first codon with a frame shift in some sequence: states 1 and 2 of EVERY sequence hold the row's running sum of omega
               const int e = SEM ? j : fe;   // (NaN tables: every cell through the recurrence as written)
               float wv = 0.0f;
               asm volatile("v_mov_b32 %0, 0" : "=v"(wv));
-              for (; j < e; j++) {
-                wv = wv + omega_v;
-                cell(j, [&](auto, float sg, auto &r) -> float {
-                  r.s0 = r.s0 + sg;
-                  return fmaxf(r.s0, wv);
-                });
-              }
+              span(e, [&](auto kc, float sg, auto &r) -> float {
+                if constexpr (decltype(kc)::value == 0) wv = wv + omega_v;   // (once per cell: the first sequence's turn)
+                r.s0 = r.s0 + sg;
+                return fmaxf(r.s0, wv);
+              });
               static_for<KT>([&](auto kc) {
                 auto &r = R.template at<decltype(kc)::value>();
                 r.s1 = r.s2 = wv;
@@ -193,23 +204,19 @@ __device__ __forceinline__ void tiled_body(const NullArgs &A, const uint8_t *__r
                 const unsigned long long z0 = zbase[static_cast<size_t>(3 * j) * ZW], z1 = ZW > 1 ? zbase[static_cast<size_t>(3 * j) * ZW + 1] : 0ull;
                 const int sb = 2 * t * KT;   // the tile's 2 KT bits out of the 128
                 const uint32_t zt = sb < 64 ? static_cast<uint32_t>((z0 >> sb) | (sb ? z1 << (64 - sb) : 0ull)) : static_cast<uint32_t>(z1 >> (sb - 64));
-                cell(j, [&](auto kc, float sg, auto &r) -> float {
+                span(j + 1, [&](auto kc, float sg, auto &r) -> float {
                   constexpr int k = decltype(kc)::value;
                   pair_step<SEM>(static_cast<int>((zt >> (2 * k)) & 3u), sg, Delta, Omega, omega, r.s0, r.s1, r.s2);
                   return ref_max3<SEM>(r.s0, r.s1, r.s2);
                 });
-                j++;
                 if (SEM) continue;
               }
-              const int e = next_event(j, jend);
-              for (; j < e; j++) {
-                cell(j, [&](auto, float sg, auto &r) -> float {
-                  r.s0 = r.s0 + sg;
-                  r.s1 = r.s1 + omega_v;
-                  r.s2 = r.s2 + omega_v;
-                  return fmaxf(fmaxf(r.s0, r.s1), r.s2);
-                });
-              }
+              span(next_event(j, jend), [&](auto, float sg, auto &r) -> float {
+                r.s0 = r.s0 + sg;
+                r.s1 = r.s1 + omega_v;
+                r.s2 = r.s2 + omega_v;
+                return fmaxf(fmaxf(r.s0, r.s1), r.s2);
+              });
             }
           }
           sample_scan_row_end(st, static_cast<uint32_t>(a));

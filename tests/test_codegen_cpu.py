@@ -246,3 +246,35 @@ def test_tiled_kernels_keep_four_wavefronts_per_simd_and_spill_nothing_in_a_cell
                 assert not any(x.startswith("scratch_") for x in b), name + ": a spill inside a cell\n" + "\n".join(b)
                 seen += 1
     assert seen >= 16
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+@pytest.mark.parametrize("unit,rows", [("rc_null_c", range(16, 22)), ("rc_null_d", range(22, 32))])
+def test_kernels_held_to_one_more_wavefront_keep_their_cells_clean(tmp_path, unit, rows):
+    """Round 6: k_null<N-1> for 17..22 rows is held to 128 VGPRs (four wavefronts per SIMD), for 25..30 rows to 168 (three) -- a SIMD needs four
+    wavefronts to issue at its rate (rc_null_kernel.h, null_min_waves).  The register allocator spills 3..35 registers to get there: the
+    straight-line cells must stay (nearly) free of them -- none up to 21 rows and from 25 to 29, at most two scratch accesses in a cell at 22 and
+    30 --, and no register an asm fetch leaves pending may be copied or spilled in front of its wait (the audit of the 7- and 12-row kernels
+    above), in any of the one-row kernels of 17..32 rows."""
+    txt = _compile_unit(tmp_path, unit)
+    names = re.findall(r"\.amdhsa_kernel (\S+)", txt)
+    for nk in rows:
+        name = next(n for n in names if "k_nullILi%dELb0ELb0ELb0ELi0E" % nk in n)
+        meta = txt[txt.index(".name:           " + name):]
+        vgprs = int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1))
+        assert vgprs <= (128 if nk <= 21 else 168 if (nk <= 23 or 24 <= nk <= 29) else 256), (nk, vgprs)
+        body = txt[txt.index(name + ":"):]
+        body = body[:body.index(".Lfunc_end")]
+        blocks, cur = [], None
+        for ln in body.split("\n"):
+            if re.match(r"^\.LBB\d+_\d+:", ln):
+                cur = []
+                blocks.append(cur)
+            elif cur is not None and ln.startswith("\t") and not ln.startswith(("\t.", "\t;")):
+                cur.append(ln.strip())
+        cells = [b for b in blocks if sum(x.startswith("ds_read_b32") for x in b) >= nk - 1]   # a sigma look-up per sequence: a straight-line cell
+        assert len(cells) >= 4, (nk, len(cells))
+        worst = max(sum(x.startswith("scratch_") for x in b) for b in cells)
+        assert worst <= (0 if nk <= 20 or 22 <= nk <= 28 or nk >= 30 else 2), (nk, worst)
+        audited, fetches = _audit_pending_registers(txt, name)
+        assert audited >= 4, (nk, audited, fetches)

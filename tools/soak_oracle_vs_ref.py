@@ -65,6 +65,9 @@ def main():
                     for q in np.flatnonzero(rng.rand(len(row)) < 0.04):
                         if row[q] != ord("-"):
                             row[q] = ord(str(rng.choice(list("NNNRYKMSWBDHVUacgt"))))
+            if rng.rand() < 0.03:   # an alignment without two of the four nucleotides: HKY85 with zero frequencies, NaN background models and the
+                for row in rows:    # reference's NaN-order-dependent MAX macro (score.h:28; the class of tests/data/soak_hss_positive_delta.json)
+                    row[:] = row.replace(b"A", b"C").replace(b"G", b"T")
             for x, row in zip(b.rows, rows):
                 x.seq = row.decode(); x.length = sum(ch != "-" for ch in x.seq)
             blocks.append(b)
