@@ -22,8 +22,8 @@ constexpr int kGenericClass = kTemplRows;   // row-count classes are indexed by 
 constexpr int kTiledMinKT = 12, kTiledMaxKT = 15;
 constexpr int kTiledClass0 = kGenericClass + 1;                                   // class of KT = kTiledMinKT
 constexpr int kClassSlots = kTiledClass0 + (kTiledMaxKT - kTiledMinKT + 1);
-constexpr int kTiledDefaultMinRows = 34;     // rc_ctx::tiledMinRows (RC_TILED_MIN_ROWS; 65 = never)
-constexpr int kTiledDefaultMaxL = 250;       // rc_ctx::tiledMaxL (RC_TILED_MAX_L): ... and only blocks of at most this many reference residues
+constexpr int kTiledDefaultMinRows = 32;     // rc_ctx::tiledMinRows (RC_TILED_MIN_ROWS; 65 = never)
+constexpr int kTiledDefaultMaxL = 250;       // rc_ctx::tiledMaxL (RC_TILED_MAX_L): ... and only blocks of at most this many reference residues (200 below 37 rows)
 // Tile size for N-1 sequences: the one that costs least by T (9 KT + 20) -- about nine instructions per sequence and cell, twenty per cell and
 // pass (the carried sum in and out, the code words, the loop), padded sequences (T KT - (N-1) of them, scored as zeros) included.
 constexpr int tiled_kt(int NK) {
@@ -41,11 +41,13 @@ constexpr int tiled_kt(int NK) {
 //   k_generic_dp     states parked in memory, any N, 4 wavefronts: 0.19 / 0.22..0.24 / 0.24..0.26 / 0.27..0.31 at 100 / 150 / 200 / 300 columns
 //   k_tiled_dp<KT>   tiles of KT sequences, the cell's sum carried between them, 4 wavefronts: 0.22..0.26 / 0.26..0.29 / 0.26..0.29 / 0.25..0.29 -- it
 //                    moves ~85 bytes per cell and sequence where the others move ~50, less where the row buffer's tail in LDS covers most of a row
-// So: templated to 33 rows (36 for long blocks), tiled from 34 rows on for blocks of up to 250 reference residues, generic for the rest from 37 on.
+// So: templated to 31 rows (36 for long blocks), tiled from 32 rows on for blocks of up to 200 reference residues and from 37 rows on up to 250,
+// generic for the rest from 37 rows on.
 // The tiled kernels score the sequences a tile's size exceeds its share by as zeros, which needs omega <= 0 (a gap state never above 0): other blocks
 // stay where they were.  (RC_GENERIC_MIN_ROWS at or below the tiled range's start switches the tiled kernels off as well: the all-generic test mode.)
 constexpr int block_class(int N, int L, float omega, int genericMinRows, int tiledMinRows, int tiledMaxL) {
-  if (N >= tiledMinRows && N <= kTemplRows && L <= tiledMaxL && genericMinRows > tiledMinRows && omega <= 0.0f) return kTiledClass0 + tiled_kt(N - 1) - kTiledMinKT;
+  const int maxL = N >= kGenericDefaultMinRows ? tiledMaxL : tiledMaxL * 4 / 5;   // (below 37 rows the templated kernels still have two wavefronts per SIMD and win on long blocks)
+  if (N >= tiledMinRows && N <= kTemplRows && L <= maxL && genericMinRows > tiledMinRows && omega <= 0.0f) return kTiledClass0 + tiled_kt(N - 1) - kTiledMinKT;
   return N < genericMinRows ? N - 1 : kGenericClass;
 }
 constexpr int kMaxNodes = 2 * kMaxRows;

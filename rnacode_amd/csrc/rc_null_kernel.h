@@ -195,6 +195,8 @@ __device__ __forceinline__ void sample_scan_last(const SampleScan &st, float &be
 // MODE 2 simulates a RANGE OF SITES of a (block, 64-sample group) and leaves the sigma codes in the item's scratch; MODE 1 then scores
 // one ROW RANGE of one strand x frame part from those codes, its S values going to a buffer instead of through the scan;
 // k_null_rowscan folds them afterwards.  MODE 0: the whole item (or one strand x frame part of it) in one workgroup.
+struct DeepFetch {};   // `kind` of a cell in the span loops that fetch TWO cells ahead (see "two cells of distance" in null_body)
+
 template <int NK, bool LDSC, bool EXACT, bool DUAL, int MODE = 0>
 __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__restrict__ blob,
                                           const DevBlock *__restrict__ dblocks, const int *__restrict__ classBlocks,
@@ -220,6 +222,10 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
   static_assert(!DUAL || (!EXACT && NK <= kDualRowsMaxNK), "two rows per pass: fast division, few sequences");
   static_assert(!(LDSC && EXACT), "the EXACT instantiation uses no LDS");
   constexpr bool ROWS = MODE == 1, SIM = MODE == 2;
+#ifndef RC_DEEP_FETCH_MAX_NK
+#define RC_DEEP_FETCH_MAX_NK 31
+#endif
+  constexpr bool kDeep = !LDSC && !EXACT && !DUAL && MODE == 0 && NK <= RC_DEEP_FETCH_MAX_NK;   // codes from L2, one row per pass: long spans fetch two cells ahead
   static_assert(MODE == 0 || (!LDSC && !EXACT && !DUAL), "rows split over workgroups: the one-row kernel that reads its codes from L2");
   // phase A: threshold table of the tree (nnodes x 64 B); phase B with LDSC: [site][NCW][64] sigma codes
   // of the current strand x frame
@@ -679,7 +685,9 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
             constexpr int t = k % CPW;
             // codes from L2: the words were fetched by the previous call and arrive in order -- wait for each one where it is first used
             // (any LDS read of the suffix cache was covered by that call's closing wait)
-            if constexpr (!LDSC && !EXACT && t == 0) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[k / CPW]) : "n"(NCW - 1 - k / CPW));
+            // (a deep cell: the other register set's NCW fetches were issued behind these and stay in flight)
+            constexpr int kYounger = std::is_same_v<std::decay_t<decltype(kind)>, DeepFetch> ? NCW : 0;
+            if constexpr (!LDSC && !EXACT && t == 0) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[k / CPW]) : "n"(NCW - 1 - k / CPW + kYounger));
             uint32_t addr;
             if constexpr (t == 0) addr = w[k / CPW]; else addr = w[k / CPW] >> (6 * t);   // bits [7:2] select the lane
             float got;
@@ -734,7 +742,8 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
             // register allocator moved w between registers at the joins -- BEFORE the wait that makes w valid --, results were wrong
             // wherever a row had frame-shift events, and the launches were 5-12 % slower on top.)  The wait for the look-ups is common
             // to both arms and behind them (inside the arms its register ties became eleven moves per arm); it covers the LDS arm's reads.
-            if (jn >= jc) fetch_cached(w, jn);
+            if constexpr (std::is_same_v<std::decay_t<decltype(kind)>, DeepFetch>) fetch_global(w, pnext);   // (the caller keeps jn in front of the suffix cache)
+            else if (jn >= jc) fetch_cached(w, jn);
             else fetch_global(w, pnext);
             wait_lookups(std::integral_constant<int, 0>{});
           } else {
@@ -875,9 +884,9 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
           constexpr int kBuf = 32;
           RowBuf buf = {};
           Regs RB;   // row a + 1 (its lut members are not used)
-          auto pristine2 = [&](uint32_t (&w)[NCW], float &wvA, float &wvB, int jn, float &vB) -> float {
+          auto pristine2 = [&](uint32_t (&w)[NCW], float &wvA, float &wvB, int jn, float &vB, auto kd) -> float {
             float sig[NK];
-            lookup(w, sig, jn, std::false_type{}, std::true_type{});
+            lookup(w, sig, jn, std::false_type{}, kd);
             wvA = wvA + omega_v;
             wvB = wvB + omega_v;
             float sumA = 0.0f, sumB = 0.0f;
@@ -895,9 +904,9 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
             vB = finish(sumB);
             return finish(sumA);
           };
-          auto fast2 = [&](uint32_t (&w)[NCW], int jn, float &vB) -> float {
+          auto fast2 = [&](uint32_t (&w)[NCW], int jn, float &vB, auto kd) -> float {
             float sig[NK];
-            lookup(w, sig, jn, std::false_type{}, std::true_type{});
+            lookup(w, sig, jn, std::false_type{}, kd);
             float sumA = 0.0f, sumB = 0.0f;
             static_for<NK>([&](auto kc) {
               constexpr int k = decltype(kc)::value;
@@ -917,9 +926,9 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
             vB = finish(sumB);
             return finish(sumA);
           };
-          auto tail2 = [&](uint32_t (&w)[NCW], int jn, float &vB) -> float {
+          auto tail2 = [&](uint32_t (&w)[NCW], int jn, float &vB, auto kd) -> float {
             float sig[NK];
-            lookup(w, sig, jn, std::false_type{}, std::true_type{});
+            lookup(w, sig, jn, std::false_type{}, kd);
             float sumA = 0.0f, sumB = 0.0f;
             static_for<NK>([&](auto kc) {
               constexpr int k = decltype(kc)::value;
@@ -991,16 +1000,39 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
                 const int idx = jj > b0 ? jj - b0 : 0;
                 buf[idx] = vB;
               };
-              {
-                const int e = next_event(j, sites);
-                for (; j < e; j++) {
-                  const int jn = j + 1 < sites ? j + 1 : j;
-                  float vB;
-                  const float v = pristine2(wcur, wvA, wvB, jn, vB);
-                  sample_scan_step(st, v, j2f, negTie);
-                  keep(vB, j);
-                  asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
+              // one cell pair (rows a and a + 1 at site jj) on the register set w: row a's value through the scan, row a + 1's into the buffer
+              auto pair_cell = [&](uint32_t (&w)[NCW], int jj, int jn, auto kd, auto &&fn) {
+                float vB;
+                const float v = fn(w, jn, vB, kd);
+                sample_scan_step(st, v, j2f, negTie);
+                keep(vB, jj);
+                const float two_c = two_v;   // (a copy: an asm operand alone does not make a generic lambda capture the variable)
+                asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_c));
+              };
+              // the cells j .. e - 1 of one kind; codes from L2: in front of the suffix cache with two cells of fetch distance on two register sets
+              // (see "Two cells of distance" at the one-row loops below)
+              auto dspan = [&](int e, auto &&fn) {
+                if constexpr (!LDSC && !EXACT && MODE == 0) {
+                  const int lim = e < jc - 2 ? e : jc - 2;
+                  if (lim - j >= 4) {
+                    uint32_t wB[NCW];
+                    {
+                      const uint32_t *p = sbase + static_cast<size_t>(j + 1) * kSiteWords;
+                      asm volatile("s_nop 4" : "+s"(p));   // a VMEM instruction must not read an SGPR within five wait states of the scalar write
+                      fetch_global(wB, p);
+                    }
+                    for (; j + 2 <= lim; j += 2) {
+                      pair_cell(wcur, j, j + 2, DeepFetch{}, fn);
+                      pair_cell(wB, j + 1, j + 3, DeepFetch{}, fn);
+                    }
+#pragma unroll
+                    for (int x = 0; x < NCW; x++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(wB[x]));   // (pending registers are not given away)
+                  }
                 }
+                for (; j < e; j++) pair_cell(wcur, j, j + 1 < sites ? j + 1 : j, std::true_type{}, fn);
+              };
+              {
+                dspan(next_event(j, sites), [&](uint32_t (&w)[NCW], int jn, float &vB, auto kd) { return pristine2(w, wvA, wvB, jn, vB, kd); });
                 static_for<NK>([&](auto kc) {
                   constexpr int k = decltype(kc)::value;
                   auto &r = R.template at<k>();
@@ -1011,12 +1043,8 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
               }
               while (j < sites) {
                 if ((zany[j >> 6] >> (j & 63)) & 1ull) {
-                  const int jn = j + 1 < sites ? j + 1 : j;
-                  float vB;
-                  const float v = event2(wcur, j, jn, vB);
-                  sample_scan_step(st, v, j2f, negTie);
-                  keep(vB, j);
-                  asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
+                  const int jev = j;
+                  pair_cell(wcur, j, j + 1 < sites ? j + 1 : j, std::true_type{}, [&](uint32_t (&w)[NCW], int jn, float &vB, auto) { return event2(w, jev, jn, vB); });
                   j++;
                 }
                 const int e = next_event(j, sites);
@@ -1028,23 +1056,9 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
                     auto &rb = RB.template at<k>();
                     rb.s1 = fmaxf(rb.s1, rb.s2);
                   });
-                  for (; j < e; j++) {
-                    const int jn = j + 1 < sites ? j + 1 : j;
-                    float vB;
-                    const float v = tail2(wcur, jn, vB);
-                    sample_scan_step(st, v, j2f, negTie);
-                    keep(vB, j);
-                    asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
-                  }
+                  dspan(e, [&](uint32_t (&w)[NCW], int jn, float &vB, auto kd) { return tail2(w, jn, vB, kd); });
                 }
-                for (; j < e; j++) {
-                  const int jn = j + 1 < sites ? j + 1 : j;
-                  float vB;
-                  const float v = fast2(wcur, jn, vB);
-                  sample_scan_step(st, v, j2f, negTie);
-                  keep(vB, j);
-                  asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
-                }
+                dspan(e, [&](uint32_t (&w)[NCW], int jn, float &vB, auto kd) { return fast2(w, jn, vB, kd); });
               }
 #pragma unroll
               for (int x = 0; x < NCW; x++) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wcur[x]));
@@ -1196,40 +1210,65 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
             const int jend = (a == sites - 1) ? sites - 1 : sites;   // the frame's final entry is handled below
             int j = a;
             float j2f = static_cast<float>(2 * a + 1);   // 2j + 1 of the cell being entered
-            // cells j .. e - 1 through body(kind)
-            auto span = [&](int e, auto &&body) {
-              for (; j < e; j++) body(std::true_type{});
-            };
-            // one cell: the site whose words are fetched behind the look-ups, EXACT's second register set, the cell, its scan step
-            auto one = [&](auto kind, auto &&cell) {
-              const int jn = j + 1 < sites ? j + 1 : j;
-              uint32_t wnext[NCW];
-              if constexpr (EXACT) load_words(jn, wnext);
-              const float v = cell(jn, kind);
+            // what becomes of a cell's S value: the item's buffer (rows split over workgroups), or getHSS's fold
+            auto take = [&](float v) {
               if constexpr (ROWS) { *sdst = v; sdst += kWave; }
               else {
                 sample_scan_step(st, v, j2f, negTie);
                 asm volatile("v_add_f32 %0, %1, %0" : "+v"(j2f) : "v"(two_v));
               }
+            };
+            // one cell on wcur: the site whose words are fetched behind the look-ups, EXACT's second register set, the cell, its scan step
+            auto one = [&](auto &&cell) {   // cell(w, jn, kind) -> S
+              const int jn = j + 1 < sites ? j + 1 : j;
+              uint32_t wnext[NCW];
+              if constexpr (EXACT) load_words(jn, wnext);
+              take(cell(wcur, jn, std::true_type{}));
               if constexpr (EXACT) {
 #pragma unroll
                 for (int x = 0; x < NCW; x++) wcur[x] = wnext[x];
               }
             };
+            // The cells j .. e - 1 of one kind.  Two cells of distance (kDeep; round 6): a fetch issued behind a cell's look-ups has the rest of
+            // that cell -- some 60 % of it -- to arrive before the next cell waits for it, against an L2 / HBM round trip of one to several cells.
+            // In a span's part in front of the suffix cache the cells therefore go in PAIRS on two register sets, wcur and wB: a cell refills its own
+            // set for the cell after next, the wait at a cell's head leaves the other set's NCW fetches in flight (lookup: kYounger), nothing is
+            // copied.  The pair loop is entered with one extra fetch (cell j + 1 into wB) and left with wB drained and dropped -- wcur then holds
+            // cell j as the single-set loop expects it, which fetches cell j + 1 once more: two fetches per span for nothing, from four cells on.
+            auto span = [&](int e, auto &&cell) {
+              if constexpr (kDeep) {
+                const int lim = e < jc - 2 ? e : jc - 2;   // a deep cell j fetches site j + 2, its partner j + 3: both in front of the suffix cache
+                if (lim - j >= 4) {
+                  uint32_t wB[NCW];
+                  {
+                    const uint32_t *p = sbase + static_cast<size_t>(j + 1) * kSiteWords;
+                    asm volatile("s_nop 4" : "+s"(p));   // a VMEM instruction must not read an SGPR within five wait states of the scalar write
+                    fetch_global(wB, p);
+                  }
+                  for (; j + 2 <= lim; j += 2) {
+                    take(cell(wcur, j + 2, DeepFetch{}));
+                    take(cell(wB, j + 3, DeepFetch{}));
+                  }
+#pragma unroll
+                  for (int x = 0; x < NCW; x++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(wB[x]));   // (pending registers are not given away)
+                }
+              }
+              for (; j < e; j++) one(cell);
+            };
             if constexpr (EXACT) {
               if (nanSem)   // (the whole row: none of the shortcuts below holds with NaN states)
                 for (; j < jend; j++) {
                   const int jj = j;
-                  one(std::true_type{}, [&](int jn, auto kd) { return nan_cell(wcur, jj, jn, kd); });
+                  one([&](uint32_t (&w)[NCW], int jn, auto kd) { return nan_cell(w, jj, jn, kd); });
                 }
             }
             {   // pristine segment: up to the row's first event
               const int e = next_event(j, jend);
               float wv = 0.0f;
               asm volatile("v_mov_b32 %0, 0" : "=v"(wv));   // keep w a per-lane register (full-rate v_add/v_max operands)
-              span(e, [&](auto kind) {
+              span(e, [&](uint32_t (&w)[NCW], int jn, auto kd) {
                 if constexpr (kProfiling) statPristine++;
-                one(kind, [&](int jn, auto kd) { return pristine_cell(wcur, wv, jn, kd); });
+                return pristine_cell(w, wv, jn, kd);
               });
               static_for<NK>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
@@ -1241,7 +1280,7 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
               if ((zany[j >> 6] >> (j & 63)) & 1ull) {               // event codon
                 if constexpr (kProfiling) statEvent++;
                 const int jj = j;
-                one(std::true_type{}, [&](int jn, auto kd) { return event_cell(wcur, jj, jn, kd); });
+                one([&](uint32_t (&w)[NCW], int jn, auto kd) { return event_cell(w, jj, jn, kd); });
                 j++;
               }
               const int e = next_event(j, jend);
@@ -1251,14 +1290,12 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
                   auto &r = R.template at<k>();
                   r.s1 = fmaxf(r.s1, r.s2);
                 });
-                span(e, [&](auto kind) {
+                span(e, [&](uint32_t (&w)[NCW], int jn, auto kd) {
                   if constexpr (kProfiling) statTail++;
-                  one(kind, [&](int jn, auto kd) { return tail_cell(wcur, jn, kd); });
+                  return tail_cell(w, jn, kd);
                 });
               }
-              span(e, [&](auto kind) {                               // tight loop: no events
-                one(kind, [&](int jn, auto kd) { return fast_cell(wcur, jn, kd); });
-              });
+              span(e, [&](uint32_t (&w)[NCW], int jn, auto kd) { return fast_cell(w, jn, kd); });   // tight loop: no events
             }
             if constexpr (!EXACT) {   // the last cell's fetch-ahead must have landed before its registers are given away
 #pragma unroll

@@ -51,6 +51,8 @@ __device__ __forceinline__ void tiled_body(const NullArgs &A, const uint8_t *__r
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   const int home = static_cast<int>(xcc & 7u);
   const int nBlocks = A.nClassBlocks;
+  // (the launch for blocks with NaN tables: k_prep_lut counted the class's flagged blocks -- none as a rule, and then no item's flag need be looked at)
+  if (A.onlyMask && A.nBlocksPtr && *A.nBlocksPtr == 0) return;
   const int parts = A.comboSplit ? 6 : 1;   // few items: one strand x frame part each (maxima meet in an atomic max), as in k_null
   for (int qi = 0; qi < 8;) {
     const int q = (home + qi) & 7;

@@ -360,6 +360,7 @@ int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t ex
           if (!b->allExact) {
             NullArgs e = r;
             e.skipMask = extraSkip; e.onlyMask = kFlagNan; e.workCounter = nanWork;
+            e.nBlocksPtr = b->dcounters.as<int>() + kCntExact + p.NK;   // the class's blocks flagged by k_prep_lut (every NaN block is one)
             (void)launch_tiled_dp(p.tiledKT, true, e, std::min(p.grid, c->numCU), p.ldsDp, base + codesAllBytes, st);
             b->nl[2]++;
           }

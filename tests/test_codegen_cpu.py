@@ -65,6 +65,7 @@ def test_k_null_cell_loops_are_wave_uniform_and_tight(tmp_path):
 
 PLAIN = "_ZN2rc6k_nullILi6ELb0ELb0ELb0ELi0EEEvNS_8NullArgsEPKhPKNS_8DevBlockEPKiPKjSA_S3_PjPf"      # k_null<6, false, false, false>
 OCC6 = "_ZN2rc10k_null_occILi6EEEvNS_8NullArgsEPKhPKNS_8DevBlockEPKiPKjSA_S3_PjPf"             # k_null_occ<6>
+NCW_WAIT_WINDOW = 12   # instructions behind a row's first fetch within which its full wait stands
 _FETCH = re.compile(r"(?:global_load_(?:dword|ubyte|ushort) (v\d+), v\d+, s\[\d+:\d+\]|ds_read_(?:b32|u8|u16) (v\d+), v\d+)")
 
 
@@ -85,12 +86,16 @@ def _audit_pending_registers(txt, name):
     body = body[:body.index(".Lfunc_end")]
     blocks, order = {}, []
     cur, hdr = None, None
+    inner = set()   # labels the assembly printer marks "This Inner Loop Header": the innermost loops
     for ln in body.split("\n"):
         m = re.match(r"^(\.LBB\d+_\d+):\s*(?:;.*Header=(BB\d+_\d+) Depth=(\d+))?", ln)
         if m:
             cur = m.group(1)
             blocks[cur] = {"ins": [], "header": ("." + "L" + m.group(2)) if m.group(2) else None, "depth": int(m.group(3) or 0), "asm": []}
             order.append(cur)
+            continue
+        if cur is not None and "This Inner Loop Header" in ln and not blocks[cur]["ins"]:
+            inner.add(cur)
             continue
         m = re.match(r"^; %bb\.\d+:\s*;.*Header=(BB\d+_\d+) Depth=(\d+)", ln)
         if m and cur is not None:   # an unlabelled block of the same loop: keep appending
@@ -103,7 +108,27 @@ def _audit_pending_registers(txt, name):
         h = b["header"] or lab
         loops.setdefault(h, []).append(lab)
     audited = fetches = 0
+    # Round 6: a span's pair loop (two cells of fetch distance) is entered behind ONE fetch into the second register set, issued in the block in
+    # front of the loop: from that fetch to the loop's header nothing may copy or spill its destination either.
+    for k, lab in enumerate(order):
+        ins = blocks[lab]["ins"]
+        if lab in inner:
+            continue
+        for at, x in enumerate(ins):
+            m = re.match(r"global_load_(?:dword|ubyte|ushort) (v\d+), v\d+, s\[\d+:\d+\]", x)
+            if not m:
+                continue
+            reg = m.group(1)
+            tail = ins[at + 1:]
+            if any(y.startswith("s_waitcnt") and "vmcnt(0)" in y for y in tail[:NCW_WAIT_WINDOW]):
+                continue   # a row's first site: fetched and waited for on the spot (load_words)
+            nxt = order[k + 1] if k + 1 < len(order) else None
+            if nxt in inner and not any(y.startswith(("s_cbranch", "s_branch")) for y in tail):   # falls through into the pair loop
+                bad = [y for y in tail if (re.match(r"v_mov_b32(_e32)? v\d+, %s$" % reg, y) or (y.startswith("scratch_store") and re.search(r"\b%s\b" % reg, y)))]
+                assert not bad, name + ": the register of a pair loop's entry fetch is copied or spilled in front of the loop:\n" + "\n".join(bad)
     for h, labs in loops.items():
+        if h not in inner:
+            continue   # (outer loops only hold such entry fetches and the rows' first sites; their blocks reuse the cells' registers for other values)
         ins = [x for lab in labs for x in blocks[lab]["ins"]]
         # the sigma look-ups of a cell: ds_bpermute_b32, or (codes from L2) ds_read_b32 from the LDS tables at an address masked with 0xfc
         table_addr = {m.group(1) for x in ins for m in [re.match(r"v_and_b32 (v\d+), 0xfc, v\d+", x)] if m}

@@ -606,7 +606,7 @@ def test_fits_on_few_samples_sum_in_the_references_order(ctx):
 
 
 def test_tiled_kernels_equal_the_oracle(monkeypatch):
-    """k_tiled_dp<KT> (rc_null_tiled.h; blocks of 34..64 rows and up to 210 reference residues by default, here from 17 rows on and any length):
+    """k_tiled_dp<KT> (rc_null_tiled.h; blocks of 32..64 rows and up to 200..250 reference residues by default, here from 17 rows on and any length):
     the sequences besides the reference in tiles of 12..15, a cell's sum carried from tile to tile in score.c's order.  Per-sample maxima, HSS
     tables and fit verdicts against the oracle for every tile size and 2..5 tiles, rows longer than the row buffer's LDS tail (300 columns), 64
     rows (the second z word, a fifth tile), a batch of one block (strand x frame parts over workgroups), a block without two of the nucleotides
