@@ -1335,7 +1335,9 @@ __device__ __forceinline__ void null_body(const NullArgs &A, const uint8_t *__re
 // 20 rows x 150 / 300 columns 0.307 / 0.388 -> 0.338 / 0.431 of the issue roof, 28 rows 0.252 / 0.325 -> 0.310 / 0.362.  Not at 23, 24 rows (three
 // scratch accesses per cell: 0.313 / 0.392 -> 0.308 / 0.373) nor at 31, 32 (six: 0.245 / 0.315 -> 0.213 / 0.237, and the audit finds a pending
 // register copied).  profiles/r06/rows_sweep_before.txt, rows_sweep_forced_occupancy.txt, rows_sweep_after.txt.
-constexpr int null_min_waves(int NK, bool EXACT, bool DUAL, int MODE) { return (EXACT || DUAL || MODE != 0) ? 1 : (NK >= 16 && NK <= 21) ? 4 : (NK >= 24 && NK <= 29) ? 3 : 1; }
+// 7, 10 and 11 rows: the second register set of the two-cell fetch distance cost these three a wavefront (78 -> 83, 90 -> 97, 95 -> 103 VGPRs); told
+// what to aim for, the register allocator fits them into 78 / 89 / 94 again without a single spill.
+constexpr int null_min_waves(int NK, bool EXACT, bool DUAL, int MODE) { return (EXACT || DUAL || MODE != 0) ? 1 : NK == 6 ? 6 : (NK == 9 || NK == 10) ? 5 : (NK >= 16 && NK <= 21) ? 4 : (NK >= 24 && NK <= 29) ? 3 : 1; }
 template <int NK, bool LDSC, bool EXACT, bool DUAL = false, int MODE = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(null_min_waves(NK, EXACT, DUAL, MODE))))
 void k_null(NullArgs A, const uint8_t *__restrict__ blob,
