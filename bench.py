@@ -744,7 +744,8 @@ def main():
     t_gen = time.perf_counter() - t0
     exchange_auto = args.exchange == "auto"
     if exchange_auto:   # every rank decides alike: the largest shard's payload
-        args.exchange = "fits" if max(counts) * args.samples * 4 > (64 << 20) else "maxima"
+        limit = float(os.environ.get("RC_BENCH_EXCHANGE_AUTO_MB", "64")) * (1 << 20)   # (the variable: a test hook)
+        args.exchange = "fits" if max(counts) * args.samples * 4 > limit else "maxima"
 
     # one GPU, the default workload: the legs that start child processes run first, before this process touches a GPU
     single = world == 1 and not multi

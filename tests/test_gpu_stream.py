@@ -457,6 +457,22 @@ def test_eight_ranks_on_one_gpu_gather_the_single_rank_result(tmp_path):
         assert eight["value"] > 0 and eight["config"]["exchange_ab"]["chosen"] == "synchronous"
 
 
+def test_eight_ranks_on_the_long_block_config_and_the_automatic_exchange(tmp_path):
+    """`bench.py --config c5 --gpus 8` (the shape of BASELINE configs[4], 64 blocks of it, all eight ranks on device 0): the gathered maxima equal
+    a single rank's; every rank's host-inclusive stream is also measured as ONE continuous stream with an exchange per pass (round 6); and
+    `--exchange auto` gathers the maxima while a rank's share is small and switches to the 16-byte fit rows above the limit (64 MB per rank and
+    step: configs[4] whole is 500 MB per rank; lowered here through the test hook)."""
+    args = ("--config", "c5", "--blocks", "64", "--samples", "256", "--no-weak")
+    one, m1 = _bench(tmp_path, 1, extra=args)
+    eight, m8 = _bench(tmp_path, 8, extra=args, env_extra={"RC_BENCH_TEST_BACKEND": "gloo"})
+    assert eight["n_gpus"] == 8 and eight["n_ranks_seen"] == 8 and m1.shape == (64, 256)
+    np.testing.assert_array_equal(m1, m8)
+    assert "all-gather of maxima (auto)" in eight["config"]["exchange"]
+    assert eight["stream"]["continuous"]["ms_per_step"] > 0 and eight["stream"]["ms_per_step"] > 0
+    fits, mf = _bench(tmp_path, 8, extra=args, env_extra={"RC_BENCH_TEST_BACKEND": "gloo", "RC_BENCH_EXCHANGE_AUTO_MB": "0.001"})
+    assert "all-gather of fits (auto)" in fits["config"]["exchange"] and mf.shape == (64, 4) and (mf[:, 0] == 1).all()
+
+
 def test_bench_survives_a_failing_collective_library(tmp_path):
     """If the RCCL path raises -- at init, in the warm-up comparison of the two exchange orders, or in a gather -- bench.py falls back
     to the synchronous exchange through host memory, records the exception text in config.exchange_ab and still prints its line with

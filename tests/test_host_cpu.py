@@ -235,3 +235,46 @@ def test_native_driver_limit_prunes_rows_like_prune_aln(tmp_path):
     assert r.stdout == ("B 0\nS hg18.chr1 0 9 + ATGGCTAAA\nS mm9.chr1 0 9 + ATGGCAAAA\nS hg18b.chr1 0 9 + ATGGCTAAG\nS canFam2.chr3 0 9 + ATG---AAG\nE\n"
                         "B 1\nS mm9.chr2 5 3 + ATG\nE\n")
     assert r.stderr.count("Skipping alignment.") == 1   # the block that lost every row
+
+
+def test_which_kernel_a_block_takes_and_the_tile_sizes(tmp_path):
+    """rc_device.h decides a block's class in one place (block_class): per-row-count kernels to 31 rows, the tiled ones (32..64 rows of short
+    blocks, omega <= 0) and the generic ones (from 37 rows on); tiled_kt picks the tile size with the least work.  Compiled on the host."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not on PATH")
+    src = tmp_path / "t.cpp"
+    src.write_text(r'''
+#include "rc_device.h"
+#include <cstdio>
+using namespace rc;
+int main() {
+  const int G = kGenericDefaultMinRows, T = kTiledDefaultMinRows, ML = kTiledDefaultMaxL;
+  int bad = 0;
+  for (int nk = 16; nk <= 63; nk++) {
+    const int kt = tiled_kt(nk), tiles = (nk + kt - 1) / kt;
+    bad += kt < kTiledMinKT || kt > kTiledMaxKT || tiles * kt - nk >= kt;          // never a whole tile of padding
+    for (int other = kTiledMinKT; other <= kTiledMaxKT; other++) {                   // ... and no other size does it in fewer passes
+      const int t2 = (nk + other - 1) / other;
+      bad += t2 < tiles;
+    }
+  }
+  bad += block_class(6, 118, -2.0f, G, T, ML) != 5;                                  // the headline's class: N - 1
+  bad += block_class(31, 300, -2.0f, G, T, ML) != 30;
+  bad += block_class(32, 150, -2.0f, G, T, ML) != kTiledClass0 + tiled_kt(31) - kTiledMinKT;
+  bad += block_class(32, 300, -2.0f, G, T, ML) != 31;                                // long blocks below 37 rows: the per-row-count kernels
+  bad += block_class(40, 150, -2.0f, G, T, ML) != kTiledClass0 + tiled_kt(39) - kTiledMinKT;
+  bad += block_class(40, 300, -2.0f, G, T, ML) != kGenericClass;
+  bad += block_class(40, 150, 0.5f, G, T, ML) != kGenericClass;                      // omega > 0: never the tiled kernels
+  bad += block_class(64, 90, -2.0f, G, T, ML) != kTiledClass0 + tiled_kt(63) - kTiledMinKT;
+  bad += block_class(65, 90, -2.0f, G, T, ML) != kGenericClass;
+  bad += block_class(40, 150, -2.0f, 3, T, ML) != kGenericClass;                     // RC_GENERIC_MIN_ROWS=3: everything generic
+  bad += block_class(40, 150, -2.0f, 65, 65, ML) != 39;                              // both switched off: k_null<39>
+  std::printf("%d\n", bad);
+  return bad != 0;
+}
+''')
+    exe = tmp_path / "t"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "rnacode_amd", "csrc"), str(src), "-o", str(exe)])
+    assert subprocess.check_output([str(exe)], text=True).strip() == "0"
