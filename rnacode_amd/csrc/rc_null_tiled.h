@@ -112,12 +112,6 @@ __device__ __forceinline__ void tiled_body(const NullArgs &A, const uint8_t *__r
           const int jend = (a == sites - 1) ? sites - 1 : sites;   // the frame's final entry is never reported (score.c:892-900)
           const int fe = next_event(a, jend);                      // the row's first codon with a frame shift in some sequence
           for (int t = 0; t < T; t++) {
-            // tile t's tables: [k][64] floats, zeros for the sequences the tile has too many of
-            static_for<KT>([&](auto kc) {
-              constexpr int k = decltype(kc)::value;
-              const int kk = t * KT + k;
-              tab[k * kWave + lane] = kk < NK ? lut[(static_cast<size_t>(s) * NK + kk) * kLutSize + lane] : 0.0f;
-            });
             const bool first = t == 0, last = t == T - 1;
             const uint32_t *__restrict__ ct = cbase + static_cast<size_t>(t) * WPT * kWave;
             Regs R;
@@ -144,6 +138,12 @@ __device__ __forceinline__ void tiled_body(const NullArgs &A, const uint8_t *__r
             };
             fetch(a, wA, pA);
             fetch(a + 1, wB, pB);
+            // tile t's tables: [k][64] floats, zeros for the sequences the tile has too many of (behind the row's first fetches: one round trip, not two)
+            static_for<KT>([&](auto kc) {
+              constexpr int k = decltype(kc)::value;
+              const int kk = t * KT + k;
+              tab[k * kWave + lane] = kk < NK ? lut[(static_cast<size_t>(s) * NK + kk) * kLutSize + lane] : 0.0f;
+            });
             float j2f = static_cast<float>(2 * a + 1);
             // one cell on the register set (w, pv): the look-ups, the set refilled for the cell after next, `step` on every sequence, the sum onward
             auto cell = [&](int j, uint32_t (&w)[WPT], float &pv, auto &&step) {
