@@ -99,6 +99,10 @@ int batch_prepare(rc_batch *b, const rc_block *blocks, int32_t n_blocks, const r
   // list is the order of dispatch (longest-processing-time-first keeps the tail short)
   if (!sameL)
     for (auto &kv : b->classes) std::stable_sort(kv.second.begin(), kv.second.end(), [&](int x, int y) { return b->meta[x].L > b->meta[y].L; });
+  // a tiled class holds several row counts: most rows first (the costlier items), each row count one contiguous piece of the list -- the native
+  // block's kernels are launched per row count (rc_schedule.cpp)
+  for (auto &kv : b->classes)
+    if (kv.first > kGenericClass) std::stable_sort(kv.second.begin(), kv.second.end(), [&](int x, int y) { return b->meta[x].NK > b->meta[y].NK; });
 
   // tail of the host part: headers and lists, so that ONE copy moves everything
   uint8_t *base = arena.host;

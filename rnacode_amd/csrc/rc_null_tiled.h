@@ -13,6 +13,9 @@
 // launches per round of items like the wide-block path: k_generic_sim<true> leaves an item's sigma codes in the tile-major layout below,
 // k_tiled_dp<KT> scores them.  Sequences a block's last tile has too many of (T KT - (N-1)) are scored as zeros: sigma table 0, z = 0, so s0 = 0,
 // the gap states never above 0 (omega <= 0: the host sends other blocks elsewhere, rc_device.h block_class) and the maximum +0.0.
+// (Two ROWS per pass on one fetch of the code words -- most of what a pass reads -- was built and measured in round 6: bit-identical, 30 % fewer
+// bytes, 18 % fewer instructions, and slower: 72..90 state registers spill at four wavefronts per SIMD (0.16 of the issue roof) and run 0.22..0.25 at
+// three, against 0.27..0.30 here.  profiles/r06/ab_tiled_two_rows.txt, docs/history/tiled_two_rows_per_pass.patch.)
 // SEM = true: the instantiation for blocks with NaN score tables (the reference's MAX macro, rc_null_kernel.h ref_max), a second launch that takes
 // only those.  Division and the maximum with Delta are the plain ones (one per cell and row, in the last pass).
 #pragma once

@@ -42,49 +42,62 @@ int launch_native_block(const RunEnv &R) {
   na.flags = b->dflags.as<uint32_t>();
   HIP_TRY(hipMemsetAsync(b->dhssCount.p, 0, static_cast<size_t>(R.n) * 6 * sizeof(int), st));
   launch_native_sigma(na, static_cast<int>(b->okBlocks.size()), st); b->nl[3]++;
-  {   // one 64-row buffer per persistent workgroup, shared by the class launches (same stream)
-    size_t need = 0;
-    for (auto &kv : b->classes) {
-      if (kv.first >= kGenericClass) continue;
-      int smaxClass = 1;
-      for (int bi : kv.second) smaxClass = std::max(smaxClass, b->meta[bi].L / 3);
-      const size_t grid = native_grid(c, kv.second.size() * 6, smaxClass, R.nativeMode);
-      need = std::max(need, grid * kWave * smaxClass);
+  // Groups of blocks with one row count, each a contiguous piece of its class's list: a per-row-count class is one group; a tiled class (row
+  // counts mixed, its list sorted by row count: rc_batch.cpp) one per row count -- the native block of its blocks goes through k_native_dp<N-1>
+  // like any block of up to 64 rows (k_native_dp_generic, one wavefront per matrix with its states in memory, took 7 ms for 1662 blocks of
+  // 40 x 150 where k_native_dp<39> takes 0.4).
+  struct Group { int NK; const int *list; size_t count; int smax; };
+  std::vector<Group> groups;
+  for (auto &kv : b->classes) {
+    if (kv.first == kGenericClass) continue;
+    const int *list = R.classList + b->classOff[kv.first];
+    const auto &mem = kv.second;
+    for (size_t at = 0; at < mem.size();) {
+      size_t end = at;
+      int smax = 1;
+      const int nk = b->meta[mem[at]].NK;
+      while (end < mem.size() && b->meta[mem[end]].NK == nk) { smax = std::max(smax, b->meta[mem[end]].L / 3); end++; }
+      groups.push_back(Group{nk, list + at, end - at, smax});
+      at = end;
     }
+  }
+  {   // one 64-row buffer per persistent workgroup, shared by the group launches (same stream)
+    size_t need = 0;
+    for (const Group &g : groups) need = std::max(need, native_grid(c, g.count * 6, g.smax, R.nativeMode) * kWave * g.smax);
     HIP_TRY(b->dnativeTile.ensure(std::max<size_t>(need, 4) * sizeof(float)));
   }
-  for (auto &kv : b->classes) {
+  if (b->classes.count(kGenericClass)) {   // more than 64 rows: states in a scratch, at most 256 blocks per launch share it
+    const auto &mem = b->classes[kGenericClass];
     NativeArgs nc = na;
-    nc.blocks = R.classList + b->classOff[kv.first];
-    if (kv.first >= kGenericClass) {   // more than 64 rows, or a tiled class (row counts mixed): states in a scratch, at most 256 blocks per launch share it
-      int maxNK = 0, smaxG = 1;
-      for (int bi : kv.second) { maxNK = std::max(maxNK, b->meta[bi].NK); smaxG = std::max(smaxG, b->meta[bi].L / 3); }
-      const size_t stride = static_cast<size_t>(3) * maxNK * kWave + static_cast<size_t>(kWave) * smaxG;   // states, then 64 rows of S
-      const int chunk = 256;
-      HIP_TRY(b->dnativeScratch.ensure(stride * 6 * std::min<size_t>(chunk, kv.second.size()) * sizeof(float)));
-      for (size_t at = 0; at < kv.second.size(); at += chunk) {
-        NativeArgs ng = nc;
-        ng.blocks = nc.blocks + at;
-        launch_native_dp_generic(ng, static_cast<int>(std::min<size_t>(chunk, kv.second.size() - at)), b->dnativeScratch.as<float>(), stride, st);
-        b->nl[3]++;
-      }
-      continue;
+    nc.blocks = R.classList + b->classOff[kGenericClass];
+    int maxNK = 0, smaxG = 1;
+    for (int bi : mem) { maxNK = std::max(maxNK, b->meta[bi].NK); smaxG = std::max(smaxG, b->meta[bi].L / 3); }
+    const size_t stride = static_cast<size_t>(3) * maxNK * kWave + static_cast<size_t>(kWave) * smaxG;   // states, then 64 rows of S
+    const int chunk = 256;
+    HIP_TRY(b->dnativeScratch.ensure(stride * 6 * std::min<size_t>(chunk, mem.size()) * sizeof(float)));
+    for (size_t at = 0; at < mem.size(); at += chunk) {
+      NativeArgs ng = nc;
+      ng.blocks = nc.blocks + at;
+      launch_native_dp_generic(ng, static_cast<int>(std::min<size_t>(chunk, mem.size() - at)), b->dnativeScratch.as<float>(), stride, st);
+      b->nl[3]++;
     }
+  }
+  for (const Group &g : groups) {
     // up to 64 rows: DP and getHSS fused, 64 rows of one matrix at a time through a per-workgroup buffer (persistent grid)
-    int smaxClass = 1;
-    for (int bi : kv.second) smaxClass = std::max(smaxClass, b->meta[bi].L / 3);
-    nc.nItems = static_cast<int>(kv.second.size()) * 6;
-    nc.tileStride = static_cast<size_t>(kWave) * smaxClass;
-    const int grid = static_cast<int>(native_grid(c, static_cast<size_t>(nc.nItems), smaxClass, R.nativeMode));
+    NativeArgs nc = na;
+    nc.blocks = g.list;
+    nc.nItems = static_cast<int>(g.count) * 6;
+    nc.tileStride = static_cast<size_t>(kWave) * g.smax;
+    const int grid = static_cast<int>(native_grid(c, static_cast<size_t>(nc.nItems), g.smax, R.nativeMode));
     nc.tile = b->dnativeTile.as<float>();
-    // every matrix of the class kept for a scan with one lane per matrix, where that fits in a sixteenth of the device memory
+    // every matrix of the group kept for a scan with one lane per matrix, where that fits in a sixteenth of the device memory
     // (headline: 10 000 blocks x 6 x 40 x 40 floats = 384 MB); otherwise DP and scan fused, 64 rows at a time
-    const size_t allFloats = static_cast<size_t>(nc.nItems) * smaxClass * smaxClass;
-    if (allFloats * sizeof(float) <= c->totalMem / 16 && nc.nItems >= 6 * 64 && (kv.first <= 16 || kv.first > 32)) {   // (17..32: see k_native_dp)
+    const size_t allFloats = static_cast<size_t>(nc.nItems) * g.smax * g.smax;
+    if (allFloats * sizeof(float) <= c->totalMem / 16 && nc.nItems >= 6 * 64 && (g.NK <= 16 || g.NK > 32)) {   // (17..32: see k_native_dp)
       HIP_TRY(b->dnativeAll.ensure(std::max<size_t>(allFloats, 4) * sizeof(float)));
-      nc.sAll = b->dnativeAll.as<float>(); nc.sAllSites = smaxClass;
+      nc.sAll = b->dnativeAll.as<float>(); nc.sAllSites = g.smax;
     }
-    if (!launch_native_dp(kv.first, nc, grid, st))
+    if (!launch_native_dp(g.NK, nc, grid, st))
       return fail(RC_ERR_UNSUPPORTED, "no native DP kernel for this number of rows");
     b->nl[3]++;
     if (nc.sAll) { launch_native_scan(nc, st); b->nl[3]++; }
@@ -177,18 +190,20 @@ int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t ex
       }
       const long long slotsD = static_cast<long long>(c->numCU) * occD;
       const long long items = static_cast<long long>(kv.second.size()) * groupsHere;
+      // The sigma codes of every item of a round lie in the scratch at once (N x L x 2 bytes per sample; 5 MB per item at 100 x 300): as few
+      // rounds as the scratch budget allows, of equal numbers of blocks.  (Rounds of a whole number of the DP's wavefront slots, as before the
+      // items went in parts, left 257 blocks of 64 x 300 -- 4112 items, all within the budget -- a second round of 16 items: a simulation and a
+      // DP of single chains on an empty chip, 180 ms against 127 for 256 blocks.)
+      const long long budgetBlocks = std::max<long long>(1, static_cast<long long>(c->genericScratchWords * sizeof(uint32_t) / p.codesBytes) / groupsHere);
+      const long long nBlocksHere = static_cast<long long>(kv.second.size());
+      const long long rounds = (nBlocksHere + budgetBlocks - 1) / budgetBlocks;
+      p.roundBlocks = static_cast<int>((nBlocksHere + rounds - 1) / rounds);
+      const long long roundItems = static_cast<long long>(p.roundBlocks) * groupsHere;
       // few items: every item's DP is split into its six strand x frame parts to fill the chip (maxima meet in an atomic max)
-      // ... and so is every item of a batch that fills the chip only a few times over: the simulation is a launch of its own here, the parts redo
+      // ... and so is every item of a round that fills the chip only a few times over: the simulation is a launch of its own here, the parts redo
       // nothing, and items of minutes-long cost otherwise quantise badly -- 257 blocks of 64 x 300 are 4112 items on 4096 wavefront slots and took as
       // long as 8192 (334 ms against 168 for 294 blocks of 56 x 300: tools/rows_sweep.py)
-      p.comboSplit = ((together ? splitAll : static_cast<double>(items) <= c->splitFactor * c->numCU * occD) || items < 8 * slotsD) ? 1 : 0;
-      // The sigma codes of every item of a round lie in the scratch at once (N x L x 2 bytes per sample; 5 MB per item at 100 x 300):
-      // rounds of as many items as the scratch budget holds -- a whole number of the DP's wavefront slots when it holds more than
-      // one (items of a class cost about the same: 4600 items on 4096 slots take as long as 8192).
-      long long roundItems = std::max<long long>(groupsHere, static_cast<long long>(c->genericScratchWords * sizeof(uint32_t) / p.codesBytes));
-      if (roundItems > slotsD) roundItems -= roundItems % slotsD;
-      p.roundBlocks = static_cast<int>(std::max<long long>(1, std::min<long long>(static_cast<long long>(kv.second.size()), roundItems / groupsHere)));
-      roundItems = static_cast<long long>(p.roundBlocks) * groupsHere;
+      p.comboSplit = ((together ? splitAll : static_cast<double>(items) <= c->splitFactor * c->numCU * occD) || roundItems < 8 * slotsD) ? 1 : 0;
       p.grid = static_cast<int>(std::min<long long>(roundItems * (p.comboSplit ? 6 : 1), slotsD));
       p.simGrid = static_cast<int>(std::min<long long>(roundItems, static_cast<long long>(c->numCU) * occS));
       p.need = (static_cast<size_t>(roundItems) * p.codesBytes + static_cast<size_t>(p.grid) * p.stateBytes + 3) / 4 + 64;
