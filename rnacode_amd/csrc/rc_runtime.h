@@ -319,7 +319,8 @@ struct rc_ctx {
   int classPrio = 0;               // priority of the class streams
   int expMode = 0;                 // the EVD fit's exp: the host C library's algorithm and variant, if it is one the library knows (rc_refexp.h)
   std::mutex streamMutex;          // ctx_stream
-  std::vector<hipStream_t> classStreams;   // k_null launches of different row-count classes, when a batch has several
+  std::vector<hipStream_t> classStreams;   // k_null launches of different row-count classes, when a batch has several: these beside the run's own stream
+  int classStreamCount = 3;                // ... that many in all (RC_CLASS_STREAMS)
   unsigned seq = 0;
   CodeTables ct62{62}, ct90{90};
   PairTable pt62, pt90;

@@ -297,22 +297,29 @@ int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t ex
   size_t scratchOff = 0;
   if (concurrent) while (b->classDone.size() < static_cast<size_t>(kMaxRounds) * plans.size()) b->classDone.emplace_back(new Event());
   trace("null: planned", b);
+  std::vector<Event *> joins;
   for (size_t pi = 0; pi < plans.size(); pi++) {
     const Plan &p = plans[pi];
     const auto &members = b->classes[p.NK];
     hipStream_t st = R.cs;
     if (concurrent) {
-      // Four streams for the classes' launches, whatever their number: the ten-class workload takes 85..87 ms on 2, 3, 4, 5, 6 or 12 of them
-      // (the launches are persistent grids that share the chip by their sizes, not by their queues), a stream costs 10 ms to create -- ten
-      // were 95 ms inside a fresh process's first submit -- and every one is a hardware queue more for the device to schedule.
-      while (c->classStreams.size() < std::min<size_t>(plans.size(), 4)) {
-        hipStream_t ns = nullptr;
-        HIP_TRY(hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, c->classPrio));
-        c->classStreams.push_back(ns);
+      // Three streams for the classes' launches, whatever their number -- this run's own and two more: as ONE resident batch the ten-class
+      // workload takes 84..86 ms on 1, 2, 3 or 5 of them (the launches are persistent grids that share the chip by their sizes, not by their
+      // queues); as a stream of 1024-block sub-batches 141 / 129 / 100 / 103 ms (consecutive sub-batches overlap through the queues); and a
+      // stream costs a fresh process 10..14 ms to create -- the first submit of the ten-class file 0.12..0.14 s with five, 0.08..0.10 with two --
+      // and is a hardware queue more for the device to schedule.  (RC_CLASS_STREAMS: their number, this run's included;
+      // profiles/r06/class_streams.txt.)
+      const size_t slot = pi % std::min<size_t>(plans.size(), static_cast<size_t>(c->classStreamCount));
+      if (slot > 0) {
+        while (c->classStreams.size() < slot) {
+          hipStream_t ns = nullptr;
+          HIP_TRY(hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, c->classPrio));
+          c->classStreams.push_back(ns);
+        }
+        st = c->classStreams[slot - 1];
       }
-      st = c->classStreams[pi % c->classStreams.size()];
       if (pi == 0) trace("null: streams", b);
-      HIP_TRY(hipStreamWaitEvent(st, fork, 0));   // the memsets / the stop marks
+      if (st != R.cs) HIP_TRY(hipStreamWaitEvent(st, fork, 0));   // the memsets / the stop marks
     }
     NullArgs a{};
     a.blob = R.blob; a.dblocks = R.dblocks;
@@ -422,11 +429,14 @@ int launch_null_groups(const RunEnv &R, int gLo, int gHi, int phase, uint32_t ex
     if (pi == 0) trace("null: first class", b);
     if (concurrent) {
       scratchOff += p.need;
-      Event &done = *b->classDone[static_cast<size_t>(phase) * plans.size() + pi];
-      HIP_TRY(done.record(st));
-      HIP_TRY(hipStreamWaitEvent(R.cs, done, 0));
+      if (st != R.cs) {   // (this run's stream waits for the others when every class is queued: a wait in between would hold its own next class back)
+        Event &done = *b->classDone[static_cast<size_t>(phase) * plans.size() + pi];
+        HIP_TRY(done.record(st));
+        joins.push_back(&done);
+      }
     }
   }
+  for (Event *done : joins) HIP_TRY(hipStreamWaitEvent(R.cs, *done, 0));
   return RC_OK;
 }
 
