@@ -16,6 +16,10 @@
 // (Two ROWS per pass on one fetch of the code words -- most of what a pass reads -- was built and measured in round 6: bit-identical, 30 % fewer
 // bytes, 18 % fewer instructions, and slower: 72..90 state registers spill at four wavefronts per SIMD (0.16 of the issue roof) and run 0.22..0.25 at
 // three, against 0.27..0.30 here.  profiles/r06/ab_tiled_two_rows.txt, docs/history/tiled_two_rows_per_pass.patch.)
+// (Also measured and taken back in round 6, each 2..4 % slower: the last two cells of a pass fetching the next pass's first two -- the other three
+// wavefronts of the SIMD already hide that round trip --, and the look-ups written out with ONE s_waitcnt behind them instead of the compiler's
+// thirteen: the cell is bound by its vector instructions (4.5 cycles of SIMD time per VALU instruction at 0.30), not by scalar issue slots.
+// profiles/r06/ab_tiled_tile_events.txt.)
 // SEM = true: the instantiation for blocks with NaN score tables (the reference's MAX macro, rc_null_kernel.h ref_max), a second launch that takes
 // only those.  Division and the maximum with Delta are the plain ones (one per cell and row, in the last pass).
 #pragma once
@@ -190,38 +194,60 @@ __device__ __forceinline__ void tiled_body(const NullArgs &A, const uint8_t *__r
                 const float tp = pA; pA = pB; pB = tp;
               }
             };
-            {   // up to the row's first codon with a frame shift in some sequence: states 1 and 2 of EVERY sequence hold the row's running sum of omega
-              const int e = SEM ? j : fe;   // (NaN tables: every cell through the recurrence as written)
-              float wv = 0.0f;
-              asm volatile("v_mov_b32 %0, 0" : "=v"(wv));
-              span(e, [&](auto kc, float sg, auto &r) -> float {
-                if constexpr (decltype(kc)::value == 0) wv = wv + omega_v;   // (once per cell: the first sequence's turn)
-                r.s0 = r.s0 + sg;
-                return fmaxf(r.s0, wv);
-              });
-              static_for<KT>([&](auto kc) {
-                auto &r = R.template at<decltype(kc)::value>();
-                r.s1 = r.s2 = wv;
-              });
-            }
-            while (j < jend) {
-              if (SEM || ((zany[j >> 6] >> (j & 63)) & 1ull)) {   // a codon with z != 0 in some sequence (score.c:512-533), wave-uniform branch per sequence
-                const unsigned long long z0 = zbase[static_cast<size_t>(3 * j) * ZW], z1 = ZW > 1 ? zbase[static_cast<size_t>(3 * j) * ZW + 1] : 0ull;
-                const int sb = 2 * t * KT;   // the tile's 2 KT bits out of the 128
-                const uint32_t zt = sb < 64 ? static_cast<uint32_t>((z0 >> sb) | (sb ? z1 << (64 - sb) : 0ull)) : static_cast<uint32_t>(z1 >> (sb - 64));
-                span(j + 1, [&](auto kc, float sg, auto &r) -> float {
-                  constexpr int k = decltype(kc)::value;
-                  pair_step<SEM>(static_cast<int>((zt >> (2 * k)) & 3u), sg, Delta, Omega, omega, r.s0, r.s1, r.s2);
-                  return ref_max3<SEM>(r.s0, r.s1, r.s2);
+            // the tile's 2 KT bits of a codon's z entries (two bits per sequence, 128 per codon)
+            auto tile_z = [&](int je) -> uint32_t {
+              const unsigned long long z0 = zbase[static_cast<size_t>(3 * je) * ZW], z1 = ZW > 1 ? zbase[static_cast<size_t>(3 * je) * ZW + 1] : 0ull;
+              const int sb = 2 * t * KT;
+              const uint32_t zt = sb < 64 ? static_cast<uint32_t>((z0 >> sb) | (sb ? z1 << (64 - sb) : 0ull)) : static_cast<uint32_t>(z1 >> (sb - 64));
+              return zt & ((1u << (2 * KT)) - 1u);
+            };
+            auto event_step = [&](uint32_t zt) {
+              return [&, zt](auto kc, float sg, auto &r) -> float {
+                constexpr int k = decltype(kc)::value;
+                pair_step<SEM>(static_cast<int>((zt >> (2 * k)) & 3u), sg, Delta, Omega, omega, r.s0, r.s1, r.s2);
+                return ref_max3<SEM>(r.s0, r.s1, r.s2);
+              };
+            };
+            if constexpr (SEM) {   // NaN tables: every cell through the recurrence as written (score.c:512-533)
+              while (j < jend) span(j + 1, event_step(tile_z(j)));
+            } else {
+              // A codon with a frame shift in some sequence (zany) is an event for THIS pass only if the sequence is one of the tile's: for the others'
+              // codons z = 0 throughout the tile, and the cell is an ordinary one -- a tile none of whose sequences shifts in the row stays in the
+              // two-instruction form below to the row's end.  (score.c:512-533 with z = 0 is the ordinary cell: same operations, same order.)
+              uint32_t zt = 0;
+              auto next_tile_event = [&](int from) -> int {   // first codon >= from with a frame shift in one of the tile's sequences (zt: its bits), or jend
+                for (int e = from;;) {
+                  e = next_event(e, jend);
+                  if (e >= jend) return jend;
+                  zt = tile_z(e);
+                  if (zt) return e;
+                  e++;
+                }
+              };
+              int e = fe < jend ? next_tile_event(fe) : jend;
+              {   // up to there: states 1 and 2 of EVERY sequence of the tile hold the row's running sum of omega
+                float wv = 0.0f;
+                asm volatile("v_mov_b32 %0, 0" : "=v"(wv));
+                span(e, [&](auto kc, float sg, auto &r) -> float {
+                  if constexpr (decltype(kc)::value == 0) wv = wv + omega_v;   // (once per cell: the first sequence's turn)
+                  r.s0 = r.s0 + sg;
+                  return fmaxf(r.s0, wv);
                 });
-                if (SEM) continue;
+                static_for<KT>([&](auto kc) {
+                  auto &r = R.template at<decltype(kc)::value>();
+                  r.s1 = r.s2 = wv;
+                });
               }
-              span(next_event(j, jend), [&](auto, float sg, auto &r) -> float {
-                r.s0 = r.s0 + sg;
-                r.s1 = r.s1 + omega_v;
-                r.s2 = r.s2 + omega_v;
-                return fmaxf(fmaxf(r.s0, r.s1), r.s2);
-              });
+              while (j < jend) {   // j: a codon with z != 0 in one of the tile's sequences (score.c:512-533), wave-uniform branch per sequence
+                span(j + 1, event_step(zt));
+                e = next_tile_event(j);
+                span(e, [&](auto, float sg, auto &r) -> float {
+                  r.s0 = r.s0 + sg;
+                  r.s1 = r.s1 + omega_v;
+                  r.s2 = r.s2 + omega_v;
+                  return fmaxf(fmaxf(r.s0, r.s1), r.s2);
+                });
+              }
             }
           }
           sample_scan_row_end(st, static_cast<uint32_t>(a));
