@@ -87,7 +87,7 @@ int batch_prepare(rc_batch *b, const rc_block *blocks, int32_t n_blocks, const r
       continue;
     }
     b->okBlocks.push_back(i);
-    auto &cls = b->classes[block_class(m.N, m.L, b->db[i].omega, ctx->genericMinRows, ctx->tiledMinRows, ctx->tiledMaxL)];
+    auto &cls = b->classes[block_class(m.N, m.L, b->db[i].omega, ctx->rule)];
     if (!cls.empty() && b->meta[cls.front()].L != m.L) sameL = false;
     cls.push_back(i);
     b->maxL = std::max(b->maxL, m.L);
@@ -174,7 +174,7 @@ int batch_upload(rc_batch *b) {
     pa.exactList = b->dexact.as<int>();
     pa.exactCount = b->dcounters.as<int>() + kCntExact;
     std::memcpy(pa.classOff, b->classOff, sizeof pa.classOff);
-    pa.genericMinRows = c->genericMinRows; pa.tiledMinRows = c->tiledMinRows; pa.tiledMaxL = c->tiledMaxL;
+    pa.rule = c->rule;
     launch_prep(pa, ps);
   }
   HIP_TRY(b->evPrep.record(ps));

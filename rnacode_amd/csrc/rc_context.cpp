@@ -137,9 +137,11 @@ int rc_ctx_create(int device, rc_ctx **out) {
   c->serialNative = std::getenv("RC_SERIAL_NATIVE") ? 1 : 0;   // profiling: one kernel at a time, clean per-kernel intervals
   c->stopTwoRoundsMinItems = 4LL * c->numCU * 16;   // the chip filled four times over
   if (const char *e = std::getenv("RC_STOP_MIN_ITEMS")) c->stopTwoRoundsMinItems = std::atoll(e);
-  if (const char *e = std::getenv("RC_GENERIC_MIN_ROWS")) c->genericMinRows = std::max(3, std::min(kTemplRows + 1, std::atoi(e)));
-  if (const char *e = std::getenv("RC_TILED_MAX_L")) c->tiledMaxL = std::max(0, std::atoi(e));
-  if (const char *e = std::getenv("RC_TILED_MIN_ROWS")) c->tiledMinRows = std::max(kTiledMaxKT + 2, std::min(kTemplRows + 1, std::atoi(e)));
+  if (const char *e = std::getenv("RC_GENERIC_MIN_ROWS")) c->rule.genericMinRows = std::max(3, std::min(kTemplRows + 1, std::atoi(e)));
+  if (const char *e = std::getenv("RC_TILED_MAX_L")) c->rule.tiledMaxL = std::max(0, std::atoi(e));
+  if (const char *e = std::getenv("RC_TILED_MIN_ROWS")) c->rule.tiledMinRows = std::max(kTiledMaxKT + 2, std::min(kTemplRows + 1, std::atoi(e)));
+  if (const char *e = std::getenv("RC_TILED_MAX_ROWS")) c->rule.tiledMaxRows = std::max(kTemplRows, std::min(kMaxRows, std::atoi(e)));
+  if (const char *e = std::getenv("RC_TILED_WIDE_MAX_L")) c->rule.tiledWideMaxL = std::max(0, std::atoi(e));
   if (const char *e = std::getenv("RC_STOP_ROUNDS")) c->stopRounds = std::max(2, std::min(kMaxRounds, std::atoi(e)));
   c->pt62.build(c->ct62);
   c->pt90.build(c->ct90);

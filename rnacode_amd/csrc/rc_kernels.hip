@@ -270,7 +270,7 @@ __global__ __launch_bounds__(64) void k_prep_lut(PrepArgs A) {   // one wavefron
     mine |= !in_div_range_dev(v);
     nan |= v != v;
   }
-  const int cls = block_class(N, db->L, db->omega, A.genericMinRows, A.tiledMinRows, A.tiledMaxL);
+  const int cls = block_class(N, db->L, db->omega, A.rule);
   if (cls == kGenericClass && threadIdx.x == 0) {   // k_generic_dp's running sums of omega, added the way the DP adds them
     float *W = reinterpret_cast<float *>(A.blob + db->off_chain);
     const int nW = db->L / 3 + 40;

@@ -89,8 +89,7 @@ struct PrepArgs {
   int *exactList;             // per class: batch indices flagged kFlagExact, at classOff[NK]
   int *exactCount;            // [kClassSlots] by class
   int classOff[kClassSlots];  // by class (N-1 for the instantiated kernels, kGenericClass for wider blocks)
-  int genericMinRows;         // blocks with at least this many rows are in the generic class
-  int tiledMinRows, tiledMaxL;   // ... and those from this many up to 64 rows, of at most this many reference residues, in the tiled classes (rc_device.h, block_class)
+  ClassRule rule;   // which blocks take which kernels (rc_device.h, block_class)
 };
 
 struct FitOut {

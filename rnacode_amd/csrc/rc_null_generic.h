@@ -314,7 +314,9 @@ __device__ __forceinline__ void generic_body(const NullArgs &A, const uint8_t *_
       const uint32_t aF64 = aF * 64u, aR64 = aR * 64u;
       uint8_t *__restrict__ kp = codes;   // sequence k's words of strand x frame 0, word 0
       const size_t kstep = static_cast<size_t>(lay.nW) * (kWave * 4);
-      for (int k0 = 0; k0 < NK; k0 += kWave) {
+      // (TILED: a chunk of sequences is a whole number of tiles, so that no word of the tiled layout straddles two chunks)
+      const int kChunk = TILED ? (kWave / A.tiledKT) * A.tiledKT : kWave;
+      for (int k0 = 0; k0 < NK; k0 += kChunk) {
         // lane l works out what sequence k0 + l needs: the word and the bits of its tip's state, its two masks
         const int kl = k0 + lane < NK ? k0 + lane : NK - 1;
         const uint32_t tctl = node_ctrl(qtip[kl + 1]);
@@ -322,7 +324,7 @@ __device__ __forceinline__ void generic_body(const NullArgs &A, const uint8_t *_
         const uint32_t mFv = (mrowF[k5] >> sh) & 63u, mRv = (mrowR[k5] >> sh) & 63u;
         const int nk = NK - k0 < kWave ? NK - k0 : kWave;
         if constexpr (TILED) {
-          // (at most 63 sequences: k0 == 0.)  A word of the tiled layout holds up to five sequences of one tile: window update as below, then
+          // A word of the tiled layout holds up to five sequences of one tile: window update as below, then
           // the codes of the word's sequences packed, field c at bits [6c + 7 : 6c + 2], one dword per strand
           const TiledLayout tl(NK, A.tiledKT);
           uint32_t *__restrict__ cwp = reinterpret_cast<uint32_t *>(codes) + lane;
@@ -333,7 +335,7 @@ __device__ __forceinline__ void generic_body(const NullArgs &A, const uint8_t *_
             uint8_t *wrow = win + (kk + 1) * kWave;
 #pragma unroll
             for (int t = 0; t < CNT; t++) {
-              cc[t] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(tctl), kk + t));
+              cc[t] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(tctl), kk - k0 + t));
               wv[t] = *reinterpret_cast<const uint16_t *>(ldsBytes + ((cc[t] & 0x7f80u) | laneSt));
               bb[t] = wrow[t * kWave];
             }
@@ -345,8 +347,8 @@ __device__ __forceinline__ void generic_body(const NullArgs &A, const uint8_t *_
               uint32_t wf = 0u, wr = 0u;
 #pragma unroll
               for (int t = 0; t < CNT; t++) {
-                const uint32_t mF = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mFv), kk + t));
-                const uint32_t mR = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mRv), kk + t));
+                const uint32_t mF = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mFv), kk - k0 + t));
+                const uint32_t mR = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mRv), kk - k0 + t));
                 wf |= static_cast<uint32_t>(pairTab[aF64 + (bb[t] & mF)]) << (6 * t + 2);
                 wr |= static_cast<uint32_t>(pairTab[aR64 + ((codon_flip(bb[t]) ^ 63u) & mR)]) << (6 * t + 2);
               }
@@ -354,7 +356,8 @@ __device__ __forceinline__ void generic_body(const NullArgs &A, const uint8_t *_
               cwp[posR + static_cast<size_t>(widx) * kWave] = wr;
             }
           };
-          for (int t = 0; t < tl.T; t++)
+          const int t0 = k0 / tl.KT, t1 = t0 + kChunk / tl.KT < tl.T ? t0 + kChunk / tl.KT : tl.T;   // this chunk's tiles
+          for (int t = t0; t < t1; t++)
             for (int x = 0; x < tl.WPT; x++) {
               const int kk = t * tl.KT + 5 * x;
               int cnt = tl.KT - 5 * x;

@@ -196,10 +196,10 @@ __device__ __forceinline__ void tiled_body(const NullArgs &A, const uint8_t *__r
             };
             // the tile's 2 KT bits of a codon's z entries (two bits per sequence, 128 per codon)
             auto tile_z = [&](int je) -> uint32_t {
-              const unsigned long long z0 = zbase[static_cast<size_t>(3 * je) * ZW], z1 = ZW > 1 ? zbase[static_cast<size_t>(3 * je) * ZW + 1] : 0ull;
-              const int sb = 2 * t * KT;
-              const uint32_t zt = sb < 64 ? static_cast<uint32_t>((z0 >> sb) | (sb ? z1 << (64 - sb) : 0ull)) : static_cast<uint32_t>(z1 >> (sb - 64));
-              return zt & ((1u << (2 * KT)) - 1u);
+              const unsigned long long *__restrict__ zj = zbase + static_cast<size_t>(3 * je) * ZW;
+              const int sb = 2 * t * KT, wi = sb >> 6, sh = sb & 63;   // the tile's 2 KT bits start in word wi at bit sh; they may run on into the next word
+              const unsigned long long lo = zj[wi] >> sh, hi = (sh && wi + 1 < ZW) ? zj[wi + 1] << (64 - sh) : 0ull;
+              return static_cast<uint32_t>(lo | hi) & ((1u << (2 * KT)) - 1u);
             };
             auto event_step = [&](uint32_t zt) {
               return [&, zt](auto kc, float sg, auto &r) -> float {

@@ -210,7 +210,7 @@ int rc_batch_native_S(const rc_batch *b, int32_t blk, int32_t strand, int32_t fr
     // the scoring pass never materialises S: recompute this block's six matrices with the same kernel (fullS set: no records written)
     rc_ctx *c = b->ctx;
     DevBuf full, tile, idx;
-    const bool generic = block_class(h.N, h.L, b->db[blk].omega, c->genericMinRows, c->tiledMinRows, c->tiledMaxL) == kGenericClass;   // (the tiled classes' native block takes k_native_dp<N-1>)
+    const bool generic = h.N > kTemplRows || block_class(h.N, h.L, b->db[blk].omega, c->rule) == kGenericClass;   // (the tiled classes' native block takes k_native_dp<N-1> up to 64 rows)
     const size_t tileStride = generic ? static_cast<size_t>(3) * h.NK * kWave + static_cast<size_t>(kWave) * smax : static_cast<size_t>(kWave) * smax;
     HIP_TRY(full.ensure(static_cast<size_t>(6) * smax * smax * sizeof(float)));
     HIP_TRY(tile.ensure(6 * tileStride * sizeof(float)));

@@ -349,9 +349,9 @@ struct rc_ctx {
   // blocks with at least this many rows take the generic kernels (RC_GENERIC_MIN_ROWS: tests run everything through them).  Where the crossover lies is
   // measured (tools/rows_sweep.py, profiles/r06/rows_sweep_*.txt): k_null<N-1> holds 3 (N-1) states in registers -- 2 wavefronts per SIMD up to 36 rows,
   // ONE from 37 on (0.11..0.18 of the issue roof at 40..64 rows), where k_generic_dp (states parked in memory, any N) runs at 0.19..0.24
-  int genericMinRows = kGenericDefaultMinRows;
-  int tiledMaxL = kTiledDefaultMaxL;
-  int tiledMinRows = kTiledDefaultMinRows;   // blocks of this many rows up to 64 (omega <= 0) take k_tiled_dp (rc_null_tiled.h; RC_TILED_MIN_ROWS, 65 = never)
+  // ... and blocks of tiledMinRows rows and more (omega <= 0, short enough) k_tiled_dp (rc_null_tiled.h; RC_TILED_MIN_ROWS, 65 = never; RC_TILED_MAX_L,
+  // RC_TILED_MAX_ROWS, RC_TILED_WIDE_MAX_L).  rc_device.h, block_class
+  ClassRule rule = kDefaultClassRule;
   int stopRounds = 6;                    // at most this many rounds (RC_STOP_ROUNDS; <= kMaxRounds)
   long long stopTwoRoundsMinItems = 0;   // --stop-early runs two rounds of sample groups only for batches with at least this many (block, group) items
   int hostThreads = 0;

@@ -63,26 +63,38 @@ int launch_native_block(const RunEnv &R) {
   }
   {   // one 64-row buffer per persistent workgroup, shared by the group launches (same stream)
     size_t need = 0;
-    for (const Group &g : groups) need = std::max(need, native_grid(c, g.count * 6, g.smax, R.nativeMode) * kWave * g.smax);
+    for (const Group &g : groups) if (g.NK < kTemplRows) need = std::max(need, native_grid(c, g.count * 6, g.smax, R.nativeMode) * kWave * g.smax);
     HIP_TRY(b->dnativeTile.ensure(std::max<size_t>(need, 4) * sizeof(float)));
   }
-  if (b->classes.count(kGenericClass)) {   // more than 64 rows: states in a scratch, at most 256 blocks per launch share it
-    const auto &mem = b->classes[kGenericClass];
-    NativeArgs nc = na;
-    nc.blocks = R.classList + b->classOff[kGenericClass];
-    int maxNK = 0, smaxG = 1;
-    for (int bi : mem) { maxNK = std::max(maxNK, b->meta[bi].NK); smaxG = std::max(smaxG, b->meta[bi].L / 3); }
-    const size_t stride = static_cast<size_t>(3) * maxNK * kWave + static_cast<size_t>(kWave) * smaxG;   // states, then 64 rows of S
+  {   // more than 64 rows: states in a scratch, at most 256 blocks per launch share it -- the generic class, and the blocks of that width in the tiled ones
+    struct Wide { const int *list; size_t count; int maxNK, smax; };
+    std::vector<Wide> wides;
+    if (b->classes.count(kGenericClass)) {
+      const auto &mem = b->classes[kGenericClass];
+      Wide w{R.classList + b->classOff[kGenericClass], mem.size(), 0, 1};
+      for (int bi : mem) { w.maxNK = std::max(w.maxNK, b->meta[bi].NK); w.smax = std::max(w.smax, b->meta[bi].L / 3); }
+      wides.push_back(w);
+    }
+    for (const Group &g : groups) if (g.NK >= kTemplRows) wides.push_back(Wide{g.list, g.count, g.NK, g.smax});
     const int chunk = 256;
-    HIP_TRY(b->dnativeScratch.ensure(stride * 6 * std::min<size_t>(chunk, mem.size()) * sizeof(float)));
-    for (size_t at = 0; at < mem.size(); at += chunk) {
-      NativeArgs ng = nc;
-      ng.blocks = nc.blocks + at;
-      launch_native_dp_generic(ng, static_cast<int>(std::min<size_t>(chunk, mem.size() - at)), b->dnativeScratch.as<float>(), stride, st);
-      b->nl[3]++;
+    auto stride_of = [](const Wide &w) { return static_cast<size_t>(3) * w.maxNK * kWave + static_cast<size_t>(kWave) * w.smax; };   // states, then 64 rows of S
+    size_t scratchFloats = 0;
+    for (const Wide &w : wides) scratchFloats = std::max(scratchFloats, stride_of(w) * 6 * std::min<size_t>(chunk, w.count));
+    if (scratchFloats) HIP_TRY(b->dnativeScratch.ensure(scratchFloats * sizeof(float)));   // (once: the launches below share it in stream order)
+    for (const Wide &w : wides) {
+      NativeArgs nc = na;
+      nc.blocks = w.list;
+      const size_t stride = stride_of(w);
+      for (size_t at = 0; at < w.count; at += chunk) {
+        NativeArgs ng = nc;
+        ng.blocks = nc.blocks + at;
+        launch_native_dp_generic(ng, static_cast<int>(std::min<size_t>(chunk, w.count - at)), b->dnativeScratch.as<float>(), stride, st);
+        b->nl[3]++;
+      }
     }
   }
   for (const Group &g : groups) {
+    if (g.NK >= kTemplRows) continue;   // (above)
     // up to 64 rows: DP and getHSS fused, 64 rows of one matrix at a time through a per-workgroup buffer (persistent grid)
     NativeArgs nc = na;
     nc.blocks = g.list;

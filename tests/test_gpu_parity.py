@@ -652,6 +652,43 @@ def test_tiled_kernels_equal_the_oracle(monkeypatch):
     ctx.close()
 
 
+def test_tiled_kernels_on_blocks_of_more_than_64_rows_equal_the_oracle(monkeypatch):
+    """The tiled kernels past the per-row-count kernels' range (RC_TILED_MAX_ROWS; rc_device.h, block_class): 65 rows (the sixth tile of 13 starts
+    in the third z word: 2 x 64 bits hold 64 sequences), 70 and 99 rows (simulation chunks of whole tiles: 60 or 52 sequences, not 64), 130 rows
+    (three chunks), NaN tables among them; the native block of such a block goes through k_native_dp_generic.  Per-sample maxima, HSS tables
+    and fit verdicts against the oracle."""
+    from oracle import binding as ob
+    from rnacode_amd import api
+    from rnacode_amd.synth import synth_block
+    monkeypatch.setenv("RC_TILED_MAX_ROWS", "200")
+    monkeypatch.setenv("RC_TILED_WIDE_MAX_L", "100000")
+    ctx = api.Context(0)
+    rng = np.random.RandomState(707)
+    shapes = [(65, 45), (70, 60), (99, 36), (130, 30), (66, 120)]
+    blocks = [synth_block(rng, n, c, index=i, gaps=True).upper() for i, (n, c) in enumerate(shapes)]
+    nan = synth_block(np.random.RandomState(78), 80, 33, index=9, gaps=True).upper()
+    for r in nan.rows:
+        r.seq = r.seq.replace("A", "C").replace("G", "T")
+    blocks.append(nan)
+    for n, seed, pars in ((130, 31, {}), (100, 33, {"Delta": 1.5})):
+        hp = api.default_params(sampleN=n, seed_base=seed, **pars)
+        b = api.Batch(ctx, blocks, hp).run()
+        assert "k_tiled_dp" in b.null_kernel(), b.null_kernel()
+        for i, blk in enumerate(blocks):
+            p = ob.default_params(n)
+            for k, v in pars.items():
+                setattr(p, k, v)
+            res = ob.run_block([r.seq for r in blk.rows], [r.name for r in blk.rows], blk.rows[0].start, blk.rows[0].length, blk.tree, blk.kappa, p, seed)
+            np.testing.assert_array_equal(b.maxScores(i), np.float32(res.maxScores), err_msg=f"block {i}: {blk.n} x {blk.cols}")
+            got, want = sorted(b.scoreAln(i), key=hss_key), sorted(res.hss, key=hss_key)
+            assert [(h["strand"], h["frame"], h["start"], h["end"], np.float32(h["score"])) for h in got] == \
+                   [(h["strand"], h["frame"], h["start"], h["end"], np.float32(h["score"])) for h in want]
+            rc, mu, lam = b.getExtremeValuePars(i)
+            assert rc == res.evd_rc and (rc != 1 or (close_p(mu, res.mu) and close_p(lam, res.lam)))
+        b.close()
+    ctx.close()
+
+
 def test_wide_blocks_in_several_rounds_equal_one_round(ctx):
     """k_generic_sim leaves the codes of a ROUND of items in the scratch for k_generic_dp (rc_schedule.cpp): with a scratch of 24 GB
     a batch of a few wide blocks is one round, with 8 MB (RC_GENERIC_SCRATCH_MB, read when a context is created) every block's
