@@ -142,6 +142,7 @@ int rc_ctx_create(int device, rc_ctx **out) {
   if (const char *e = std::getenv("RC_TILED_MIN_ROWS")) c->rule.tiledMinRows = std::max(kTiledMaxKT + 2, std::min(kTemplRows + 1, std::atoi(e)));
   if (const char *e = std::getenv("RC_TILED_MAX_ROWS")) c->rule.tiledMaxRows = std::max(kTemplRows, std::min(kMaxRows, std::atoi(e)));
   if (const char *e = std::getenv("RC_TILED_WIDE_MAX_L")) c->rule.tiledWideMaxL = std::max(0, std::atoi(e));
+  if (const char *e = std::getenv("RC_TILED_ANY_L_MIN_ROWS")) c->rule.tiledAnyLMinRows = std::max(kTemplRows + 1, std::atoi(e));
   if (const char *e = std::getenv("RC_STOP_ROUNDS")) c->stopRounds = std::max(2, std::min(kMaxRounds, std::atoi(e)));
   c->pt62.build(c->ct62);
   c->pt90.build(c->ct90);

@@ -17,7 +17,7 @@ constexpr int kTemplRows = 64;    // N <= 64: kernels instantiated per N-1 (k_nu
 constexpr int kFastRows = 32;     // N <= 32: register-resident fast instantiations; 33..64 the EXACT instantiation only
 constexpr int kGenericDefaultMinRows = 37;   // rc_ctx::genericMinRows: from this many rows on the generic kernels are the faster ones (RC_GENERIC_MIN_ROWS overrides, 65 = never below 65)
 constexpr int kGenericClass = kTemplRows;   // row-count classes are indexed by N-1 (2..63); all wider blocks share this one
-// k_tiled_dp<KT> (rc_null_tiled.h): blocks of kTiledMinRows..128 rows whose sequences besides the reference are scored in T tiles of KT (12..15)
+// k_tiled_dp<KT> (rc_null_tiled.h): blocks of kTiledMinRows rows and more whose sequences besides the reference are scored in T tiles of KT (12..15)
 // with the running sum of a cell carried from tile to tile -- one class per tile size behind the generic one
 constexpr int kTiledMinKT = 12, kTiledMaxKT = 15;
 constexpr int kTiledClass0 = kGenericClass + 1;                                   // class of KT = kTiledMinKT
@@ -42,19 +42,25 @@ constexpr int tiled_kt(int NK) {
 //   k_tiled_dp<KT>   tiles of KT sequences, the cell's sum carried between them, 4 wavefronts: 0.22..0.26 / 0.26..0.29 / 0.26..0.29 / 0.25..0.29 -- it
 //                    moves ~85 bytes per cell and sequence where the others move ~50, less where the row buffer's tail in LDS covers most of a row
 // So: templated to 31 rows (36 for long blocks), tiled from 32 rows on for blocks of up to 200 reference residues and from 37 rows on up to 250
-// (65..128 rows: up to 200 again), generic for the rest from 37 rows on.
+// (65..111 rows: up to 200 again; from 112 rows on every block), generic for the rest from 37 rows on.
 // The tiled kernels score the sequences a tile's size exceeds its share by as zeros, which needs omega <= 0 (a gap state never above 0): other blocks
 // stay where they were.  (RC_GENERIC_MIN_ROWS at or below the tiled range's start switches the tiled kernels off as well: the all-generic test mode.)
 // Wider blocks (65 rows and more, no per-row-count kernel): tiled up to tiledMaxRows rows and tiledWideMaxL reference residues, generic beyond
-// (RC_TILED_MAX_ROWS, RC_TILED_WIDE_MAX_L).  65 / 80 / 100 / 128 rows, tiled against generic (profiles/r06/rows_sweep_wide_tiled.txt):
+// (RC_TILED_MAX_ROWS, RC_TILED_WIDE_MAX_L, RC_TILED_ANY_L_MIN_ROWS).  65 / 80 / 100 / 128 rows, tiled against generic (profiles/r06/rows_sweep_wide_tiled.txt):
 // 0.25 / 0.24 / 0.23 / 0.22 against 0.21 / 0.21 / 0.21 / 0.18 at 100 columns, 0.27 / 0.26 / 0.26 / 0.24 against 0.23 / 0.23 / 0.22 / 0.21 at 150,
 // level at 200 (0.27 / 0.27 / 0.27 / 0.25 against 0.26 / 0.28 / 0.28 / 0.24), generic ahead at 300 (0.28 against 0.30..0.32).
-struct ClassRule { int genericMinRows, tiledMinRows, tiledMaxL, tiledMaxRows, tiledWideMaxL; };
-constexpr int kTiledDefaultMaxRows = 128;
+// From tiledAnyLMinRows rows on the tiled kernels win at every length: the generic kernel parks three states per sequence and eight-cell group in
+// memory, and that traffic grows with N where the tiled kernel's carried sum does not (tools/time_wide.py, profiles/r06/very_wide_tiled.txt: 128 x 300
+// 255 -> 230 ms, 200 x 90 150 -> 103, 300 x 300 510 -> 289, 500 x 150 451 -> 186; 100 x 300 the other way, 0.31 against 0.285 of the issue roof).
+struct ClassRule { int genericMinRows, tiledMinRows, tiledMaxL, tiledMaxRows, tiledWideMaxL, tiledAnyLMinRows; };
+constexpr int kTiledDefaultMaxRows = kMaxRows;
 constexpr int kTiledDefaultWideMaxL = 200;
-constexpr ClassRule kDefaultClassRule{kGenericDefaultMinRows, kTiledDefaultMinRows, kTiledDefaultMaxL, kTiledDefaultMaxRows, kTiledDefaultWideMaxL};
+constexpr int kTiledDefaultAnyLMinRows = 112;
+constexpr ClassRule kDefaultClassRule{kGenericDefaultMinRows, kTiledDefaultMinRows, kTiledDefaultMaxL, kTiledDefaultMaxRows, kTiledDefaultWideMaxL,
+                                      kTiledDefaultAnyLMinRows};
 constexpr int block_class(int N, int L, float omega, const ClassRule &r) {
-  const int maxL = N > kTemplRows ? r.tiledWideMaxL : N >= kGenericDefaultMinRows ? r.tiledMaxL : r.tiledMaxL * 4 / 5;   // (below 37 rows the templated kernels still have two wavefronts per SIMD and win on long blocks)
+  // (below 37 rows the templated kernels still have two wavefronts per SIMD and win on long blocks)
+  const int maxL = N > kTemplRows ? (N >= r.tiledAnyLMinRows ? (1 << 30) : r.tiledWideMaxL) : N >= kGenericDefaultMinRows ? r.tiledMaxL : r.tiledMaxL * 4 / 5;
   const int maxRows = r.tiledMaxRows > kTemplRows ? r.tiledMaxRows : kTemplRows;
   if (N >= r.tiledMinRows && r.tiledMinRows <= kTemplRows && N <= maxRows && L <= maxL && r.genericMinRows > r.tiledMinRows && omega <= 0.0f) return kTiledClass0 + tiled_kt(N - 1) - kTiledMinKT;
   return N < r.genericMinRows ? N - 1 : kGenericClass;

@@ -717,12 +717,17 @@ def test_wide_blocks_in_several_rounds_equal_one_round(ctx):
     small.close()
 
 
-def test_blocks_beyond_64_rows_against_oracle(ctx):
-    """65..500 rows (the reference's own limit, rnaz_utils.h:7; 100-way genome alignments): k_generic_sim / k_generic_dp and
-    k_native_dp_generic keep the per-sequence states in global memory instead of registers.  Same seeds through the HIP
-    path and the oracle, blocks of different widths in ONE launch (they share the generic class), mixed with narrow ones,
-    as one batch, as a stream and with --stop-early; backtrack of a wide block."""
+@pytest.mark.parametrize("kernels", ["tiled", "generic"])
+def test_blocks_beyond_64_rows_against_oracle(monkeypatch, kernels):
+    """65..500 rows (the reference's own limit, rnaz_utils.h:7; 100-way genome alignments): k_generic_sim with k_tiled_dp (the default for
+    these shapes) or, with the tiled kernels held to 64 rows, k_generic_dp, which keeps the per-sequence states in global memory as
+    k_native_dp_generic does.  Same seeds through the HIP path and the oracle, blocks of different widths in ONE launch, mixed with
+    narrow ones, as one batch, as a stream and with --stop-early; backtrack of a wide block."""
     from oracle import binding as ob
+    if kernels == "generic":
+        monkeypatch.setenv("RC_TILED_MAX_ROWS", "64")
+    from rnacode_amd import api as _api
+    ctx = _api.Context(0)
     from rnacode_amd import api
     from rnacode_amd.synth import synth_blocks
     shapes = [(65, 36, 51), (100, 45, 52), (200, 24, 53), (500, 12, 54)]
@@ -731,6 +736,7 @@ def test_blocks_beyond_64_rows_against_oracle(ctx):
     n, seed = 70, 13
     p = api.default_params(sampleN=n, seed_base=seed)
     batch = api.Batch(ctx, blocks, p).run()
+    assert ("k_tiled_dp" if kernels == "tiled" else "k_generic_dp") in batch.null_kernel(), batch.null_kernel()
     results = []
     for i, b in enumerate(blocks):
         rows, names = [r.seq for r in b.rows], [r.name for r in b.rows]
@@ -774,6 +780,7 @@ def test_blocks_beyond_64_rows_against_oracle(ctx):
     again = api.Batch(ctx, refit, p).run()
     assert [again.status(i) for i in range(3)] == [api.RC_OK] * 3
     again.close()
+    ctx.close()
 
 
 def batch_hss_for_backtrack(ctx, block, p):

@@ -239,7 +239,7 @@ def test_native_driver_limit_prunes_rows_like_prune_aln(tmp_path):
 
 def test_which_kernel_a_block_takes_and_the_tile_sizes(tmp_path):
     """rc_device.h decides a block's class in one place (block_class): per-row-count kernels to 31 rows, the tiled ones (32..64 rows of short
-    blocks, 65..128 rows of blocks of up to 200 residues; omega <= 0) and the generic ones (from 37 rows on); tiled_kt picks the tile size with the least work.  Compiled on the host."""
+    blocks, 65..111 rows of blocks of up to 200 residues, every block from 112 rows on; omega <= 0) and the generic ones (from 37 rows on); tiled_kt picks the tile size with the least work.  Compiled on the host."""
     import shutil
     import subprocess
     if shutil.which("g++") is None:
@@ -251,12 +251,12 @@ def test_which_kernel_a_block_takes_and_the_tile_sizes(tmp_path):
 using namespace rc;
 int main() {
   const ClassRule D = kDefaultClassRule;
-  ClassRule W = D; W.tiledMaxRows = 300;
+  ClassRule W = D; W.tiledMaxRows = 300; W.tiledAnyLMinRows = 1000;
   ClassRule allGeneric = D; allGeneric.genericMinRows = 3;
   ClassRule off = D; off.genericMinRows = 65; off.tiledMinRows = 65;
   ClassRule offW = off; offW.tiledMaxRows = 300;
   int bad = 0;
-  for (int nk = 16; nk <= 199; nk++) {
+  for (int nk = 16; nk <= 499; nk++) {
     const int kt = tiled_kt(nk), tiles = (nk + kt - 1) / kt;
     bad += kt < kTiledMinKT || kt > kTiledMaxKT || tiles * kt - nk >= kt;          // never a whole tile of padding
     for (int other = kTiledMinKT; other <= kTiledMaxKT && nk <= 63; other++) {      // ... and to 64 rows no other size does it in fewer passes
@@ -273,12 +273,13 @@ int main() {
   bad += block_class(40, 150, 0.5f, D) != kGenericClass;                      // omega > 0: never the tiled kernels
   bad += block_class(64, 90, -2.0f, D) != kTiledClass0 + tiled_kt(63) - kTiledMinKT;
   bad += block_class(65, 90, -2.0f, D) != kTiledClass0 + tiled_kt(64) - kTiledMinKT;      // ... and on to 128 rows for blocks of up to 200 residues
-  bad += block_class(128, 200, -2.0f, D) != kTiledClass0 + tiled_kt(127) - kTiledMinKT;
-  bad += block_class(129, 90, -2.0f, D) != kGenericClass;
+  bad += block_class(111, 200, -2.0f, D) != kTiledClass0 + tiled_kt(110) - kTiledMinKT;
   bad += block_class(100, 201, -2.0f, D) != kGenericClass;
+  bad += block_class(112, 3000, -2.0f, D) != kTiledClass0 + tiled_kt(111) - kTiledMinKT;   // from 112 rows on at every length
+  bad += block_class(500, 300, -2.0f, D) != kTiledClass0 + tiled_kt(499) - kTiledMinKT;
   bad += block_class(40, 150, -2.0f, allGeneric) != kGenericClass;                     // RC_GENERIC_MIN_ROWS=3: everything generic
   bad += block_class(40, 150, -2.0f, off) != 39;                              // both switched off: k_null<39>
-  bad += block_class(200, 150, -2.0f, W) != kTiledClass0 + tiled_kt(199) - kTiledMinKT;  // RC_TILED_MAX_ROWS=300: wider blocks in tiles too
+  bad += block_class(200, 150, -2.0f, W) != kTiledClass0 + tiled_kt(199) - kTiledMinKT;  // RC_TILED_MAX_ROWS=300, RC_TILED_ANY_L_MIN_ROWS=1000
   bad += block_class(100, 300, -2.0f, W) != kGenericClass;                               // ... the short ones
   bad += block_class(301, 150, -2.0f, W) != kGenericClass;
   bad += block_class(100, 150, -2.0f, offW) != kGenericClass;                            // RC_TILED_MIN_ROWS=65 switches all of it off
