@@ -791,7 +791,7 @@ def main():
     if extras:
         legs["end_to_end"] = end_to_end_leg(blocks, args.samples, args.seed_base)
         legs["end_to_end_100k"] = end_to_end_leg(blocks, args.samples, args.seed_base, runs=3, repeat=10)
-        legs["end_to_end_mixed"] = end_to_end_leg(mixed, args.samples, args.seed_base, runs=3)   # file in -> listing out on the ten-class workload
+        legs["end_to_end_mixed"] = end_to_end_leg(mixed, args.samples, args.seed_base, runs=5)   # file in -> listing out on the ten-class workload
         legs["end_to_end_mixed_100k"] = end_to_end_leg(mixed, args.samples, args.seed_base, runs=3, repeat=10)   # ... at steady state: the same ten times over
         legs["end_to_end_c5"] = end_to_end_leg(blocks5, CONFIGS["c5"][3], args.seed_base, runs=3)   # a 1000-block 12 x 300 file at n = 10 000 (configs[4]'s shape)
 

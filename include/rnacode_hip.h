@@ -176,8 +176,7 @@ void rc_stream_destroy(rc_stream *s);   /* also destroys the batches it still ho
 /* How to cut n_blocks blocks into sub-batches for a stream: writes the sizes (they sum to n_blocks), returns how many.  A small
  * first sub-batch starts the GPU early; the next ones double, so that each is queued before its predecessor drains; all but the
  * first fill the chip's wavefront slots a whole number of times (slots / sample groups blocks do so once), the odd remainder
- * goes first; no sub-batch exceeds eight such rounds (up to thirty-two in an input long enough for a dozen of them), except that a
- * tail shorter than half a sub-batch goes with the last one.
+ * goes first; no sub-batch exceeds eight such rounds, except that a tail shorter than half a sub-batch goes with the last one.
  * row_classes: distinct row counts among the blocks (each is a launch of
  * its own, side by side with the others). */
 int rc_stream_plan(const rc_ctx *ctx, const rc_params *par, int32_t n_blocks, int32_t row_classes, int32_t *sizes, int32_t cap);

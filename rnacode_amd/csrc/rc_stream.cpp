@@ -36,10 +36,11 @@ int rc_stream_plan(const rc_ctx *c, const rc_params *par, int32_t n_blocks, int3
   const long long slots = static_cast<long long>(c->numCU) * 16;                 // k_null with its codes staged in LDS: 16 wavefronts per CU
   // several row-count classes are several launches side by side: each gets its share of the slots
   const long long r = std::max<long long>(1, slots / groups) * std::max(1, (row_classes + 1) / 2);
-  // a long stream: bounded memory, results keep flowing -- eight rounds of the chip per sub-batch, up to thirty-two where the input is long enough
-  // for a dozen of those (every sub-batch is a launch with a tail of its own: 100 000 blocks of 6 x 120 in sub-batches of 2048 took 565 ms from
-  // the first submit to the last result, 130 % of the resident time)
-  const long long most = r * std::min<long long>(32, std::max<long long>(8, n_blocks / (12 * r)));
+  // a long stream: bounded memory, results keep flowing.  (Up to thirty-two rounds per sub-batch in inputs long enough for a dozen of those -- fewer
+  // launches, fewer tails -- were measured on the native driver with 100 000 blocks of 6 x 120: 0.72..0.75 s from main() to the last byte,
+  // against 0.62 with eight: the trees of a sub-batch, its results and its part of the listing are all the longer in front of and behind the
+  // GPU's work.  profiles/r06/e2e100k_plan_ab.txt)
+  const long long most = 8 * r;
   int n = 0;
   long long left = n_blocks;
   auto put = [&](long long v) { if (v > 0 && n < cap) { sizes[n++] = static_cast<int32_t>(v); left -= v; } };

@@ -19,11 +19,7 @@ TWO_ROWS = "_ZN2rc6k_nullILi5ELb1ELb0ELb1ELi0EEEvNS_8NullArgsEPKhPKNS_8DevBlockE
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
 def test_k_null_cell_loops_are_wave_uniform_and_tight(tmp_path):
-    out = tmp_path / "rc_null_a.s"
-    flags = "-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize".split()
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "--cuda-device-only", "-S", *flags, "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "rnacode_amd", "csrc", "rc_null_a.hip"), "-o", str(out)])
-    txt = out.read_text()
+    txt = _compile_unit(tmp_path, "rc_null_a")
 
     def loops_of(name):
         body = txt[txt.index(name + ":"):]
@@ -69,12 +65,24 @@ NCW_WAIT_WINDOW = 12   # instructions behind a row's first fetch within which it
 _FETCH = re.compile(r"(?:global_load_(?:dword|ubyte|ushort) (v\d+), v\d+, s\[\d+:\d+\]|ds_read_(?:b32|u8|u16) (v\d+), v\d+)")
 
 
+_UNITS = ("rc_null_a", "rc_null_b", "rc_null_c", "rc_null_d", "rc_null_t", "rc_kernels")   # what the tests of this module look at
+_COMPILES = {}   # unit -> (process, path of its assembly): all started by the first test that needs one (minutes of hipcc side by side, not in a row)
+
+
 def _compile_unit(tmp_path, unit):
-    out = tmp_path / (unit + ".s")
-    flags = "-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize".split()
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "--cuda-device-only", "-S", *flags, "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "rnacode_amd", "csrc", unit + ".hip"), "-o", str(out)])
-    return out.read_text()
+    """The gfx950 assembly of one instantiation unit, compiled the way the Makefile does."""
+    if not _COMPILES:
+        import tempfile
+        d = tempfile.mkdtemp(prefix="rc_codegen_")
+        flags = "-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize".split()
+        for u in _UNITS:
+            out = os.path.join(d, u + ".s")
+            _COMPILES[u] = (subprocess.Popen(["hipcc", "--offload-arch=gfx950", "--cuda-device-only", "-S", *flags, "-I", os.path.join(ROOT, "include"),
+                                              os.path.join(ROOT, "rnacode_amd", "csrc", u + ".hip"), "-o", out]), out)
+    proc, out = _COMPILES[unit]
+    assert proc.wait() == 0, unit + " does not compile"
+    with open(out) as f:
+        return f.read()
 
 
 def _audit_pending_registers(txt, name):
