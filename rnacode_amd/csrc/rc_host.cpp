@@ -274,8 +274,12 @@ struct SeqGenHky {
 // r > P[j] (evolve.c:167-175, twister.c:162-166).  r is monotone in the 32-bit integer u, so the
 // comparison has an exact integer form: r > P  <=>  u > threshold_of(P).
 // Returns the largest u with u*c <= P, or -1 if even u = 0 gives r > P.
+// P = NaN: `r > P` is false for every r -- the walk stops there -- so no u exceeds it.  (A block with one purine and one pyrimidine only, say
+// G and T: Seq-Gen's alphaR is 0 / 0, every branch matrix NaN and every simulated residue state 0; a soak found it in round 6 -- this function
+// had answered -1, "every u exceeds it", for anything that is not >= 0.  tests/data/sim_nan_branch_matrix.json)
 int64_t threshold_of(double P) {
   const double c = 1.0 / 4294967295.0;
+  if (P != P) return 4294967295LL;
   if (!(0.0 <= P)) return -1;
   if (4294967295.0 * c <= P) return 4294967295LL;
   // u -> fl(u * c) is non-decreasing, so the answer is next to P / c: start there and step to the boundary

@@ -605,6 +605,47 @@ def test_fits_on_few_samples_sum_in_the_references_order(ctx):
                 assert lam == wlam and abs(mu - wmu) <= 1e-15 * max(1.0, abs(wmu)), (n, spread, mu, wmu, lam, wlam)   # (mu goes through the device's log: one ulp)
 
 
+def test_blocks_with_one_purine_and_one_pyrimidine_follow_the_reference(ctx, monkeypatch):
+    """A block of G and T only (or A and C, A and T, C and G): with both other frequencies zero Seq-Gen's alphaR is 0 / 0, every branch matrix
+    NaN, `r > P` false for every draw (evolve.c:167-175) and every simulated residue state 0 -- the null samples are all-A alignments with the
+    block's gaps.  The library's integer thresholds took NaN for "every draw exceeds it" until a soak found this block in round 6
+    (rc_host.cpp, threshold_of).  tests/data/sim_nan_branch_matrix.json holds the UNMODIFIED reference's per-sample maxima, HSS and fit verdicts
+    (tests/data/make_sim_nan_fixture.py); here every kernel family must reproduce them: the per-row-count kernels, the tiled and the generic ones."""
+    import json
+    import os
+    from rnacode_amd import api
+    from rnacode_amd.alnio import AlnBlock, AlnRow
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "data", "sim_nan_branch_matrix.json")))
+    blocks = []
+    for e in d["cases"]:
+        rows = [AlnRow(n, s) for n, s in zip(e["names"], e["rows"])]
+        rows[0].start, rows[0].length = e["start"], e["length"]
+        blocks.append(AlnBlock(rows, e["name"], e["tree"], e["kappa"]))
+    e0 = d["cases"][0]
+    hp = api.default_params(sampleN=e0["n_samples"], seed_base=e0["seed"])
+
+    def check(c):
+        for batch in ([blocks], [[b] for b in blocks]):
+            at = 0
+            for bl in batch:
+                b = api.Batch(c, bl, hp).run()
+                for i in range(len(bl)):
+                    e = d["cases"][at + i]
+                    np.testing.assert_array_equal(b.maxScores(i), np.float32(e["maxScores"]), err_msg=e["name"])
+                    got, want = sorted(b.scoreAln(i), key=hss_key), sorted(e["hss"], key=hss_key)
+                    assert [(h["strand"], h["frame"], h["start"], h["end"], np.float32(h["score"])) for h in got] == \
+                           [(h["strand"], h["frame"], h["start"], h["end"], np.float32(h["score"])) for h in want], e["name"]
+                    assert b.getExtremeValuePars(i)[0] == e["evd_rc"]
+                at += len(bl)
+                b.close()
+
+    check(ctx)
+    monkeypatch.setenv("RC_GENERIC_MIN_ROWS", "3")
+    c2 = api.Context(0)
+    check(c2)
+    c2.close()
+
+
 def test_tiled_kernels_equal_the_oracle(monkeypatch):
     """k_tiled_dp<KT> (rc_null_tiled.h; blocks of 32..64 rows and up to 200..250 reference residues by default, here from 17 rows on and any length):
     the sequences besides the reference in tiles of 12..15, a cell's sum carried from tile to tile in score.c's order.  Per-sample maxima, HSS

@@ -136,3 +136,17 @@ def test_reference_out_of_bounds_draw_is_the_only_divergence(name):
     got, ref = np.float32(res.maxScores), np.float32(doc["ref_maxScores"])
     assert list(np.flatnonzero(got != ref)) == doc["ub_samples"]
     np.testing.assert_array_equal(got, np.float32(doc["oracle_maxScores"]))
+
+
+def test_one_purine_and_one_pyrimidine_blocks_against_the_reference():
+    """tests/data/sim_nan_branch_matrix.json (made by tests/data/make_sim_nan_fixture.py from the unmodified reference): blocks whose two absent
+    nucleotides leave Seq-Gen with NaN branch matrices -- every simulated residue state 0.  The oracle restates evolve.c:167-175 literally."""
+    import json
+    import os
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "data", "sim_nan_branch_matrix.json")))
+    for e in d["cases"]:
+        res = ob.run_block(e["rows"], e["names"], e["start"], e["length"], e["tree"], e["kappa"], ob.default_params(e["n_samples"]), e["seed"])
+        np.testing.assert_array_equal(np.float32(res.maxScores), np.float32(e["maxScores"]), err_msg=e["name"])
+        assert res.evd_rc == e["evd_rc"] and len(res.hss) == len(e["hss"])
+        sim, _ = ob.simulate_null(e["tree"], e["rows"], e["names"], res.models[0]["freqs"], e["kappa"], e["seed"])
+        assert set("".join(sim)) <= {"A", "-"}, e["name"]

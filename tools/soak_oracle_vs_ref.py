@@ -68,6 +68,10 @@ def main():
             if rng.rand() < 0.03:   # an alignment without two of the four nucleotides: HKY85 with zero frequencies, NaN background models and the
                 for row in rows:    # reference's NaN-order-dependent MAX macro (score.h:28; the class of tests/data/soak_hss_positive_delta.json)
                     row[:] = row.replace(b"A", b"C").replace(b"G", b"T")
+            if rng.rand() < 0.04:   # any two or three of the four nucleotides: one purine and one pyrimidine leave Seq-Gen's alphaR 0 / 0 -- NaN branch
+                keep = list(rng.permutation(list("ACGT"))[:int(rng.choice([2, 2, 3]))])   # matrices, every simulated residue state 0 (evolve.c:167-175)
+                for k_, row in enumerate(rows):
+                    rows[k_] = bytearray("".join(ch if ch in keep or ch not in "ACGT" else keep[(ord(ch) + q) % len(keep)] for q, ch in enumerate(row.decode())).encode())
             for x, row in zip(b.rows, rows):
                 x.seq = row.decode(); x.length = sum(ch != "-" for ch in x.seq)
             blocks.append(b)

@@ -75,6 +75,10 @@ def soak(budget=60.0, rng_seed=1, mode="", max_blocks=None, log=print):
                         if row[q] != ord("-"):
                             row[q] = ord(str(rng.choice(list("NNNRYKMSWBDHVU"))))
                     x.seq = row.decode()
+            if rng.rand() < 0.05:   # two or three of the four nucleotides only: zero frequencies -- NaN or infinite background models and branch
+                keep = list(rng.permutation(list("ACGT"))[:int(rng.choice([2, 2, 3]))])   # matrices (G and T only: every simulated residue state 0, evolve.c:167-175)
+                for x in b.rows:
+                    x.seq = "".join(ch if ch in keep or ch not in "ACGT" else keep[(ord(ch) + q) % len(keep)] for q, ch in enumerate(x.seq))
             blocks.append(b)
         stop = rng.rand() < 0.2
         if stop:
