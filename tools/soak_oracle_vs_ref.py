@@ -18,6 +18,9 @@ from rnacode_amd.alnio import write_harness_blocks  # noqa: E402
 from rnacode_amd.synth import synth_block  # noqa: E402
 
 HARNESS = os.path.join("oracle", "_ref", "ref_harness")
+EXOTIC = os.environ.get("RC_SOAK_EXOTIC", "") not in ("", "0")   # degenerate block classes as well (tools/soak_exotic.py)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from soak_exotic import exotic  # noqa: E402
 
 
 def key(h):
@@ -74,6 +77,8 @@ def main():
                     rows[k_] = bytearray("".join(ch if ch in keep or ch not in "ACGT" else keep[(ord(ch) + q) % len(keep)] for q, ch in enumerate(row.decode())).encode())
             for x, row in zip(b.rows, rows):
                 x.seq = row.decode(); x.length = sum(ch != "-" for ch in x.seq)
+            if EXOTIC:
+                exotic(rng, b)
             blocks.append(b)
         want_bt = bool(rng.rand() < 0.3)   # also the backtrack of the best HSS (score.c:558-797), a third of the rounds
         if only and rounds != only:

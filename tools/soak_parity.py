@@ -1,6 +1,6 @@
 """Randomised parity soak: random block shapes, sample counts, seeds and parameters through the HIP path and the
 oracle until the time budget is used up; any difference in per-sample maxima, HSS tables or fit results is printed.
-usage: python tools/soak_parity.py [seconds] [rng_seed] [wide|fat]     wide: 65..300 rows only (the kernels for more than 64 rows);
+usage: python tools/soak_parity.py [seconds] [rng_seed] [wide|fat]     (RC_SOAK_EXOTIC=1: degenerate block classes as well)     wide: 65..300 rows only (the kernels for more than 64 rows);
        fat: one row count per batch, 3..6 rows, up to 156 columns (the batches that take k_null's two-rows-per-pass instantiations)
 tests/test_gpu_soak.py runs a bounded slice of every mode under pytest -m gpu (soak(budget, seed, mode, max_blocks))."""
 import re
@@ -14,6 +14,11 @@ sys.path.insert(0, "tests")
 from oracle import binding as ob  # noqa: E402
 from rnacode_amd import api  # noqa: E402
 from rnacode_amd.synth import synth_block  # noqa: E402
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+from soak_exotic import exotic  # noqa: E402
+
+EXOTIC = __import__("os").environ.get("RC_SOAK_EXOTIC", "") not in ("", "0")   # degenerate block classes as well (tools/soak_exotic.py)
 
 
 def key(h):
@@ -79,6 +84,8 @@ def soak(budget=60.0, rng_seed=1, mode="", max_blocks=None, log=print):
                 keep = list(rng.permutation(list("ACGT"))[:int(rng.choice([2, 2, 3]))])   # matrices (G and T only: every simulated residue state 0, evolve.c:167-175)
                 for x in b.rows:
                     x.seq = "".join(ch if ch in keep or ch not in "ACGT" else keep[(ord(ch) + q) % len(keep)] for q, ch in enumerate(x.seq))
+            if EXOTIC:
+                exotic(rng, b)
             blocks.append(b)
         stop = rng.rand() < 0.2
         if stop:
