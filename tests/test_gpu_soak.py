@@ -1,5 +1,5 @@
 """The randomised evidence that used to be manual (tools/soak_parity.py, tools/knob_suite.sh), bounded so that it runs with
-`pytest -m gpu`: (1) a slice of the parity soak in each of its five modes -- random shapes, sample counts, seeds, matrices, gap
+`pytest -m gpu`: (1) a slice of the parity soak in each of its modes -- random shapes, sample counts, seeds, matrices, gap
 parameters, ambiguity codes, ties, --stop-early, streams of random sub-batches, backtrack paths -- HIP path against the CPU oracle;
 (2) a parity subset -- reference-scored goldens and a stream-equals-batch check -- under every non-default RC_* switch of the
 library (each is read when a context is created, so every case gets a context of its own)."""
@@ -30,10 +30,13 @@ SOAK = [
     ("", {"RC_GENERIC_MIN_ROWS": "3"}, 240),
     ("", {"RC_GENERIC_MIN_ROWS": "65", "RC_TILED_MIN_ROWS": "65"}, 240),   # the k_null<36..63> instantiations: by default blocks of 34 rows and more take the tiled or the generic kernels (rc_device.h)
     ("", {"RC_TILED_MIN_ROWS": "17", "RC_TILED_MAX_L": "100000"}, 240),   # k_tiled_dp for every block of 17..64 rows
+    ("wide", {"RC_TILED_MAX_ROWS": "64"}, 40),                            # k_generic_dp for every block of more than 64 rows (by default most of them take the tiled kernels)
+    ("", {"RC_SOAK_EXOTIC": "1"}, 400),   # degenerate inputs among the blocks (tools/soak_exotic.py: one or two letters only, kappa 0.01..900, zero or saturated branches, gap rows ...)
 ]
 
 
-@pytest.mark.parametrize("mode,env,blocks", SOAK, ids=["default", "fat", "wide", "codes-from-L2", "all-generic", "templated-to-64-rows", "tiled-from-17-rows"])
+@pytest.mark.parametrize("mode,env,blocks", SOAK, ids=["default", "fat", "wide", "codes-from-L2", "all-generic", "templated-to-64-rows", "tiled-from-17-rows", "generic-past-64-rows",
+                              "degenerate-blocks"])
 def test_soak_slice(monkeypatch, mode, env, blocks):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
