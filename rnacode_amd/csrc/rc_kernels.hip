@@ -661,8 +661,9 @@ __device__ __forceinline__ double fit_exp(int mode, double a) { return mode == 2
 // LDS or barriers.  A sum over n terms in another order differs by ~n 2^-53 relative, which cannot matter to a fit -- except in the
 // comparisons that steer it (|f| < 1e-5, the signs in the bisection), on maxima so degenerate that f is only known to its tolerance (the
 // class of tests/data/soak_fit_*.json).  So the fast evaluation (lawless416: strided partial sums, a tree over lanes) is what runs, and
-// this one decides wherever a difference in the last bits could: fits on few samples, every evaluation from the twelfth Newton step on
-// (a fit that converges takes < 10), the bisection fallback, and any evaluation whose |f| lands within 1e-8 of the tolerance.
+// this one decides wherever a difference in the last bits could: fits on few samples, a fit that has not converged after twelve Newton steps
+// (one that converges takes < 10; the slow one is replayed from the start in this order), the bisection fallback, and any evaluation whose |f|
+// lands within 1e-8 of the tolerance.
 template <typename T>
 __device__ void lawless416_serial(int mode, const T *x, int n, double lambda, double *f, double *df) {
   const int lane = threadIdx.x & (kWave - 1);
@@ -713,7 +714,7 @@ __device__ void lawless416(int mode, const T *x, int n, double lambda, double *s
 }
 
 constexpr int kFitSerialMaxN = 128;    // fits on at most this many samples: every evaluation in the reference's order
-constexpr int kFitSerialFromStep = 12; // Newton steps from this one on: the same
+constexpr int kFitSerialFromStep = 12; // a fit on more samples that has not converged after this many Newton steps: again from the start, the same
 
 template <int THREADS, typename T>
 __device__ int evd_fit_block(int mode, const T *x, int n, double *sh, double *mu_out, double *lambda_out) {
@@ -726,12 +727,21 @@ __device__ int evd_fit_block(int mode, const T *x, int n, double *sh, double *mu
     lawless416<THREADS, T>(mode, x, n, lam, sh, &fx, &dfx);
     if (fabs(fabs(fx) - tol) < 1e-8) lawless416_serial<T>(mode, x, n, lam, &fx, &dfx);
   };
-  int it;
-  for (it = 0; it < 100; it++) {
-    eval(lambda, small || it >= kFitSerialFromStep);
-    if (fabs(fx) < tol) break;
-    lambda = lambda - fx / dfx;
-    if (lambda <= 0.) lambda = 0.001;
+  // Newton-Raphson (extreme_fit.c:170-191).  A fit that converges takes fewer than ten steps and does not care about the last bits of its sums.  One
+  // that has not converged after twelve is on a path only the reference's own rounding leads along (129 maxima of two values, 122 and 7 of them:
+  // thirty-four steps through lambda = 130, where exp(-lambda x) is 1e-320 and the sums' order decides whether the next step is finite; a soak
+  // found it in round 6, tests/data/soak_fit_two_values.json): it is started again from lambda = 0.2 with every evaluation in the reference's order.
+  int it = 0;
+  for (int replay = small ? 1 : 0; replay < 2; replay++) {
+    const int steps = replay ? 100 : kFitSerialFromStep;
+    lambda = 0.2;
+    for (it = 0; it < steps; it++) {
+      eval(lambda, replay != 0);
+      if (fabs(fx) < tol) break;
+      lambda = lambda - fx / dfx;
+      if (lambda <= 0.) lambda = 0.001;
+    }
+    if (it < steps) break;
   }
   if (it == 100) {  // bisection fallback (extreme_fit.c:193-236)
     double left = 0.2, right = 0.2, mid = 0.2;

@@ -46,6 +46,8 @@ def soak(budget=60.0, rng_seed=1, mode="", max_blocks=None, log=print):
             pars = dict(Delta=float(rng.uniform(0, 2)))
         elif r < 0.3:
             pars = dict(blosum=90)
+        elif EXOTIC and r < 0.38:   # any sign and size for every gap and stop parameter (omega > 0 keeps a block out of the tiled kernels, Delta >= 0 takes the EXACT ones)
+            pars = {k: float(np.float32(rng.uniform(-12, 3))) for k in ("Delta", "Omega", "omega", "stopPenalty_k", "stopPenalty_0") if rng.rand() < 0.7}
         blocks = []
         fat_n = int(rng.choice([3, 4, 5, 6]))
         most = int(__import__('os').environ.get('RC_SOAK_MAX_BLOCKS_PER_BATCH', 0)) or (5 if wide else 24)   # (tiny batches: the row-split path)
