@@ -36,6 +36,13 @@ def exotic(rng, b):
         for x in b.rows[1:]:
             x.seq = b.rows[0].seq
         kind = "identical rows"
+    elif r < 0.17:    # branch lengths in exponent notation (what %g prints for short branches)
+        b.tree = re.sub(r":([0-9.]+)", lambda m: ":%.5e" % float(m.group(1)), b.tree)
+        kind = "exponent notation"
+    elif r < 0.19:    # lower case and U among the residues
+        for x in b.rows:
+            x.seq = "".join((c.lower() if rng.rand() < 0.3 else c) for c in x.seq.replace("T", "U" if rng.rand() < 0.5 else "T"))
+        kind = "lower case and U"
     if kind:
         for x in b.rows:
             x.length = sum(c != "-" for c in x.seq)

@@ -37,6 +37,8 @@ def soak(budget=60.0, rng_seed=1, mode="", max_blocks=None, log=print):
     while time.time() - t0 < budget and (max_blocks is None or blocks_done < max_blocks):
         rounds += 1
         n_samples = int(rng.choice([1, 2, 63, 64, 65, 100, 129, 200, 333]))
+        if EXOTIC and rng.rand() < 0.15:
+            n_samples = int(rng.choice([3, 4, 127, 128, 255, 256, 257, 512, 1000]))
         seed = int(rng.randint(1, 2 ** 31 - 1))
         pars = {}
         r = rng.rand()
@@ -61,6 +63,8 @@ def soak(budget=60.0, rng_seed=1, mode="", max_blocks=None, log=print):
                 n = int(rng.choice([65, 66, 70, 90, 128, 129, 200, 300]))
                 cols = int(rng.choice([9, 30, 60, 99, 120, 150, 200]))
                 cols = max(9, min(cols, 9000 // n))
+            elif EXOTIC and n <= 6 and n_samples <= 129 and rng.rand() < 0.04:
+                cols = int(rng.choice([600, 999, 1500]))   # long blocks: rows longer than every staging area
             elif n * cols > 4000:
                 cols = max(9, 4000 // n)
             if n > 32 and not wide:
@@ -108,7 +112,7 @@ def soak(budget=60.0, rng_seed=1, mode="", max_blocks=None, log=print):
                     setattr(p, k, v)
             if batch.status(i) != 0:
                 continue
-            res = ob.run_block([x.seq for x in b.rows], [x.name for x in b.rows], b.rows[0].start, b.rows[0].length, b.tree, b.kappa, p, seed)
+            res = ob.run_block([x.seq.upper() for x in b.rows], [x.name for x in b.rows], b.rows[0].start, b.rows[0].length, b.tree, b.kappa, p, seed)   # (the readers upper-case what they read, the library what it is given)
             rc0 = batch.getExtremeValuePars(i)[0]
             # --stop-early: a decided block (rc -1) may have fewer samples simulated here than the reference had when it left its loop
             why = []
@@ -130,7 +134,7 @@ def soak(budget=60.0, rng_seed=1, mode="", max_blocks=None, log=print):
                 h = got[0]
                 strand = 0 if h["strand"] == "+" else 1
                 st, z, tr = batch.backtrack(i, strand, h["start"], h["end"])
-                rows, names = [x.seq for x in b.rows], [x.name for x in b.rows]
+                rows, names = [x.seq.upper() for x in b.rows], [x.name for x in b.rows]
                 bl = pars.get("blosum", 62)
                 m = ob.get_models(b.tree, rows, names, b.kappa, bl)
                 rrows = ob.rev_aln(rows)
