@@ -98,8 +98,20 @@ def main():
         finally:
             os.unlink(path)
         if out.returncode != 0:
-            print(f"harness failed (rc {out.returncode}) in round {rounds}: {out.stderr.decode()[:200]}")
-            bad += 1
+            # the documented out-of-bounds draw (seqgen/evolve.c:173,304: state 4, the next branch's probabilities read past their array) can end in a
+            # segmentation fault instead of a wrong sample: if the oracle counts a clamped draw in one of the round's blocks, that is what happened
+            clamped = 0
+            for b in blocks:
+                p = ob.default_params(n_samples, blosum=blosum)
+                for k, v in pars.items():
+                    setattr(p, k, v)
+                clamped += ob.run_block([x.seq.upper() for x in b.rows], [x.name for x in b.rows], b.rows[0].start, b.rows[0].length, b.tree, b.kappa, p, seed).clamped
+            if clamped > 0:
+                ub += 1
+                print(f"reference UB round {rounds}: the harness died (rc {out.returncode}) on a round with {clamped} clamped draw(s)")
+            else:
+                print(f"harness failed (rc {out.returncode}) in round {rounds}: {out.stderr.decode()[:200]}")
+                bad += 1
             continue
         try:   # printf writes nan / inf where JSON wants NaN / Infinity
             refs = [json.loads(re.sub(r"(?<![A-Za-z])(-?)inf(?![A-Za-z])", r"\1Infinity", re.sub(r"-?nan", "NaN", l)))
