@@ -612,7 +612,8 @@ def test_blocks_with_one_purine_and_one_pyrimidine_follow_the_reference(ctx, mon
     NaN, `r > P` false for every draw (evolve.c:167-175) and every simulated residue state 0 -- the null samples are all-A alignments with the
     block's gaps.  The library's integer thresholds took NaN for "every draw exceeds it" until a soak found this block in round 6
     (rc_host.cpp, threshold_of).  tests/data/sim_nan_branch_matrix.json holds the UNMODIFIED reference's per-sample maxima, HSS and fit verdicts
-    (tests/data/make_sim_nan_fixture.py); here every kernel family must reproduce them: the per-row-count kernels, the tiled and the generic ones."""
+    (tests/data/make_sim_nan_fixture.py); here both simulations must reproduce them: the per-row-count kernels' and, with every block sent to the generic
+    kernels, k_generic_sim's (which the tiled kernels share)."""
     import json
     import os
     from rnacode_amd import api
